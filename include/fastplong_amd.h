@@ -1,0 +1,259 @@
+/*
+ * fastplong_amd.h -- C-ABI of the MI355X-native per-read hot path.
+ *
+ * The reference (OpenGene/fastplong v0.4.1) has no plugin/FFI interface; the seam this
+ * library replaces is the C++ call
+ *     bool SingleEndProcessor::processSingleEnd(ReadPack*, ThreadConfig*)
+ *         (reference src/seprocessor.h:30, body src/seprocessor.cpp:180-329)
+ * together with the per-thread accumulators it updates (Stats x2 + FilterResult,
+ * src/threadconfig.h:16-59) and the serial merge that follows the join
+ * (Stats::merge src/stats.cpp:1013-1082, FilterResult::merge src/filterresult.cpp:28-61).
+ *
+ * Shape of the replacement: the caller hands over a *batch* of variable-length reads in CSR
+ * form (all bases concatenated, all quality bytes concatenated, n+1 byte offsets) and gets
+ * back one fixed-size record per read (bounds of the surviving fragment(s) + filter code)
+ * while all additive counters stay resident on the device until fpl_get_counters().
+ * Bases are never written back: the host slices its own copy using the returned offsets.
+ *
+ * Conventions: plain C types only; the caller owns every buffer it passes in; functions
+ * return 0 or a negative FPL_ERR_* code and never call exit(); one context per device, one
+ * batch in flight per context; contexts on different devices may be driven from different
+ * threads.  There is no CPU fallback: fpl_create() fails with FPL_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef FASTPLONG_AMD_H
+#define FASTPLONG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPL_ABI_VERSION 1
+
+/* limits */
+#define FPL_MAX_ADAPTER_LEN 256 /* longest adapter the device path accepts            */
+#define FPL_MAX_ADAPTERS 1024   /* start + end + FASTA adapters                      */
+#define FPL_END_WINDOW 200      /* WINDOW,      reference src/adaptertrimmer.cpp:169,239 */
+#define FPL_PATTERN_LEN 16      /* PATTERN_LEN, reference src/adaptertrimmer.cpp:170,240 */
+
+/* filter result codes, reference src/common.h:43-50 */
+#define FPL_PASS_FILTER 0
+#define FPL_FAIL_N_BASE 12
+#define FPL_FAIL_LENGTH 16
+#define FPL_FAIL_TOO_LONG 17
+#define FPL_FAIL_QUALITY 20
+#define FPL_FAIL_COMPLEXITY 24
+#define FPL_FILTER_RESULT_TYPES 32
+
+/* error codes */
+#define FPL_OK 0
+#define FPL_ERR_ARG (-1)       /* null pointer / inconsistent argument                  */
+#define FPL_ERR_NO_DEVICE (-2) /* no usable HIP device: this library has no CPU path    */
+#define FPL_ERR_HIP (-3)       /* a HIP runtime call failed (see fpl_last_error)        */
+#define FPL_ERR_ADAPTER (-4)   /* adapter longer than FPL_MAX_ADAPTER_LEN / too many    */
+#define FPL_ERR_CAPACITY (-5)  /* read longer than the context's max_cycles capacity    */
+#define FPL_ERR_STATE (-6)     /* call not valid in the current state                   */
+
+/*
+ * Options the path reads.  Field-for-field mirror of the parts of the reference's `Options`
+ * that processSingleEnd and its callees consult (src/options.h:56-184); defaults in
+ * fpl_options_default() are the reference CLI defaults (src/main.cpp:27-103).
+ */
+typedef struct fpl_options {
+    /* TrimmingOptions, src/options.h:149-161: -f / -t */
+    int32_t trim_front;
+    int32_t trim_tail;
+    /* QualityCutOptions, src/options.h:69-98: --cut_front/--cut_tail and their windows */
+    int32_t cut_front;        /* enabledFront */
+    int32_t cut_tail;         /* enabledTail  */
+    int32_t cut_front_window; /* windowSizeFront 1..1000 */
+    int32_t cut_front_quality; /* qualityFront, phred (not +33) */
+    int32_t cut_tail_window;
+    int32_t cut_tail_quality;
+    /* PolyXTrimmerOptions, src/options.h:57-66: -x / --poly_x_min_len */
+    int32_t polyx;
+    int32_t polyx_min_len;
+    /* AdapterOptions, src/options.h:126-147: -A, -d, --trimming_extension */
+    int32_t adapter_enabled;
+    double ed_max;            /* distance_threshold: round(ed_max*len) is done in double on the host */
+    int32_t trimming_extension;
+    /* QualityFilteringOptions, src/options.h:163-184: -Q -q -u -n --n_base_limit -m */
+    int32_t qual_filter;      /* enabled */
+    int32_t qualified_qual;   /* qualifiedQual as the raw ASCII char (phred+33), '0' = Q15 */
+    int32_t unqualified_percent_limit;
+    int32_t n_base_limit;     /* 1000000 means "no limit" (src/filter.cpp:46) */
+    int32_t n_base_percent_limit;
+    int32_t avg_qual_req;     /* -m, 0 = off */
+    /* ReadLengthFilteringOptions, src/options.h:186-200: -L -l --length_limit */
+    int32_t length_filter;    /* enabled */
+    int32_t required_length;
+    int32_t max_length;       /* 0 = no limit */
+    /* LowComplexityFilterOptions, src/options.h:43-53: -y -Y (integer percent 0..100;
+       the reference stores percent/100.0 and compares doubles -- equivalent) */
+    int32_t complexity_filter;
+    int32_t complexity_percent;
+} fpl_options;
+
+typedef struct fpl_adapter {
+    const char* seq; /* raw bytes, not NUL-terminated */
+    int32_t len;
+} fpl_adapter;
+
+/*
+ * One record per input read, written in input order.  Everything a writer needs to do what
+ * src/seprocessor.cpp:265-281 does (serialize passing fragments; tag failed reads) without
+ * touching the bases again.  All positions are byte offsets relative to the start of the
+ * ORIGINAL read.  36 bytes.
+ *
+ *  dropped = 1 : Filter::trimAndCut returned NULL (src/filter.cpp:137-139,165,197,221): the
+ *                read is counted in the pre-filter statistics and nowhere else.
+ *  r1_start/r1_len : the read after trimAndCut + polyX + adapter end trims ("r1"); this is
+ *                what --failed_out receives when exactly one fragment exists and it fails.
+ *  n_frag 0..2 : fragments after the middle-adapter split (Read::breakByGap,
+ *                src/read.cpp:192-215); kind 0 = unsplit r1, 1 = "split-by-adapter-left-",
+ *                2 = "split-by-adapter-right-".
+ *  code[i]     : Filter::passFilter result for fragment i (FPL_PASS_FILTER / FPL_FAIL_*).
+ *  median_q_pre: per-read median quality char of the original read (Stats::statRead,
+ *                src/stats.cpp:352-363); 0 when the read is empty.
+ *  median_q_post[i]: same for fragment i, valid only when code[i] == FPL_PASS_FILTER.
+ */
+typedef struct fpl_read_result {
+    uint32_t r1_start;
+    uint32_t r1_len;
+    uint32_t frag_start[2];
+    uint32_t frag_len[2];
+    uint8_t n_frag;
+    uint8_t dropped;
+    uint8_t code[2];
+    uint8_t kind[2];
+    uint8_t median_q_pre;
+    uint8_t median_q_post[2];
+    uint8_t reserved[3];
+} fpl_read_result;
+
+/*
+ * Flat int64 counter buffer ("what the RCCL all-reduce sums").  C = max_cycles capacity.
+ *
+ *   [ pre-filter Stats | post-filter Stats | FilterResult | adapter-key histogram ]
+ *
+ * One Stats block (FPL_STATS_LEN(C) entries), replacing the members of the reference's
+ * class Stats that statRead updates (src/stats.h:70-110):
+ *   cyc[c][kind*8 + cls], c < C, cycle-major so that growing C appends:
+ *        kind 0 mCycleBaseContents, 1 mCycleBaseQual, 2 mCycleQ20Bases, 3 mCycleQ30Bases,
+ *        cls = base ASCII & 7 (A1 C3 T4 U5 N6 G7, src/stats.h:60-69);
+ *        mCycleTotalBase / mCycleTotalQual are the sums over cls and are not stored.
+ *   base_qual_hist[128]   mBaseQualHistogram
+ *   median_hist[128]      mMedianReadQualHistogram
+ *   median_bases[128]     mMedianReadQualBases
+ *   kmer[1024]            mKmer (the reference allocates 2048, indices are 10 bit)
+ *   reads, length_sum     mReads, mLengthSum
+ *
+ * FilterResult block (FPL_FR_LEN entries), src/filterresult.h:57-64:
+ *   filter_read_stats[32], adapter_trimmed_reads, adapter_trimmed_bases,
+ *   polyx_reads[4], polyx_bases[4]      (A,T,C,G order of ATCG_BASES, src/common.h:26)
+ *
+ * Adapter-key histogram: key_hist[a][side][cmplen], a < n_adapters, side 0 = trimmed at
+ * read start (key = adapter.substr(alen-cmplen, cmplen)), side 1 = trimmed at read end
+ * (key = adapter.substr(0, cmplen)), cmplen <= FPL_MAX_ADAPTER_LEN; cmplen == alen is the
+ * full adapter.  The host turns indices into the strings of the reference's
+ * map<string,long> mAdapter (src/filterresult.cpp:68-76).
+ * Adapter slot order: 0 = start adapter, 1 = end adapter, 2.. = FASTA adapters in the order
+ * given (the caller sorts them by FASTA header like src/options.cpp:50-59).
+ */
+#define FPL_CYC_STRIDE 32
+#define FPL_STATS_TAIL (128 * 3 + 1024 + 2)
+#define FPL_STATS_LEN(C) ((size_t)(C) * FPL_CYC_STRIDE + FPL_STATS_TAIL)
+#define FPL_ST_CYC(c, kind, cls) ((size_t)(c) * FPL_CYC_STRIDE + (size_t)(kind) * 8 + (size_t)(cls))
+#define FPL_ST_BASE_QUAL_HIST(C) ((size_t)(C) * FPL_CYC_STRIDE)
+#define FPL_ST_MEDIAN_HIST(C) (FPL_ST_BASE_QUAL_HIST(C) + 128)
+#define FPL_ST_MEDIAN_BASES(C) (FPL_ST_BASE_QUAL_HIST(C) + 256)
+#define FPL_ST_KMER(C) (FPL_ST_BASE_QUAL_HIST(C) + 384)
+#define FPL_ST_READS(C) (FPL_ST_BASE_QUAL_HIST(C) + 384 + 1024)
+#define FPL_ST_LENGTH_SUM(C) (FPL_ST_READS(C) + 1)
+#define FPL_FR_LEN 42
+#define FPL_FR_FILTER 0
+#define FPL_FR_ADAPTER_READS 32
+#define FPL_FR_ADAPTER_BASES 33
+#define FPL_FR_POLYX_READS 34
+#define FPL_FR_POLYX_BASES 38
+#define FPL_KEY_STRIDE (FPL_MAX_ADAPTER_LEN + 1)
+#define FPL_KEYHIST_LEN(nad) ((size_t)(nad) * 2 * FPL_KEY_STRIDE)
+#define FPL_COUNTERS_LEN(C, nad) (2 * FPL_STATS_LEN(C) + FPL_FR_LEN + FPL_KEYHIST_LEN(nad))
+#define FPL_OFF_PRE(C) ((size_t)0)
+#define FPL_OFF_POST(C) (FPL_STATS_LEN(C))
+#define FPL_OFF_FR(C) (2 * FPL_STATS_LEN(C))
+#define FPL_OFF_KEYHIST(C) (2 * FPL_STATS_LEN(C) + FPL_FR_LEN)
+
+typedef struct fpl_ctx fpl_ctx;
+
+/* Reference CLI defaults (src/main.cpp:27-103, src/options.h ctors). */
+void fpl_options_default(fpl_options* opt);
+
+/*
+ * Create a context on HIP device `device` (>= 0).
+ *  start/end  : adapter strings of --start_adapter / --end_adapter after the CLI resolved
+ *               them (src/main.cpp:131-140); len 0 = empty string.
+ *  fasta      : sequences of --adapter_fasta in the order trimByMultiSequences must visit
+ *               them (src/adaptertrimmer.cpp:42-57); n_fasta = 0 means hasFasta = false.
+ *  max_cycles : initial capacity C of the per-cycle tables (grown on demand).
+ */
+int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter, int32_t start_len,
+               const char* end_adapter, int32_t end_len, const fpl_adapter* fasta, int32_t n_fasta,
+               int32_t device, uint32_t max_cycles);
+void fpl_destroy(fpl_ctx* ctx);
+
+/*
+ * Process one batch whose buffers already live in device memory (HBM).
+ *  d_seq, d_qual : n_bytes bytes each; read i occupies [d_off[i], d_off[i+1]).
+ *  d_off         : n_reads + 1 uint64 offsets, non-decreasing, d_off[n_reads] <= n_bytes.
+ *  max_read_len  : upper bound of the read lengths in the batch (the caller knows it from
+ *                  its offsets); used to size the launch and to check capacity.
+ *  d_results     : n_reads records, device memory.
+ *  stream        : hipStream_t (NULL = default stream).  Asynchronous: returns after the
+ *                  launches are enqueued.
+ */
+int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual,
+                             const uint64_t* d_off, uint32_t n_reads, uint64_t n_bytes,
+                             uint32_t max_read_len, fpl_read_result* d_results, void* stream);
+
+/*
+ * Same, from host buffers (pinned recommended): copies in, processes, copies the records
+ * back and synchronizes.  This is the call a host worker loop makes in place of
+ * processSingleEnd().
+ */
+int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint64_t* off,
+                      uint32_t n_reads, fpl_read_result* results);
+
+/* Counter buffer: capacity, number of adapter slots, length, device pointer, host copy. */
+uint32_t fpl_max_cycles(const fpl_ctx* ctx);
+int32_t fpl_n_adapters(const fpl_ctx* ctx);
+size_t fpl_counters_len(const fpl_ctx* ctx);
+/* Grow the per-cycle capacity (all ranks must agree on C before an all-reduce). */
+int fpl_reserve_cycles(fpl_ctx* ctx, uint32_t max_cycles);
+/* int64 device buffer of fpl_counters_len() entries; valid until the next grow/destroy. A
+   multi-GPU host all-reduces (sum) this buffer in place over RCCL. */
+void* fpl_counters_device_ptr(fpl_ctx* ctx);
+int fpl_get_counters(fpl_ctx* ctx, int64_t* host_buf, size_t n);
+int fpl_reset_counters(fpl_ctx* ctx);
+int fpl_synchronize(fpl_ctx* ctx);
+
+/*
+ * Per-kernel timing of the most recent fpl_process_batch_device() call, measured with HIP
+ * events on the stream the kernels were launched on.  Enable before the call; reading
+ * synchronizes on the recorded events.  names[i] are static strings.
+ */
+#define FPL_MAX_KERNEL_TIMES 16
+int fpl_enable_timing(fpl_ctx* ctx, int enable);
+int fpl_get_kernel_times(fpl_ctx* ctx, float* ms, const char** names, int* n);
+
+const char* fpl_strerror(int code);
+const char* fpl_last_error(const fpl_ctx* ctx);
+int fpl_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTPLONG_AMD_H */

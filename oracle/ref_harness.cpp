@@ -1,0 +1,202 @@
+/*
+ * ref_harness.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A line-protocol driver around the REAL reference objects (compiled in place from
+ * /root/reference/src by oracle/Makefile into oracle/_ref/).  It contains no algorithm of its
+ * own: every answer it prints comes out of reference code.  Linked reference files:
+ * editdistance, filter, polyx, stats, filterresult, read, options, fastareader, jsonreporter,
+ * htmlreporter.  NOT linked (they include Google Highway / ISA-L headers the image lacks):
+ * adaptertrimmer, sequence, fastqreader, seprocessor, evaluator, main.
+ *
+ * Protocol (stdin, one command per line, fields separated by one space, strings carry a
+ * leading '=' so that the empty string is "="):
+ *   ED =a =b                                   -> edit_distance
+ *   TAC front tail cf ct wf qf wt qt =seq =qual -> Filter::trimAndCut
+ *   PX minlen =seq =qual                        -> PolyX::trimPolyX
+ *   PF qf qq up nbl npl aq lf rl ml cf cp =seq =qual -> Filter::passFilter
+ *   TF n =seq =qual / RS n =seq =qual           -> Read::trimFront / Read::resize
+ *   BG start len =name =seq =strand =qual       -> Read::breakByGap + appendToString
+ *   TAG code =name =seq =strand =qual           -> Read::appendToStringWithTag(FAILED_TYPES[code])
+ *   JSON block: J_BEGIN threads seqlen isrna adapter_enabled polyx complexity =start =end
+ *               J_PRE =seq =qual | J_POST =seq =qual | J_FR code | J_AD =key | J_ART bases
+ *               | J_PXT base len | J_END =path   -> Stats/FilterResult/JsonReporter::report
+ */
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "editdistance.h"
+#include "filter.h"
+#include "filterresult.h"
+#include "jsonreporter.h"
+#include "options.h"
+#include "polyx.h"
+#include "read.h"
+#include "stats.h"
+
+using namespace std;
+
+/* the two globals main.cpp normally owns (the reference's test/globals.cpp does the same) */
+string command;
+mutex logmtx;
+
+static vector<string> split(const string& s) {
+    vector<string> out;
+    size_t i = 0;
+    while (i <= s.size()) {
+        size_t j = s.find(' ', i);
+        if (j == string::npos) j = s.size();
+        out.push_back(s.substr(i, j - i));
+        i = j + 1;
+    }
+    return out;
+}
+static string str(const string& tok) { return tok.empty() ? string() : tok.substr(1); }
+
+struct JsonJob {
+    Options opt;
+    vector<Stats*> pre, post;
+    vector<FilterResult*> fr;
+    int threads = 1;
+    long npre = 0;
+    void clear() {
+        for (auto p : pre) delete p;
+        for (auto p : post) delete p;
+        for (auto p : fr) delete p;
+        pre.clear();
+        post.clear();
+        fr.clear();
+        npre = 0;
+    }
+};
+
+int main() {
+    ios::sync_with_stdio(false);
+    string line;
+    JsonJob job;
+    long cur_thread = 0;
+    while (getline(cin, line)) {
+        if (line.empty()) continue;
+        vector<string> t = split(line);
+        const string& op = t[0];
+        if (op == "ED") {
+            string a = str(t[1]), b = str(t[2]);
+            cout << edit_distance(a.c_str(), a.length(), b.c_str(), b.length()) << "\n";
+        } else if (op == "TAC") {
+            Options opt;
+            int front = atoi(t[1].c_str()), tail = atoi(t[2].c_str());
+            opt.qualityCut.enabledFront = atoi(t[3].c_str());
+            opt.qualityCut.enabledTail = atoi(t[4].c_str());
+            opt.qualityCut.windowSizeFront = atoi(t[5].c_str());
+            opt.qualityCut.qualityFront = atoi(t[6].c_str());
+            opt.qualityCut.windowSizeTail = atoi(t[7].c_str());
+            opt.qualityCut.qualityTail = atoi(t[8].c_str());
+            Filter filter(&opt);
+            Read r("@n", str(t[9]).c_str(), "+", str(t[10]).c_str());
+            int frontTrimmed = 0;
+            Read* ret = filter.trimAndCut(&r, front, tail, frontTrimmed);
+            if (ret == NULL) cout << "NULL\n";
+            else cout << frontTrimmed << " =" << *ret->mSeq << " =" << *ret->mQuality << "\n";
+        } else if (op == "PX") {
+            Read r("@n", str(t[2]).c_str(), "+", str(t[3]).c_str());
+            FilterResult fr(NULL, false);
+            PolyX::trimPolyX(&r, &fr, atoi(t[1].c_str()));
+            /* per-base counters are private: print them through the reference's own JSON writer */
+            cout << "=" << *r.mSeq << " " << fr.getTotalPolyXTrimmedReads() << " "
+                 << fr.getTotalPolyXTrimmedBases() << "\n";
+        } else if (op == "PF") {
+            Options opt;
+            opt.qualfilter.enabled = atoi(t[1].c_str());
+            opt.qualfilter.qualifiedQual = (char)atoi(t[2].c_str());
+            opt.qualfilter.unqualifiedPercentLimit = atoi(t[3].c_str());
+            opt.qualfilter.nBaseLimit = atoi(t[4].c_str());
+            opt.qualfilter.nBasePercentLimit = atoi(t[5].c_str());
+            opt.qualfilter.avgQualReq = atoi(t[6].c_str());
+            opt.lengthFilter.enabled = atoi(t[7].c_str());
+            opt.lengthFilter.requiredLength = atoi(t[8].c_str());
+            opt.lengthFilter.maxLength = atoi(t[9].c_str());
+            opt.complexityFilter.enabled = atoi(t[10].c_str());
+            /* exactly what src/main.cpp:219 computes from -Y */
+            opt.complexityFilter.threshold = (min(100, max(0, atoi(t[11].c_str())))) / 100.0;
+            Filter filter(&opt);
+            Read r("@n", str(t[12]).c_str(), "+", str(t[13]).c_str());
+            cout << filter.passFilter(&r) << "\n";
+        } else if (op == "TF" || op == "RS") {
+            Read r("@n", str(t[2]).c_str(), "+", str(t[3]).c_str());
+            if (op == "TF") r.trimFront(atoi(t[1].c_str()));
+            else r.resize(atoi(t[1].c_str()));
+            cout << "=" << *r.mSeq << " =" << *r.mQuality << "\n";
+        } else if (op == "BG") {
+            Read r(str(t[3]).c_str(), str(t[4]).c_str(), str(t[5]).c_str(), str(t[6]).c_str());
+            vector<Read*> out = r.breakByGap(atoi(t[1].c_str()), atoi(t[2].c_str()));
+            string s;
+            for (size_t i = 0; i < out.size(); i++) {
+                out[i]->appendToString(&s);
+                delete out[i];
+            }
+            cout << out.size() << " " << s.size() << "\n" << s;
+        } else if (op == "TAG") {
+            Read r(str(t[2]).c_str(), str(t[3]).c_str(), str(t[4]).c_str(), str(t[5]).c_str());
+            string s;
+            r.appendToStringWithTag(&s, FAILED_TYPES[atoi(t[1].c_str())]);
+            cout << s.size() << "\n" << s;
+        } else if (op == "J_BEGIN") {
+            job.clear();
+            job.threads = atoi(t[1].c_str());
+            job.opt = Options();
+            job.opt.seqLen = atoi(t[2].c_str());
+            job.opt.isRNA = atoi(t[3].c_str());
+            job.opt.adapter.enabled = atoi(t[4].c_str());
+            job.opt.polyXTrim.enabled = atoi(t[5].c_str());
+            job.opt.complexityFilter.enabled = atoi(t[6].c_str());
+            job.opt.adapter.sequenceStart = str(t[7]);
+            job.opt.adapter.sequenceEnd = str(t[8]);
+            job.opt.adapter.hasFasta = false;
+            for (int i = 0; i < job.threads; i++) { /* what ThreadConfig does, src/threadconfig.cpp:4-17 */
+                job.pre.push_back(new Stats(&job.opt));
+                job.post.push_back(new Stats(&job.opt));
+                job.fr.push_back(new FilterResult(&job.opt));
+            }
+            cur_thread = 0;
+        } else if (op == "J_PRE") {
+            /* packs of PACK_SIZE reads go round-robin to the workers, src/seprocessor.cpp:373-378 */
+            cur_thread = (job.npre / PACK_SIZE) % job.threads;
+            job.npre++;
+            Read r("@n", str(t[1]).c_str(), "+", str(t[2]).c_str());
+            job.pre[cur_thread]->statRead(&r);
+        } else if (op == "J_POST") {
+            Read r("@n", str(t[1]).c_str(), "+", str(t[2]).c_str());
+            job.post[cur_thread]->statRead(&r);
+        } else if (op == "J_FR") {
+            job.fr[cur_thread]->addFilterResult(atoi(t[1].c_str()), 1);
+        } else if (op == "J_AD") {
+            job.fr[cur_thread]->addAdapterTrimmed(str(t[1]));
+        } else if (op == "J_ART") {
+            job.fr[cur_thread]->addReadTrimmed(atoi(t[1].c_str()));
+        } else if (op == "J_PXT") {
+            job.fr[cur_thread]->addPolyXTrimmed(atoi(t[1].c_str()), atoi(t[2].c_str()));
+        } else if (op == "J_END") {
+            job.opt.jsonFile = str(t[1]);
+            /* what SingleEndProcessor::process does after the join, src/seprocessor.cpp:108-142 */
+            Stats* finalPre = Stats::merge(job.pre);
+            Stats* finalPost = Stats::merge(job.post);
+            FilterResult* finalFr = FilterResult::merge(job.fr);
+            command = "";
+            JsonReporter jr(&job.opt);
+            jr.report(finalFr, finalPre, finalPost);
+            delete finalPre;
+            delete finalPost;
+            delete finalFr;
+            job.clear();
+            cout << "OK\n";
+        } else {
+            cout << "ERR unknown op " << op << "\n";
+        }
+        cout.flush();
+    }
+    return 0;
+}
