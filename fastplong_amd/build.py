@@ -1,0 +1,82 @@
+"""Build the native pieces in-tree: the HIP library (hipcc, gfx950) and the C++ host tools."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+LIB = os.path.join(HERE, "libfastplong_amd.so")
+HOST_LIB = os.path.join(HERE, "libfastplong_host.so")
+CLI = os.path.join(ROOT, "bin", "fastplong_amd")
+
+
+def _newer(target, srcs):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def hip_sources():
+    return [os.path.join(CSRC, f) for f in ("fpl_hip.hip", "kernels.h", "pipeline.h", "dev_prims.h", "dev_types.h")] + [
+        os.path.join(ROOT, "include", "fastplong_amd.h")]
+
+
+def build_hip(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> fastplong_amd/libfastplong_amd.so (cross-compiles without a GPU)"""
+    srcs = hip_sources()
+    if force or _newer(LIB, srcs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB, srcs[0]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def host_sources():
+    if not os.path.isdir(HOST):
+        return []
+    return sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".h")))
+
+
+def build_host(force=False, verbose=False):
+    """g++ -> fastplong_amd/libfastplong_host.so (FASTQ I/O, report writers) and bin/fastplong_amd (CLI)"""
+    srcs = host_sources()
+    cpps = [s for s in srcs if s.endswith(".cpp")]
+    if not cpps:
+        return None
+    lib_cpps = [s for s in cpps if not s.endswith("cli.cpp")]
+    hdr = os.path.join(ROOT, "include", "fastplong_amd.h")
+    if force or _newer(HOST_LIB, srcs + [hdr]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
+               "-o", HOST_LIB] + lib_cpps + ["-ldl", "-lz"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    cli_src = os.path.join(HOST, "cli.cpp")
+    if os.path.exists(cli_src) and (force or _newer(CLI, srcs + [hdr])):
+        os.makedirs(os.path.dirname(CLI), exist_ok=True)
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", CLI, cli_src,
+               "-L" + HERE, "-lfastplong_host", "-Wl,-rpath," + HERE, "-ldl", "-lz"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force=True, verbose=True)

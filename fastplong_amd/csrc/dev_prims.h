@@ -1,0 +1,135 @@
+/*
+ * dev_prims.h -- the handful of wave-level primitives the kernels are written against.
+ * Device build (hipcc, gfx950): thin wrappers over CDNA4 builtins; wave = 64 lanes.
+ * FPL_EMU build (g++, tests only): the same names on top of tests/emu/hip_emu.h.
+ */
+#ifndef FPL_DEV_PRIMS_H
+#define FPL_DEV_PRIMS_H
+
+#include <stdint.h>
+
+#ifdef FPL_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+namespace fpl {
+
+constexpr int WAVE = 64;
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+struct u32x4 {
+    u32 x, y, z, w;
+};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
+
+__device__ __forceinline__ u64 wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
+
+/* order this wave's LDS traffic across lanes (zero -> atomics -> reads of a per-wave table) */
+__device__ __forceinline__ void wave_sync() {
+#ifdef FPL_EMU
+    emu_wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+__device__ __forceinline__ u32 shfl_u32(u32 v, int src) { return (u32)__shfl((int)v, src, 64); }
+__device__ __forceinline__ int shfl_i32(int v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ u32 shfl_up_u32(u32 v, unsigned d) { return (u32)__shfl_up((int)v, d, 64); }
+__device__ __forceinline__ u32 shfl_down_u32(u32 v, unsigned d) { return (u32)__shfl_down((int)v, d, 64); }
+__device__ __forceinline__ u32 shfl_xor_u32(u32 v, int m) { return (u32)__shfl_xor((int)v, m, 64); }
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    u32 lo = shfl_u32((u32)v, src), hi = shfl_u32((u32)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    u32 lo = shfl_xor_u32((u32)v, m), hi = shfl_xor_u32((u32)(v >> 32), m);
+    return ((u64)hi << 32) | lo;
+}
+
+/* wave-wide reductions / scans (all 64 lanes must call) */
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u32(v, m);
+    return v;
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        u64 o = shfl_xor_u64(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        u32 o = shfl_xor_u32(v, m);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+/* inclusive prefix sum across lanes */
+__device__ __forceinline__ u32 wave_scan_incl_u32(u32 v) {
+    int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 o = shfl_up_u32(v, d);
+        if (l >= d) v += o;
+    }
+    return v;
+}
+
+/* bytes [n, n+4) of the 8-byte little-endian value hi:lo, n in 0..3 */
+__device__ __forceinline__ u32 alignbyte(u32 hi, u32 lo, u32 n) {
+#ifdef FPL_EMU
+    return (u32)(((((u64)hi) << 32) | lo) >> (8 * (n & 3)));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, n);
+#endif
+}
+
+/* 0x01 in every byte of x that is non-zero */
+__device__ __forceinline__ u32 nonzero_bytes01(u32 x) {
+    u32 y = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ((y | x) >> 7) & 0x01010101u;
+}
+
+/* 16-byte load from an arbitrarily aligned address (gfx950 global loads take any
+ * alignment; the compiler emits one global_load_dwordx4) */
+__device__ __forceinline__ u32x4 load16(const u8* p) {
+    u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+/* guarded variant: bytes at or beyond `end` read as 0 */
+__device__ __forceinline__ u32x4 load16_guard(const u8* p, const u8* end) {
+    if (p + 16 <= end) return load16(p);
+    u32 w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++)
+        if (p + i < end) w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
+    u32x4 v = {w[0], w[1], w[2], w[3]};
+    return v;
+}
+__device__ __forceinline__ u32 load4_guard(const u8* p, const u8* end) {
+    u32 w = 0;
+    if (p + 4 <= end) {
+        __builtin_memcpy(&w, p, 4);
+        return w;
+    }
+    for (int i = 0; i < 4; i++)
+        if (p + i < end) w |= (u32)p[i] << (8 * i);
+    return w;
+}
+
+}  // namespace fpl
+#endif

@@ -1,0 +1,100 @@
+/*
+ * dev_types.h -- plain-old-data shared by the kernels and the host side of the C-ABI, plus the
+ * host-only code that fills it (thresholds in double, Myers Peq bit-vectors per adapter).
+ */
+#ifndef FPL_DEV_TYPES_H
+#define FPL_DEV_TYPES_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/fastplong_amd.h"
+
+namespace fpl {
+
+constexpr int PEQ_WORDS = 4; /* 4 x 64 columns >= FPL_MAX_ADAPTER_LEN */
+
+/* One adapter slot in device memory. */
+struct DevAdapter {
+    int32_t len;  /* alen */
+    int32_t plen; /* min(PATTERN_LEN, alen), reference src/adaptertrimmer.cpp:181,251 */
+    uint8_t seq[256];
+    uint32_t seqw[256];          /* seq[i] replicated into the 4 bytes of a dword (SWAR compare) */
+    uint32_t peq16_start[256];   /* Myers Peq of the LAST plen bytes  (start trim, :203)  */
+    uint32_t peq16_end[256];     /* Myers Peq of the FIRST plen bytes (end trim,   :274)  */
+    uint64_t peq_full[256][PEQ_WORDS]; /* Myers Peq of the whole adapter, bit j <-> seq[j]  */
+};
+
+/* Options as the kernels consume them: integers only. */
+struct DevConfig {
+    int32_t trim_front, trim_tail;
+    int32_t cut_front, cut_tail;
+    int32_t cut_front_w, cut_front_thr; /* thr = (33 + quality) * window: total >= thr  <=>  mean >= 33+q */
+    int32_t cut_tail_w, cut_tail_thr;
+    int32_t polyx, polyx_min_len;
+    int32_t adapter_enabled, ext;
+    int32_t has_start, has_end, n_fasta;
+    int32_t qual_filter, qualified_qual, unqual_pct, n_base_limit, n_pct_limit, avg_qual_req;
+    int32_t length_filter, required_length, max_length;
+    int32_t complexity, complexity_pct;
+    int32_t thr[FPL_MAX_ADAPTER_LEN + 1]; /* (int)round(ed_max * len), computed in double on the host */
+};
+
+/* r1 after the end trims, in coordinates of the original read */
+struct ReadState {
+    uint32_t s, e;
+    uint32_t dropped;
+    uint32_t pad;
+};
+
+inline void build_adapter(DevAdapter* a, const char* seq, int len) {
+    memset(a, 0, sizeof(*a));
+    a->len = len;
+    a->plen = len < FPL_PATTERN_LEN ? len : FPL_PATTERN_LEN;
+    for (int i = 0; i < len; i++) {
+        uint8_t c = (uint8_t)seq[i];
+        a->seq[i] = c;
+        a->seqw[i] = 0x01010101u * c;
+        a->peq_full[c][i >> 6] |= 1ull << (i & 63);
+    }
+    for (int j = 0; j < a->plen; j++) {
+        a->peq16_start[(uint8_t)seq[len - a->plen + j]] |= 1u << j;
+        a->peq16_end[(uint8_t)seq[j]] |= 1u << j;
+    }
+}
+
+inline void build_config(DevConfig* c, const fpl_options* o, int start_len, int end_len, int n_fasta) {
+    memset(c, 0, sizeof(*c));
+    c->trim_front = o->trim_front;
+    c->trim_tail = o->trim_tail;
+    c->cut_front = o->cut_front != 0;
+    c->cut_tail = o->cut_tail != 0;
+    c->cut_front_w = o->cut_front_window;
+    c->cut_front_thr = (33 + o->cut_front_quality) * o->cut_front_window;
+    c->cut_tail_w = o->cut_tail_window;
+    c->cut_tail_thr = (33 + o->cut_tail_quality) * o->cut_tail_window;
+    c->polyx = o->polyx != 0;
+    c->polyx_min_len = o->polyx_min_len;
+    c->adapter_enabled = o->adapter_enabled != 0;
+    c->ext = o->trimming_extension;
+    c->has_start = start_len > 0;
+    c->has_end = end_len > 0;
+    c->n_fasta = n_fasta;
+    c->qual_filter = o->qual_filter != 0;
+    c->qualified_qual = o->qualified_qual;
+    c->unqual_pct = o->unqualified_percent_limit;
+    c->n_base_limit = o->n_base_limit;
+    c->n_pct_limit = o->n_base_percent_limit;
+    c->avg_qual_req = o->avg_qual_req;
+    c->length_filter = o->length_filter != 0;
+    c->required_length = o->required_length;
+    c->max_length = o->max_length;
+    c->complexity = o->complexity_filter != 0;
+    int y = o->complexity_percent; /* src/main.cpp:219 clamps -Y to 0..100 */
+    c->complexity_pct = y < 0 ? 0 : (y > 100 ? 100 : y);
+    for (int l = 0; l <= FPL_MAX_ADAPTER_LEN; l++) c->thr[l] = (int)round(o->ed_max * l);
+}
+
+}  // namespace fpl
+#endif

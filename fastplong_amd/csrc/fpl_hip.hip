@@ -1,0 +1,365 @@
+/*
+ * fpl_hip.hip -- the C-ABI of include/fastplong_amd.h on top of the gfx950 kernels.
+ * Built by hipcc only (--offload-arch=gfx950); there is no CPU path in this library.
+ */
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "pipeline.h"
+
+using namespace fpl;
+
+struct fpl_ctx {
+    int device = -1;
+    u32 n_cu = 256;
+    int n_adapters = 2;
+    u32 C = 0;
+    DevConfig* d_cfg = nullptr;
+    DevAdapter* d_ads = nullptr;
+    long long* d_counters = nullptr;
+    /* per-batch workspace, grown on demand */
+    u32 ws_reads = 0;
+    ReadState* d_state = nullptr;
+    uint64_t* d_frag_off = nullptr;
+    u32* d_frag_len = nullptr;
+    u32* d_work_ctr = nullptr;
+    /* staging for the host-pointer entry point */
+    uint64_t st_bytes = 0;
+    u32 st_reads = 0;
+    u8* d_seq = nullptr;
+    u8* d_qual = nullptr;
+    uint64_t* d_off = nullptr;
+    fpl_read_result* d_results = nullptr;
+    hipStream_t stream = nullptr; /* owned; used by fpl_process_batch() */
+    /* timing */
+    int timing = 0;
+    static constexpr int EV_RING = 128;
+    hipEvent_t ev[EV_RING][N_STAGES + 1] = {};
+    int ev_calls = 0; /* batches recorded since fpl_enable_timing() */
+    std::string err;
+};
+
+#define FPL_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            return FPL_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+extern "C" {
+
+int fpl_abi_version(void) { return FPL_ABI_VERSION; }
+
+const char* fpl_strerror(int code) {
+    switch (code) {
+        case FPL_OK: return "ok";
+        case FPL_ERR_ARG: return "invalid argument";
+        case FPL_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+        case FPL_ERR_HIP: return "HIP runtime error";
+        case FPL_ERR_ADAPTER: return "adapter too long or too many adapters";
+        case FPL_ERR_CAPACITY: return "read longer than the per-cycle capacity";
+        case FPL_ERR_STATE: return "invalid state";
+        default: return "unknown error";
+    }
+}
+
+const char* fpl_last_error(const fpl_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+void fpl_options_default(fpl_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->cut_front_window = o->cut_tail_window = 4;
+    o->cut_front_quality = o->cut_tail_quality = 20;
+    o->polyx_min_len = 10;
+    o->adapter_enabled = 1;
+    o->ed_max = 0.25;
+    o->trimming_extension = 10;
+    o->qual_filter = 1;
+    o->qualified_qual = '0';
+    o->unqualified_percent_limit = 40;
+    o->n_base_limit = 1000000;
+    o->n_base_percent_limit = 10;
+    o->length_filter = 1;
+    o->required_length = 20;
+    o->complexity_percent = 30;
+}
+
+static int alloc_counters(fpl_ctx* ctx, u32 C, long long** out) {
+    size_t n = FPL_COUNTERS_LEN(C, ctx->n_adapters);
+    FPL_HIP(hipMalloc((void**)out, n * sizeof(long long)));
+    FPL_HIP(hipMemset(*out, 0, n * sizeof(long long)));
+    return FPL_OK;
+}
+
+int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter, int32_t start_len,
+               const char* end_adapter, int32_t end_len, const fpl_adapter* fasta, int32_t n_fasta,
+               int32_t device, uint32_t max_cycles) {
+    if (!out || !opt || start_len < 0 || end_len < 0 || n_fasta < 0 || (start_len && !start_adapter) ||
+        (end_len && !end_adapter) || (n_fasta && !fasta))
+        return FPL_ERR_ARG;
+    *out = nullptr;
+    if (start_len > FPL_MAX_ADAPTER_LEN || end_len > FPL_MAX_ADAPTER_LEN || 2 + n_fasta > FPL_MAX_ADAPTERS)
+        return FPL_ERR_ADAPTER;
+    for (int i = 0; i < n_fasta; i++)
+        if (fasta[i].len < 0 || fasta[i].len > FPL_MAX_ADAPTER_LEN || (fasta[i].len && !fasta[i].seq)) return FPL_ERR_ADAPTER;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FPL_ERR_NO_DEVICE;
+    fpl_ctx* ctx = new (std::nothrow) fpl_ctx();
+    if (!ctx) return FPL_ERR_ARG;
+    ctx->device = device;
+    ctx->n_adapters = 2 + n_fasta;
+    int rc = [&]() -> int {
+        FPL_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        FPL_HIP(hipGetDeviceProperties(&prop, device));
+        ctx->n_cu = prop.multiProcessorCount > 0 ? (u32)prop.multiProcessorCount : 256;
+        FPL_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        DevConfig cfg;
+        build_config(&cfg, opt, start_len, end_len, n_fasta);
+        std::vector<DevAdapter> ads(ctx->n_adapters);
+        build_adapter(&ads[0], start_adapter, start_len);
+        build_adapter(&ads[1], end_adapter, end_len);
+        for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
+        FPL_HIP(hipMalloc((void**)&ctx->d_cfg, sizeof(DevConfig)));
+        FPL_HIP(hipMemcpy(ctx->d_cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
+        FPL_HIP(hipMalloc((void**)&ctx->d_ads, sizeof(DevAdapter) * ads.size()));
+        FPL_HIP(hipMemcpy(ctx->d_ads, ads.data(), sizeof(DevAdapter) * ads.size(), hipMemcpyHostToDevice));
+        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, sizeof(u32)));
+        ctx->C = max_cycles ? max_cycles : 1;
+        int r = alloc_counters(ctx, ctx->C, &ctx->d_counters);
+        if (r != FPL_OK) return r;
+        for (int r = 0; r < fpl_ctx::EV_RING; r++)
+            for (int i = 0; i <= N_STAGES; i++) FPL_HIP(hipEventCreate(&ctx->ev[r][i]));
+        return FPL_OK;
+    }();
+    if (rc != FPL_OK) {
+        fprintf(stderr, "fpl_create: %s (%s)\n", fpl_strerror(rc), ctx->err.c_str());
+        fpl_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return FPL_OK;
+}
+
+void fpl_destroy(fpl_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    void* ptrs[] = {ctx->d_cfg, ctx->d_ads, ctx->d_counters, ctx->d_state, ctx->d_frag_off, ctx->d_frag_len,
+                    ctx->d_work_ctr, ctx->d_seq, ctx->d_qual, ctx->d_off, ctx->d_results};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int r = 0; r < fpl_ctx::EV_RING; r++)
+        for (int i = 0; i <= N_STAGES; i++)
+            if (ctx->ev[r][i]) (void)hipEventDestroy(ctx->ev[r][i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+uint32_t fpl_max_cycles(const fpl_ctx* ctx) { return ctx ? ctx->C : 0; }
+int32_t fpl_n_adapters(const fpl_ctx* ctx) { return ctx ? ctx->n_adapters : 0; }
+size_t fpl_counters_len(const fpl_ctx* ctx) { return ctx ? FPL_COUNTERS_LEN(ctx->C, ctx->n_adapters) : 0; }
+void* fpl_counters_device_ptr(fpl_ctx* ctx) { return ctx ? ctx->d_counters : nullptr; }
+
+int fpl_synchronize(fpl_ctx* ctx) {
+    if (!ctx) return FPL_ERR_ARG;
+    FPL_HIP(hipSetDevice(ctx->device));
+    FPL_HIP(hipDeviceSynchronize());
+    return FPL_OK;
+}
+
+/* cycle-major layout: growing C moves the two Stats tails and appends zero cycles */
+int fpl_reserve_cycles(fpl_ctx* ctx, uint32_t max_cycles) {
+    if (!ctx) return FPL_ERR_ARG;
+    if (max_cycles <= ctx->C) return FPL_OK;
+    FPL_HIP(hipSetDevice(ctx->device));
+    FPL_HIP(hipDeviceSynchronize());
+    long long* nw = nullptr;
+    const u32 Co = ctx->C, Cn = max_cycles;
+    int r = alloc_counters(ctx, Cn, &nw);
+    if (r != FPL_OK) return r;
+    for (int k = 0; k < 2; k++) {
+        const long long* so = ctx->d_counters + (size_t)k * FPL_STATS_LEN(Co);
+        long long* sn = nw + (size_t)k * FPL_STATS_LEN(Cn);
+        FPL_HIP(hipMemcpy(sn, so, (size_t)Co * FPL_CYC_STRIDE * sizeof(long long), hipMemcpyDeviceToDevice));
+        FPL_HIP(hipMemcpy(sn + (size_t)Cn * FPL_CYC_STRIDE, so + (size_t)Co * FPL_CYC_STRIDE,
+                          FPL_STATS_TAIL * sizeof(long long), hipMemcpyDeviceToDevice));
+    }
+    FPL_HIP(hipMemcpy(nw + FPL_OFF_FR(Cn), ctx->d_counters + FPL_OFF_FR(Co),
+                      (FPL_FR_LEN + FPL_KEYHIST_LEN(ctx->n_adapters)) * sizeof(long long), hipMemcpyDeviceToDevice));
+    FPL_HIP(hipFree(ctx->d_counters));
+    ctx->d_counters = nw;
+    ctx->C = Cn;
+    return FPL_OK;
+}
+
+int fpl_get_counters(fpl_ctx* ctx, int64_t* host_buf, size_t n) {
+    if (!ctx || !host_buf || n != fpl_counters_len(ctx)) return FPL_ERR_ARG;
+    FPL_HIP(hipSetDevice(ctx->device));
+    FPL_HIP(hipDeviceSynchronize());
+    FPL_HIP(hipMemcpy(host_buf, ctx->d_counters, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return FPL_OK;
+}
+
+int fpl_reset_counters(fpl_ctx* ctx) {
+    if (!ctx) return FPL_ERR_ARG;
+    FPL_HIP(hipSetDevice(ctx->device));
+    FPL_HIP(hipDeviceSynchronize());
+    FPL_HIP(hipMemset(ctx->d_counters, 0, fpl_counters_len(ctx) * sizeof(long long)));
+    return FPL_OK;
+}
+
+static int ensure_workspace(fpl_ctx* ctx, u32 n_reads) {
+    if (n_reads <= ctx->ws_reads) return FPL_OK;
+    FPL_HIP(hipDeviceSynchronize());
+    if (ctx->d_state) (void)hipFree(ctx->d_state);
+    if (ctx->d_frag_off) (void)hipFree(ctx->d_frag_off);
+    if (ctx->d_frag_len) (void)hipFree(ctx->d_frag_len);
+    ctx->d_state = nullptr;
+    ctx->d_frag_off = nullptr;
+    ctx->d_frag_len = nullptr;
+    ctx->ws_reads = 0;
+    FPL_HIP(hipMalloc((void**)&ctx->d_state, sizeof(ReadState) * (size_t)n_reads));
+    FPL_HIP(hipMalloc((void**)&ctx->d_frag_off, sizeof(uint64_t) * 2 * (size_t)n_reads));
+    FPL_HIP(hipMalloc((void**)&ctx->d_frag_len, sizeof(u32) * 2 * (size_t)n_reads));
+    ctx->ws_reads = n_reads;
+    return FPL_OK;
+}
+
+int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual, const uint64_t* d_off,
+                             uint32_t n_reads, uint64_t n_bytes, uint32_t max_read_len, fpl_read_result* d_results,
+                             void* stream_v) {
+    if (!ctx) return FPL_ERR_ARG;
+    if (n_reads && (!d_seq || !d_qual || !d_off || !d_results)) return FPL_ERR_ARG;
+    if (n_reads > 0x7FFFFFFFu / 2) return FPL_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_v;
+    FPL_HIP(hipSetDevice(ctx->device));
+    if (max_read_len > ctx->C) {
+        int r = fpl_reserve_cycles(ctx, max_read_len);
+        if (r != FPL_OK) return r;
+    }
+    if (n_reads) {
+        int r = ensure_workspace(ctx, n_reads);
+        if (r != FPL_OK) return r;
+        FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, sizeof(u32), stream));
+    }
+    BatchArgs a;
+    a.seq = d_seq;
+    a.qual = d_qual;
+    a.off = d_off;
+    a.n_reads = n_reads;
+    a.n_bytes = n_bytes;
+    a.max_read_len = max_read_len;
+    a.cfg = ctx->d_cfg;
+    a.ads = ctx->d_ads;
+    a.state = ctx->d_state;
+    a.results = d_results;
+    a.frag_off = ctx->d_frag_off;
+    a.frag_len = ctx->d_frag_len;
+    a.counters = ctx->d_counters;
+    a.C = ctx->C;
+    a.work_ctr = ctx->d_work_ctr;
+    a.n_cu = ctx->n_cu;
+    const bool timing = ctx->timing != 0;
+    const int slot = ctx->ev_calls % fpl_ctx::EV_RING;
+    hipError_t ev_err = hipSuccess;
+    enqueue_batch(a, stream, [&](int i) {
+        if (timing) {
+            hipError_t e = hipEventRecord(ctx->ev[slot][i], stream);
+            if (e != hipSuccess) ev_err = e;
+        }
+    });
+    FPL_HIP(hipGetLastError());
+    FPL_HIP(ev_err);
+    if (timing) ctx->ev_calls++;
+    return FPL_OK;
+}
+
+int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n_reads,
+                      fpl_read_result* results) {
+    if (!ctx) return FPL_ERR_ARG;
+    if (n_reads == 0) return FPL_OK;
+    if (!seq || !qual || !off || !results) return FPL_ERR_ARG;
+    FPL_HIP(hipSetDevice(ctx->device));
+    const uint64_t n_bytes = off[n_reads];
+    u32 max_len = 0;
+    for (u32 i = 0; i < n_reads; i++) {
+        if (off[i + 1] < off[i] || off[i + 1] - off[i] > 0x7FFFFFFFull) return FPL_ERR_ARG;
+        const u32 l = (u32)(off[i + 1] - off[i]);
+        if (l > max_len) max_len = l;
+    }
+    if (n_bytes > ctx->st_bytes || !ctx->d_seq) {
+        FPL_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_seq) (void)hipFree(ctx->d_seq);
+        if (ctx->d_qual) (void)hipFree(ctx->d_qual);
+        ctx->d_seq = ctx->d_qual = nullptr;
+        ctx->st_bytes = 0;
+        const uint64_t cap = n_bytes + n_bytes / 4 + 64;
+        FPL_HIP(hipMalloc((void**)&ctx->d_seq, cap));
+        FPL_HIP(hipMalloc((void**)&ctx->d_qual, cap));
+        ctx->st_bytes = cap;
+    }
+    if (n_reads > ctx->st_reads) {
+        FPL_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_off) (void)hipFree(ctx->d_off);
+        if (ctx->d_results) (void)hipFree(ctx->d_results);
+        ctx->d_off = nullptr;
+        ctx->d_results = nullptr;
+        ctx->st_reads = 0;
+        const u32 cap = n_reads + n_reads / 4 + 16;
+        FPL_HIP(hipMalloc((void**)&ctx->d_off, sizeof(uint64_t) * ((size_t)cap + 1)));
+        FPL_HIP(hipMalloc((void**)&ctx->d_results, sizeof(fpl_read_result) * (size_t)cap));
+        ctx->st_reads = cap;
+    }
+    if (n_bytes) {
+        FPL_HIP(hipMemcpyAsync(ctx->d_seq, seq, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+        FPL_HIP(hipMemcpyAsync(ctx->d_qual, qual, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    FPL_HIP(hipMemcpyAsync(ctx->d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
+    int r = fpl_process_batch_device(ctx, ctx->d_seq, ctx->d_qual, ctx->d_off, n_reads, n_bytes, max_len, ctx->d_results,
+                                     ctx->stream);
+    if (r != FPL_OK) return r;
+    FPL_HIP(hipMemcpyAsync(results, ctx->d_results, sizeof(fpl_read_result) * (size_t)n_reads, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    FPL_HIP(hipStreamSynchronize(ctx->stream));
+    return FPL_OK;
+}
+
+int fpl_enable_timing(fpl_ctx* ctx, int enable) {
+    if (!ctx) return FPL_ERR_ARG;
+    ctx->timing = enable ? 1 : 0;
+    ctx->ev_calls = 0;
+    return FPL_OK;
+}
+
+int fpl_get_kernel_times(fpl_ctx* ctx, float* ms, const char** names, int* n, int* n_batches) {
+    if (!ctx || !ms || !n) return FPL_ERR_ARG;
+    if (ctx->ev_calls <= 0) return FPL_ERR_STATE;
+    FPL_HIP(hipSetDevice(ctx->device));
+    const int calls = ctx->ev_calls < fpl_ctx::EV_RING ? ctx->ev_calls : fpl_ctx::EV_RING;
+    for (int i = 0; i < N_STAGES; i++) ms[i] = 0.f;
+    for (int c = 0; c < calls; c++) {
+        const int slot = (ctx->ev_calls - 1 - c) % fpl_ctx::EV_RING;
+        FPL_HIP(hipEventSynchronize(ctx->ev[slot][N_STAGES]));
+        for (int i = 0; i < N_STAGES; i++) {
+            float t = 0.f;
+            FPL_HIP(hipEventElapsedTime(&t, ctx->ev[slot][i], ctx->ev[slot][i + 1]));
+            ms[i] += t;
+        }
+    }
+    for (int i = 0; i < N_STAGES; i++)
+        if (names) names[i] = STAGE_NAMES[i];
+    *n = N_STAGES;
+    if (n_batches) *n_batches = calls;
+    return FPL_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,1017 @@
+/*
+ * kernels.h -- the per-read hot path as CDNA4 (gfx950) kernels.  wave = 64 lanes.
+ *
+ *   k_trim_ends   : Filter::trimAndCut -> PolyX::trimPolyX -> trimBySequenceStart/End ->
+ *                   trimByMultiSequences.  One wave per read, lanes = candidate positions.
+ *   k_cycle_stats : the per-cycle / k-mer part of Stats::statRead.  Block = (cycle tile,
+ *                   slice of reads); counters privatised in LDS, one flush per block.
+ *   k_scan        : whole-read pass on r1: both middle-adapter Hamming scans
+ *                   (findMiddleAdapters), the passFilter sums, the per-read quality histogram
+ *                   (median, base-quality histogram); then resolves the read: Levenshtein
+ *                   confirm, breakByGap, passFilter code, result record, counters.
+ *
+ * Reference behaviour restated here is cited per function (file:line under the reference's
+ * src/).  All arithmetic is integer; `round(edMax*len)` arrives as the host-built table
+ * DevConfig::thr.
+ */
+#ifndef FPL_KERNELS_H
+#define FPL_KERNELS_H
+
+#include "dev_prims.h"
+#include "dev_types.h"
+
+namespace fpl {
+
+/* =========================================================================================
+ * Bit-parallel Levenshtein (Myers 1999 / Hyyro 2001, global-distance variant).  The
+ * reference's edit_distance (src/editdistance.cpp:30-61,100-126) computes the same exact
+ * distance; the pattern here is always a slice of an adapter, whose Peq vectors the host
+ * prebuilt (DevAdapter), and the text is a window of the read.
+ * ======================================================================================= */
+
+/* pattern <= 32 columns, one 32-bit word */
+__device__ __forceinline__ int lev_bp32(const u32* __restrict__ peq, int m, const u8* __restrict__ text, int n) {
+    if (m == 0) return n;
+    u32 Pv = ~0u, Mv = 0;
+    int score = m;
+    const u32 top = 1u << (m - 1);
+    for (int j = 0; j < n; j++) {
+        u32 Eq = peq[text[j]];
+        u32 Xv = Eq | Mv;
+        u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        u32 Ph = Mv | ~(Xh | Pv);
+        u32 Mh = Pv & Xh;
+        if (Ph & top) score++;
+        else if (Mh & top) score--;
+        Ph = (Ph << 1) | 1u; /* D[0][j] = j */
+        Mh <<= 1;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+    }
+    return score;
+}
+
+/* word w of (peq_full[c] >> shift) */
+__device__ __forceinline__ u64 peq_word(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int c, int shift, int w) {
+    int i = (shift >> 6) + w, r = shift & 63;
+    u64 lo = i < PEQ_WORDS ? peq[c][i] : 0;
+    if (r == 0) return lo;
+    u64 hi = (i + 1) < PEQ_WORDS ? peq[c][i + 1] : 0;
+    return (lo >> r) | (hi << (64 - r));
+}
+
+/* pattern = adapter[shift, shift+m), up to 4 x 64 columns (block-wise with horizontal carries) */
+__device__ __forceinline__ int lev_bp64(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
+                                        const u8* __restrict__ text, int n) {
+    if (m == 0) return n;
+    if (n == 0) return m;
+    const int W = (m + 63) >> 6;
+    u64 Pv[PEQ_WORDS], Mv[PEQ_WORDS];
+#pragma unroll
+    for (int b = 0; b < PEQ_WORDS; b++) {
+        Pv[b] = ~0ull;
+        Mv[b] = 0;
+    }
+    int score = m;
+    const u64 last_top = 1ull << ((m - 1) & 63);
+    for (int j = 0; j < n; j++) {
+        const int c = text[j];
+        int hin = 1; /* D[0][j] - D[0][j-1] */
+#pragma unroll
+        for (int b = 0; b < PEQ_WORDS; b++) {
+            if (b < W) {
+                u64 Eq = peq_word(peq, c, shift, b);
+                const u64 pv = Pv[b], mv = Mv[b];
+                const u64 Xv = Eq | mv;
+                if (hin < 0) Eq |= 1ull;
+                const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                u64 Ph = mv | ~(Xh | pv);
+                u64 Mh = pv & Xh;
+                const u64 hb = (b == W - 1) ? last_top : (1ull << 63);
+                int hout = 0;
+                if (Ph & hb) hout = 1;
+                else if (Mh & hb) hout = -1;
+                Ph <<= 1;
+                Mh <<= 1;
+                if (hin < 0) Mh |= 1ull;
+                else if (hin > 0) Ph |= 1ull;
+                Pv[b] = Mh | ~(Xv | Ph);
+                Mv[b] = Ph & Xv;
+                hin = hout;
+            }
+        }
+        score += hin;
+    }
+    return score;
+}
+
+/* run f() on lane 0 only and hand its int result to every lane */
+#define FPL_LANE0_INT(expr) shfl_i32((lane_id() == 0) ? (expr) : 0, 0)
+
+/* =========================================================================================
+ * k_trim_ends
+ * ======================================================================================= */
+
+/* Filter::trimAndCut, src/filter.cpp:130-232.  Returns false when the reference returns NULL.
+ * [s,e) is the surviving window in coordinates of the original read (length l). */
+__device__ inline bool trim_and_cut_wave(const u8* __restrict__ sq, const u8* __restrict__ ql, int l,
+                                         const DevConfig* __restrict__ cfg, int& s_out, int& e_out) {
+    const int lane = lane_id();
+    int front = cfg->trim_front, tail = cfg->trim_tail;
+    s_out = 0;
+    e_out = l;
+    if (front == 0 && tail == 0 && !cfg->cut_front && !cfg->cut_tail) return true; /* :133-134 */
+    int rlen = l - front - tail;
+    if (rlen < 0) return false; /* :137-139 */
+    if (!cfg->cut_front && !cfg->cut_tail) { /* :141-151 */
+        s_out = front;
+        e_out = front + rlen;
+        return true;
+    }
+    if (cfg->cut_front) { /* :159-189 */
+        const int w = cfg->cut_front_w, thr = cfg->cut_front_thr;
+        if (l - front - tail - w <= 0) return false;
+        const int lim = l - tail - w; /* loop runs while s < lim */
+        int s = lim;                  /* value of s when the loop ends without a break */
+        for (int s0 = front; s0 < lim; s0 += 64) {
+            const int sc = s0 + lane;
+            int tot = 0;
+            if (sc < lim)
+                for (int i = 0; i < w; i++) tot += ql[sc + i];
+            const u64 m = wave_ballot(sc < lim && tot >= thr);
+            if (m) {
+                s = s0 + __ffsll(m) - 1;
+                break;
+            }
+        }
+        if (s > 0) s = s + w - 1;
+        for (;;) { /* while (s < l && seq[s] == 'N') s++ */
+            const int p = s + lane;
+            const u64 stop = wave_ballot(!(p < l && sq[p] == 'N'));
+            if (stop) {
+                s += __ffsll(stop) - 1;
+                break;
+            }
+            s += 64;
+        }
+        front = s;
+        rlen = l - front - tail;
+    }
+    if (cfg->cut_tail) { /* :191-219 */
+        const int w = cfg->cut_tail_w, thr = cfg->cut_tail_thr;
+        if (l - front - tail - w <= 0) return false;
+        const int tstart = l - tail - 1, tlow = front + w; /* loop runs while t >= tlow */
+        int t = tlow - 1;                                  /* value of t when the loop ends without a break */
+        for (int t0 = tstart; t0 >= tlow; t0 -= 64) {
+            const int tc = t0 - lane;
+            int tot = 0;
+            if (tc >= tlow)
+                for (int i = 0; i < w; i++) tot += ql[tc - i];
+            const u64 m = wave_ballot(tc >= tlow && tot >= thr);
+            if (m) {
+                t = t0 - (__ffsll(m) - 1);
+                break;
+            }
+        }
+        if (t < l - 1) t = t - w + 1;
+        for (;;) { /* while (t >= 0 && seq[t] == 'N') t-- */
+            const int p = t - lane;
+            const u64 stop = wave_ballot(!(p >= 0 && sq[p] == 'N'));
+            if (stop) {
+                t -= __ffsll(stop) - 1;
+                break;
+            }
+            t -= 64;
+        }
+        rlen = t - front + 1;
+    }
+    if (rlen <= 0 || front >= l - 1) return false; /* :221-222 */
+    s_out = front;
+    e_out = front + rlen;
+    return true;
+}
+
+/* PolyX::trimPolyX, src/polyx.cpp:11-78, on the window r[0, rlen).  Returns the new length
+ * and, when a polyX was cut, poly (0..3 = A,T,C,G) and the number of bases trimmed. */
+__device__ inline int trim_polyx_wave(const u8* __restrict__ r, int rlen, int compareReq, int& poly_out, int& trimmed_out) {
+    const int lane = lane_id();
+    poly_out = -1;
+    trimmed_out = 0;
+    int carry[4] = {0, 0, 0, 0};
+    int P = rlen; /* value of pos when the scan ends without a break */
+    int cnt[4] = {0, 0, 0, 0};
+    bool broke = false;
+    for (int p0 = 0; p0 < rlen; p0 += 64) {
+        const int pos = p0 + lane;
+        const bool valid = pos < rlen;
+        u32 oh = 0; /* one-hot, one byte per base: A | T<<8 | C<<16 | G<<24 */
+        if (valid) {
+            const u8 c = r[rlen - pos - 1];
+            if (c == 'A') oh = 0x00000001u;
+            else if (c == 'T') oh = 0x00000100u;
+            else if (c == 'C') oh = 0x00010000u;
+            else if (c == 'G') oh = 0x01000000u;
+            else if (c == 'N') oh = 0x01010101u;
+        }
+        const u32 sc = wave_scan_incl_u32(oh); /* per-byte counts <= 64 */
+        const int nA = carry[0] + (int)(sc & 0xFF), nT = carry[1] + (int)((sc >> 8) & 0xFF);
+        const int nC = carry[2] + (int)((sc >> 16) & 0xFF), nG = carry[3] + (int)(sc >> 24);
+        const int cmp = pos + 1;
+        const int allowed = min(5, cmp / 8);
+        const bool need = (cmp - nA > allowed) && (cmp - nT > allowed) && (cmp - nC > allowed) && (cmp - nG > allowed);
+        const bool brk = valid && need && (pos >= 8 || pos + 1 >= compareReq - 1);
+        const u64 m = wave_ballot(brk);
+        const int src = m ? (__ffsll(m) - 1) : 63;
+        /* counts at the break lane, or the running totals when the round ends without one */
+        cnt[0] = shfl_i32(nA, src);
+        cnt[1] = shfl_i32(nT, src);
+        cnt[2] = shfl_i32(nC, src);
+        cnt[3] = shfl_i32(nG, src);
+        if (m) {
+            P = p0 + src;
+            broke = true;
+            break;
+        }
+        carry[0] = cnt[0];
+        carry[1] = cnt[1];
+        carry[2] = cnt[2];
+        carry[3] = cnt[3];
+    }
+    (void)broke;
+    if (P + 1 < compareReq) return rlen; /* :57 */
+    int poly = 0, maxc = -1;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+        if (cnt[b] > maxc) {
+            maxc = cnt[b];
+            poly = b;
+        }
+    const u8 polyBase = poly == 0 ? 'A' : (poly == 1 ? 'T' : (poly == 2 ? 'C' : 'G'));
+    /* :71  walk pos down from P until r[rlen-pos-1] == polyBase  <=>  first index >= max(0,rlen-P-1)
+       holding polyBase; index -1 (P == rlen) never matches; pos = -1 when nothing matches */
+    int idx0 = rlen - P - 1;
+    if (idx0 < 0) idx0 = 0;
+    int found = -1;
+    for (int i0 = idx0; i0 < rlen; i0 += 64) {
+        const int i = i0 + lane;
+        const u64 m = wave_ballot(i < rlen && r[i] == polyBase);
+        if (m) {
+            found = i0 + __ffsll(m) - 1;
+            break;
+        }
+    }
+    const int pos = found >= 0 ? rlen - found - 1 : -1;
+    poly_out = poly;
+    trimmed_out = pos + 1;
+    return rlen - pos - 1; /* Read::resize: a no-op when pos == -1 */
+}
+
+__device__ __forceinline__ int hamming_bytes(const u8* __restrict__ r, const u8* __restrict__ a, int alen) {
+    int mm = 0;
+    for (int i = 0; i < alen; i++) mm += (r[i] != a[i]);
+    return mm;
+}
+
+/* AdapterTrimmer::trimBySequenceStart, src/adaptertrimmer.cpp:168-236 (searchAdapter in its
+ * asRightAsPossible mode, :109-131, inlined).  rd = first base of the original read; [s,e) is
+ * updated; returns the reference's return value; keylen = cmplen handed to addAdapterTrimmed. */
+__device__ inline int trim_start_wave(const u8* __restrict__ rd, int& s, int& e, const DevAdapter* __restrict__ ad,
+                                      const DevConfig* __restrict__ cfg, int& keylen) {
+    const int lane = lane_id();
+    const int rlen = e - s;
+    keylen = 0;
+    if (rlen < FPL_PATTERN_LEN) return 0;
+    const u8* r = rd + s;
+    const int alen = ad->len, plen = ad->plen, ext = cfg->ext;
+    const int thrA = cfg->thr[alen];
+    int mpos = -1;
+    const int searchEnd = min(rlen, FPL_END_WINDOW);
+    if (alen <= rlen && searchEnd > alen) {
+        const int npos = searchEnd - alen + 1; /* p = searchEnd-alen .. 0 */
+        int hit = -1;
+        u64 best = ~0ull;
+        for (int p0 = 0; p0 < npos; p0 += 64) {
+            const int p = p0 + lane;
+            int mm = 0x7fffffff;
+            if (p < npos) mm = hamming_bytes(r + p, ad->seq, alen);
+            const u64 m = wave_ballot(p < npos && mm <= thrA);
+            if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
+            if (p < npos) {
+                const u64 k = ((u64)(u32)mm << 32) | (u32)p; /* ties: leftmost (descending scan, <=) */
+                best = k < best ? k : best;
+            }
+        }
+        if (hit >= 0) mpos = hit; /* returned at once, no edit-distance check (:121-124) */
+        else {
+            best = wave_min_u64(best);
+            if (best != ~0ull) {
+                const int pos = (int)(u32)best;
+                const int ed = FPL_LANE0_INT(lev_bp64(ad->peq_full, 0, alen, r + pos, alen));
+                if (ed <= thrA) mpos = pos;
+            }
+        }
+    }
+    if (mpos >= 0) { /* :185-193 */
+        mpos = min(mpos + ext, rlen - alen);
+        keylen = alen;
+        s += min(rlen - 1, mpos + alen); /* Read::trimFront */
+        return mpos + alen;
+    }
+    /* partial match of the last plen adapter bases, :202-216: first minimum among ed <= thr */
+    const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
+    const int thrP = cfg->thr[plen];
+    u64 best = ~0ull;
+    for (int p0 = 0; p0 < lim; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < lim) {
+            const int ed = lev_bp32(ad->peq16_start, plen, r + p, plen);
+            if (ed <= thrP) {
+                const u64 k = ((u64)(u32)ed << 32) | (u32)p;
+                best = k < best ? k : best;
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (best != ~0ull) { /* :218-233 */
+        int pos = (int)(u32)best;
+        const int cmplen = min(pos + plen, alen);
+        const int ed = FPL_LANE0_INT(lev_bp64(ad->peq_full, alen - cmplen, cmplen, r + pos + plen - cmplen, cmplen));
+        if (ed <= cfg->thr[cmplen]) {
+            pos = min(pos + ext, rlen - alen);
+            keylen = cmplen;
+            const int n = min(rlen - 1, pos + plen); /* Read::trimFront; negative erases everything */
+            if (n < 0) s = e;
+            else s += n;
+            return pos + plen;
+        }
+    }
+    return 0;
+}
+
+/* AdapterTrimmer::trimBySequenceEnd, src/adaptertrimmer.cpp:238-302 (searchAdapter in its
+ * asLeftAsPossible mode, :84-107, inlined). */
+__device__ inline int trim_end_wave(const u8* __restrict__ rd, int& s, int& e, const DevAdapter* __restrict__ ad,
+                                    const DevConfig* __restrict__ cfg, int& keylen) {
+    const int lane = lane_id();
+    const int rlen = e - s;
+    keylen = 0;
+    if (rlen < FPL_PATTERN_LEN) return 0;
+    const u8* r = rd + s;
+    const int alen = ad->len, plen = ad->plen, ext = cfg->ext;
+    const int thrA = cfg->thr[alen];
+    const int ss = max(0, rlen - FPL_END_WINDOW);
+    int mpos = -1;
+    if (ss + alen <= rlen) {
+        const int pend = rlen - alen; /* p in [ss, pend) : the last position is never tested */
+        int hit = -1;
+        u64 best = ~0ull;
+        for (int p0 = ss; p0 < pend; p0 += 64) {
+            const int p = p0 + lane;
+            int mm = 0x7fffffff;
+            if (p < pend) mm = hamming_bytes(r + p, ad->seq, alen);
+            const u64 m = wave_ballot(p < pend && mm <= thrA);
+            if (m) {
+                hit = p0 + __ffsll(m) - 1; /* leftmost hit, returned at once (:98-101) */
+                break;
+            }
+            if (p < pend) {
+                const u64 k = ((u64)(u32)mm << 32) | (u32)(0xFFFFFFFFu - (u32)p); /* ties: rightmost (<=) */
+                best = k < best ? k : best;
+            }
+        }
+        if (hit >= 0) mpos = hit;
+        else {
+            best = wave_min_u64(best);
+            if (best != ~0ull) {
+                const int pos = (int)(0xFFFFFFFFu - (u32)best);
+                const int ed = FPL_LANE0_INT(lev_bp64(ad->peq_full, 0, alen, r + pos, alen));
+                if (ed <= thrA) mpos = pos;
+            }
+        }
+    }
+    if (mpos >= 0) { /* :256-264 */
+        mpos = max(0, mpos - ext);
+        keylen = alen;
+        e = s + mpos; /* Read::resize */
+        return rlen - mpos;
+    }
+    /* partial match of the first plen adapter bases walking in from the tail, :273-286:
+       qualifying positions in ascending p; stop at the first increase; ties take the later */
+    const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
+    const int thrP = cfg->thr[plen];
+    int pos = -1, mined = -1;
+    bool stop = false;
+    for (int p0 = 0; p0 < lim && !stop; p0 += 64) {
+        const int p = p0 + lane;
+        int ed = 0x7fffffff;
+        if (p < lim) ed = lev_bp32(ad->peq16_end, plen, r + rlen - plen - p, plen);
+        u64 q = wave_ballot(p < lim && ed <= thrP);
+        while (q && !stop) {
+            const int b = __ffsll(q) - 1;
+            q &= q - 1;
+            const int edb = shfl_i32(ed, b);
+            if (pos < 0) {
+                pos = p0 + b;
+                mined = edb;
+            } else if (edb > mined) {
+                stop = true;
+            } else {
+                pos = p0 + b;
+                mined = edb;
+            }
+        }
+    }
+    if (pos > 0) { /* :288 strict */
+        const int cmplen = min(pos + plen, alen);
+        const int ed = FPL_LANE0_INT(lev_bp64(ad->peq_full, 0, cmplen, r + rlen - plen - pos, cmplen));
+        if (ed <= cfg->thr[cmplen]) {
+            pos = min(pos + ext, rlen - plen);
+            keylen = cmplen;
+            e = s + (rlen - plen - pos); /* Read::resize */
+            return pos + plen;
+        }
+    }
+    return 0;
+}
+
+/* LDS accumulator of one k_trim_ends block: FilterResult scalars + the key histogram of the
+ * two command-line adapters (the FASTA slots go straight to global atomics). */
+struct TrimBlockAcc {
+    u64 fr[FPL_FR_LEN];
+    u32 key[2 * 2 * FPL_KEY_STRIDE];
+};
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
+            const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads, ReadState* __restrict__ state,
+            long long* __restrict__ counters, u32 C) {
+    __shared__ TrimBlockAcc acc;
+    const int lane = lane_id();
+    for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x) acc.fr[i] = 0;
+    for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x) acc.key[i] = 0;
+    __syncthreads();
+
+    const u32 wave_global = blockIdx.x * WAVES + wave_in_block();
+    const u32 n_waves = gridDim.x * WAVES;
+    long long* keyh = counters + FPL_OFF_KEYHIST(C);
+    for (u32 ri = wave_global; ri < n_reads; ri += n_waves) {
+        const uint64_t o0 = off[ri];
+        const int l = (int)(off[ri + 1] - o0);
+        const u8* sq = seq + o0;
+        const u8* ql = qual + o0;
+        int s, e;
+        bool alive = trim_and_cut_wave(sq, ql, l, cfg, s, e);
+        if (alive && cfg->polyx) { /* src/seprocessor.cpp:198-201 */
+            int poly, tl;
+            const int nl = trim_polyx_wave(sq + s, e - s, cfg->polyx_min_len, poly, tl);
+            e = s + nl;
+            if (poly >= 0 && lane == 0) {
+                atomicAdd(&acc.fr[FPL_FR_POLYX_READS + poly], (u64)1);
+                atomicAdd(&acc.fr[FPL_FR_POLYX_BASES + poly], (u64)tl);
+            }
+        }
+        if (alive && cfg->adapter_enabled) { /* src/seprocessor.cpp:205-216 */
+            int trimmed = 0, kl;
+            if (cfg->has_start) {
+                trimmed += trim_start_wave(sq, s, e, &ads[0], cfg, kl);
+                if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
+            }
+            if (cfg->has_end) {
+                trimmed += trim_end_wave(sq, s, e, &ads[1], cfg, kl);
+                if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
+            }
+            for (int a = 0; a < cfg->n_fasta; a++) { /* trimByMultiSequences, src/adaptertrimmer.cpp:42-57 */
+                trimmed += trim_start_wave(sq, s, e, &ads[2 + a], cfg, kl);
+                if (kl > 0 && lane == 0)
+                    atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
+                trimmed += trim_end_wave(sq, s, e, &ads[2 + a], cfg, kl);
+                if (kl > 0 && lane == 0)
+                    atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
+            }
+            if (trimmed > 0 && lane == 0) { /* FilterResult::addReadTrimmed */
+                atomicAdd(&acc.fr[FPL_FR_ADAPTER_READS], (u64)1);
+                atomicAdd(&acc.fr[FPL_FR_ADAPTER_BASES], (u64)trimmed);
+            }
+        }
+        if (lane == 0) {
+            ReadState st;
+            st.s = alive ? (u32)s : 0;
+            st.e = alive ? (u32)e : 0;
+            st.dropped = alive ? 0 : 1;
+            st.pad = 0;
+            state[ri] = st;
+        }
+    }
+    __syncthreads();
+    long long* fr = counters + FPL_OFF_FR(C);
+    for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x)
+        if (acc.fr[i]) atomicAdd((u64*)&fr[i], acc.fr[i]);
+    for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x)
+        if (acc.key[i]) atomicAdd((u64*)&keyh[i], (u64)acc.key[i]);
+}
+
+/* =========================================================================================
+ * k_cycle_stats: the per-cycle tables and the 5-mer counts of Stats::statRead
+ * (src/stats.cpp:265-347) for a list of items (original reads, or passing fragments with the
+ * cycle re-based to the fragment start, src/seprocessor.cpp:277).
+ *
+ * Block (x = slice of items, y = tile of T cycles).  A wave takes one item at a time and reads
+ * its T-byte tile with one 16-byte load per lane.  Per (cycle, base class) one packed 64-bit
+ * LDS counter: bits 0..21 sum of raw quality bytes, 22..35 count, 36..49 count(q>='5'),
+ * 50..63 count(q>='?'); a slice holds <= 16383 items so no field overflows.  The LDS slot of
+ * cycle c is (c%16)*64 + c/16 within the tile, so the 64 lanes of one ds_add_u64 touch 64
+ * consecutive slots (no bank conflicts).
+ * ======================================================================================= */
+constexpr int CS_T = 1024;
+constexpr u32 CS_MAX_ITEMS_PER_SLICE = 16383;
+
+__device__ __forceinline__ int base2val_dev(u32 b, bool& valid) {
+    /* Stats::base2val, src/stats.cpp:411-425: A0 T/U1 C2 G3 else invalid */
+    const u32 d = b - 0x41u;
+    valid = d < 32u && ((0x00180045u >> d) & 1u);
+    const u32 c = (b >> 1) & 3u; /* A0 C1 T/U2 G3 */
+    return (int)(((c & 1u) << 1) | (c >> 1));
+}
+
+template <int WAVES, bool PRE>
+__global__ void __launch_bounds__(WAVES * 64)
+k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_bytes,
+              const uint64_t* __restrict__ item_off, const u32* __restrict__ item_len, u32 n_items,
+              u32 items_per_slice, long long* __restrict__ stats, u32 C) {
+    __shared__ u64 cyc[8 * CS_T];
+    __shared__ u32 kmer[1024];
+    const int lane = lane_id();
+    for (u32 i = threadIdx.x; i < 8 * CS_T; i += blockDim.x) cyc[i] = 0;
+    for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) kmer[i] = 0;
+    __syncthreads();
+
+    const u32 tile_start = blockIdx.y * CS_T;
+    const u32 i_begin = blockIdx.x * items_per_slice;
+    const u32 i_end = min(n_items, i_begin + items_per_slice);
+    const u8* seq_end = seq + n_bytes;
+    const u8* qual_end = qual + n_bytes;
+
+    for (u32 ib = i_begin + 64 * wave_in_block(); ib < i_end; ib += 64 * WAVES) {
+        const u32 it = ib + lane;
+        u32 L = 0;
+        if (it < i_end) L = PRE ? (u32)(item_off[it + 1] - item_off[it]) : item_len[it];
+        u64 m = wave_ballot(L > tile_start);
+        while (m) {
+            const int b = __ffsll(m) - 1;
+            m &= m - 1;
+            const u32 itemL = shfl_u32(L, b);
+            const uint64_t start = item_off[ib + b];
+            const u32 c0 = tile_start + 16 * lane; /* cycle of this lane's first byte */
+            const int nvalid = itemL > c0 ? (int)min(16u, itemL - c0) : 0;
+            u32x4 sv = {0, 0, 0, 0}, qv = {0, 0, 0, 0};
+            if (nvalid > 0) {
+                sv = load16_guard(seq + start + c0, seq_end);
+                qv = load16_guard(qual + start + c0, qual_end);
+            }
+            /* the four bases in front of this lane's chunk: previous lane's last dword */
+            u32 halo = shfl_up_u32(sv.w, 1);
+            bool have_halo = true;
+            if (lane == 0) {
+                have_halo = tile_start >= 4;
+                halo = have_halo ? load4_guard(seq + start + tile_start - 4, seq_end) : 0;
+            }
+            if (nvalid > 0) {
+                int run = 0;
+                u32 kidx = 0;
+                if (have_halo) {
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        bool v;
+                        const int val = base2val_dev((halo >> (8 * h)) & 0xFF, v);
+                        run = v ? run + 1 : 0;
+                        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
+                    }
+                }
+                const u32 sw[4] = {sv.x, sv.y, sv.z, sv.w};
+                const u32 qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < nvalid) {
+                        const u32 bb = (sw[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                        const u32 q = (qw[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                        const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);
+                        atomicAdd(&cyc[(bb & 7u) * CS_T + k * 64 + lane], inc);
+                        bool v;
+                        const int val = base2val_dev(bb, v);
+                        run = v ? run + 1 : 0;
+                        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
+                        if (run >= 5) atomicAdd(&kmer[kidx], 1u);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    /* flush: slot -> cycle, unpack, one global atomic per non-zero counter */
+    for (u32 slot = threadIdx.x; slot < CS_T; slot += blockDim.x) {
+        const u32 c = tile_start + 16 * (slot & 63) + (slot >> 6);
+        if (c < C) {
+#pragma unroll
+            for (int cls = 0; cls < 8; cls++) {
+                const u64 v = cyc[cls * CS_T + slot];
+                if (v) {
+                    const u64 cnt = (v >> 22) & 0x3FFF, q20 = (v >> 36) & 0x3FFF, q30 = v >> 50;
+                    const long long qsum = (long long)(v & 0x3FFFFF) - 33ll * (long long)cnt; /* += qual-33 */
+                    atomicAdd((u64*)&stats[FPL_ST_CYC(c, 0, cls)], cnt);
+                    atomicAdd((u64*)&stats[FPL_ST_CYC(c, 1, cls)], (u64)qsum);
+                    if (q20) atomicAdd((u64*)&stats[FPL_ST_CYC(c, 2, cls)], q20);
+                    if (q30) atomicAdd((u64*)&stats[FPL_ST_CYC(c, 3, cls)], q30);
+                }
+            }
+        }
+    }
+    long long* kg = stats + FPL_ST_KMER(C);
+    for (u32 i = threadIdx.x; i < 1024; i += blockDim.x)
+        if (kmer[i]) atomicAdd((u64*)&kg[i], (u64)kmer[i]);
+}
+
+/* =========================================================================================
+ * k_scan
+ * ======================================================================================= */
+constexpr int HIST_COPIES = 32; /* per-wave quality histogram: 128 bins x 32 lane-copies (bank = lane & 31) */
+
+struct ScanBlockAcc {
+    u64 bqh[2][128];   /* mBaseQualHistogram        pre / post */
+    u64 medh[2][128];  /* mMedianReadQualHistogram  pre / post */
+    u64 medb[2][128];  /* mMedianReadQualBases      pre / post */
+    u64 reads[2], lensum[2];
+    u64 fr[FPL_FILTER_RESULT_TYPES];
+};
+
+struct RangeSums {
+    u32 lowq, nn, totq, diff;
+};
+
+__device__ __forceinline__ void hist_zero(u32* __restrict__ h) {
+    const int lane = lane_id();
+    wave_sync();
+    for (int i = lane; i < 128 * HIST_COPIES; i += 64) h[i] = 0;
+    wave_sync();
+}
+
+/* totals of bins 2*lane and 2*lane+1 over the lane copies */
+__device__ __forceinline__ void hist_totals(const u32* __restrict__ h, u32& t0, u32& t1) {
+    const int lane = lane_id();
+    t0 = 0;
+    t1 = 0;
+    wave_sync();
+#pragma unroll 8
+    for (int c = 0; c < HIST_COPIES; c++) {
+        const int cc = (c + lane) & (HIST_COPIES - 1); /* rotate so that lanes hit different banks */
+        t0 += h[(2 * lane) * HIST_COPIES + cc];
+        t1 += h[(2 * lane + 1) * HIST_COPIES + cc];
+    }
+}
+
+/* median as Stats::statRead computes it, src/stats.cpp:352-363: smallest q with
+ * cumulative count > len/2.  t0/t1 = this lane's two bins; len > 0. */
+__device__ __forceinline__ int hist_median(u32 t0, u32 t1, u32 len) {
+    const u32 v = t0 + t1;
+    const u32 incl = wave_scan_incl_u32(v);
+    const u32 excl = incl - v;
+    const u32 half = len >> 1;
+    const u64 m = wave_ballot(incl > half);
+    const int L = __ffsll(m) - 1; /* m != 0 because the total is len > half */
+    const int mine = 2 * lane_id() + ((excl + t0 > half) ? 0 : 1);
+    return shfl_i32(mine, L);
+}
+
+/* Hamming distances between the adapter and the 16 windows starting at this lane's 16 bytes.
+ * p points at the lane's first byte, cur holds its 16 bytes; acc = 16 packed byte counters. */
+__device__ __forceinline__ void hamming16(const u8* __restrict__ p, const u8* __restrict__ end, u32x4 cur,
+                                          const u32* __restrict__ adw, int alen, u32 acc[4]) {
+    acc[0] = acc[1] = acc[2] = acc[3] = 0;
+    for (int m0 = 0; m0 < alen; m0 += 16) {
+        const u32x4 nxt = load16_guard(p + m0 + 16, end);
+        const u32 w[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            if (m0 + t < alen) { /* wave-uniform */
+                const u32 a = adw[m0 + t];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u32 x = (t & 3) ? alignbyte(w[(t >> 2) + j + 1], w[(t >> 2) + j], t & 3) : w[(t >> 2) + j];
+                    acc[j] += nonzero_bytes01(x ^ a);
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
+/*
+ * One pass over bytes [a, b) of a read (rb/qb = first base / quality of the original read):
+ *   - quality histogram into h (LDS, this wave's),
+ *   - the sums Filter::passFilter needs (src/filter.cpp:27-39, 67-81), when SUMS,
+ *   - when NADS == 2, the Hamming argmin of both middle-adapter scans
+ *     (searchAdapter default mode, src/adaptertrimmer.cpp:133-151) over positions
+ *     p in [0, (b-a) - alen), as keys (mismatches << 32 | p), ~0 when nothing was tested.
+ */
+template <bool SUMS, bool HAM>
+__device__ inline void range_scan(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
+                                  const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
+                                  u32* __restrict__ h, int qualified_qual, RangeSums& sums,
+                                  const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
+                                  u64& key0, u64& key1) {
+    const int lane = lane_id();
+    const int blen = b - a;
+    u32 lowq = 0, nn = 0, totq = 0, diff = 0;
+    u32 bmm0 = 0xFFFFFFFFu, bp0 = 0xFFFFFFFFu, bmm1 = 0xFFFFFFFFu, bp1 = 0xFFFFFFFFu;
+    const int npos0 = HAM ? blen - ad0->len : 0, npos1 = HAM ? blen - ad1->len : 0;
+    u32 prev_last = 0; /* last byte of the previous tile */
+    for (int t0 = 0; t0 < blen; t0 += 16 * 64) {
+        const int j0 = t0 + 16 * lane;
+        const int nvalid = blen > j0 ? min(16, blen - j0) : 0;
+        u32x4 sv = {0, 0, 0, 0}, qv = {0, 0, 0, 0};
+        if (nvalid > 0) {
+            sv = load16_guard(rb + a + j0, seq_end);
+            qv = load16_guard(qb + a + j0, qual_end);
+        }
+        u32 prevb = shfl_up_u32(sv.w >> 24, 1);
+        if (lane == 0) prevb = prev_last;
+        prev_last = shfl_u32(sv.w >> 24, 63);
+        const u32 sw[4] = {sv.x, sv.y, sv.z, sv.w};
+        const u32 qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < nvalid) {
+                const u32 bb = (sw[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                const u32 q = (qw[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                atomicAdd(&h[(q & 127u) * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u); /* q < 128 in FASTQ */
+                if (SUMS) {
+                    lowq += ((int)q < qualified_qual);
+                    nn += (bb == 'N');
+                    totq += q;
+                    diff += (bb != prevb) && (j0 + k > 0);
+                    prevb = bb;
+                }
+            }
+        }
+        if (HAM) {
+            u32 acc[4];
+            if (npos0 > t0) { /* wave-uniform: some position of this tile is tested */
+                hamming16(rb + a + j0, seq_end, sv, ad0->seqw, ad0->len, acc);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const u32 mm = (acc[j >> 2] >> (8 * (j & 3))) & 0xFF;
+                    if (j0 + j < npos0 && mm < bmm0) {
+                        bmm0 = mm;
+                        bp0 = (u32)(j0 + j);
+                    }
+                }
+            }
+            if (npos1 > t0) {
+                hamming16(rb + a + j0, seq_end, sv, ad1->seqw, ad1->len, acc);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const u32 mm = (acc[j >> 2] >> (8 * (j & 3))) & 0xFF;
+                    if (j0 + j < npos1 && mm < bmm1) {
+                        bmm1 = mm;
+                        bp1 = (u32)(j0 + j);
+                    }
+                }
+            }
+        }
+    }
+    if (SUMS) {
+        sums.lowq = wave_sum_u32(lowq);
+        sums.nn = wave_sum_u32(nn);
+        sums.totq = wave_sum_u32(totq);
+        sums.diff = wave_sum_u32(diff);
+    }
+    if (HAM) {
+        key0 = wave_min_u64(((u64)bmm0 << 32) | bp0);
+        key1 = wave_min_u64(((u64)bmm1 << 32) | bp1);
+    }
+}
+
+/* Filter::passFilter + passLowComplexityFilter from the sums, src/filter.cpp:12-81.  The
+ * reference's double comparisons are equivalent to these integer cross-multiplications
+ * ("float <-> integer equivalences"). */
+__device__ __forceinline__ int filter_code(const DevConfig* __restrict__ cfg, int len, const RangeSums& sm) {
+    if (len == 0) return FPL_FAIL_LENGTH;
+    if (cfg->qual_filter) {
+        const int totalQual = (int)sm.totq - 33 * len;
+        if ((long long)sm.lowq * 100 > (long long)cfg->unqual_pct * len) return FPL_FAIL_QUALITY;
+        else if (cfg->avg_qual_req > 0 && (totalQual / len) < cfg->avg_qual_req) return FPL_FAIL_QUALITY;
+        else if ((long long)sm.nn * 100 > (long long)len * cfg->n_pct_limit) return FPL_FAIL_N_BASE;
+        else if (cfg->n_base_limit != 1000000 && (int)sm.nn > cfg->n_base_limit) return FPL_FAIL_N_BASE;
+    }
+    if (cfg->length_filter) {
+        if (len < cfg->required_length) return FPL_FAIL_LENGTH;
+        if (cfg->max_length > 0 && len > cfg->max_length) return FPL_FAIL_TOO_LONG;
+    }
+    if (cfg->complexity) {
+        if (len <= 1) return FPL_FAIL_COMPLEXITY;
+        if (!((long long)sm.diff * 100 >= (long long)cfg->complexity_pct * (len - 1))) return FPL_FAIL_COMPLEXITY;
+    }
+    return FPL_PASS_FILTER;
+}
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
+       uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
+       const ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
+       uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, long long* __restrict__ counters, u32 C,
+       u32* __restrict__ work_ctr) {
+    __shared__ u32 hist_all[WAVES][128 * HIST_COPIES];
+    __shared__ ScanBlockAcc acc;
+    const int lane = lane_id();
+    u32* h = hist_all[wave_in_block()];
+    {
+        u64* z = (u64*)&acc;
+        for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
+    }
+    __syncthreads();
+    const u8* seq_end = seq + n_bytes;
+    const u8* qual_end = qual + n_bytes;
+    const int qq = cfg->qualified_qual;
+
+    for (;;) {
+        u32 ri = 0;
+        if (lane == 0) ri = atomicAdd(work_ctr, 1u);
+        ri = shfl_u32(ri, 0);
+        if (ri >= n_reads) break;
+        const uint64_t o0 = off[ri];
+        const int l = (int)(off[ri + 1] - o0);
+        const u8* rb = seq + o0;
+        const u8* qb = qual + o0;
+        const ReadState st = state[ri];
+        const int s = (int)st.s, e = (int)st.e;
+        const bool dropped = st.dropped != 0;
+        const int blen = e - s;
+
+        /* ---- r1 body: histogram + filter sums + (adapters enabled) both Hamming scans */
+        hist_zero(h);
+        RangeSums sm = {0, 0, 0, 0};
+        u64 key0 = ~0ull, key1 = ~0ull;
+        const bool ham = !dropped && cfg->adapter_enabled;
+        if (ham) range_scan<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
+        else range_scan<true, false>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, nullptr, nullptr, key0, key1);
+        u32 hb0, hb1;
+        hist_totals(h, hb0, hb1);
+        /* ---- the trimmed-off ends only feed the pre-filter histogram */
+        {
+            RangeSums dummy;
+            u64 d0, d1;
+            if (s > 0) range_scan<false, false>(rb, qb, 0, s, seq_end, qual_end, h, qq, dummy, nullptr, nullptr, d0, d1);
+            if (l > e) range_scan<false, false>(rb, qb, e, l, seq_end, qual_end, h, qq, dummy, nullptr, nullptr, d0, d1);
+        }
+        u32 ht0, ht1;
+        hist_totals(h, ht0, ht1);
+        int med_pre = 0;
+        if (l > 0) med_pre = hist_median(ht0, ht1, (u32)l);
+        /* pre-filter Stats scalars, src/stats.cpp:265-271,352-374 */
+        if (ht0) atomicAdd(&acc.bqh[0][2 * lane], (u64)ht0);
+        if (ht1) atomicAdd(&acc.bqh[0][2 * lane + 1], (u64)ht1);
+        if (lane == 0) {
+            if (l > 0) {
+                atomicAdd(&acc.medh[0][med_pre], (u64)1);
+                atomicAdd(&acc.medb[0][med_pre], (u64)l);
+            }
+            atomicAdd(&acc.reads[0], (u64)1);
+            atomicAdd(&acc.lensum[0], (u64)l);
+        }
+
+        fpl_read_result res;
+        res.r1_start = dropped ? 0 : (u32)s;
+        res.r1_len = dropped ? 0 : (u32)blen;
+        res.frag_start[0] = res.frag_start[1] = 0;
+        res.frag_len[0] = res.frag_len[1] = 0;
+        res.n_frag = 0;
+        res.dropped = dropped ? 1 : 0;
+        res.code[0] = res.code[1] = 0;
+        res.kind[0] = res.kind[1] = 0;
+        res.median_q_pre = (u8)med_pre;
+        res.median_q_post[0] = res.median_q_post[1] = 0;
+        res.reserved[0] = res.reserved[1] = res.reserved[2] = 0;
+        uint64_t fo[2] = {0, 0};
+        u32 fl[2] = {0, 0};
+
+        if (!dropped) {
+            /* ---- findMiddleAdapters, src/adaptertrimmer.cpp:13-40 */
+            bool split = false;
+            int gs = 0, glen = 0;
+            if (ham) {
+                const int al0 = ads[0].len, al1 = ads[1].len;
+                int sp = -1, ep = -1;
+                if (key0 != ~0ull) {
+                    const int p = (int)(u32)key0;
+                    const int ed = FPL_LANE0_INT(lev_bp64(ads[0].peq_full, 0, al0, rb + s + p, al0));
+                    if (ed <= cfg->thr[al0]) sp = p;
+                }
+                if (key1 != ~0ull) {
+                    const int p = (int)(u32)key1;
+                    const int ed = FPL_LANE0_INT(lev_bp64(ads[1].peq_full, 0, al1, rb + s + p, al1));
+                    if (ed <= cfg->thr[al1]) ep = p;
+                }
+                const int ext = cfg->ext;
+                if (sp >= 0 && ep >= 0) {
+                    int gstart = min(sp, ep), gend = max(sp + al0, ep + al1);
+                    gstart = max(0, gstart - ext);
+                    gend = min(blen, gend + ext);
+                    gs = gstart;
+                    glen = gend - gstart;
+                    split = true;
+                } else if (sp >= 0) {
+                    const int gend = min(blen, sp + al0 + ext);
+                    gs = max(0, sp - ext);
+                    glen = gend - gs;
+                    split = true;
+                } else if (ep >= 0) {
+                    const int gend = min(blen, ep + al1 + ext);
+                    gs = max(0, ep - ext);
+                    glen = gend - gs;
+                    split = true;
+                }
+            }
+            /* ---- fragments: Read::breakByGap, src/read.cpp:192-215 */
+            int nf = 0, fa[2] = {0, 0}, fb[2] = {0, 0}, fk[2] = {0, 0};
+            if (split) {
+                const int len1 = gs, len2 = blen - gs - glen;
+                if (len1 > 0) {
+                    fa[nf] = s;
+                    fb[nf] = s + len1;
+                    fk[nf++] = 1;
+                }
+                if (len2 > 0) {
+                    fa[nf] = s + gs + glen;
+                    fb[nf] = e;
+                    fk[nf++] = 2;
+                }
+            } else {
+                fa[0] = s;
+                fb[0] = e;
+                fk[0] = 0;
+                nf = 1;
+            }
+            res.n_frag = (u8)nf;
+            /* ---- passFilter per fragment, counters, post-filter Stats scalars (src/seprocessor.cpp:265-281) */
+            for (int f = 0; f < nf; f++) {
+                const int flen = fb[f] - fa[f];
+                u32 t0 = hb0, t1 = hb1;
+                RangeSums fs = sm;
+                if (split) { /* rare: re-derive sums and histogram for this fragment */
+                    hist_zero(h);
+                    u64 d0, d1;
+                    range_scan<true, false>(rb, qb, fa[f], fb[f], seq_end, qual_end, h, qq, fs, nullptr, nullptr, d0, d1);
+                    hist_totals(h, t0, t1);
+                }
+                const int code = filter_code(cfg, flen, fs);
+                res.frag_start[f] = (u32)fa[f];
+                res.frag_len[f] = (u32)flen;
+                res.code[f] = (u8)code;
+                res.kind[f] = (u8)fk[f];
+                if (lane == 0) atomicAdd(&acc.fr[code], (u64)1);
+                if (code == FPL_PASS_FILTER) {
+                    const int med = hist_median(t0, t1, (u32)flen); /* flen > 0 when passing */
+                    res.median_q_post[f] = (u8)med;
+                    if (t0) atomicAdd(&acc.bqh[1][2 * lane], (u64)t0);
+                    if (t1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)t1);
+                    if (lane == 0) {
+                        atomicAdd(&acc.medh[1][med], (u64)1);
+                        atomicAdd(&acc.medb[1][med], (u64)flen);
+                        atomicAdd(&acc.reads[1], (u64)1);
+                        atomicAdd(&acc.lensum[1], (u64)flen);
+                    }
+                    fo[f] = o0 + (uint64_t)fa[f];
+                    fl[f] = (u32)flen;
+                }
+            }
+        }
+        if (lane == 0) {
+            results[ri] = res;
+            frag_off[2 * ri] = fo[0];
+            frag_off[2 * ri + 1] = fo[1];
+            frag_len[2 * ri] = fl[0];
+            frag_len[2 * ri + 1] = fl[1];
+        }
+    }
+    __syncthreads();
+    /* flush the block accumulators */
+    for (int k = 0; k < 2; k++) {
+        long long* st = counters + (k == 0 ? FPL_OFF_PRE(C) : FPL_OFF_POST(C));
+        for (u32 i = threadIdx.x; i < 128; i += blockDim.x) {
+            if (acc.bqh[k][i]) atomicAdd((u64*)&st[FPL_ST_BASE_QUAL_HIST(C) + i], acc.bqh[k][i]);
+            if (acc.medh[k][i]) atomicAdd((u64*)&st[FPL_ST_MEDIAN_HIST(C) + i], acc.medh[k][i]);
+            if (acc.medb[k][i]) atomicAdd((u64*)&st[FPL_ST_MEDIAN_BASES(C) + i], acc.medb[k][i]);
+        }
+        if (threadIdx.x == 0) {
+            if (acc.reads[k]) atomicAdd((u64*)&st[FPL_ST_READS(C)], acc.reads[k]);
+            if (acc.lensum[k]) atomicAdd((u64*)&st[FPL_ST_LENGTH_SUM(C)], acc.lensum[k]);
+        }
+    }
+    long long* fr = counters + FPL_OFF_FR(C);
+    for (u32 i = threadIdx.x; i < FPL_FILTER_RESULT_TYPES; i += blockDim.x)
+        if (acc.fr[i]) atomicAdd((u64*)&fr[FPL_FR_FILTER + i], acc.fr[i]);
+}
+
+}  // namespace fpl
+#endif

@@ -1,0 +1,203 @@
+"""Python front end of libfastplong_amd.so (the HIP library behind include/fastplong_amd.h).
+
+There is no fallback of any kind: if the library has not been built, or no MI355X is visible,
+construction raises.  torch is used only as plumbing (device memory, streams, collectives)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfastplong_amd.so")
+
+EXPORTS = [
+    "fpl_abi_version", "fpl_strerror", "fpl_last_error", "fpl_options_default", "fpl_create", "fpl_destroy",
+    "fpl_process_batch_device", "fpl_process_batch", "fpl_max_cycles", "fpl_n_adapters", "fpl_counters_len",
+    "fpl_reserve_cycles", "fpl_counters_device_ptr", "fpl_get_counters", "fpl_reset_counters", "fpl_synchronize",
+    "fpl_enable_timing", "fpl_get_kernel_times",
+]
+
+
+class FplError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library and declare its prototypes; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FplError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.fpl_abi_version.restype = C.c_int
+    L.fpl_strerror.restype = C.c_char_p
+    L.fpl_strerror.argtypes = [C.c_int]
+    L.fpl_last_error.restype = C.c_char_p
+    L.fpl_last_error.argtypes = [C.c_void_p]
+    L.fpl_options_default.restype = None
+    L.fpl_options_default.argtypes = [C.POINTER(abi.FplOptions)]
+    L.fpl_create.restype = C.c_int
+    L.fpl_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(abi.FplOptions), C.c_char_p, C.c_int32, C.c_char_p,
+                             C.c_int32, C.POINTER(abi.FplAdapter), C.c_int32, C.c_int32, C.c_uint32]
+    L.fpl_destroy.restype = None
+    L.fpl_destroy.argtypes = [C.c_void_p]
+    L.fpl_process_batch_device.restype = C.c_int
+    L.fpl_process_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                           C.c_uint32, C.c_void_p, C.c_void_p]
+    L.fpl_process_batch.restype = C.c_int
+    L.fpl_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.fpl_max_cycles.restype = C.c_uint32
+    L.fpl_max_cycles.argtypes = [C.c_void_p]
+    L.fpl_n_adapters.restype = C.c_int32
+    L.fpl_n_adapters.argtypes = [C.c_void_p]
+    L.fpl_counters_len.restype = C.c_size_t
+    L.fpl_counters_len.argtypes = [C.c_void_p]
+    L.fpl_reserve_cycles.restype = C.c_int
+    L.fpl_reserve_cycles.argtypes = [C.c_void_p, C.c_uint32]
+    L.fpl_counters_device_ptr.restype = C.c_void_p
+    L.fpl_counters_device_ptr.argtypes = [C.c_void_p]
+    L.fpl_get_counters.restype = C.c_int
+    L.fpl_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.fpl_reset_counters.restype = C.c_int
+    L.fpl_reset_counters.argtypes = [C.c_void_p]
+    L.fpl_synchronize.restype = C.c_int
+    L.fpl_synchronize.argtypes = [C.c_void_p]
+    L.fpl_enable_timing.restype = C.c_int
+    L.fpl_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    L.fpl_get_kernel_times.restype = C.c_int
+    L.fpl_get_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int)]
+    if L.fpl_abi_version() != abi.FPL_ABI_VERSION:
+        raise FplError("ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _b(s):
+    return s.encode("latin-1") if isinstance(s, str) else bytes(s)
+
+
+class Engine:
+    """One fpl_ctx on one device."""
+
+    def __init__(self, opt=None, start_adapter="", end_adapter="", fasta=(), device=0, max_cycles=1024):
+        self.L = load_library()
+        self.opt = opt if opt is not None else abi.FplOptions.default()
+        self.start, self.end = _b(start_adapter), _b(end_adapter)
+        self.fasta = [_b(a) for a in fasta]
+        arr = (abi.FplAdapter * max(1, len(self.fasta)))()
+        for i, a in enumerate(self.fasta):
+            arr[i].seq, arr[i].len = a, len(a)
+        h = C.c_void_p()
+        rc = self.L.fpl_create(C.byref(h), C.byref(self.opt), self.start, len(self.start), self.end, len(self.end),
+                               arr, len(self.fasta), device, max_cycles)
+        if rc != 0:
+            raise FplError("fpl_create: %s" % self.L.fpl_strerror(rc).decode())
+        self.h = h
+        self.device = device
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FplError("%s: %s (%s)" % (what, self.L.fpl_strerror(rc).decode(),
+                                            (self.L.fpl_last_error(self.h) or b"").decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fpl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_adapters(self):
+        return 2 + len(self.fasta)
+
+    @property
+    def max_cycles(self):
+        return int(self.L.fpl_max_cycles(self.h))
+
+    def reserve_cycles(self, c):
+        self._check(self.L.fpl_reserve_cycles(self.h, int(c)), "fpl_reserve_cycles")
+
+    def process_host(self, seq, qual, off):
+        """fpl_process_batch: host numpy buffers in, structured result array out."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        res = np.zeros(max(n, 1), dtype=abi.RESULT_DTYPE)
+        if seq.size == 0:
+            seq = np.zeros(1, np.uint8)
+            qual = np.zeros(1, np.uint8)
+        self._check(self.L.fpl_process_batch(self.h, seq.ctypes.data, qual.ctypes.data, off.ctypes.data, n,
+                                             res.ctypes.data), "fpl_process_batch")
+        return res[:n]
+
+    def process_device(self, seq_t, qual_t, off_t, max_read_len, results_t=None, stream=None):
+        """fpl_process_batch_device on torch CUDA tensors (uint8, uint8, int64 offsets).
+        Asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+
+        n = off_t.numel() - 1
+        if results_t is None:
+            results_t = torch.empty(max(n, 1) * C.sizeof(abi.FplReadResult), dtype=torch.uint8, device=seq_t.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(seq_t.device).cuda_stream
+        self._check(self.L.fpl_process_batch_device(self.h, seq_t.data_ptr(), qual_t.data_ptr(), off_t.data_ptr(), n,
+                                                    seq_t.numel(), int(max_read_len), results_t.data_ptr(),
+                                                    C.c_void_p(stream)), "fpl_process_batch_device")
+        return results_t
+
+    @staticmethod
+    def results_to_numpy(results_t, n):
+        return results_t.cpu().numpy().view(abi.RESULT_DTYPE)[:n]
+
+    def counters(self):
+        n = int(self.L.fpl_counters_len(self.h))
+        buf = np.zeros(n, dtype=np.int64)
+        self._check(self.L.fpl_get_counters(self.h, buf.ctypes.data, n), "fpl_get_counters")
+        return buf
+
+    def counters_tensor(self):
+        """Zero-copy torch view (int64) of the device counter buffer, e.g. for
+        torch.distributed.all_reduce over RCCL.  Invalid after a capacity grow."""
+        import torch
+
+        n = int(self.L.fpl_counters_len(self.h))
+        ptr = int(self.L.fpl_counters_device_ptr(self.h))
+
+        class _Holder:
+            pass
+
+        hld = _Holder()
+        hld.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+        hld._keep = self
+        return torch.as_tensor(hld, device="cuda:%d" % self.device)
+
+    def reset_counters(self):
+        self._check(self.L.fpl_reset_counters(self.h), "fpl_reset_counters")
+
+    def synchronize(self):
+        self._check(self.L.fpl_synchronize(self.h), "fpl_synchronize")
+
+    def enable_timing(self, on=True):
+        self._check(self.L.fpl_enable_timing(self.h, int(on)), "fpl_enable_timing")
+
+    def kernel_times(self):
+        """-> ({kernel name: ms summed over the window}, n_batches)"""
+        ms = (C.c_float * 16)()
+        names = (C.c_char_p * 16)()
+        n, nb = C.c_int(0), C.c_int(0)
+        self._check(self.L.fpl_get_kernel_times(self.h, ms, names, C.byref(n), C.byref(nb)), "fpl_get_kernel_times")
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}, nb.value

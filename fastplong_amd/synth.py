@@ -188,14 +188,28 @@ def to_fastq(seq, qual, off, prefix="read"):
     return b"".join(out)
 
 
+def _variant_pool(rng, ad, err, n_variants):
+    """n_variants noisy copies of an adapter as a padded matrix + lengths"""
+    vs = [_mutate(rng, ad, err) for _ in range(n_variants)]
+    lmax = max(1, max(len(v) for v in vs))
+    mat = np.zeros((n_variants, lmax), np.uint8)
+    lens = np.zeros(n_variants, np.int64)
+    for i, v in enumerate(vs):
+        mat[i, :len(v)] = v
+        lens[i] = len(v)
+    return mat, lens
+
+
 def device_batch(n_reads, seed=1, median_len=8000, sigma_len=0.5, min_len=50, max_len=None,
                  start_adapter=START_ADAPTER, end_adapter=END_ADAPTER, p_start=0.7, p_end=0.6,
                  err=0.10, p_polya=0.05, p_middle=0.01, mu=18.0, sigma=8.0, device="cuda",
-                 chunk=1 << 27):
-    """Build an ONT-like CSR batch directly in HBM.  Bodies and qualities are generated with
-    torch on the device in chunks; the per-read decorations (noisy adapters, polyA tails, middle
-    adapters) are drawn on the host with numpy and scattered in as one flat index_copy.
-    Returns (seq u8 [n_bytes], qual u8 [n_bytes], off i64/u64-compatible [n+1], max_len)."""
+                 chunk=1 << 27, n_variants=2048):
+    """Build an ONT-like CSR batch directly in HBM: lognormal
+    lengths, iid ACGT + 0.1 % N, quality clamp(round(N(mu, sigma)), 2, 50) + 33, noisy start /
+    end adapters after 0..30 leading bases, polyA tails, adapters in the middle.  Bodies and
+    qualities are generated on the device in chunks; decorations OVERWRITE bases (lengths stay
+    as drawn) and are scattered in with vectorised index_put.
+    Returns (seq u8 [n_bytes], qual u8 [n_bytes], off int64 [n+1], max_len)."""
     import torch
 
     rng = np.random.default_rng(seed)
@@ -213,43 +227,53 @@ def device_batch(n_reads, seed=1, median_len=8000, sigma_len=0.5, min_len=50, ma
         b = min(total, a + chunk)
         idx = torch.randint(0, 4, (b - a,), generator=g, device=device, dtype=torch.int64)
         s = lut[idx]
+        del idx
         s[torch.rand(b - a, generator=g, device=device) < 0.001] = ord("N")
         seq[a:b] = s
+        del s
         q = torch.randn(b - a, generator=g, device=device) * sigma + mu
-        qual[a:b] = (q.round().clamp(2, 50) + 33).to(torch.uint8)
-        del idx, s, q
-    # decorations: overwrite (not insert) so that lengths stay as drawn
-    sa = np.frombuffer(start_adapter.encode(), np.uint8) if start_adapter else None
-    ea = np.frombuffer(end_adapter.encode(), np.uint8) if end_adapter else None
-    pos_list, val_list = [], []
+        qual[a:b] = (q.round_().clamp_(2, 50) + 33).to(torch.uint8)
+        del q
+
+    def scatter(read_idx, pos_in_read, mat, vlen, variant):
+        """seq[off[r] + pos + j] = mat[variant, j] for j < vlen[variant]"""
+        if len(read_idx) == 0:
+            return
+        base = torch.from_numpy(off[read_idx] + pos_in_read).to(device)
+        var = torch.from_numpy(variant).to(device)
+        m = torch.from_numpy(mat).to(device)
+        vl = torch.from_numpy(vlen).to(device)
+        j = torch.arange(m.shape[1], device=device)
+        flat = base[:, None] + j[None, :]
+        mask = j[None, :] < vl[var][:, None]
+        seq[flat[mask]] = m[var][mask]
+
     u = rng.random((n_reads, 4))
     lead = rng.integers(0, 31, (n_reads, 2))
-    for i in np.nonzero((u[:, 0] < p_start) | (u[:, 1] < p_end) | (u[:, 2] < p_polya) | (u[:, 3] < p_middle))[0]:
-        base, L = int(off[i]), int(lens[i])
-        tail_used = 0
-        if ea is not None and u[i, 1] < p_end:
-            ad = _mutate(rng, ea, err)
-            p = L - int(lead[i, 1]) - len(ad)
-            pos_list.append(base + p + np.arange(len(ad)))
-            val_list.append(ad)
-            tail_used = L - p
-        if u[i, 2] < p_polya:
-            k = int(rng.integers(10, 41))
-            p = L - tail_used - k
-            pos_list.append(base + p + np.arange(k))
-            val_list.append(np.full(k, ord("A"), np.uint8))
-        if sa is not None and u[i, 0] < p_start:
-            ad = _mutate(rng, sa, err)
-            pos_list.append(base + int(lead[i, 0]) + np.arange(len(ad)))
-            val_list.append(ad)
-        if u[i, 3] < p_middle and L > 600:
-            ad = _mutate(rng, sa if (rng.random() < 0.5 or ea is None) else ea, err)
-            p = int(rng.integers(250, L - 300))
-            pos_list.append(base + p + np.arange(len(ad)))
-            val_list.append(ad)
-    if pos_list:
-        pos = torch.from_numpy(np.concatenate(pos_list)).to(device)
-        val = torch.from_numpy(np.concatenate(val_list).astype(np.uint8)).to(device)
-        seq.index_copy_(0, pos, val)
+    tail_used = np.zeros(n_reads, np.int64)
+    if end_adapter:
+        mat, vlen = _variant_pool(rng, np.frombuffer(end_adapter.encode(), np.uint8), err, n_variants)
+        ri = np.nonzero(u[:, 1] < p_end)[0]
+        var = rng.integers(0, n_variants, len(ri))
+        pos = lens[ri] - lead[ri, 1] - vlen[var]
+        scatter(ri, pos, mat, vlen, var)
+        tail_used[ri] = lens[ri] - pos
+    if p_polya > 0:
+        ri = np.nonzero(u[:, 2] < p_polya)[0]
+        k = rng.integers(10, 41, len(ri))
+        mat = np.full((1, 40), ord("A"), np.uint8)
+        pos = lens[ri] - tail_used[ri] - k
+        # one "variant" per distinct length: reuse scatter with per-row lengths
+        scatter(ri, pos, np.repeat(mat, 31, axis=0), np.arange(10, 41, dtype=np.int64), (k - 10).astype(np.int64))
+    if start_adapter:
+        mat, vlen = _variant_pool(rng, np.frombuffer(start_adapter.encode(), np.uint8), err, n_variants)
+        ri = np.nonzero(u[:, 0] < p_start)[0]
+        var = rng.integers(0, n_variants, len(ri))
+        scatter(ri, lead[ri, 0].astype(np.int64), mat, vlen, var)
+        ri = np.nonzero((u[:, 3] < p_middle) & (lens > 600))[0]
+        if len(ri):
+            var = rng.integers(0, n_variants, len(ri))
+            pos = 250 + (rng.random(len(ri)) * (lens[ri] - 550)).astype(np.int64)
+            scatter(ri, pos, mat, vlen, var)
     off_t = torch.from_numpy(off).to(device)
     return seq, qual, off_t, int(lens.max())

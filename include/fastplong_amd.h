@@ -34,7 +34,7 @@ extern "C" {
 #define FPL_ABI_VERSION 1
 
 /* limits */
-#define FPL_MAX_ADAPTER_LEN 256 /* longest adapter the device path accepts            */
+#define FPL_MAX_ADAPTER_LEN 255 /* longest adapter the device path accepts            */
 #define FPL_MAX_ADAPTERS 1024   /* start + end + FASTA adapters                      */
 #define FPL_END_WINDOW 200      /* WINDOW,      reference src/adaptertrimmer.cpp:169,239 */
 #define FPL_PATTERN_LEN 16      /* PATTERN_LEN, reference src/adaptertrimmer.cpp:170,240 */
@@ -241,13 +241,15 @@ int fpl_reset_counters(fpl_ctx* ctx);
 int fpl_synchronize(fpl_ctx* ctx);
 
 /*
- * Per-kernel timing of the most recent fpl_process_batch_device() call, measured with HIP
- * events on the stream the kernels were launched on.  Enable before the call; reading
- * synchronizes on the recorded events.  names[i] are static strings.
+ * Per-kernel timing, measured with HIP events recorded on the stream the kernels are launched
+ * on.  fpl_enable_timing(ctx, 1) starts a measurement window; every later
+ * fpl_process_batch_device() records one event set (a ring of 128).  fpl_get_kernel_times()
+ * waits for the recorded events and returns, per kernel, the time SUMMED over the batches of
+ * the window (n_batches of them); names[i] are static strings.
  */
 #define FPL_MAX_KERNEL_TIMES 16
 int fpl_enable_timing(fpl_ctx* ctx, int enable);
-int fpl_get_kernel_times(fpl_ctx* ctx, float* ms, const char** names, int* n);
+int fpl_get_kernel_times(fpl_ctx* ctx, float* ms, const char** names, int* n, int* n_batches);
 
 const char* fpl_strerror(int code);
 const char* fpl_last_error(const fpl_ctx* ctx);

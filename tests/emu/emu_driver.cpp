@@ -1,0 +1,75 @@
+/*
+ * emu_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+ * Compiles the product kernels (fastplong_amd/csrc/kernels.h + pipeline.h) for the host on top
+ * of hip_emu.h and runs one batch through the same launch sequence the HIP library uses.
+ * Built as tests/emu/libfpl_emu.so by tests/emu/build.py; loaded only by tests.
+ */
+#define FPL_EMU 1
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../fastplong_amd/csrc/pipeline.h"
+
+using namespace fpl;
+
+extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int start_len, const char* end,
+                                 int end_len, const fpl_adapter* fasta, int n_fasta, const uint8_t* seq,
+                                 const uint8_t* qual, const uint64_t* off, uint32_t n_reads, int64_t* counters,
+                                 uint32_t C, fpl_read_result* results, uint32_t n_cu) {
+    DevConfig cfg;
+    build_config(&cfg, opt, start_len, end_len, n_fasta);
+    std::vector<DevAdapter> ads(2 + n_fasta);
+    build_adapter(&ads[0], start, start_len);
+    build_adapter(&ads[1], end, end_len);
+    for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
+
+    uint64_t n_bytes = n_reads ? off[n_reads] : 0;
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        uint32_t l = (uint32_t)(off[i + 1] - off[i]);
+        if (l > max_len) max_len = l;
+    }
+    if (max_len > C) return FPL_ERR_CAPACITY;
+    std::vector<ReadState> state(n_reads ? n_reads : 1);
+    std::vector<uint64_t> frag_off(2 * (size_t)n_reads + 2, 0);
+    std::vector<uint32_t> frag_len(2 * (size_t)n_reads + 2, 0);
+    uint32_t work_ctr = 0;
+    /* the kernels never read past n_bytes, but give the buffers an end guard anyway */
+    BatchArgs a;
+    a.seq = seq;
+    a.qual = qual;
+    a.off = off;
+    a.n_reads = n_reads;
+    a.n_bytes = n_bytes;
+    a.max_read_len = max_len;
+    a.cfg = &cfg;
+    a.ads = ads.data();
+    a.state = state.data();
+    a.results = results;
+    a.frag_off = frag_off.data();
+    a.frag_len = frag_len.data();
+    a.counters = (long long*)counters;
+    a.C = C;
+    a.work_ctr = &work_ctr;
+    a.n_cu = n_cu ? n_cu : 2;
+    enqueue_batch(a, nullptr, [](int) {});
+    return 0;
+}
+
+/* direct hooks for unit tests of the bit-parallel Levenshtein code */
+extern "C" int emu_lev_bp64(const char* adapter, int alen, int shift, int m, const char* text, int n) {
+    static DevAdapter ad;
+    build_adapter(&ad, adapter, alen);
+    return lev_bp64(ad.peq_full, shift, m, (const u8*)text, n);
+}
+extern "C" int emu_lev_bp32_start(const char* adapter, int alen, const char* text, int n) {
+    static DevAdapter ad;
+    build_adapter(&ad, adapter, alen);
+    return lev_bp32(ad.peq16_start, ad.plen, (const u8*)text, n);
+}
+extern "C" int emu_lev_bp32_end(const char* adapter, int alen, const char* text, int n) {
+    static DevAdapter ad;
+    build_adapter(&ad, adapter, alen);
+    return lev_bp32(ad.peq16_end, ad.plen, (const u8*)text, n);
+}

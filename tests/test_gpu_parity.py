@@ -1,0 +1,192 @@
+"""Parity tests proper: the HIP path through the C-ABI (libfastplong_amd.so) against the oracle
+on the same seeded inputs, bit for bit (integer / byte / index work => exact equality), plus
+size-independent properties at larger sizes.  Need a real MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+from fastplong_amd import abi, synth
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "the -m gpu tests need a GPU"
+    from fastplong_amd import engine
+
+    engine.load_library()
+    return engine
+
+
+CASES = {
+    "defaults_adapters": dict(opt=dict(), start=synth.START_ADAPTER, end=synth.END_ADAPTER),
+    "full_pipeline": dict(opt=dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
+                                   complexity_filter=1), start=synth.START_ADAPTER, end=synth.END_ADAPTER),
+    "no_adapter_trimming": dict(opt=dict(adapter_enabled=0), start="", end=""),
+    "quality_filter_only": dict(opt=dict(adapter_enabled=0, length_filter=0), start="", end=""),
+    "nasty_options": dict(opt=dict(trim_front=3, trim_tail=2, cut_front=1, cut_tail=1, cut_front_window=7,
+                                   cut_front_quality=15, cut_tail_window=3, cut_tail_quality=25, polyx=1,
+                                   polyx_min_len=8, complexity_filter=1, complexity_percent=40,
+                                   qualified_qual=33 + 20, unqualified_percent_limit=30, n_base_percent_limit=5,
+                                   avg_qual_req=12, required_length=30, max_length=350, ed_max=0.3,
+                                   trimming_extension=5), start=synth.START_ADAPTER, end=synth.END_ADAPTER),
+    "auto_literal": dict(opt=dict(), start="auto", end="auto"),  # undetected "auto" is used literally
+    "long_window": dict(opt=dict(cut_front=1, cut_tail=1, cut_front_window=50, cut_tail_window=1000),
+                        start=synth.START_ADAPTER, end=synth.END_ADAPTER),
+}
+
+
+def _run_both(orc, engine_mod, cfgd, seq, qual, off, fasta=(), via="host"):
+    import torch
+
+    cfg = orc.Config(abi.FplOptions.default(**cfgd["opt"]), cfgd["start"], cfgd["end"], fasta)
+    n = len(off) - 1
+    C = max(1, int(np.diff(off.astype(np.int64)).max()) if n else 1)
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    eng = engine_mod.Engine(cfg.opt, cfgd["start"], cfgd["end"], fasta, device=0, max_cycles=C)
+    if via == "host":
+        got_res = eng.process_host(seq, qual, off)
+    else:
+        st = torch.from_numpy(seq.copy()).cuda()
+        qt = torch.from_numpy(qual.copy()).cuda()
+        ot = torch.from_numpy(off.astype(np.int64)).cuda()
+        rt = eng.process_device(st, qt, ot, C)
+        torch.cuda.synchronize()
+        got_res = eng.results_to_numpy(rt, n)
+    got_cnt = eng.counters()
+    assert eng.max_cycles == C
+    eng.close()
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    return want_res, want_cnt
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_adversarial_reads_bit_exact(orc, engine_mod, name):
+    seq, qual, off = synth.adversarial(3000, seed=100 + len(name))
+    _run_both(orc, engine_mod, CASES[name], seq, qual, off)
+
+
+@pytest.mark.parametrize("name", ["defaults_adapters", "full_pipeline"])
+def test_ont_like_reads_bit_exact(orc, engine_mod, name):
+    # lengths up to tens of kb: several cycle tiles, several scan tiles per read
+    seq, qual, off = synth.ont_like(400, seed=5, median_len=6000, p_middle=0.05)
+    res, _ = _run_both(orc, engine_mod, CASES[name], seq, qual, off, via="device")
+    assert (res["n_frag"] == 2).any()
+
+
+def test_multi_adapter_fasta_bit_exact(orc, engine_mod):
+    fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA",
+             "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG",
+             "".join("ACGT"[(i * 7 + i // 3) % 4] for i in range(200))]
+    seq, qual, off = synth.adversarial(2000, seed=33, fasta=fasta)
+    _run_both(orc, engine_mod, CASES["defaults_adapters"], seq, qual, off, fasta=fasta)
+
+
+def test_hifi_like_64_adapters_bit_exact(orc, engine_mod):
+    seq, qual, off, ads = synth.hifi_like(60, seed=5, mean_len=9000, sd_len=1500, n_adapters=64)
+    cfgd = dict(opt=dict(), start=ads[0], end=synth.revcomp(ads[0]))
+    _run_both(orc, engine_mod, cfgd, seq, qual, off, fasta=sorted(ads))
+
+
+def test_edge_batches(orc, engine_mod):
+    cfgd = CASES["full_pipeline"]
+    # empty batch
+    eng = engine_mod.Engine(abi.FplOptions.default(**cfgd["opt"]), cfgd["start"], cfgd["end"], device=0, max_cycles=4)
+    r = eng.process_host(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(r) == 0 and not eng.counters().any()
+    eng.close()
+    # empty reads, 1-base reads, a read of only N, only polyA, one long read among short ones
+    reads = [b"", b"A", b"N" * 50, b"A" * 300, b"ACGT" * 5000, b"", b"acgtn" * 20, b"G" * 16, b"T" * 15]
+    rng = np.random.default_rng(1)
+    seq = np.frombuffer(b"".join(reads), np.uint8).copy()
+    qual = (33 + rng.integers(2, 45, len(seq))).astype(np.uint8)
+    off = np.zeros(len(reads) + 1, np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    for name in ("defaults_adapters", "full_pipeline", "nasty_options"):
+        _run_both(orc, engine_mod, CASES[name], seq, qual, off)
+
+
+def test_capacity_growth_and_accumulation(orc, engine_mod):
+    """counters accumulate across batches; the per-cycle capacity grows on demand"""
+    cfgd = CASES["full_pipeline"]
+    cfg = orc.Config(abi.FplOptions.default(**cfgd["opt"]), cfgd["start"], cfgd["end"])
+    b1 = synth.adversarial(500, seed=1)
+    b2 = synth.ont_like(60, seed=2, median_len=3000)
+    c2 = int(np.diff(b2[2].astype(np.int64)).max())
+    eng = engine_mod.Engine(cfg.opt, cfgd["start"], cfgd["end"], device=0, max_cycles=16)
+    eng.process_host(*b1)
+    eng.process_host(*b2)
+    got = eng.counters()
+    C = eng.max_cycles
+    assert C >= c2
+    eng.close()
+    want = np.zeros(abi.counters_len(C, 2), np.int64)
+    orc.process_batch(cfg, *b1, max_cycles=C, counters=want)
+    orc.process_batch(cfg, *b2, max_cycles=C, counters=want)
+    parity.assert_counters_equal(got, want, C, 2)
+
+
+def test_large_batch_properties(engine_mod):
+    """BASELINE-sized reads without the oracle: size-independent properties.
+    (1) conservation: every read is dropped or yields fragments inside r1 inside the read;
+    (2) idempotence of the statistics: post-filter Stats of a run == pre-filter Stats of a run
+        over exactly the passing fragments with trimming/filters off;
+    (3) partition invariance: counters of one batch == sum of counters of its two halves."""
+    import torch
+
+    opt = abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
+                                 complexity_filter=1)
+    seq_t, qual_t, off_t, max_len = synth.device_batch(20000, seed=9, median_len=8000)
+    n = off_t.numel() - 1
+    eng = engine_mod.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=max_len)
+    rt = eng.process_device(seq_t, qual_t, off_t, max_len)
+    torch.cuda.synchronize()
+    res = eng.results_to_numpy(rt, n)
+    cnt = eng.counters()
+    C = eng.max_cycles
+    eng.close()
+    off = off_t.cpu().numpy().astype(np.int64)
+    lens = np.diff(off)
+    v = abi.CountersView(cnt, C, 2)
+    assert int(v.pre.reads) == n and int(v.pre.length_sum) == int(lens.sum())
+    assert int(v.pre.cyc[:, 0, :].sum()) == int(lens.sum())
+    assert int(v.pre.base_qual_hist.sum()) == int(lens.sum())
+    # (1)
+    alive = res["dropped"] == 0
+    assert (res["r1_start"][alive] + res["r1_len"][alive] <= lens[alive]).all()
+    for i in range(2):
+        m = res["n_frag"] > i
+        assert (res["frag_start"][m, i] >= res["r1_start"][m]).all()
+        assert (res["frag_start"][m, i] + res["frag_len"][m, i] <= res["r1_start"][m] + res["r1_len"][m]).all()
+    assert int(v.filter.sum()) == int(res["n_frag"].sum())
+    passing = [(res["n_frag"] > i) & (res["code"][:, i] == 0) for i in range(2)]
+    assert int(v.post.reads) == int(passing[0].sum() + passing[1].sum())
+    assert int(v.post.length_sum) == int(res["frag_len"][:, 0][passing[0]].sum() + res["frag_len"][:, 1][passing[1]].sum())
+    # (2) build the batch of passing fragments on the device and run it with everything off
+    starts = np.concatenate([off[:-1][passing[i]] + res["frag_start"][:, i][passing[i]] for i in range(2)])
+    flens = np.concatenate([res["frag_len"][:, i][passing[i]] for i in range(2)]).astype(np.int64)
+    foff = np.zeros(len(flens) + 1, np.int64)
+    foff[1:] = np.cumsum(flens)
+    idx = torch.from_numpy(np.repeat(starts - foff[:-1], flens)).cuda() + torch.arange(int(foff[-1]), device="cuda")
+    fseq, fqual = seq_t[idx], qual_t[idx]
+    plain = abi.FplOptions.default(adapter_enabled=0, qual_filter=0, length_filter=0)
+    eng2 = engine_mod.Engine(plain, "", "", device=0, max_cycles=C)
+    eng2.process_device(fseq, fqual, torch.from_numpy(foff).cuda(), int(flens.max()))
+    cnt2 = eng2.counters()
+    eng2.close()
+    v2 = abi.CountersView(cnt2, C, 2)
+    for f in ("cyc", "base_qual_hist", "median_hist", "median_bases", "kmer", "reads", "length_sum"):
+        assert np.array_equal(np.asarray(getattr(v.post, f)), np.asarray(getattr(v2.pre, f))), f
+    # (3)
+    h = n // 2
+    eng3 = engine_mod.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=C)
+    cut = int(off[h])
+    eng3.process_device(seq_t[:cut], qual_t[:cut], off_t[:h + 1].contiguous(), max_len)
+    eng3.process_device(seq_t[cut:].contiguous(), qual_t[cut:].contiguous(), (off_t[h:] - cut).contiguous(), max_len)
+    cnt3 = eng3.counters()
+    eng3.close()
+    assert np.array_equal(cnt, cnt3)

@@ -1,0 +1,102 @@
+"""The product kernels (fastplong_amd/csrc/kernels.h), compiled for the host on the test-only
+lock-step emulator, against the oracle on seeded batches.  This is host-logic coverage for the
+`-m "not gpu"` run; the real parity tests (-m gpu) run the same comparisons on an MI355X."""
+import numpy as np
+import pytest
+
+from fastplong_amd import abi, synth
+from tests import parity
+from tests.emu import emu
+
+
+def _lev_cases(rng, n):
+    for _ in range(n):
+        alen = int(rng.choice([1, 2, 6, 15, 16, 17, 24, 33, 63, 64, 65, 100, 128, 129, 200, 255]))
+        ad = "".join("ACGTN"[i] for i in rng.integers(0, 5, alen))
+        yield ad
+
+
+def test_bitparallel_levenshtein_matches_oracle(orc):
+    rng = np.random.default_rng(3)
+    L = emu.lib()
+    for ad in _lev_cases(rng, 120):
+        alen = len(ad)
+        adb = ad.encode()
+        for _ in range(6):
+            # (shift, m) slices as the kernels use them: whole adapter, suffix, prefix
+            m = int(rng.integers(1, alen + 1))
+            shift = int(rng.choice([0, alen - m]))
+            pat = ad[shift:shift + m]
+            n = int(rng.choice([m, m, max(0, m - 3), m + 5]))
+            if rng.random() < 0.6:
+                text = list(pat[:n].ljust(n, "A"))
+                for i in np.nonzero(rng.random(n) < 0.2)[0]:
+                    text[i] = "ACGT"[rng.integers(4)]
+                text = "".join(text)
+            else:
+                text = "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+            want = orc.edit_distance(pat, text)
+            got = L.emu_lev_bp64(adb, alen, shift, m, text.encode(), n)
+            assert got == want, (ad, shift, m, text)
+        plen = min(16, alen)
+        for _ in range(4):
+            text = "".join("ACGTN"[i] for i in rng.integers(0, 5, plen))
+            assert L.emu_lev_bp32_start(adb, alen, text.encode(), plen) == orc.edit_distance(ad[alen - plen:], text)
+            assert L.emu_lev_bp32_end(adb, alen, text.encode(), plen) == orc.edit_distance(ad[:plen], text)
+
+
+CASES = {
+    "defaults_adapters": dict(opt=dict(), start=synth.START_ADAPTER, end=synth.END_ADAPTER),
+    "full_pipeline": dict(opt=dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
+                                   complexity_filter=1), start=synth.START_ADAPTER, end=synth.END_ADAPTER),
+    "no_adapter_trimming": dict(opt=dict(adapter_enabled=0), start="", end=""),
+    "nasty_options": dict(opt=dict(trim_front=3, trim_tail=2, cut_front=1, cut_tail=1, cut_front_window=7,
+                                   cut_front_quality=15, cut_tail_window=3, cut_tail_quality=25, polyx=1,
+                                   polyx_min_len=8, complexity_filter=1, complexity_percent=40,
+                                   qualified_qual=33 + 20, unqualified_percent_limit=30, n_base_percent_limit=5,
+                                   avg_qual_req=12, required_length=30, max_length=350, ed_max=0.3,
+                                   trimming_extension=5), start=synth.START_ADAPTER, end=synth.END_ADAPTER),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_emulated_kernels_match_oracle_adversarial(orc, name):
+    case = CASES[name]
+    cfg = orc.Config(abi.FplOptions.default(**case["opt"]), case["start"], case["end"])
+    seq, qual, off = synth.adversarial(160, seed=hash(name) % 1000, start_adapter=synth.START_ADAPTER,
+                                       end_adapter=synth.END_ADAPTER)
+    C = int(np.diff(off.astype(np.int64)).max()) + 3
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
+def test_emulated_kernels_match_oracle_ont_like(orc):
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
+                                            complexity_filter=1), synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = synth.ont_like(24, seed=2, median_len=1500, p_middle=0.3, p_polya=0.3)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    assert (want_res["n_frag"] == 2).any()  # the middle-adapter split path ran
+
+
+def test_emulated_kernels_multi_adapter(orc):
+    fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA", "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG"]
+    cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER, fasta)
+    seq, qual, off = synth.adversarial(100, seed=21, fasta=fasta)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
+def test_emulated_kernels_empty_batch(orc):
+    cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER)
+    off = np.zeros(1, np.uint64)
+    res, cnt = emu.process_batch(cfg, np.zeros(0, np.uint8), np.zeros(0, np.uint8), off, 8)
+    assert len(res) == 0 and not cnt.any()
