@@ -32,6 +32,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: PyTorch-ROCm carries its own libamdhip64; loading ours afterwards makes the
+    # dynamic loader resolve to that same runtime, so device pointers and streams are shared.
+    # (Loading the system HIP runtime before torch leaves two runtimes in one process.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise FplError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
