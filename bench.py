@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--median-len", type=int, default=8000)
     ap.add_argument("--workload", default="c3_full_pipeline", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-bases", type=float, default=1e9, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--set", default="", help="ablation only: comma separated fpl_options overrides, e.g. adapter_enabled=0")
     ap.add_argument("--hbm-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     args = ap.parse_args()
@@ -106,7 +107,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wl = WORKLOADS[args.workload]
-    opt = abi.FplOptions.default(**wl["opt"])
+    okw = dict(wl["opt"])
+    for kv in filter(None, args.set.split(",")):
+        k, val = kv.split("=")
+        okw[k] = float(val) if k == "ed_max" else int(val)
+    opt = abi.FplOptions.default(**okw)
     # synthetic shard of this rank (weak scaling: every rank gets --reads reads of its own)
     seq_t, qual_t, off_t, max_len = synth.device_batch(args.reads, seed=1 + rank, median_len=args.median_len,
                                                        device=dev)
@@ -172,9 +177,10 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": "%s: BASELINE.json configs[%d] -- %d synthetic ONT-like reads per GPU, lognormal lengths "
+                "workload": "%s%s: BASELINE.json configs[%d] -- %d synthetic ONT-like reads per GPU, lognormal lengths "
                             "(median %d, sigma 0.5, N50 ~10 kb), Q~N(18,8), %s; inputs resident in HBM" % (
-                                args.workload, 2 if args.workload.startswith("c3") else 1, n, args.median_len,
+                                args.workload, (" [ABLATION " + args.set + "]") if args.set else "",
+                                2 if args.workload.startswith("c3") else 1, n, args.median_len,
                                 wl["flags"]),
                 "reads_per_gpu": n, "bases_per_gpu": n_bases, "max_read_len": max_len,
                 "parallelism": "shard%d (independent read shards, one RCCL all-reduce of the counters)" % world,
