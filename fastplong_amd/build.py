@@ -63,10 +63,14 @@ def build_host(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     cli_src = os.path.join(HOST, "cli.cpp")
-    if os.path.exists(cli_src) and (force or _newer(CLI, srcs + [hdr])):
+    if os.path.exists(cli_src) and (force or _newer(CLI, srcs + [hdr, LIB])):
+        build_hip(force, verbose)
         os.makedirs(os.path.dirname(CLI), exist_ok=True)
-        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", CLI, cli_src,
-               "-L" + HERE, "-lfastplong_host", "-Wl,-rpath," + HERE, "-ldl", "-lz"]
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(rocm, "include"), "-o", CLI, cli_src, "-L" + HERE, "-lfastplong_host",
+               "-lfastplong_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl",
+               "-Wl,-rpath,$ORIGIN/../fastplong_amd", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-ldl", "-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

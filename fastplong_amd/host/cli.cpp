@@ -1,0 +1,414 @@
+/*
+ * cli.cpp -- `fastplong_amd`: fastplong's command line (flag names, short forms, defaults and
+ * validation messages of reference src/main.cpp:27-103 and src/options.cpp:68-207) in front of
+ * the MI355X hot path.  The host keeps what the reference's host keeps -- FASTQ reader/writer,
+ * batching, report writers -- and calls fpl_process_batch() where the reference's workers call
+ * SingleEndProcessor::processSingleEnd() (src/seprocessor.cpp:440).
+ *
+ * Batches are cut in input order and dealt round-robin to --gpus devices (one fpl_ctx and one
+ * host thread per device); outputs are written back in input order; at the end the per-device
+ * counter buffers are summed with one RCCL all-reduce (the replacement of Stats::merge /
+ * FilterResult::merge, src/seprocessor.cpp:108-121) and rank 0's copy feeds the reports.
+ *
+ * Not implemented (SURVEY.md section 8f "next" rows): adapter auto-detection (an undetected
+ * "auto" is used literally, as the reference does when detection fails), --break / --mask,
+ * --split*, the HTML report.
+ */
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fastplong_amd.h"
+#include "fastq.h"
+#include "report.h"
+
+using namespace std;
+
+static void error_exit(const string& msg) { /* src/util.h:270-273 */
+    cerr << "ERROR: " << msg << endl;
+    exit(-1);
+}
+
+struct Flag {
+    const char* name;
+    char shortc;
+    bool has_value;
+    const char* def;
+};
+/* the flag table of src/main.cpp:27-103, plus --gpus / --batch_mbases of this host */
+static const Flag FLAGS[] = {
+    {"in", 'i', true, ""}, {"out", 'o', true, ""}, {"failed_out", 0, true, ""}, {"compression", 'z', true, "4"},
+    {"stdin", 0, false, ""}, {"stdout", 0, false, ""}, {"reads_to_process", 0, true, "0"}, {"dont_overwrite", 0, false, ""},
+    {"verbose", 'V', false, ""}, {"disable_adapter_trimming", 'A', false, ""}, {"start_adapter", 's', true, "auto"},
+    {"end_adapter", 'e', true, "auto"}, {"adapter_fasta", 'a', true, ""}, {"distance_threshold", 'd', true, "0.25"},
+    {"trimming_extension", 0, true, "10"}, {"trim_front", 'f', true, "0"}, {"trim_tail", 't', true, "0"},
+    {"trim_poly_x", 'x', false, ""}, {"poly_x_min_len", 0, true, "10"}, {"cut_front", '5', false, ""},
+    {"cut_tail", '3', false, ""}, {"cut_window_size", 'W', true, "4"}, {"cut_mean_quality", 'M', true, "20"},
+    {"cut_front_window_size", 0, true, "4"}, {"cut_front_mean_quality", 0, true, "20"},
+    {"cut_tail_window_size", 0, true, "4"}, {"cut_tail_mean_quality", 0, true, "20"}, {"mask", 'N', false, ""},
+    {"mask_window_size", 0, true, "50"}, {"mask_mean_quality", 0, true, "10"}, {"break", 'b', false, ""},
+    {"break_window_size", 0, true, "100"}, {"break_mean_quality", 0, true, "10"},
+    {"disable_quality_filtering", 'Q', false, ""}, {"qualified_quality_phred", 'q', true, "15"},
+    {"unqualified_percent_limit", 'u', true, "40"}, {"n_base_limit", 0, true, "1000000"},
+    {"n_percent_limit", 'n', true, "10"}, {"mean_qual", 'm', true, "0"}, {"disable_length_filtering", 'L', false, ""},
+    {"length_required", 'l', true, "20"}, {"length_limit", 0, true, "0"}, {"low_complexity_filter", 'y', false, ""},
+    {"complexity_threshold", 'Y', true, "30"}, {"json", 'j', true, "fastplong.json"}, {"html", 'h', true, "fastplong.html"},
+    {"report_title", 'R', true, "fastplong report"}, {"thread", 'w', true, "3"}, {"split", 0, true, "0"},
+    {"split_by_lines", 0, true, "0"}, {"split_prefix_digits", 0, true, "4"},
+    {"gpus", 0, true, "1"}, {"batch_mbases", 0, true, "256"}, {"batch_reads", 0, true, "0"},
+};
+
+struct Args {
+    map<string, string> val;
+    map<string, bool> seen;
+    bool exist(const string& k) const { return seen.count(k) > 0; }
+    string str(const string& k) const { return val.at(k); }
+    int i(const string& k) const { return atoi(val.at(k).c_str()); }
+    long l(const string& k) const { return atol(val.at(k).c_str()); }
+    double d(const string& k) const { return atof(val.at(k).c_str()); }
+};
+
+static Args parse(int argc, char** argv) {
+    Args a;
+    for (const Flag& f : FLAGS) a.val[f.name] = f.def;
+    for (int i = 1; i < argc; i++) {
+        string t = argv[i];
+        const Flag* fl = nullptr;
+        string inline_val;
+        bool has_inline = false;
+        if (t.rfind("--", 0) == 0) {
+            string name = t.substr(2);
+            size_t eq = name.find('=');
+            if (eq != string::npos) {
+                inline_val = name.substr(eq + 1);
+                name = name.substr(0, eq);
+                has_inline = true;
+            }
+            for (const Flag& f : FLAGS)
+                if (name == f.name) fl = &f;
+            if (!fl) error_exit("undefined option: --" + name);
+        } else if (t.size() == 2 && t[0] == '-') {
+            for (const Flag& f : FLAGS)
+                if (f.shortc && t[1] == f.shortc) fl = &f;
+            if (!fl) error_exit("undefined short option: " + t);
+        } else {
+            error_exit("unexpected argument: " + t);
+        }
+        a.seen[fl->name] = true;
+        if (fl->has_value) {
+            if (has_inline) a.val[fl->name] = inline_val;
+            else {
+                if (i + 1 >= argc) error_exit(string("option needs value: --") + fl->name);
+                a.val[fl->name] = argv[++i];
+            }
+        }
+    }
+    return a;
+}
+
+/* Sequence::reverseComplement, src/sequence.cpp:29-77: A<->T, C<->G (either case), else N */
+static string reverse_complement(const string& s) {
+    string r(s.rbegin(), s.rend());
+    for (char& c : r) {
+        switch (c) {
+            case 'A': case 'a': c = 'T'; break;
+            case 'T': case 't': c = 'A'; break;
+            case 'C': case 'c': c = 'G'; break;
+            case 'G': case 'g': c = 'C'; break;
+            default: c = 'N';
+        }
+    }
+    return r;
+}
+
+/* FastaReader + Options::loadFastaAdapters (src/fastareader.cpp:45-101, src/options.cpp:39-66): records keyed
+ * by the full header line (=> visited in header-sorted order), sequences upper-cased and stripped to
+ * letters / '-' / '*', entries shorter than 6 skipped. */
+static vector<string> load_fasta_adapters(const string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) error_exit("There is a problem with the provided fasta file: could NOT read " + path);
+    string data;
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) data.append(buf, n);
+    fclose(f);
+    map<string, string> contigs;
+    size_t p = data.find('>');
+    while (p != string::npos) {
+        size_t eol = data.find('\n', p);
+        if (eol == string::npos) eol = data.size();
+        string header = data.substr(p + 1, eol - p - 1);
+        size_t next = data.find('>', eol);
+        string body = data.substr(min(eol + 1, data.size()), (next == string::npos ? data.size() : next) - min(eol + 1, data.size()));
+        string seq;
+        for (char c : body) {
+            if (c >= 'a' && c <= 'z') c -= ('a' - 'A');
+            if (isalpha((unsigned char)c) || c == '-' || c == '*') seq += c;
+        }
+        contigs[header] = seq;
+        p = next;
+    }
+    vector<string> out;
+    for (auto& kv : contigs) {
+        if (kv.second.length() >= 6) out.push_back(kv.second);
+        else cerr << "skip too short adapter sequence in " << path << " (6bp required): " << kv.second << endl;
+    }
+    return out;
+}
+
+struct Device {
+    fpl_ctx* ctx = nullptr;
+    fplh::Batch batch;
+    vector<fpl_read_result> res;
+    string out, failed;
+    int rc = 0;
+};
+
+int main(int argc, char* argv[]) {
+    if (argc == 1) {
+        cerr << "fastplong_amd: fastplong's per-read hot path on MI355X" << endl << "version 0.4.1-compatible" << endl;
+        return 0;
+    }
+    if (argc == 2 && (strcmp(argv[1], "-v") == 0 || strcmp(argv[1], "--version") == 0)) {
+        cout << "fastplong 0.4.1" << endl;
+        return 0;
+    }
+    Args cmd = parse(argc, argv);
+
+    string in = cmd.str("in"), out = cmd.str("out"), failedOut = cmd.str("failed_out");
+    const bool fromStdin = cmd.exist("stdin"), toStdout = cmd.exist("stdout");
+    const int readsToProcess = cmd.i("reads_to_process");
+    if (fromStdin) in = "/dev/stdin";
+
+    fpl_options o;
+    fpl_options_default(&o);
+    o.adapter_enabled = !cmd.exist("disable_adapter_trimming");
+    string startAd = cmd.str("start_adapter"), endAd = cmd.str("end_adapter");
+    o.ed_max = cmd.d("distance_threshold");
+    o.trimming_extension = cmd.i("trimming_extension");
+    if (startAd != "auto" && endAd == "auto") endAd = reverse_complement(startAd); /* src/main.cpp:138-140 */
+    vector<string> fasta;
+    if (!cmd.str("adapter_fasta").empty()) fasta = load_fasta_adapters(cmd.str("adapter_fasta"));
+    o.trim_front = cmd.i("trim_front");
+    o.trim_tail = cmd.i("trim_tail");
+    o.polyx = cmd.exist("trim_poly_x");
+    o.polyx_min_len = cmd.i("poly_x_min_len");
+    o.cut_front = cmd.exist("cut_front");
+    o.cut_tail = cmd.exist("cut_tail");
+    const int wShared = cmd.i("cut_window_size"), qShared = cmd.i("cut_mean_quality");
+    o.cut_front_window = cmd.exist("cut_front_window_size") ? cmd.i("cut_front_window_size") : wShared;
+    o.cut_front_quality = cmd.exist("cut_front_mean_quality") ? cmd.i("cut_front_mean_quality") : qShared;
+    o.cut_tail_window = cmd.exist("cut_tail_window_size") ? cmd.i("cut_tail_window_size") : wShared;
+    o.cut_tail_quality = cmd.exist("cut_tail_mean_quality") ? cmd.i("cut_tail_mean_quality") : qShared;
+    if (!o.cut_front && !o.cut_tail &&
+        (cmd.exist("cut_window_size") || cmd.exist("cut_mean_quality") || cmd.exist("cut_front_window_size") ||
+         cmd.exist("cut_front_mean_quality") || cmd.exist("cut_tail_window_size") || cmd.exist("cut_tail_mean_quality")))
+        cerr << "WARNING: you specified the options for cutting by quality, but forgot to enable any of "
+                "cut_front/cut_tail/cut_right. This will have no effect." << endl;
+    o.qual_filter = !cmd.exist("disable_quality_filtering");
+    o.qualified_qual = 33 + cmd.i("qualified_quality_phred"); /* num2qual */
+    o.unqualified_percent_limit = cmd.i("unqualified_percent_limit");
+    o.avg_qual_req = cmd.i("mean_qual");
+    o.n_base_percent_limit = cmd.i("n_percent_limit");
+    o.n_base_limit = cmd.i("n_base_limit");
+    o.length_filter = !cmd.exist("disable_length_filtering");
+    o.required_length = cmd.i("length_required");
+    o.max_length = cmd.i("length_limit");
+    o.complexity_filter = cmd.exist("low_complexity_filter");
+    o.complexity_percent = min(100, max(0, cmd.i("complexity_threshold")));
+    if (cmd.exist("mask") || cmd.exist("break")) error_exit("--mask / --break are not implemented in fastplong_amd yet");
+    if (cmd.exist("split") || cmd.exist("split_by_lines")) error_exit("--split / --split_by_lines are not implemented in fastplong_amd");
+    const string jsonFile = cmd.str("json");
+    const int nGpus = max(1, cmd.i("gpus"));
+    const uint64_t batchBases = (uint64_t)max(1L, cmd.l("batch_mbases")) * 1000000ull;
+    const uint32_t batchReads = cmd.l("batch_reads") > 0 ? (uint32_t)cmd.l("batch_reads") : 0x3FFFFFFFu;
+
+    stringstream ss; /* src/main.cpp:252-256 */
+    for (int i = 0; i < argc; i++) ss << argv[i] << " ";
+    const string command = ss.str();
+    time_t t1 = time(NULL);
+
+    /* Options::validate, src/options.cpp:68-207 (the checks that concern this path) */
+    if (in.empty()) error_exit("read input should be specified by --in, or enable --stdin if you want to read STDIN");
+    if (toStdout && !out.empty()) {
+        cerr << "In STDOUT mode, ignore the output filename " << out << endl;
+        out = "";
+    }
+    if (!failedOut.empty() && failedOut == out) error_exit("--failed_out and --out shouldn't have same file name");
+    if (readsToProcess < 0) error_exit("the number of reads to process (--reads_to_process) cannot be negative");
+    if (o.trim_front < 0) error_exit("trim_front1 (--trim_front1) should be >0, suggest 0 ~ 100");
+    if (o.trim_tail < 0) error_exit("trim_tail1 (--trim_tail1) should be >0, suggest 0 ~ 100");
+    if (o.qualified_qual - 33 < 0 || o.qualified_qual - 33 > 93)
+        error_exit("qualitified phred (--qualified_quality_phred) should be 0 ~ 93, suggest 3 ~ 20");
+    if (o.avg_qual_req < 0 || o.avg_qual_req > 93)
+        error_exit("average quality score requirement (--mean_qual) should be 0 ~ 93, suggest 5 ~ 30");
+    if (o.unqualified_percent_limit < 0 || o.unqualified_percent_limit > 100)
+        error_exit("unqualified percent limit (--unqualified_percent_limit) should be 0 ~ 100, suggest 20 ~ 60");
+    if (o.n_base_percent_limit < 0 || o.n_base_percent_limit > 100)
+        error_exit("N base percent limit (--n_percent_limit) should be 0 ~ 100, suggest 5 ~ 20");
+    if (o.n_base_limit < 0 || o.n_base_limit > 1000000) error_exit("N base number limit (--n_base_limit) should be 0 ~ 1000000");
+    if (o.required_length < 0) error_exit("length requirement (--length_required) should be >0, suggest >50");
+    if (o.cut_front || o.cut_tail) {
+        if (wShared < 1 || wShared > 1000) error_exit("the sliding window size for cutting by quality (--cut_window_size) should be between 1~1000.");
+        if (qShared < 1 || qShared > 30) error_exit("the mean quality requirement for cutting by quality (--cut_mean_quality) should be 1 ~ 30, suggest 15 ~ 20.");
+        if (o.cut_front_window < 1 || o.cut_front_window > 1000) error_exit("the sliding window size for cutting by quality (--cut_front_window_size) should be between 1~1000.");
+        if (o.cut_front_quality < 1 || o.cut_front_quality > 30) error_exit("the mean quality requirement for cutting by quality (--cut_front_mean_quality) should be 1 ~ 30, suggest 15 ~ 20.");
+        if (o.cut_tail_window < 1 || o.cut_tail_window > 1000) error_exit("the sliding window size for cutting by quality (--cut_tail_window_size) should be between 1~1000.");
+        if (o.cut_tail_quality < 1 || o.cut_tail_quality > 30) error_exit("the mean quality requirement for cutting by quality (--cut_tail_mean_quality) should be 1 ~ 30, suggest 13 ~ 20.");
+    }
+    if (startAd != "auto" && !startAd.empty()) {
+        if (startAd.length() <= 3) error_exit("the sequence of <adapter_sequence> should be longer than 3");
+        for (char c : startAd)
+            if (c != 'A' && c != 'T' && c != 'C' && c != 'G')
+                error_exit("the adapter <adapter_sequence> can only have bases in {A, T, C, G}, but the given sequence is: " + startAd);
+    }
+    if (o.ed_max < 0 || o.ed_max > 1.0) error_exit("the adapter <distance_threshold> should be 0.0 ~ 1.0, suggest 0.1 ~ 0.3");
+    if (o.trimming_extension < 0 || o.trimming_extension > 100) error_exit("the adapter <trimming_extension> should be 0 ~ 100, suggest 5 ~ 30");
+    if (o.adapter_enabled && (startAd == "auto" || endAd == "auto"))
+        cerr << "NOTE: adapter auto-detection is not implemented in fastplong_amd; an undetected adapter is used "
+                "literally as \"auto\", exactly as the reference does when detection finds nothing. Pass -s/-e." << endl;
+
+    /* Evaluator::evaluateSeqLenAndCheckRNA, src/evaluator.cpp:16-61: U vs T in the first 100 reads */
+    bool isRNA = false;
+    if (!fromStdin && in != "/dev/stdin") {
+        fplh::FastqReader ev(in);
+        if (!ev.ok()) error_exit("Failed to open file: " + in);
+        fplh::Batch b;
+        ev.fill(b, ~0ull, 100);
+        long numT = 0, numU = 0;
+        for (uint8_t c : b.seq) {
+            numT += c == 'T';
+            numU += c == 'U';
+        }
+        if (numT > 0 && numU > 0) error_exit("This data contains both U and T");
+        if (numU > 0) {
+            isRNA = true;
+            cerr << "RNA direct sequencing data" << endl;
+        }
+    }
+
+    /* one context + one host thread per device */
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < nGpus)
+        error_exit("fastplong_amd needs " + to_string(nGpus) + " HIP device(s); there is no CPU path");
+    vector<fpl_adapter> fa(fasta.size());
+    for (size_t i = 0; i < fasta.size(); i++) fa[i] = fpl_adapter{fasta[i].data(), (int32_t)fasta[i].size()};
+    vector<Device> dev(nGpus);
+    for (int d = 0; d < nGpus; d++) {
+        int rc = fpl_create(&dev[d].ctx, &o, startAd.data(), (int32_t)startAd.size(), endAd.data(), (int32_t)endAd.size(),
+                            fa.data(), (int32_t)fa.size(), d, 65536);
+        if (rc != FPL_OK) error_exit(string("fpl_create: ") + fpl_strerror(rc));
+    }
+
+    fplh::FastqReader reader(in);
+    if (!reader.ok()) error_exit("Failed to open file: " + in);
+    auto open_out = [](const string& path) -> gzFile {
+        if (path.empty()) return nullptr;
+        const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+        gzFile f = gzopen(path.c_str(), gz ? "wb4" : "wbT"); /* "T": transparent (no compression) */
+        if (!f) error_exit("Failed to write: " + path);
+        return f;
+    };
+    gzFile fout = toStdout ? gzdopen(1, "wbT") : open_out(out);
+    gzFile ffail = open_out(failedOut);
+
+    long readsLeft = readsToProcess > 0 ? readsToProcess : -1;
+    bool done = false;
+    while (!done) {
+        int used = 0;
+        for (int d = 0; d < nGpus && !done; d++) { /* cut the next nGpus batches in input order */
+            Device& D = dev[d];
+            D.batch.clear();
+            uint32_t maxReads = batchReads;
+            if (readsLeft >= 0) maxReads = (uint32_t)min<long>(readsLeft, maxReads);
+            if (maxReads == 0 || reader.fill(D.batch, batchBases, maxReads) == 0) {
+                done = true;
+                break;
+            }
+            if (readsLeft >= 0) readsLeft -= D.batch.n();
+            used++;
+        }
+        vector<thread> th;
+        for (int d = 0; d < used; d++)
+            th.emplace_back([&, d]() {
+                Device& D = dev[d];
+                D.res.resize(D.batch.n());
+                D.rc = fpl_process_batch(D.ctx, D.batch.seq.data(), D.batch.qual.data(), D.batch.off.data(), D.batch.n(),
+                                         D.res.data());
+                D.out.clear();
+                D.failed.clear();
+                if (D.rc == FPL_OK) fplh::format_batch(D.batch, D.res.data(), D.out, ffail ? &D.failed : nullptr);
+            });
+        for (auto& t : th) t.join();
+        for (int d = 0; d < used; d++) { /* in input order */
+            Device& D = dev[d];
+            if (D.rc != FPL_OK) error_exit(string("fpl_process_batch: ") + fpl_strerror(D.rc) + " " + fpl_last_error(D.ctx));
+            if (fout && !D.out.empty()) gzwrite(fout, D.out.data(), (unsigned)D.out.size());
+            if (ffail && !D.failed.empty()) gzwrite(ffail, D.failed.data(), (unsigned)D.failed.size());
+        }
+    }
+    if (fout) gzclose(fout);
+    if (ffail) gzclose(ffail);
+
+    /* merge: agree on the per-cycle capacity, then ONE all-reduce (sum, int64) over RCCL */
+    uint32_t C = 0;
+    for (auto& D : dev) C = max(C, fpl_max_cycles(D.ctx));
+    for (auto& D : dev)
+        if (fpl_reserve_cycles(D.ctx, C) != FPL_OK) error_exit("fpl_reserve_cycles failed");
+    const size_t ncnt = fpl_counters_len(dev[0].ctx);
+    if (nGpus > 1) {
+        vector<ncclComm_t> comms(nGpus);
+        vector<int> ids(nGpus);
+        for (int d = 0; d < nGpus; d++) ids[d] = d;
+        if (ncclCommInitAll(comms.data(), nGpus, ids.data()) != ncclSuccess) error_exit("ncclCommInitAll failed");
+        ncclGroupStart();
+        for (int d = 0; d < nGpus; d++) {
+            (void)hipSetDevice(d);
+            void* p = fpl_counters_device_ptr(dev[d].ctx);
+            ncclAllReduce(p, p, ncnt, ncclInt64, ncclSum, comms[d], 0);
+        }
+        ncclGroupEnd();
+        for (int d = 0; d < nGpus; d++) {
+            (void)hipSetDevice(d);
+            (void)hipDeviceSynchronize();
+            ncclCommDestroy(comms[d]);
+        }
+    }
+    vector<int64_t> counters(ncnt);
+    if (fpl_get_counters(dev[0].ctx, counters.data(), ncnt) != FPL_OK) error_exit("fpl_get_counters failed");
+    for (auto& D : dev) fpl_destroy(D.ctx);
+
+    fplh::ReportInputs ri;
+    ri.counters = counters.data();
+    ri.C = C;
+    ri.adapters.push_back(startAd);
+    ri.adapters.push_back(endAd);
+    for (auto& s : fasta) ri.adapters.push_back(s);
+    ri.adapter_enabled = o.adapter_enabled;
+    ri.polyx = o.polyx;
+    ri.complexity = o.complexity_filter;
+    ri.length_filter = o.length_filter;
+    ri.max_length = o.max_length;
+    ri.is_rna = isRNA;
+    ri.command = command;
+    cerr << fplh::summary_text(ri);
+    if (!fplh::write_json(jsonFile, ri)) error_exit("Failed to write: " + jsonFile);
+
+    time_t t2 = time(NULL);
+    cerr << endl << "JSON report: " << jsonFile << endl;
+    cerr << endl << command << endl;
+    cerr << "fastplong v0.4.1 (fastplong_amd), time used: " << (t2) - t1 << " seconds" << endl;
+    return 0;
+}

@@ -1,0 +1,101 @@
+"""Committed golden fixtures (tests/golden/*, produced by tests/golden/make_golden.py from the
+oracle + the real reference report writer).  CPU: the oracle and the host formatter reproduce
+them.  GPU (-m gpu): the `fastplong_amd` CLI -- FASTQ in, HIP path through the C-ABI, FASTQ +
+fastplong.json out -- reproduces them byte for byte (JSON modulo the `command` line)."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from fastplong_amd import abi, build, synth
+from tests import hostio
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+CASES = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+
+OPTS = {
+    "c1_qualfilter": (dict(adapter_enabled=0), "auto", "auto"),
+    "c3_full": (dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1),
+                synth.START_ADAPTER, synth.END_ADAPTER),
+    "c5_fasta": (dict(ed_max=0.3, trimming_extension=5, required_length=30, n_base_percent_limit=5, avg_qual_req=12),
+                 synth.START_ADAPTER, synth.revcomp(synth.START_ADAPTER)),
+}
+
+
+def gz(path):
+    with gzip.open(path, "rb") as f:
+        return f.read()
+
+
+def parse_fastq(text):
+    lines = text.split(b"\n")
+    names, strands, seqs, quals = [], [], [], []
+    for i in range(0, len(lines) - 1, 4):
+        names.append(lines[i])
+        seqs.append(np.frombuffer(lines[i + 1], np.uint8))
+        strands.append(lines[i + 2])
+        quals.append(np.frombuffer(lines[i + 3], np.uint8))
+    seq, qual, off = synth.pack(list(zip(seqs, quals)))
+    return seq, qual, off, names, strands
+
+
+def fasta_list(case):
+    p = os.path.join(GOLD, case, "ADAPTERS.fa")
+    if not os.path.exists(p):
+        return []
+    recs, name = {}, None
+    for line in open(p):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            name = line[1:]
+            recs[name] = ""
+        else:
+            recs[name] += line
+    return [recs[k].upper() for k in sorted(recs) if len(recs[k]) >= 6]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_reproduces_golden(orc, case):
+    okw, start, end = OPTS[case]
+    seq, qual, off, names, strands = parse_fastq(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    cfg = orc.Config(abi.FplOptions.default(**okw), start, end, fasta_list(case))
+    res, counters = orc.process_batch(cfg, seq, qual, off)
+    out, failed = hostio.expected_outputs(seq, qual, off, names, strands, res)
+    assert out == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    assert failed == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    C = int(np.diff(off.astype(np.int64)).max())
+    assert int(abi.CountersView(counters, C, cfg.n_adapters).post.reads) == meta["fragments_passing"]
+    # the JSON fixture agrees with the oracle's counters on the headline numbers
+    js = json.loads(gz(os.path.join(GOLD, case, "expected.json.gz")).replace(b"},\n}", b"}\n}"))
+    v = abi.CountersView(counters, C, cfg.n_adapters)
+    assert js["summary"]["before_filtering"]["total_reads"] == int(v.pre.reads) == meta["reads"]
+    assert js["summary"]["after_filtering"]["total_reads"] == int(v.post.reads)
+    assert js["filtering_result"]["passed_filter_reads"] == int(v.filter[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("batch_reads", ["0", "37"])  # 37 reads per batch: several batches, counters accumulate
+def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
+    build.build_all()
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    flags = [f if f != "ADAPTERS.fa" else os.path.join(GOLD, case, "ADAPTERS.fa") for f in meta["flags"]]
+    cmd = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "--failed_out", str(tmp_path / "failed.fq"),
+           "-j", str(tmp_path / "out.json"), "--batch_reads", batch_reads] + flags
+    if batch_reads != "0":
+        cmd += ["--reads_to_process", str(meta["reads"])]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert (tmp_path / "out.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    assert (tmp_path / "failed.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
+    got = [l for l in (tmp_path / "out.json").read_bytes().split(b"\n") if not l.startswith(b'\t"command":')]
+    want = gz(os.path.join(GOLD, case, "expected.json.gz")).split(b"\n")
+    assert got == want
+    assert b"reads passed filter: " in p.stderr

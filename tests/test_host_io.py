@@ -1,0 +1,104 @@
+"""Host side of the path on the CPU: FASTQ -> CSR batches, result records -> output FASTQ text
+(fastplong_amd/host/fastq.cpp), and the record formats pinned against the real reference
+Read::breakByGap / appendToString / appendToStringWithTag (oracle/_ref)."""
+import ctypes as C
+import gzip
+
+import numpy as np
+import pytest
+
+from fastplong_amd import abi, build, synth
+from tests import hostio
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    build.build_host()
+    L = C.CDLL(build.HOST_LIB)
+    L.fplh_batch_read.restype = C.c_void_p
+    L.fplh_batch_read.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32]
+    L.fplh_batch_n.restype = C.c_uint32
+    L.fplh_batch_n.argtypes = [C.c_void_p]
+    L.fplh_batch_bytes.restype = C.c_uint64
+    L.fplh_batch_bytes.argtypes = [C.c_void_p]
+    for f in (L.fplh_batch_seq, L.fplh_batch_qual, L.fplh_batch_off):
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p]
+    L.fplh_batch_free.argtypes = [C.c_void_p]
+    L.fplh_format_batch.restype = C.c_int
+    L.fplh_format_batch.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.fplh_free.argtypes = [C.c_void_p]
+    return L
+
+
+def read_batch(L, path):
+    b = L.fplh_batch_read(str(path).encode(), 2 ** 62, 2 ** 30)
+    assert b
+    n, nb = L.fplh_batch_n(b), L.fplh_batch_bytes(b)
+    seq = np.ctypeslib.as_array(C.cast(L.fplh_batch_seq(b), C.POINTER(C.c_uint8)), (max(nb, 1),))[:nb].copy()
+    qual = np.ctypeslib.as_array(C.cast(L.fplh_batch_qual(b), C.POINTER(C.c_uint8)), (max(nb, 1),))[:nb].copy()
+    off = np.ctypeslib.as_array(C.cast(L.fplh_batch_off(b), C.POINTER(C.c_uint64)), (n + 1,)).copy()
+    return b, seq, qual, off
+
+
+@pytest.mark.parametrize("variant", ["plain", "crlf", "gz", "noeol", "junk"])
+def test_fastq_to_csr(hostlib, tmp_path, variant):
+    seq, qual, off = synth.adversarial(200, seed=3)
+    # the reader cannot represent a record whose sequence line is empty differently from a blank
+    # line between records; the reference has the same property -- keep empty reads out of this file
+    keep = np.nonzero(np.diff(off.astype(np.int64)) > 0)[0]
+    reads = [(seq[int(off[i]):int(off[i + 1])], qual[int(off[i]):int(off[i + 1])]) for i in keep]
+    seq, qual, off = synth.pack(reads)
+    text, names, strands = hostio.make_fastq(seq, qual, off, crlf=(variant == "crlf"), strand_names=True)
+    if variant == "noeol":
+        text = text[:-1]
+    if variant == "junk":  # blank lines and stray non-@ lines between records are skipped
+        text = b"\n\ngarbage line\n" + text
+    p = tmp_path / ("in.fq.gz" if variant == "gz" else "in.fq")
+    if variant == "gz":
+        with gzip.open(p, "wb") as f:
+            f.write(text)
+    else:
+        p.write_bytes(text)
+    b, s2, q2, o2 = read_batch(hostlib, p)
+    hostlib.fplh_batch_free(b)
+    assert np.array_equal(o2, off) and np.array_equal(s2, seq) and np.array_equal(q2, qual)
+
+
+def test_format_batch_matches_python_composition(orc, hostlib, tmp_path):
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1, complexity_filter=1),
+                     synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = synth.adversarial(400, seed=8)
+    keep = np.nonzero(np.diff(off.astype(np.int64)) > 0)[0]
+    seq, qual, off = synth.pack([(seq[int(off[i]):int(off[i + 1])], qual[int(off[i]):int(off[i + 1])]) for i in keep])
+    text, names, strands = hostio.make_fastq(seq, qual, off, strand_names=True)
+    p = tmp_path / "in.fq"
+    p.write_bytes(text)
+    res, _ = orc.process_batch(cfg, seq, qual, off)
+    assert (res["n_frag"] == 2).any() and (res["dropped"] == 1).any()
+    b, *_ = read_batch(hostlib, p)
+    out, failed = C.c_void_p(), C.c_void_p()
+    ol, fl = C.c_uint64(), C.c_uint64()
+    assert hostlib.fplh_format_batch(b, res.ctypes.data, C.byref(out), C.byref(ol), C.byref(failed), C.byref(fl)) == 0
+    got_out, got_failed = C.string_at(out, ol.value), C.string_at(failed, fl.value)
+    hostlib.fplh_free(out)
+    hostlib.fplh_free(failed)
+    hostlib.fplh_batch_free(b)
+    want_out, want_failed = hostio.expected_outputs(seq, qual, off, names, strands, res)
+    assert got_out == want_out
+    assert got_failed == want_failed
+    assert len(want_failed) > 0 and b"split-by-adapter-right-" in want_out
+
+
+def test_record_formats_match_reference(ref):
+    """names of split fragments and the failed-read tag line, from the reference's own Read code"""
+    out = ref.run(["BG 3 2 =@r1_desc =ACGTACGTAC =+xyz =IIIIIJJJJJ"])
+    head, body = out.split("\n", 1)
+    assert head.split()[0] == "2"
+    assert body == "@split-by-adapter-left-r1_desc\nACG\n+xyz\nIII\n@split-by-adapter-right-r1_desc\nCGTAC\n+xyz\nJJJJJ\n"
+    for code, tag in ((12, "failed_too_many_n_bases"), (16, "failed_too_short"), (17, "failed_too_long"),
+                      (20, "failed_quality_filter"), (24, "failed_low_complexity")):
+        assert abi.FAILED_TYPES[code] == tag
+        out = ref.run(["TAG %d =@r1 =ACGT =+ =IIII" % code])
+        assert out.split("\n", 1)[1] == "@r1 %s\nACGT\n+\nIIII\n" % tag
