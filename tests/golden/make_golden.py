@@ -58,6 +58,7 @@ def main():
         for (s, q, o) in (a, b):
             reads += [(s[int(o[i]):int(o[i + 1])], q[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1) if o[i + 1] > o[i]]
         seq, qual, off = synth.pack(reads)
+        seq[seq == ord("U")] = ord("R")  # a file with both U and T is rejected up front (src/evaluator.cpp:50-52)
         text, names, strands = hostio.make_fastq(seq, qual, off, strand_names=True)
         cfg = oracle.Config(abi.FplOptions.default(**c["opt"]), c["start"], c["end"], fasta)
         C = int(np.diff(off.astype(np.int64)).max())
