@@ -90,7 +90,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from fastplong_amd import abi, engine, synth
+    from fastplong_amd import abi, dist as fdist, engine, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -118,10 +118,7 @@ def main():
     n = off_t.numel() - 1
     n_bases = int(off_t[-1].item())
     # all ranks agree on the per-cycle capacity so that the counter buffers line up for the all-reduce
-    cap = torch.tensor([max_len], device=dev, dtype=torch.int64)
-    if world > 1:
-        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-    C = int(cap.item())
+    C = fdist.agree_capacity(max_len, device=dev)
     eng = engine.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=local_rank, max_cycles=C)
     res_t = torch.empty(n * 36, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -142,7 +139,7 @@ def main():
         step()
     if world > 1:
         # the only collective of the path: sum the Stats / FilterResult counters over RCCL
-        dist.all_reduce(eng.counters_tensor(), op=dist.ReduceOp.SUM)
+        fdist.allreduce_counters(eng.counters_tensor())
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
