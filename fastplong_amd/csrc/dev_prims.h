@@ -98,6 +98,69 @@ __device__ __forceinline__ u32 alignbyte(u32 hi, u32 lo, u32 n) {
 #endif
 }
 
+/* bits [n, n+32) of the 64-bit value hi:lo, n in 0..31 */
+__device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 n) {
+#ifdef FPL_EMU
+    return (u32)(((((u64)hi) << 32) | lo) >> (n & 31));
+#else
+    return __builtin_amdgcn_alignbit(hi, lo, n);
+#endif
+}
+
+/* any three-input bitwise function in one VALU op (v_bitop3_b32); TT = f(0xF0, 0xCC, 0xAA) */
+template <int TT>
+__device__ __forceinline__ u32 bitop3(u32 a, u32 b, u32 c) {
+#ifdef FPL_EMU
+    u32 r = 0;
+    for (int i = 0; i < 32; i++) {
+        const int idx = (((a >> i) & 1) << 2) | (((b >> i) & 1) << 1) | ((c >> i) & 1);
+        r |= (u32)((TT >> idx) & 1) << i;
+    }
+    return r;
+#else
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#endif
+}
+/* carry-save adder on bit-planes: (h, l) = a + b + c */
+__device__ __forceinline__ void csa(u32& h, u32& l, u32 a, u32 b, u32 c) {
+    const u32 hh = bitop3<0xE8>(a, b, c); /* majority */
+    l = bitop3<0x96>(a, b, c);            /* parity   */
+    h = hh;
+}
+
+/* sum over the 4 bytes of a.byte * b.byte, plus c (v_dot4_u32_u8) */
+__device__ __forceinline__ u32 udot4(u32 a, u32 b, u32 c) {
+#ifdef FPL_EMU
+    u32 r = c;
+    for (int i = 0; i < 4; i++) r += ((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+    return r;
+#else
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+/* sum of the 4 bytes of a, plus c (v_sad_u8 against 0) */
+__device__ __forceinline__ u32 sum_bytes(u32 a, u32 c) {
+#ifdef FPL_EMU
+    return c + (a & 0xFF) + ((a >> 8) & 0xFF) + ((a >> 16) & 0xFF) + (a >> 24);
+#else
+    return __builtin_amdgcn_sad_u8(a, 0u, c);
+#endif
+}
+/* result byte i = byte sel.byte[i] (0..3) of tbl (v_perm_b32 with a zero high half) */
+__device__ __forceinline__ u32 perm_lo(u32 tbl, u32 sel) {
+#ifdef FPL_EMU
+    u32 r = 0;
+    for (int i = 0; i < 4; i++) {
+        const u32 k = (sel >> (8 * i)) & 0xFF;
+        r |= ((k < 4 ? (tbl >> (8 * k)) : 0) & 0xFF) << (8 * i);
+    }
+    return r;
+#else
+    return __builtin_amdgcn_perm(0u, tbl, sel);
+#endif
+}
+__device__ __forceinline__ u32 popc32(u32 x) { return (u32)__popc(x); }
+
 /* 0x01 in every byte of x that is non-zero */
 __device__ __forceinline__ u32 nonzero_bytes01(u32 x) {
     u32 y = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;

@@ -24,6 +24,10 @@ struct DevAdapter {
     uint32_t peq16_start[256];   /* Myers Peq of the LAST plen bytes  (start trim, :203)  */
     uint32_t peq16_end[256];     /* Myers Peq of the FIRST plen bytes (end trim,   :274)  */
     uint64_t peq_full[256][PEQ_WORDS]; /* Myers Peq of the whole adapter, bit j <-> seq[j]  */
+    /* bit-sliced middle-adapter scan (k_scan): for adapter offset i, (plane word offset << 8) | shift,
+       plane word offset = code(seq[i]) * 64 + (i >> 5), shift = i & 31, code A0 C1 T2 G3 */
+    uint32_t term[64];
+    int32_t acgt_only; /* every byte is one of A C G T and len <= 64 */
 };
 
 /* Options as the kernels consume them: integers only. */
@@ -38,6 +42,7 @@ struct DevConfig {
     int32_t qual_filter, qualified_qual, unqual_pct, n_base_limit, n_pct_limit, avg_qual_req;
     int32_t length_filter, required_length, max_length;
     int32_t complexity, complexity_pct;
+    int32_t ham_fast; /* both command-line adapters are ACGT-only and <= 64 long: bit-sliced scan */
     int32_t thr[FPL_MAX_ADAPTER_LEN + 1]; /* (int)round(ed_max * len), computed in double on the host */
 };
 
@@ -57,6 +62,13 @@ inline void build_adapter(DevAdapter* a, const char* seq, int len) {
         a->seq[i] = c;
         a->seqw[i] = 0x01010101u * c;
         a->peq_full[c][i >> 6] |= 1ull << (i & 63);
+    }
+    a->acgt_only = len <= 64;
+    for (int i = 0; i < len && i < 64; i++) {
+        const uint8_t c = (uint8_t)seq[i];
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') a->acgt_only = 0;
+        const uint32_t code = (c >> 1) & 3u; /* A0 C1 T2 G3 */
+        a->term[i] = ((code * 64u + (uint32_t)(i >> 5)) << 8) | (uint32_t)(i & 31);
     }
     for (int j = 0; j < a->plen; j++) {
         a->peq16_start[(uint8_t)seq[len - a->plen + j]] |= 1u << j;

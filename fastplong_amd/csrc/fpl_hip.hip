@@ -128,6 +128,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         build_adapter(&ads[0], start_adapter, start_len);
         build_adapter(&ads[1], end_adapter, end_len);
         for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
+        cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
         FPL_HIP(hipMalloc((void**)&ctx->d_cfg, sizeof(DevConfig)));
         FPL_HIP(hipMemcpy(ctx->d_cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
         FPL_HIP(hipMalloc((void**)&ctx->d_ads, sizeof(DevAdapter) * ads.size()));

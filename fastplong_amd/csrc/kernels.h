@@ -634,7 +634,15 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
 /* =========================================================================================
  * k_scan
  * ======================================================================================= */
-constexpr int HIST_COPIES = 32; /* per-wave quality histogram: 128 bins x 32 lane-copies (bank = lane & 31) */
+constexpr int HIST_COPIES = 16; /* per-wave quality histogram: 128 bins x 16 lane-copies */
+constexpr int SC_CHUNK = 32;    /* bases per lane per tile in the bit-sliced scan */
+constexpr int SC_LANES_HAM = 62; /* lanes 62/63 only provide the plane words the last windows reach into */
+
+/* per-wave LDS of k_scan */
+struct ScanWaveLds {
+    u32 planes[4][64];            /* letter bit-planes of the current tile: [A,C,T,G][chunk] */
+    u32 hist[128 * HIST_COPIES];
+};
 
 struct ScanBlockAcc {
     u64 bqh[2][128];   /* mBaseQualHistogram        pre / post */
@@ -714,7 +722,7 @@ __device__ __forceinline__ void hamming16(const u8* __restrict__ p, const u8* __
  *     p in [0, (b-a) - alen), as keys (mismatches << 32 | p), ~0 when nothing was tested.
  */
 template <bool SUMS, bool HAM>
-__device__ inline void range_scan(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
+__device__ inline void range_scan_bytes(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
                                   const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
                                   u32* __restrict__ h, int qualified_qual, RangeSums& sums,
                                   const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
@@ -791,6 +799,232 @@ __device__ inline void range_scan(const u8* __restrict__ rb, const u8* __restric
     }
 }
 
+
+/* ---- bit-sliced scan ------------------------------------------------------------------
+ * Letter bit-planes of 32 bases held as 8 dwords: bit j of P_X = (base j == X), X in A C T G,
+ * compared as raw bytes (lower case, N, U, ... match nothing).  byte -> bit compaction with
+ * v_dot4_u32_u8 against power-of-two weights: 4 bases per instruction and plane. */
+__device__ __forceinline__ void build_planes(const u32 s[8], u32& PA, u32& PC, u32& PT, u32& PG) {
+    u32 L = 0, H = 0, X = 0;
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+        u32 lb = 0, hb = 0, xb = 0;
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const u32 w = s[2 * pr + hh];
+            const u32 wt = hh ? 0x80402010u : 0x08040201u;
+            const u32 w1 = w >> 1;
+            lb = udot4(w1 & 0x01010101u, wt, lb);        /* ASCII bit 1: A0 C1 T0 G1 */
+            hb = udot4((w >> 2) & 0x01010101u, wt, hb);  /* ASCII bit 2: A0 C0 T1 G1 */
+            const u32 e = perm_lo(0x47544341u, w1 & 0x03030303u); /* the letter that code stands for */
+            const u32 t = e ^ w;                                   /* zero byte <=> exactly that letter */
+            const u32 nz = ((((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) >> 7) & 0x01010101u;
+            xb = udot4(nz, wt, xb);
+        }
+        L |= lb << (8 * pr);
+        H |= hb << (8 * pr);
+        X |= xb << (8 * pr);
+    }
+    const u32 V = ~X;
+    PA = bitop3<0x10>(V, H, L); /* V & ~H & ~L */
+    PC = bitop3<0x20>(V, H, L); /* V & ~H &  L */
+    PT = bitop3<0x40>(V, H, L); /* V &  H & ~L */
+    PG = bitop3<0x80>(V, H, L); /* V &  H &  L */
+}
+
+/* Number of adapter bases that match at each of this lane's 32 positions, as 7 bit-planes
+ * (count <= 64).  plane_lane = &planes[0][lane] in LDS; term i fetches the plane of adapter letter
+ * i shifted by i positions (two neighbouring words + v_alignbit); Harley-Seal carry-save adders
+ * (v_bitop3 majority / parity) sum eight 1-bit planes with seven CSAs. */
+__device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane, const DevAdapter* __restrict__ ad, u32 B[7]) {
+    const int alen = ad->len;
+#pragma unroll
+    for (int b = 0; b < 7; b++) B[b] = 0;
+    for (int i0 = 0; i0 < alen; i0 += 8) {
+        u32 m[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            m[k] = 0;
+            if (i0 + k < alen) { /* wave-uniform */
+                const u32 tw = ad->term[i0 + k];
+                const u32* p = plane_lane + (tw >> 8);
+                m[k] = alignbit(p[1], p[0], tw & 31u);
+            }
+        }
+        u32 t1, t2, t3, t4, f1, f2, e;
+        csa(t1, B[0], B[0], m[0], m[1]);
+        csa(t2, B[0], B[0], m[2], m[3]);
+        csa(f1, B[1], B[1], t1, t2);
+        csa(t3, B[0], B[0], m[4], m[5]);
+        csa(t4, B[0], B[0], m[6], m[7]);
+        csa(f2, B[1], B[1], t3, t4);
+        csa(e, B[2], B[2], f1, f2);
+        u32 c = e; /* ripple the eights carry upwards */
+#pragma unroll
+        for (int b = 3; b < 7; b++) {
+            const u32 t = B[b] & c;
+            B[b] ^= c;
+            c = t;
+        }
+    }
+}
+
+/* largest count among the positions in `cand` (non-zero) and the first position holding it */
+__device__ __forceinline__ void sliced_max(const u32 B[7], u32 cand, int& val, int& first) {
+    val = 0;
+#pragma unroll
+    for (int b = 6; b >= 0; b--) {
+        const u32 t = cand & B[b];
+        if (t) {
+            cand = t;
+            val |= 1 << b;
+        }
+    }
+    first = __ffs(cand) - 1;
+}
+
+/* passFilter sums over 32 bytes with SWAR byte tricks (quality and base bytes < 128):
+ *   lowq: bytes with q < qq          totq: sum of q (v_sad_u8)
+ *   nn  : bytes == 'N'               diff: bytes that differ from their predecessor (pw = byte before s[0]) */
+__device__ __forceinline__ void sums32(const u32 s[8], const u32 q[8], u32 prev_dword, u32 qqrep, u32& lowq, u32& nn,
+                                       u32& totq, u32& diff) {
+    u32 pd = prev_dword;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const u32 t = (q[d] | 0x80808080u) - qqrep; /* per byte, no borrow: bit 7 survives iff q >= qq */
+        lowq += popc32(~t & 0x80808080u);
+        totq = sum_bytes(q[d], totq);
+        const u32 x = s[d] ^ 0x4E4E4E4Eu;
+        const u32 zx = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+        nn += popc32(~zx & 0x80808080u);
+        const u32 y = s[d] ^ alignbyte(s[d], pd, 3);
+        const u32 zy = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
+        diff += popc32(zy & 0x80808080u);
+        pd = s[d];
+    }
+}
+
+/*
+ * One pass over bytes [a, b) of a read, 32 bases per lane and tile:
+ *   - quality histogram into w->hist,
+ *   - the passFilter sums (src/filter.cpp:27-39, 67-81) when SUMS,
+ *   - when HAM, the Hamming argmin of both middle-adapter scans (searchAdapter default mode,
+ *     src/adaptertrimmer.cpp:133-151: positions p in [0, (b-a) - alen), first global minimum)
+ *     by the bit-sliced method above; keys (mismatches << 32 | p), ~0 when nothing was tested.
+ *     Requires ACGT-only adapters of <= 64 bases (DevConfig::ham_fast).
+ */
+template <bool SUMS, bool HAM>
+__device__ inline void range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
+                                       const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
+                                       ScanWaveLds* __restrict__ w, int qualified_qual, RangeSums& sums,
+                                       const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
+                                       u64& key0, u64& key1) {
+    const int lane = lane_id();
+    const int blen = b - a;
+    constexpr int ACTIVE = HAM ? SC_LANES_HAM : 64;
+    constexpr int ADV = ACTIVE * SC_CHUNK;
+    u32* const h = w->hist;
+    u32 lowq = 0, nn = 0, totq = 0, diff = 0;
+    int bm0 = -1, bp0 = 0, bm1 = -1, bp1 = 0; /* best match count / its position, per lane */
+    const int npos0 = HAM ? blen - ad0->len : 0, npos1 = HAM ? blen - ad1->len : 0;
+    const u32 qqrep = 0x01010101u * (u32)(qualified_qual & 0x7F);
+    u32 prev_tile_last = 0;
+    for (int t0 = 0; t0 < blen; t0 += ADV) {
+        const int j0 = t0 + SC_CHUNK * lane;
+        const int navail = blen > j0 ? min(SC_CHUNK, blen - j0) : 0; /* bytes of the range in this chunk */
+        const int nstat = lane < ACTIVE ? navail : 0;                 /* bytes this lane accounts for */
+        u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (navail > 0) {
+            const u32x4 s0 = load16_guard(rb + a + j0, seq_end), s1 = load16_guard(rb + a + j0 + 16, seq_end);
+            s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w;
+            s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+        }
+        if (nstat > 0) {
+            const u32x4 q0 = load16_guard(qb + a + j0, qual_end), q1 = load16_guard(qb + a + j0 + 16, qual_end);
+            q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
+            q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+        }
+        /* predecessor of this chunk's first byte: last dword of the previous lane / previous tile */
+        u32 prevd = shfl_up_u32(s[7], 1);
+        if (lane == 0) prevd = prev_tile_last;
+        prev_tile_last = shfl_u32(s[7], ACTIVE - 1);
+        if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
+        if (nstat == SC_CHUNK) {
+#pragma unroll
+            for (int k = 0; k < SC_CHUNK; k++) {
+                const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0x7Fu;
+                atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
+            }
+            if (SUMS) sums32(s, q, prevd, qqrep, lowq, nn, totq, diff);
+        } else if (nstat > 0) { /* ragged last chunk */
+            u32 pb = prevd >> 24;
+            for (int k = 0; k < nstat; k++) {
+                const u32 bb = (s[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                atomicAdd(&h[(qq & 127u) * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
+                if (SUMS) {
+                    lowq += ((int)qq < qualified_qual);
+                    nn += (bb == 'N');
+                    totq += qq;
+                    diff += (bb != pb) && (j0 + k > 0);
+                    pb = bb;
+                }
+            }
+        }
+        if (HAM) {
+            if (npos0 > t0 || npos1 > t0) { /* wave-uniform: some window of this tile is tested */
+                u32 PA, PC, PT, PG;
+                build_planes(s, PA, PC, PT, PG);
+                wave_sync(); /* previous tile's plane reads are done */
+                w->planes[0][lane] = PA;
+                w->planes[1][lane] = PC;
+                w->planes[2][lane] = PT;
+                w->planes[3][lane] = PG;
+                wave_sync();
+                /* lanes 62/63 hold halo words only; their (clamped) plane reads are never used */
+                const u32* plane_lane = &w->planes[0][lane < ACTIVE ? lane : 0];
+                u32 B[7];
+                if (npos0 > t0) {
+                    match_counts(plane_lane, ad0, B);
+                    const int nv = npos0 - j0;
+                    const u32 vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+                    if (vm) {
+                        int val, first;
+                        sliced_max(B, vm, val, first);
+                        if (val > bm0) {
+                            bm0 = val;
+                            bp0 = j0 + first;
+                        }
+                    }
+                }
+                if (npos1 > t0) {
+                    match_counts(plane_lane, ad1, B);
+                    const int nv = npos1 - j0;
+                    const u32 vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+                    if (vm) {
+                        int val, first;
+                        sliced_max(B, vm, val, first);
+                        if (val > bm1) {
+                            bm1 = val;
+                            bp1 = j0 + first;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (SUMS) {
+        sums.lowq = wave_sum_u32(lowq);
+        sums.nn = wave_sum_u32(nn);
+        sums.totq = wave_sum_u32(totq);
+        sums.diff = wave_sum_u32(diff);
+    }
+    if (HAM) {
+        key0 = wave_min_u64(bm0 < 0 ? ~0ull : (((u64)(u32)(ad0->len - bm0) << 32) | (u32)bp0));
+        key1 = wave_min_u64(bm1 < 0 ? ~0ull : (((u64)(u32)(ad1->len - bm1) << 32) | (u32)bp1));
+    }
+}
+
 /* Filter::passFilter + passLowComplexityFilter from the sums, src/filter.cpp:12-81.  The
  * reference's double comparisons are equivalent to these integer cross-multiplications
  * ("float <-> integer equivalences"). */
@@ -821,10 +1055,11 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
        const ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
        uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, long long* __restrict__ counters, u32 C,
        u32* __restrict__ work_ctr) {
-    __shared__ u32 hist_all[WAVES][128 * HIST_COPIES];
+    __shared__ ScanWaveLds wlds[WAVES];
     __shared__ ScanBlockAcc acc;
     const int lane = lane_id();
-    u32* h = hist_all[wave_in_block()];
+    ScanWaveLds* const wl = &wlds[wave_in_block()];
+    u32* h = wl->hist;
     {
         u64* z = (u64*)&acc;
         for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
@@ -853,16 +1088,20 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         RangeSums sm = {0, 0, 0, 0};
         u64 key0 = ~0ull, key1 = ~0ull;
         const bool ham = !dropped && cfg->adapter_enabled;
-        if (ham) range_scan<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
-        else range_scan<true, false>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, nullptr, nullptr, key0, key1);
+        if (ham && cfg->ham_fast)
+            range_scan_fast<true, true>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, &ads[0], &ads[1], key0, key1);
+        else if (ham) /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
+            range_scan_bytes<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
+        else
+            range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, nullptr, nullptr, key0, key1);
         u32 hb0, hb1;
         hist_totals(h, hb0, hb1);
         /* ---- the trimmed-off ends only feed the pre-filter histogram */
         {
             RangeSums dummy;
             u64 d0, d1;
-            if (s > 0) range_scan<false, false>(rb, qb, 0, s, seq_end, qual_end, h, qq, dummy, nullptr, nullptr, d0, d1);
-            if (l > e) range_scan<false, false>(rb, qb, e, l, seq_end, qual_end, h, qq, dummy, nullptr, nullptr, d0, d1);
+            if (s > 0) range_scan_fast<false, false>(rb, qb, 0, s, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+            if (l > e) range_scan_fast<false, false>(rb, qb, e, l, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
         }
         u32 ht0, ht1;
         hist_totals(h, ht0, ht1);
@@ -961,7 +1200,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 if (split) { /* rare: re-derive sums and histogram for this fragment */
                     hist_zero(h);
                     u64 d0, d1;
-                    range_scan<true, false>(rb, qb, fa[f], fb[f], seq_end, qual_end, h, qq, fs, nullptr, nullptr, d0, d1);
+                    range_scan_fast<true, false>(rb, qb, fa[f], fb[f], seq_end, qual_end, wl, qq, fs, nullptr, nullptr, d0, d1);
                     hist_totals(h, t0, t1);
                 }
                 const int code = filter_code(cfg, flen, fs);

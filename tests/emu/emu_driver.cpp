@@ -23,6 +23,8 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     build_adapter(&ads[0], start, start_len);
     build_adapter(&ads[1], end, end_len);
     for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
+    cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
+    if (getenv("FPL_EMU_NO_HAM_FAST")) cfg.ham_fast = 0;
 
     uint64_t n_bytes = n_reads ? off[n_reads] : 0;
     uint32_t max_len = 0;

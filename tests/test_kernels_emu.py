@@ -100,3 +100,15 @@ def test_emulated_kernels_empty_batch(orc):
     off = np.zeros(1, np.uint64)
     res, cnt = emu.process_batch(cfg, np.zeros(0, np.uint8), np.zeros(0, np.uint8), off, 8)
     assert len(res) == 0 and not cnt.any()
+
+
+def test_emulated_kernels_byte_scan_fallback(orc):
+    """adapters with bytes outside ACGT (or longer than 64) take the byte-wise scan in k_scan"""
+    cfg = orc.Config(abi.FplOptions.default(), "AAGGATTCATTCCNACGGTAACAC", "GTGTTACCGTNGGAATGAATCCTT")
+    seq, qual, off = synth.adversarial(80, seed=5, start_adapter="AAGGATTCATTCCNACGGTAACAC",
+                                       end_adapter="GTGTTACCGTNGGAATGAATCCTT")
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
