@@ -14,6 +14,12 @@
 #include <hip/hip_runtime.h>
 #endif
 
+#ifdef FPL_EMU
+#define FPL_NOINLINE
+#else
+#define FPL_NOINLINE __attribute__((noinline))
+#endif
+
 namespace fpl {
 
 constexpr int WAVE = 64;
@@ -174,14 +180,17 @@ __device__ __forceinline__ u32x4 load16(const u8* p) {
     __builtin_memcpy(&v, p, 16);
     return v;
 }
-/* guarded variant: bytes at or beyond `end` read as 0 */
-__device__ __forceinline__ u32x4 load16_guard(const u8* p, const u8* end) {
-    if (p + 16 <= end) return load16(p);
+/* guarded variant: bytes at or beyond `end` read as 0 (the slow tail path is kept out of line) */
+__device__ FPL_NOINLINE u32x4 load16_tail(const u8* p, const u8* end) {
     u32 w[4] = {0, 0, 0, 0};
     for (int i = 0; i < 16; i++)
         if (p + i < end) w[i >> 2] |= (u32)p[i] << (8 * (i & 3));
     u32x4 v = {w[0], w[1], w[2], w[3]};
     return v;
+}
+__device__ __forceinline__ u32x4 load16_guard(const u8* p, const u8* end) {
+    if (p + 16 <= end) return load16(p);
+    return load16_tail(p, end);
 }
 __device__ __forceinline__ u32 load4_guard(const u8* p, const u8* end) {
     u32 w = 0;

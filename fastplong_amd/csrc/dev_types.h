@@ -42,6 +42,7 @@ struct DevConfig {
     int32_t qual_filter, qualified_qual, unqual_pct, n_base_limit, n_pct_limit, avg_qual_req;
     int32_t length_filter, required_length, max_length;
     int32_t complexity, complexity_pct;
+    int32_t dbg;      /* FPL_DEBUG_FLAGS: ablation switches for profiling (wrong results when set) */
     int32_t ham_fast; /* both command-line adapters are ACGT-only and <= 64 long: bit-sliced scan */
     int32_t thr[FPL_MAX_ADAPTER_LEN + 1]; /* (int)round(ed_max * len), computed in double on the host */
 };
@@ -64,6 +65,7 @@ inline void build_adapter(DevAdapter* a, const char* seq, int len) {
         a->peq_full[c][i >> 6] |= 1ull << (i & 63);
     }
     a->acgt_only = len <= 64;
+    for (int i = 0; i < 64; i++) a->term[i] = (4u * 64u) << 8; /* padding: the all-zero plane row */
     for (int i = 0; i < len && i < 64; i++) {
         const uint8_t c = (uint8_t)seq[i];
         if (c != 'A' && c != 'C' && c != 'G' && c != 'T') a->acgt_only = 0;

@@ -18,6 +18,7 @@ using namespace fpl;
 struct fpl_ctx {
     int device = -1;
     u32 n_cu = 256;
+    int dbg = 0;
     int n_adapters = 2;
     u32 C = 0;
     DevConfig* d_cfg = nullptr;
@@ -129,6 +130,8 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         build_adapter(&ads[1], end_adapter, end_len);
         for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
         cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
+        if (const char* e = getenv("FPL_DEBUG_FLAGS")) cfg.dbg = atoi(e);
+        ctx->dbg = cfg.dbg;
         FPL_HIP(hipMalloc((void**)&ctx->d_cfg, sizeof(DevConfig)));
         FPL_HIP(hipMemcpy(ctx->d_cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
         FPL_HIP(hipMalloc((void**)&ctx->d_ads, sizeof(DevAdapter) * ads.size()));
@@ -269,6 +272,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.C = ctx->C;
     a.work_ctr = ctx->d_work_ctr;
     a.n_cu = ctx->n_cu;
+    a.dbg = ctx->dbg;
     const bool timing = ctx->timing != 0;
     const int slot = ctx->ev_calls % fpl_ctx::EV_RING;
     hipError_t ev_err = hipSuccess;

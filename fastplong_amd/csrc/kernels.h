@@ -538,7 +538,7 @@ template <int WAVES, bool PRE>
 __global__ void __launch_bounds__(WAVES * 64)
 k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_bytes,
               const uint64_t* __restrict__ item_off, const u32* __restrict__ item_len, u32 n_items,
-              u32 items_per_slice, long long* __restrict__ stats, u32 C) {
+              u32 items_per_slice, long long* __restrict__ stats, u32 C, int dbg) {
     __shared__ u64 cyc[8 * CS_T];
     __shared__ u32 kmer[1024];
     const int lane = lane_id();
@@ -551,31 +551,53 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
     const u32 i_end = min(n_items, i_begin + items_per_slice);
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
+    const u32 c0 = tile_start + 16 * lane; /* cycle of this lane's first byte */
 
+    /* One wave = 64 candidate items per round: offsets and lengths arrive with one coalesced load,
+       the items that reach this tile are walked from the ballot mask, and the 16-byte loads of the
+       NEXT item are in flight while the current one is counted (two-deep software pipeline). */
     for (u32 ib = i_begin + 64 * wave_in_block(); ib < i_end; ib += 64 * WAVES) {
         const u32 it = ib + lane;
         u32 L = 0;
-        if (it < i_end) L = PRE ? (u32)(item_off[it + 1] - item_off[it]) : item_len[it];
+        uint64_t st = 0;
+        if (it < i_end) {
+            st = item_off[it];
+            L = PRE ? (u32)(item_off[it + 1] - st) : item_len[it];
+        }
         u64 m = wave_ballot(L > tile_start);
-        while (m) {
-            const int b = __ffsll(m) - 1;
-            m &= m - 1;
-            const u32 itemL = shfl_u32(L, b);
-            const uint64_t start = item_off[ib + b];
-            const u32 c0 = tile_start + 16 * lane; /* cycle of this lane's first byte */
+        if (!m) continue;
+        u32x4 svN = {0, 0, 0, 0}, qvN = {0, 0, 0, 0};
+        u32 haloN = 0, LN = 0;
+        auto issue = [&](int bit) { /* start the loads of item `bit` of this round */
+            LN = shfl_u32(L, bit);
+            const uint64_t start = shfl_u64(st, bit);
+            svN = {0, 0, 0, 0};
+            qvN = {0, 0, 0, 0};
+            if (LN > c0) {
+                svN = load16_guard(seq + start + c0, seq_end);
+                qvN = load16_guard(qual + start + c0, qual_end);
+            }
+            haloN = 0;
+            if (lane == 0 && tile_start >= 4) haloN = load4_guard(seq + start + tile_start - 4, seq_end);
+        };
+        int b = __ffsll(m) - 1;
+        m &= m - 1;
+        issue(b);
+        for (;;) {
+            const u32x4 sv = svN, qv = qvN;
+            const u32 itemL = LN;
+            u32 halo = haloN;
+            const bool more = m != 0;
+            if (more) {
+                b = __ffsll(m) - 1;
+                m &= m - 1;
+                issue(b);
+            }
             const int nvalid = itemL > c0 ? (int)min(16u, itemL - c0) : 0;
-            u32x4 sv = {0, 0, 0, 0}, qv = {0, 0, 0, 0};
-            if (nvalid > 0) {
-                sv = load16_guard(seq + start + c0, seq_end);
-                qv = load16_guard(qual + start + c0, qual_end);
-            }
             /* the four bases in front of this lane's chunk: previous lane's last dword */
-            u32 halo = shfl_up_u32(sv.w, 1);
-            bool have_halo = true;
-            if (lane == 0) {
-                have_halo = tile_start >= 4;
-                halo = have_halo ? load4_guard(seq + start + tile_start - 4, seq_end) : 0;
-            }
+            const u32 up = shfl_up_u32(sv.w, 1);
+            const bool have_halo = lane > 0 || tile_start >= 4;
+            if (lane > 0) halo = up;
             if (nvalid > 0) {
                 int run = 0;
                 u32 kidx = 0;
@@ -596,19 +618,21 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
                         const u32 bb = (sw[k >> 2] >> (8 * (k & 3))) & 0xFF;
                         const u32 q = (qw[k >> 2] >> (8 * (k & 3))) & 0xFF;
                         const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);
-                        atomicAdd(&cyc[(bb & 7u) * CS_T + k * 64 + lane], inc);
+                        if (!(dbg & 8)) atomicAdd(&cyc[(bb & 7u) * CS_T + k * 64 + lane], inc);
                         bool v;
                         const int val = base2val_dev(bb, v);
                         run = v ? run + 1 : 0;
                         kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
-                        if (run >= 5) atomicAdd(&kmer[kidx], 1u);
+                        if (run >= 5 && !(dbg & 16)) atomicAdd(&kmer[kidx], 1u);
                     }
                 }
             }
+            if (!more) break;
         }
     }
     __syncthreads();
     /* flush: slot -> cycle, unpack, one global atomic per non-zero counter */
+    if (dbg & 32) return;
     for (u32 slot = threadIdx.x; slot < CS_T; slot += blockDim.x) {
         const u32 c = tile_start + 16 * (slot & 63) + (slot >> 6);
         if (c < C) {
@@ -640,7 +664,7 @@ constexpr int SC_LANES_HAM = 62; /* lanes 62/63 only provide the plane words the
 
 /* per-wave LDS of k_scan */
 struct ScanWaveLds {
-    u32 planes[4][64];            /* letter bit-planes of the current tile: [A,C,T,G][chunk] */
+    u32 planes[5][64];            /* letter bit-planes of the current tile: [A,C,T,G][chunk]; row 4 stays zero */
     u32 hist[128 * HIST_COPIES];
 };
 
@@ -843,13 +867,10 @@ __device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane,
     for (int i0 = 0; i0 < alen; i0 += 8) {
         u32 m[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            m[k] = 0;
-            if (i0 + k < alen) { /* wave-uniform */
-                const u32 tw = ad->term[i0 + k];
-                const u32* p = plane_lane + (tw >> 8);
-                m[k] = alignbit(p[1], p[0], tw & 31u);
-            }
+        for (int k = 0; k < 8; k++) { /* terms past alen point at the all-zero plane row */
+            const u32 tw = ad->term[i0 + k];
+            const u32* p = plane_lane + (tw >> 8);
+            m[k] = alignbit(p[1], p[0], tw & 31u);
         }
         u32 t1, t2, t3, t4, f1, f2, e;
         csa(t1, B[0], B[0], m[0], m[1]);
@@ -914,11 +935,11 @@ __device__ __forceinline__ void sums32(const u32 s[8], const u32 q[8], u32 prev_
  *     Requires ACGT-only adapters of <= 64 bases (DevConfig::ham_fast).
  */
 template <bool SUMS, bool HAM>
-__device__ inline void range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
-                                       const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
-                                       ScanWaveLds* __restrict__ w, int qualified_qual, RangeSums& sums,
-                                       const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
-                                       u64& key0, u64& key1) {
+__device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
+                                                const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
+                                                ScanWaveLds* __restrict__ w, int qualified_qual, RangeSums& sums,
+                                                const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
+                                                u64& key0, u64& key1) {
     const int lane = lane_id();
     const int blen = b - a;
     constexpr int ACTIVE = HAM ? SC_LANES_HAM : 64;
@@ -927,6 +948,8 @@ __device__ inline void range_scan_fast(const u8* __restrict__ rb, const u8* __re
     u32 lowq = 0, nn = 0, totq = 0, diff = 0;
     int bm0 = -1, bp0 = 0, bm1 = -1, bp1 = 0; /* best match count / its position, per lane */
     const int npos0 = HAM ? blen - ad0->len : 0, npos1 = HAM ? blen - ad1->len : 0;
+    const int dbg = qualified_qual >> 8; /* ablation switches ride in the high bits */
+    qualified_qual &= 0xFF;
     const u32 qqrep = 0x01010101u * (u32)(qualified_qual & 0x7F);
     u32 prev_tile_last = 0;
     for (int t0 = 0; t0 < blen; t0 += ADV) {
@@ -950,12 +973,15 @@ __device__ inline void range_scan_fast(const u8* __restrict__ rb, const u8* __re
         prev_tile_last = shfl_u32(s[7], ACTIVE - 1);
         if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
         if (nstat == SC_CHUNK) {
+            if (!(dbg & 1)) {
 #pragma unroll
-            for (int k = 0; k < SC_CHUNK; k++) {
-                const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0x7Fu;
-                atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
+                for (int k = 0; k < SC_CHUNK; k++) {
+                    const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0x7Fu;
+                    atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
+                }
             }
-            if (SUMS) sums32(s, q, prevd, qqrep, lowq, nn, totq, diff);
+            if (SUMS && !(dbg & 2)) sums32(s, q, prevd, qqrep, lowq, nn, totq, diff);
+            if (dbg & 4) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
         } else if (nstat > 0) { /* ragged last chunk */
             u32 pb = prevd >> 24;
             for (int k = 0; k < nstat; k++) {
@@ -1054,12 +1080,13 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
        uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
        const ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
        uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, long long* __restrict__ counters, u32 C,
-       u32* __restrict__ work_ctr) {
+       u32* __restrict__ work_ctr, u32 chunk) {
     __shared__ ScanWaveLds wlds[WAVES];
     __shared__ ScanBlockAcc acc;
     const int lane = lane_id();
     ScanWaveLds* const wl = &wlds[wave_in_block()];
     u32* h = wl->hist;
+    wl->planes[4][lane] = 0;
     {
         u64* z = (u64*)&acc;
         for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
@@ -1067,13 +1094,21 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     __syncthreads();
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
-    const int qq = cfg->qualified_qual;
+    const int qq = cfg->qualified_qual | (cfg->dbg << 8);
 
+    /* dynamic work distribution in chunks: one device-scope atomic serves `chunk` reads (a single
+       hot counter sustains only ~80 atomics/us, which a per-read dequeue would saturate) */
+    u32 chunk_next = 0, chunk_end = 0;
     for (;;) {
-        u32 ri = 0;
-        if (lane == 0) ri = atomicAdd(work_ctr, 1u);
-        ri = shfl_u32(ri, 0);
-        if (ri >= n_reads) break;
+        if (chunk_next >= chunk_end) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(work_ctr, chunk);
+            base = shfl_u32(base, 0);
+            if (base >= n_reads) break;
+            chunk_next = base;
+            chunk_end = min(n_reads, base + chunk);
+        }
+        const u32 ri = chunk_next++;
         const uint64_t o0 = off[ri];
         const int l = (int)(off[ri + 1] - o0);
         const u8* rb = seq + o0;

@@ -18,10 +18,12 @@ namespace fpl {
 
 #ifdef FPL_EMU
 constexpr int KWAVES = 2; /* two waves per block keep the emulator's thread count low */
+constexpr int SWAVES = 2;
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
 typedef void* fpl_stream_t;
 #else
 constexpr int KWAVES = 4;
+constexpr int SWAVES = 8; /* k_cycle_stats: 8 waves share one 68 KiB LDS table -> 16 waves per CU */
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 typedef hipStream_t fpl_stream_t;
 #endif
@@ -43,6 +45,7 @@ struct BatchArgs {
     u32 C;
     u32* work_ctr; /* zeroed before the batch */
     u32 n_cu;      /* compute units of the device (grid sizing) */
+    int dbg = 0;   /* FPL_DEBUG_FLAGS ablation switches (profiling only) */
 };
 
 constexpr int N_STAGES = 4;
@@ -85,24 +88,27 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, CS_T);
     {
         const u32 per = stats_items_per_slice(n, n_tiles, a.n_cu);
-        FPL_LAUNCH((k_cycle_stats<KWAVES, true>), dim3(cdiv(n, per), n_tiles), block, stream, a.seq, a.qual, a.n_bytes,
-                   a.off, (const u32*)nullptr, n, per, a.counters + FPL_OFF_PRE(a.C), a.C);
+        FPL_LAUNCH((k_cycle_stats<SWAVES, true>), dim3(cdiv(n, per), n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
+                   a.off, (const u32*)nullptr, n, per, a.counters + FPL_OFF_PRE(a.C), a.C, a.dbg);
     }
     mark(2);
     {
         u32 blocks = cdiv(n, KWAVES);
-        const u32 cap = 2 * a.n_cu; /* LDS (64 KiB of histograms per block) admits two blocks per CU */
+        const u32 cap = 3 * a.n_cu; /* registers / LDS admit three blocks per CU */
         if (blocks > cap) blocks = cap;
+        u32 chunk = n / (blocks * KWAVES * 32u); /* ~32 dequeues per wave keep the tail short */
+        if (chunk < 1) chunk = 1;
+        if (chunk > 64) chunk = 64;
         FPL_LAUNCH((k_scan<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
-                   (const ReadState*)a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr);
+                   (const ReadState*)a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk);
     }
     mark(3);
     {
         const u32 items = 2 * n;
         const u32 per = stats_items_per_slice(items, n_tiles, a.n_cu);
-        FPL_LAUNCH((k_cycle_stats<KWAVES, false>), dim3(cdiv(items, per), n_tiles), block, stream, a.seq, a.qual,
+        FPL_LAUNCH((k_cycle_stats<SWAVES, false>), dim3(cdiv(items, per), n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual,
                    a.n_bytes, (const uint64_t*)a.frag_off, (const u32*)a.frag_len, items, per,
-                   a.counters + FPL_OFF_POST(a.C), a.C);
+                   a.counters + FPL_OFF_POST(a.C), a.C, a.dbg);
     }
     mark(4);
 }
