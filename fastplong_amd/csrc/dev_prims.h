@@ -62,6 +62,38 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
     return ((u64)hi << 32) | lo;
 }
 
+/* value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS traffic */
+__device__ __forceinline__ u32 readlane_u32(u32 v, int src) {
+#ifdef FPL_EMU
+    return shfl_u32(v, src);
+#else
+    return (u32)__builtin_amdgcn_readlane((int)v, src);
+#endif
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int src) {
+    return ((u64)readlane_u32((u32)(v >> 32), src) << 32) | readlane_u32((u32)v, src);
+}
+/* a per-lane value every lane may read at wave-uniform indices: v_readlane on the device; the
+ * emulator snapshots all 64 values once instead of paying a rendezvous per read */
+struct WaveVals64 {
+#ifdef FPL_EMU
+    u64 vals[64];
+    u64 get(int t) const { return vals[t]; }
+#else
+    u64 v;
+    __device__ __forceinline__ u64 get(int t) const { return readlane_u64(v, t); }
+#endif
+};
+__device__ __forceinline__ WaveVals64 wave_publish(u64 v) {
+    WaveVals64 w;
+#ifdef FPL_EMU
+    emu_gather_u64(v, w.vals);
+#else
+    w.v = v;
+#endif
+    return w;
+}
+
 /* wave-wide reductions / scans (all 64 lanes must call) */
 __device__ __forceinline__ u32 wave_sum_u32(u32 v) {
 #pragma unroll

@@ -29,24 +29,30 @@ namespace fpl {
  * prebuilt (DevAdapter), and the text is a window of the read.
  * ======================================================================================= */
 
-/* pattern <= 32 columns, one 32-bit word */
+/* pattern <= 16 columns in one 32-bit word; text of n <= 16 bytes.  The n table lookups are
+ * issued up front (they do not depend on the recurrence), then the recurrence runs in registers. */
 __device__ __forceinline__ int lev_bp32(const u32* __restrict__ peq, int m, const u8* __restrict__ text, int n) {
     if (m == 0) return n;
+    u32 eq[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) eq[j] = j < n ? peq[text[j]] : 0u;
     u32 Pv = ~0u, Mv = 0;
     int score = m;
     const u32 top = 1u << (m - 1);
-    for (int j = 0; j < n; j++) {
-        u32 Eq = peq[text[j]];
-        u32 Xv = Eq | Mv;
-        u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-        u32 Ph = Mv | ~(Xh | Pv);
-        u32 Mh = Pv & Xh;
-        if (Ph & top) score++;
-        else if (Mh & top) score--;
-        Ph = (Ph << 1) | 1u; /* D[0][j] = j */
-        Mh <<= 1;
-        Pv = Mh | ~(Xv | Ph);
-        Mv = Ph & Xv;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j < n) { /* wave-uniform */
+            const u32 Eq = eq[j];
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            score += (Ph & top) ? 1 : ((Mh & top) ? -1 : 0);
+            Ph = (Ph << 1) | 1u; /* D[0][j] = j */
+            Mh <<= 1;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+        }
     }
     return score;
 }
@@ -101,6 +107,67 @@ __device__ __forceinline__ int lev_bp64(const uint64_t (*__restrict__ peq)[PEQ_W
             }
         }
         score += hin;
+    }
+    return score;
+}
+
+/* Same distance, computed by the whole wave: lanes fetch text bytes and their Peq words in
+ * parallel (64 columns per round), then every lane runs the identical recurrence on
+ * v_readlane-broadcast words -- no serial chain of dependent memory loads, result wave-uniform. */
+__device__ inline int lev_wave(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
+                               const u8* __restrict__ text, int n) {
+    if (m == 0) return n;
+    if (n == 0) return m;
+    const int W = (m + 63) >> 6;
+    const int lane = lane_id();
+    u64 Pv[PEQ_WORDS], Mv[PEQ_WORDS];
+#pragma unroll
+    for (int b = 0; b < PEQ_WORDS; b++) {
+        Pv[b] = ~0ull;
+        Mv[b] = 0;
+    }
+    int score = m;
+    const u64 last_top = 1ull << ((m - 1) & 63);
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        u64 eqw[PEQ_WORDS] = {0, 0, 0, 0};
+        if (j0 + lane < n) {
+            const int c = text[j0 + lane];
+#pragma unroll
+            for (int b = 0; b < PEQ_WORDS; b++)
+                if (b < W) eqw[b] = peq_word(peq, c, shift, b);
+        }
+        WaveVals64 pub[PEQ_WORDS];
+#pragma unroll
+        for (int b = 0; b < PEQ_WORDS; b++)
+            if (b < W) pub[b] = wave_publish(eqw[b]);
+        const int cnt = min(64, n - j0);
+        for (int t = 0; t < cnt; t++) {
+            int hin = 1; /* D[0][j] - D[0][j-1] */
+#pragma unroll
+            for (int b = 0; b < PEQ_WORDS; b++) {
+                if (b < W) {
+                    u64 Eq = pub[b].get(t);
+                    const u64 pv = Pv[b], mv = Mv[b];
+                    const u64 Xv = Eq | mv;
+                    if (hin < 0) Eq |= 1ull;
+                    const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                    u64 Ph = mv | ~(Xh | pv);
+                    u64 Mh = pv & Xh;
+                    const u64 hb = (b == W - 1) ? last_top : (1ull << 63);
+                    int hout = 0;
+                    if (Ph & hb) hout = 1;
+                    else if (Mh & hb) hout = -1;
+                    Ph <<= 1;
+                    Mh <<= 1;
+                    if (hin < 0) Mh |= 1ull;
+                    else if (hin > 0) Ph |= 1ull;
+                    Pv[b] = Mh | ~(Xv | Ph);
+                    Mv[b] = Ph & Xv;
+                    hin = hout;
+                }
+            }
+            score += hin;
+        }
     }
     return score;
 }
@@ -275,13 +342,16 @@ __device__ __forceinline__ int hamming_bytes(const u8* __restrict__ r, const u8*
 /* AdapterTrimmer::trimBySequenceStart, src/adaptertrimmer.cpp:168-236 (searchAdapter in its
  * asRightAsPossible mode, :109-131, inlined).  rd = first base of the original read; [s,e) is
  * updated; returns the reference's return value; keylen = cmplen handed to addAdapterTrimmed. */
-__device__ inline int trim_start_wave(const u8* __restrict__ rd, int& s, int& e, const DevAdapter* __restrict__ ad,
-                                      const DevConfig* __restrict__ cfg, int& keylen) {
+/* r = first base of r1 -- the global read or a copy of its first 200 bytes in LDS; peq16 / peqf = the
+ * adapter's Myers tables, global or LDS copies. */
+__device__ __forceinline__ int trim_start_wave(const u8* __restrict__ r, int& s, int& e, const DevAdapter* __restrict__ ad,
+                                               const u32* __restrict__ peq16,
+                                               const uint64_t (*__restrict__ peqf)[PEQ_WORDS],
+                                               const DevConfig* __restrict__ cfg, int& keylen) {
     const int lane = lane_id();
     const int rlen = e - s;
     keylen = 0;
     if (rlen < FPL_PATTERN_LEN) return 0;
-    const u8* r = rd + s;
     const int alen = ad->len, plen = ad->plen, ext = cfg->ext;
     const int thrA = cfg->thr[alen];
     int mpos = -1;
@@ -293,7 +363,7 @@ __device__ inline int trim_start_wave(const u8* __restrict__ rd, int& s, int& e,
         for (int p0 = 0; p0 < npos; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < npos) mm = hamming_bytes(r + p, ad->seq, alen);
+            if (p < npos && !(cfg->dbg & 256)) mm = hamming_bytes(r + p, ad->seq, alen);
             const u64 m = wave_ballot(p < npos && mm <= thrA);
             if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
             if (p < npos) {
@@ -306,7 +376,7 @@ __device__ inline int trim_start_wave(const u8* __restrict__ rd, int& s, int& e,
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(u32)best;
-                const int ed = FPL_LANE0_INT(lev_bp64(ad->peq_full, 0, alen, r + pos, alen));
+                const int ed = (cfg->dbg & 64) ? 999 : lev_wave(peqf, 0, alen, r + pos, alen);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -321,10 +391,10 @@ __device__ inline int trim_start_wave(const u8* __restrict__ rd, int& s, int& e,
     const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
     const int thrP = cfg->thr[plen];
     u64 best = ~0ull;
-    for (int p0 = 0; p0 < lim; p0 += 64) {
+    for (int p0 = 0; p0 < lim && !(cfg->dbg & 128); p0 += 64) {
         const int p = p0 + lane;
         if (p < lim) {
-            const int ed = lev_bp32(ad->peq16_start, plen, r + p, plen);
+            const int ed = lev_bp32(peq16, plen, r + p, plen);
             if (ed <= thrP) {
                 const u64 k = ((u64)(u32)ed << 32) | (u32)p;
                 best = k < best ? k : best;
@@ -335,7 +405,7 @@ __device__ inline int trim_start_wave(const u8* __restrict__ rd, int& s, int& e,
     if (best != ~0ull) { /* :218-233 */
         int pos = (int)(u32)best;
         const int cmplen = min(pos + plen, alen);
-        const int ed = FPL_LANE0_INT(lev_bp64(ad->peq_full, alen - cmplen, cmplen, r + pos + plen - cmplen, cmplen));
+        const int ed = lev_wave(peqf, alen - cmplen, cmplen, r + pos + plen - cmplen, cmplen);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - alen);
             keylen = cmplen;
@@ -350,13 +420,16 @@ __device__ inline int trim_start_wave(const u8* __restrict__ rd, int& s, int& e,
 
 /* AdapterTrimmer::trimBySequenceEnd, src/adaptertrimmer.cpp:238-302 (searchAdapter in its
  * asLeftAsPossible mode, :84-107, inlined). */
-__device__ inline int trim_end_wave(const u8* __restrict__ rd, int& s, int& e, const DevAdapter* __restrict__ ad,
-                                    const DevConfig* __restrict__ cfg, int& keylen) {
+/* r = first base of r1 as an address: only its last 200 bytes are dereferenced, so r may point
+ * 200 - rlen bytes in front of an LDS copy of that tail. */
+__device__ __forceinline__ int trim_end_wave(const u8* __restrict__ r, int& s, int& e, const DevAdapter* __restrict__ ad,
+                                             const u32* __restrict__ peq16,
+                                             const uint64_t (*__restrict__ peqf)[PEQ_WORDS],
+                                             const DevConfig* __restrict__ cfg, int& keylen) {
     const int lane = lane_id();
     const int rlen = e - s;
     keylen = 0;
     if (rlen < FPL_PATTERN_LEN) return 0;
-    const u8* r = rd + s;
     const int alen = ad->len, plen = ad->plen, ext = cfg->ext;
     const int thrA = cfg->thr[alen];
     const int ss = max(0, rlen - FPL_END_WINDOW);
@@ -384,7 +457,7 @@ __device__ inline int trim_end_wave(const u8* __restrict__ rd, int& s, int& e, c
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(0xFFFFFFFFu - (u32)best);
-                const int ed = FPL_LANE0_INT(lev_bp64(ad->peq_full, 0, alen, r + pos, alen));
+                const int ed = lev_wave(peqf, 0, alen, r + pos, alen);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -404,7 +477,7 @@ __device__ inline int trim_end_wave(const u8* __restrict__ rd, int& s, int& e, c
     for (int p0 = 0; p0 < lim && !stop; p0 += 64) {
         const int p = p0 + lane;
         int ed = 0x7fffffff;
-        if (p < lim) ed = lev_bp32(ad->peq16_end, plen, r + rlen - plen - p, plen);
+        if (p < lim) ed = lev_bp32(peq16, plen, r + rlen - plen - p, plen);
         u64 q = wave_ballot(p < lim && ed <= thrP);
         while (q && !stop) {
             const int b = __ffsll(q) - 1;
@@ -423,7 +496,7 @@ __device__ inline int trim_end_wave(const u8* __restrict__ rd, int& s, int& e, c
     }
     if (pos > 0) { /* :288 strict */
         const int cmplen = min(pos + plen, alen);
-        const int ed = FPL_LANE0_INT(lev_bp64(ad->peq_full, 0, cmplen, r + rlen - plen - pos, cmplen));
+        const int ed = lev_wave(peqf, 0, cmplen, r + rlen - plen - pos, cmplen);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - plen);
             keylen = cmplen;
@@ -441,16 +514,49 @@ struct TrimBlockAcc {
     u32 key[2 * 2 * FPL_KEY_STRIDE];
 };
 
+/* LDS copies for the two command-line adapters: their 16-column Peq tables, their full Peq tables,
+ * and per wave the first / last 200 bases of the read being trimmed.  Everything the 2 x 184 Myers
+ * runs and the window Hamming scans touch is then an LDS read instead of a dependent global load. */
+constexpr int TRIM_WIN = 208; /* FPL_END_WINDOW rounded up to dwords + slack */
+template <int WAVES>
+struct TrimLds {
+    u32 peq16[2][256];             /* [0] = start adapter's peq16_start, [1] = end adapter's peq16_end */
+    uint64_t peqf[2][256][PEQ_WORDS];
+    u32 win[WAVES][2][TRIM_WIN / 4];
+};
+
+/* copy bytes [from, from + n) of a read (n <= TRIM_WIN) into this wave's window, 4 bytes per lane */
+__device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __restrict__ src, int n,
+                                             const u8* __restrict__ seq_end) {
+    const int lane = lane_id();
+    wave_sync();
+    if (lane < TRIM_WIN / 4) dst[lane] = (4 * lane < n) ? load4_guard(src + 4 * lane, seq_end) : 0u;
+    wave_sync();
+}
+
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
-            const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads, ReadState* __restrict__ state,
-            long long* __restrict__ counters, u32 C) {
+            uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
+            ReadState* __restrict__ state, long long* __restrict__ counters, u32 C) {
     __shared__ TrimBlockAcc acc;
+    __shared__ TrimLds<WAVES> lds;
     const int lane = lane_id();
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x) acc.fr[i] = 0;
     for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x) acc.key[i] = 0;
+    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
+        lds.peq16[0][i] = ads[0].peq16_start[i];
+        lds.peq16[1][i] = ads[1].peq16_end[i];
+#pragma unroll
+        for (int w = 0; w < PEQ_WORDS; w++) {
+            lds.peqf[0][i][w] = ads[0].peq_full[i][w];
+            lds.peqf[1][i][w] = ads[1].peq_full[i][w];
+        }
+    }
     __syncthreads();
+    const u8* seq_end = seq + n_bytes;
+    u32* const win_s = lds.win[wave_in_block()][0];
+    u32* const win_e = lds.win[wave_in_block()][1];
 
     const u32 wave_global = blockIdx.x * WAVES + wave_in_block();
     const u32 n_waves = gridDim.x * WAVES;
@@ -473,19 +579,31 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
         }
         if (alive && cfg->adapter_enabled) { /* src/seprocessor.cpp:205-216 */
             int trimmed = 0, kl;
-            if (cfg->has_start) {
-                trimmed += trim_start_wave(sq, s, e, &ads[0], cfg, kl);
+            if (cfg->has_start && ads[0].len <= FPL_END_WINDOW) {
+                /* the start trim only looks at r1[0, 200) */
+                stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end);
+                trimmed += trim_start_wave((const u8*)win_s, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
+                if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
+            } else if (cfg->has_start) {
+                trimmed += trim_start_wave(sq + s, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             }
-            if (cfg->has_end) {
-                trimmed += trim_end_wave(sq, s, e, &ads[1], cfg, kl);
+            if (cfg->has_end && ads[1].len <= FPL_END_WINDOW) {
+                /* the end trim only looks at the last 200 bases of r1 */
+                const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
+                stage_window(win_e, sq + e - wl, wl, seq_end);
+                trimmed += trim_end_wave((const u8*)win_e - (rlen - wl), s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
+                if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
+            } else if (cfg->has_end) {
+                trimmed += trim_end_wave(sq + s, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             }
             for (int a = 0; a < cfg->n_fasta; a++) { /* trimByMultiSequences, src/adaptertrimmer.cpp:42-57 */
-                trimmed += trim_start_wave(sq, s, e, &ads[2 + a], cfg, kl);
+                const DevAdapter* ad = &ads[2 + a];
+                trimmed += trim_start_wave(sq + s, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
                 if (kl > 0 && lane == 0)
                     atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
-                trimmed += trim_end_wave(sq, s, e, &ads[2 + a], cfg, kl);
+                trimmed += trim_end_wave(sq + s, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
                 if (kl > 0 && lane == 0)
                     atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
             }
@@ -598,6 +716,19 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
             const u32 up = shfl_up_u32(sv.w, 1);
             const bool have_halo = lane > 0 || tile_start >= 4;
             if (lane > 0) halo = up;
+            /* one byte of the tile: packed per-cycle counter + rolling 5-mer */
+#define FPL_CS_BYTE(k)                                                                                      \
+    {                                                                                                       \
+        const u32 bb = (sw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                              \
+        const u32 q = (qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                               \
+        const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);          \
+        if (!(dbg & 8)) atomicAdd(&cyc[(bb & 7u) * CS_T + (k)*64 + lane], inc);                             \
+        bool v;                                                                                             \
+        const int val = base2val_dev(bb, v);                                                                \
+        run = v ? run + 1 : 0;                                                                              \
+        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;                                                           \
+        if (run >= 5 && !(dbg & 16)) atomicAdd(&kmer[kidx], 1u);                                            \
+    }
             if (nvalid > 0) {
                 int run = 0;
                 u32 kidx = 0;
@@ -612,21 +743,16 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
                 }
                 const u32 sw[4] = {sv.x, sv.y, sv.z, sv.w};
                 const u32 qw[4] = {qv.x, qv.y, qv.z, qv.w};
+                if (itemL >= tile_start + CS_T) { /* wave-uniform: the item covers the whole tile */
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    if (k < nvalid) {
-                        const u32 bb = (sw[k >> 2] >> (8 * (k & 3))) & 0xFF;
-                        const u32 q = (qw[k >> 2] >> (8 * (k & 3))) & 0xFF;
-                        const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);
-                        if (!(dbg & 8)) atomicAdd(&cyc[(bb & 7u) * CS_T + k * 64 + lane], inc);
-                        bool v;
-                        const int val = base2val_dev(bb, v);
-                        run = v ? run + 1 : 0;
-                        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
-                        if (run >= 5 && !(dbg & 16)) atomicAdd(&kmer[kidx], 1u);
-                    }
+                    for (int k = 0; k < 16; k++) FPL_CS_BYTE(k)
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (k < nvalid) FPL_CS_BYTE(k)
                 }
             }
+#undef FPL_CS_BYTE
             if (!more) break;
         }
     }
@@ -1178,12 +1304,12 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 int sp = -1, ep = -1;
                 if (key0 != ~0ull) {
                     const int p = (int)(u32)key0;
-                    const int ed = FPL_LANE0_INT(lev_bp64(ads[0].peq_full, 0, al0, rb + s + p, al0));
+                    const int ed = lev_wave(ads[0].peq_full, 0, al0, rb + s + p, al0);
                     if (ed <= cfg->thr[al0]) sp = p;
                 }
                 if (key1 != ~0ull) {
                     const int p = (int)(u32)key1;
-                    const int ed = FPL_LANE0_INT(lev_bp64(ads[1].peq_full, 0, al1, rb + s + p, al1));
+                    const int ed = lev_wave(ads[1].peq_full, 0, al1, rb + s + p, al1);
                     if (ed <= cfg->thr[al1]) ep = p;
                 }
                 const int ext = cfg->ext;

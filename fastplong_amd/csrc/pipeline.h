@@ -81,8 +81,8 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         u32 blocks = cdiv(n, KWAVES);
         const u32 cap = 16 * a.n_cu;
         if (blocks > cap) blocks = cap;
-        FPL_LAUNCH((k_trim_ends<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.cfg, a.ads, a.state,
-                   a.counters, a.C);
+        FPL_LAUNCH((k_trim_ends<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
+                   a.state, a.counters, a.C);
     }
     mark(1);
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, CS_T);

@@ -73,6 +73,14 @@ inline auto emu_xchg(uint64_t v, F&& reader) {
     return r;
 }
 
+inline void emu_gather_u64(unsigned long long v, unsigned long long* out) {
+    emu::Wave* w = emu::t_wave;
+    w->slot[emu::t_lane] = v;
+    w->bar.arrive_and_wait();
+    for (int i = 0; i < 64; i++) out[i] = w->slot[i];
+    w->bar.arrive_and_wait();
+}
+
 inline unsigned long long __ballot(int pred) {
     return emu_xchg(pred ? 1 : 0, [](emu::Wave* w) {
         unsigned long long m = 0;
