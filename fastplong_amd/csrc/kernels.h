@@ -22,6 +22,13 @@
 
 namespace fpl {
 
+/* profiling-only ablation switches (FPL_DEBUG_FLAGS); compiled out unless -DFPL_ABLATE */
+#ifdef FPL_ABLATE
+#define FPL_DBG(x, bit) ((x) & (bit))
+#else
+#define FPL_DBG(x, bit) 0
+#endif
+
 /* =========================================================================================
  * Bit-parallel Levenshtein (Myers 1999 / Hyyro 2001, global-distance variant).  The
  * reference's edit_distance (src/editdistance.cpp:30-61,100-126) computes the same exact
@@ -339,12 +346,168 @@ __device__ __forceinline__ int hamming_bytes(const u8* __restrict__ r, const u8*
     return mm;
 }
 
+/* Byte access to r1 for the end trims.  LDSWIN: an LDS copy of a <= 200-byte window of the read
+ * (r1 byte j lives at window byte j - bias); reads are aligned ds_read_b32 + v_alignbyte, because
+ * byte-granular or unaligned wide LDS reads stall the LDS pipe.  Otherwise: the read itself in
+ * global memory (FASTA adapter chain, adapters longer than the window), byte loads. */
+template <bool LDSWIN>
+struct Win {
+    const u8* r;  /* global: first base of r1 */
+    const u32* w; /* LDS window */
+    int bias;
+    int rlen;
+    __device__ __forceinline__ u32 byte(int j) const {
+        if (LDSWIN) {
+            const int b = j - bias;
+            return (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+        }
+        return r[j];
+    }
+    /* d[k] = bytes [j + 4k, j + 4k + 4) for k < N; bytes at or beyond rlen are unspecified (LDS) / 0 (global) */
+    template <int N>
+    __device__ __forceinline__ void get(int j, u32 (&d)[N]) const {
+        if (LDSWIN) {
+            const int b = j - bias;
+            const u32* p = w + (b >> 2);
+            const u32 sh = (u32)b & 3u;
+            u32 x[N + 1];
+#pragma unroll
+            for (int k = 0; k <= N; k++) x[k] = p[k];
+#pragma unroll
+            for (int k = 0; k < N; k++) d[k] = alignbyte(x[k + 1], x[k], sh);
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                u32 v = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (j + 4 * k + t < rlen) v |= (u32)r[j + 4 * k + t] << (8 * t);
+                d[k] = v;
+            }
+        }
+    }
+};
+
+/* Hamming distance between the adapter and r1[p, p + alen): 4 bytes per XOR + zero-byte test */
+template <bool LDSWIN>
+__device__ __forceinline__ int hamming_win(const Win<LDSWIN>& win, int p, const DevAdapter* __restrict__ ad) {
+    const int alen = ad->len;
+    const u32* __restrict__ ad32 = (const u32*)ad->seq;
+    int mm = 0;
+    for (int i0 = 0; i0 < alen; i0 += 16) {
+        u32 d[4];
+        win.template get<4>(p + i0, d);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rem = alen - (i0 + 4 * k); /* wave-uniform */
+            if (rem > 0) {
+                u32 x = d[k] ^ ad32[(i0 >> 2) + k];
+                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                const u32 z = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+                mm += (int)popc32(z & 0x80808080u);
+            }
+        }
+    }
+    return mm;
+}
+
+/* 16-column Myers run on r1[p, p + n), n <= 16 */
+template <bool LDSWIN>
+__device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const u32* __restrict__ peq, int m, int n) {
+    if (m == 0) return n;
+    u32 d[4];
+    win.template get<4>(p, d);
+    u32 eq[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) eq[j] = j < n ? peq[(d[j >> 2] >> (8 * (j & 3))) & 0xFFu] : 0u;
+    u32 Pv = ~0u, Mv = 0;
+    int score = m;
+    const u32 top = 1u << (m - 1);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j < n) { /* wave-uniform */
+            const u32 Eq = eq[j];
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            score += (Ph & top) ? 1 : ((Mh & top) ? -1 : 0);
+            Ph = (Ph << 1) | 1u;
+            Mh <<= 1;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+        }
+    }
+    return score;
+}
+
+/* lev_wave (above) with the text taken from a Win */
+template <bool LDSWIN>
+__device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
+                                            const Win<LDSWIN>& win, int p, int n) {
+    if (m == 0) return n;
+    if (n == 0) return m;
+    const int W = (m + 63) >> 6;
+    const int lane = lane_id();
+    u64 Pv[PEQ_WORDS], Mv[PEQ_WORDS];
+#pragma unroll
+    for (int b = 0; b < PEQ_WORDS; b++) {
+        Pv[b] = ~0ull;
+        Mv[b] = 0;
+    }
+    int score = m;
+    const u64 last_top = 1ull << ((m - 1) & 63);
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        u64 eqw[PEQ_WORDS] = {0, 0, 0, 0};
+        if (j0 + lane < n) {
+            const int c = (int)win.byte(p + j0 + lane);
+#pragma unroll
+            for (int b = 0; b < PEQ_WORDS; b++)
+                if (b < W) eqw[b] = peq_word(peq, c, shift, b);
+        }
+        WaveVals64 pub[PEQ_WORDS];
+#pragma unroll
+        for (int b = 0; b < PEQ_WORDS; b++)
+            if (b < W) pub[b] = wave_publish(eqw[b]);
+        const int cnt = min(64, n - j0);
+        for (int t = 0; t < cnt; t++) {
+            int hin = 1;
+#pragma unroll
+            for (int b = 0; b < PEQ_WORDS; b++) {
+                if (b < W) {
+                    u64 Eq = pub[b].get(t);
+                    const u64 pv = Pv[b], mv = Mv[b];
+                    const u64 Xv = Eq | mv;
+                    if (hin < 0) Eq |= 1ull;
+                    const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                    u64 Ph = mv | ~(Xh | pv);
+                    u64 Mh = pv & Xh;
+                    const u64 hb = (b == W - 1) ? last_top : (1ull << 63);
+                    int hout = 0;
+                    if (Ph & hb) hout = 1;
+                    else if (Mh & hb) hout = -1;
+                    Ph <<= 1;
+                    Mh <<= 1;
+                    if (hin < 0) Mh |= 1ull;
+                    else if (hin > 0) Ph |= 1ull;
+                    Pv[b] = Mh | ~(Xv | Ph);
+                    Mv[b] = Ph & Xv;
+                    hin = hout;
+                }
+            }
+            score += hin;
+        }
+    }
+    return score;
+}
+
 /* AdapterTrimmer::trimBySequenceStart, src/adaptertrimmer.cpp:168-236 (searchAdapter in its
  * asRightAsPossible mode, :109-131, inlined).  rd = first base of the original read; [s,e) is
  * updated; returns the reference's return value; keylen = cmplen handed to addAdapterTrimmed. */
 /* r = first base of r1 -- the global read or a copy of its first 200 bytes in LDS; peq16 / peqf = the
  * adapter's Myers tables, global or LDS copies. */
-__device__ __forceinline__ int trim_start_wave(const u8* __restrict__ r, int& s, int& e, const DevAdapter* __restrict__ ad,
+template <bool LDSWIN>
+__device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                                const u32* __restrict__ peq16,
                                                const uint64_t (*__restrict__ peqf)[PEQ_WORDS],
                                                const DevConfig* __restrict__ cfg, int& keylen) {
@@ -363,7 +526,7 @@ __device__ __forceinline__ int trim_start_wave(const u8* __restrict__ r, int& s,
         for (int p0 = 0; p0 < npos; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < npos && !(cfg->dbg & 256)) mm = hamming_bytes(r + p, ad->seq, alen);
+            if (p < npos && !FPL_DBG(cfg->dbg, 256)) mm = hamming_win(win, p, ad);
             const u64 m = wave_ballot(p < npos && mm <= thrA);
             if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
             if (p < npos) {
@@ -376,7 +539,7 @@ __device__ __forceinline__ int trim_start_wave(const u8* __restrict__ r, int& s,
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(u32)best;
-                const int ed = (cfg->dbg & 64) ? 999 : lev_wave(peqf, 0, alen, r + pos, alen);
+                const int ed = FPL_DBG(cfg->dbg, 64) ? 999 : lev_wave_win(peqf, 0, alen, win, pos, alen);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -391,10 +554,10 @@ __device__ __forceinline__ int trim_start_wave(const u8* __restrict__ r, int& s,
     const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
     const int thrP = cfg->thr[plen];
     u64 best = ~0ull;
-    for (int p0 = 0; p0 < lim && !(cfg->dbg & 128); p0 += 64) {
+    for (int p0 = 0; p0 < lim && !FPL_DBG(cfg->dbg, 128); p0 += 64) {
         const int p = p0 + lane;
         if (p < lim) {
-            const int ed = lev_bp32(peq16, plen, r + p, plen);
+            const int ed = lev16_win(win, p, peq16, plen, plen);
             if (ed <= thrP) {
                 const u64 k = ((u64)(u32)ed << 32) | (u32)p;
                 best = k < best ? k : best;
@@ -405,7 +568,7 @@ __device__ __forceinline__ int trim_start_wave(const u8* __restrict__ r, int& s,
     if (best != ~0ull) { /* :218-233 */
         int pos = (int)(u32)best;
         const int cmplen = min(pos + plen, alen);
-        const int ed = lev_wave(peqf, alen - cmplen, cmplen, r + pos + plen - cmplen, cmplen);
+        const int ed = lev_wave_win(peqf, alen - cmplen, cmplen, win, pos + plen - cmplen, cmplen);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - alen);
             keylen = cmplen;
@@ -422,7 +585,8 @@ __device__ __forceinline__ int trim_start_wave(const u8* __restrict__ r, int& s,
  * asLeftAsPossible mode, :84-107, inlined). */
 /* r = first base of r1 as an address: only its last 200 bytes are dereferenced, so r may point
  * 200 - rlen bytes in front of an LDS copy of that tail. */
-__device__ __forceinline__ int trim_end_wave(const u8* __restrict__ r, int& s, int& e, const DevAdapter* __restrict__ ad,
+template <bool LDSWIN>
+__device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                              const u32* __restrict__ peq16,
                                              const uint64_t (*__restrict__ peqf)[PEQ_WORDS],
                                              const DevConfig* __restrict__ cfg, int& keylen) {
@@ -441,7 +605,7 @@ __device__ __forceinline__ int trim_end_wave(const u8* __restrict__ r, int& s, i
         for (int p0 = ss; p0 < pend; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < pend) mm = hamming_bytes(r + p, ad->seq, alen);
+            if (p < pend) mm = hamming_win(win, p, ad);
             const u64 m = wave_ballot(p < pend && mm <= thrA);
             if (m) {
                 hit = p0 + __ffsll(m) - 1; /* leftmost hit, returned at once (:98-101) */
@@ -457,7 +621,7 @@ __device__ __forceinline__ int trim_end_wave(const u8* __restrict__ r, int& s, i
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(0xFFFFFFFFu - (u32)best);
-                const int ed = lev_wave(peqf, 0, alen, r + pos, alen);
+                const int ed = lev_wave_win(peqf, 0, alen, win, pos, alen);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -477,7 +641,7 @@ __device__ __forceinline__ int trim_end_wave(const u8* __restrict__ r, int& s, i
     for (int p0 = 0; p0 < lim && !stop; p0 += 64) {
         const int p = p0 + lane;
         int ed = 0x7fffffff;
-        if (p < lim) ed = lev_bp32(peq16, plen, r + rlen - plen - p, plen);
+        if (p < lim) ed = lev16_win(win, rlen - plen - p, peq16, plen, plen);
         u64 q = wave_ballot(p < lim && ed <= thrP);
         while (q && !stop) {
             const int b = __ffsll(q) - 1;
@@ -496,7 +660,7 @@ __device__ __forceinline__ int trim_end_wave(const u8* __restrict__ r, int& s, i
     }
     if (pos > 0) { /* :288 strict */
         const int cmplen = min(pos + plen, alen);
-        const int ed = lev_wave(peqf, 0, cmplen, r + rlen - plen - pos, cmplen);
+        const int ed = lev_wave_win(peqf, 0, cmplen, win, rlen - plen - pos, cmplen);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - plen);
             keylen = cmplen;
@@ -517,7 +681,7 @@ struct TrimBlockAcc {
 /* LDS copies for the two command-line adapters: their 16-column Peq tables, their full Peq tables,
  * and per wave the first / last 200 bases of the read being trimmed.  Everything the 2 x 184 Myers
  * runs and the window Hamming scans touch is then an LDS read instead of a dependent global load. */
-constexpr int TRIM_WIN = 208; /* FPL_END_WINDOW rounded up to dwords + slack */
+constexpr int TRIM_WIN = 256; /* FPL_END_WINDOW rounded up, plus slack for the aligned dword reads */
 template <int WAVES>
 struct TrimLds {
     u32 peq16[2][256];             /* [0] = start adapter's peq16_start, [1] = end adapter's peq16_end */
@@ -582,28 +746,34 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
             if (cfg->has_start && ads[0].len <= FPL_END_WINDOW) {
                 /* the start trim only looks at r1[0, 200) */
                 stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end);
-                trimmed += trim_start_wave((const u8*)win_s, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
+                const Win<true> wn = {nullptr, win_s, 0, e - s};
+                trimmed += trim_start_wave(wn, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             } else if (cfg->has_start) {
-                trimmed += trim_start_wave(sq + s, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
+                const Win<false> wn = {sq + s, nullptr, 0, e - s};
+                trimmed += trim_start_wave(wn, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             }
             if (cfg->has_end && ads[1].len <= FPL_END_WINDOW) {
                 /* the end trim only looks at the last 200 bases of r1 */
                 const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
                 stage_window(win_e, sq + e - wl, wl, seq_end);
-                trimmed += trim_end_wave((const u8*)win_e - (rlen - wl), s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
+                const Win<true> wn = {nullptr, win_e, rlen - wl, rlen};
+                trimmed += trim_end_wave(wn, s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             } else if (cfg->has_end) {
-                trimmed += trim_end_wave(sq + s, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
+                const Win<false> wn = {sq + s, nullptr, 0, e - s};
+                trimmed += trim_end_wave(wn, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             }
             for (int a = 0; a < cfg->n_fasta; a++) { /* trimByMultiSequences, src/adaptertrimmer.cpp:42-57 */
                 const DevAdapter* ad = &ads[2 + a];
-                trimmed += trim_start_wave(sq + s, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
+                const Win<false> ws = {sq + s, nullptr, 0, e - s};
+                trimmed += trim_start_wave(ws, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
                 if (kl > 0 && lane == 0)
                     atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
-                trimmed += trim_end_wave(sq + s, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
+                const Win<false> we = {sq + s, nullptr, 0, e - s};
+                trimmed += trim_end_wave(we, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
                 if (kl > 0 && lane == 0)
                     atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
             }
@@ -643,6 +813,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
  * ======================================================================================= */
 constexpr int CS_T = 1024;
 constexpr u32 CS_MAX_ITEMS_PER_SLICE = 16383;
+constexpr int CS_GROUP = 4; /* items whose loads are in flight together, per wave */
 
 __device__ __forceinline__ int base2val_dev(u32 b, bool& valid) {
     /* Stats::base2val, src/stats.cpp:411-425: A0 T/U1 C2 G3 else invalid */
@@ -683,82 +854,83 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
             L = PRE ? (u32)(item_off[it + 1] - st) : item_len[it];
         }
         u64 m = wave_ballot(L > tile_start);
-        if (!m) continue;
-        u32x4 svN = {0, 0, 0, 0}, qvN = {0, 0, 0, 0};
-        u32 haloN = 0, LN = 0;
-        auto issue = [&](int bit) { /* start the loads of item `bit` of this round */
-            LN = shfl_u32(L, bit);
-            const uint64_t start = shfl_u64(st, bit);
-            svN = {0, 0, 0, 0};
-            qvN = {0, 0, 0, 0};
-            if (LN > c0) {
-                svN = load16_guard(seq + start + c0, seq_end);
-                qvN = load16_guard(qual + start + c0, qual_end);
+        /* groups of CS_GROUP items: all their 16-byte loads are issued before the first one is
+           counted, so each wave keeps CS_GROUP x 2 KiB of HBM reads in flight */
+        while (m) {
+            u32x4 svG[CS_GROUP], qvG[CS_GROUP];
+            u32 haloG[CS_GROUP], LG[CS_GROUP];
+#pragma unroll
+            for (int g = 0; g < CS_GROUP; g++) {
+                svG[g] = {0, 0, 0, 0};
+                qvG[g] = {0, 0, 0, 0};
+                haloG[g] = 0;
+                LG[g] = 0;
+                if (m) { /* wave-uniform */
+                    const int bit = __ffsll(m) - 1;
+                    m &= m - 1;
+                    LG[g] = shfl_u32(L, bit);
+                    const uint64_t start = shfl_u64(st, bit);
+                    if (LG[g] > c0) {
+                        svG[g] = load16_guard(seq + start + c0, seq_end);
+                        qvG[g] = load16_guard(qual + start + c0, qual_end);
+                    }
+                    if (lane == 0 && tile_start >= 4) haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
+                }
             }
-            haloN = 0;
-            if (lane == 0 && tile_start >= 4) haloN = load4_guard(seq + start + tile_start - 4, seq_end);
-        };
-        int b = __ffsll(m) - 1;
-        m &= m - 1;
-        issue(b);
-        for (;;) {
-            const u32x4 sv = svN, qv = qvN;
-            const u32 itemL = LN;
-            u32 halo = haloN;
-            const bool more = m != 0;
-            if (more) {
-                b = __ffsll(m) - 1;
-                m &= m - 1;
-                issue(b);
-            }
-            const int nvalid = itemL > c0 ? (int)min(16u, itemL - c0) : 0;
-            /* the four bases in front of this lane's chunk: previous lane's last dword */
-            const u32 up = shfl_up_u32(sv.w, 1);
-            const bool have_halo = lane > 0 || tile_start >= 4;
-            if (lane > 0) halo = up;
-            /* one byte of the tile: packed per-cycle counter + rolling 5-mer */
+#pragma unroll
+            for (int g = 0; g < CS_GROUP; g++) {
+                const u32 itemL = LG[g];
+                if (itemL <= tile_start) continue; /* wave-uniform: empty slot of the last group */
+                const u32x4 sv = svG[g], qv = qvG[g];
+                u32 halo = haloG[g];
+                const int nvalid = itemL > c0 ? (int)min(16u, itemL - c0) : 0;
+                /* the four bases in front of this lane's chunk: previous lane's last dword */
+                const u32 up = shfl_up_u32(sv.w, 1);
+                const bool have_halo = lane > 0 || tile_start >= 4;
+                if (lane > 0) halo = up;
+    /* one byte of the tile: packed per-cycle counter + rolling 5-mer */
 #define FPL_CS_BYTE(k)                                                                                      \
     {                                                                                                       \
         const u32 bb = (sw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                              \
         const u32 q = (qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                               \
         const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);          \
-        if (!(dbg & 8)) atomicAdd(&cyc[(bb & 7u) * CS_T + (k)*64 + lane], inc);                             \
+        if (!FPL_DBG(dbg, 8)) atomicAdd(&cyc[(bb & 7u) * CS_T + (k)*64 + lane], inc);                             \
         bool v;                                                                                             \
         const int val = base2val_dev(bb, v);                                                                \
         run = v ? run + 1 : 0;                                                                              \
         kidx = ((kidx << 2) & 0x3FCu) | (u32)val;                                                           \
-        if (run >= 5 && !(dbg & 16)) atomicAdd(&kmer[kidx], 1u);                                            \
+        if (run >= 5 && !FPL_DBG(dbg, 16)) atomicAdd(&kmer[kidx], 1u);                                            \
     }
-            if (nvalid > 0) {
-                int run = 0;
-                u32 kidx = 0;
-                if (have_halo) {
+                if (nvalid > 0) {
+                    int run = 0;
+                    u32 kidx = 0;
+                    if (have_halo) {
 #pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        bool v;
-                        const int val = base2val_dev((halo >> (8 * h)) & 0xFF, v);
-                        run = v ? run + 1 : 0;
-                        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
+                        for (int h = 0; h < 4; h++) {
+                            bool v;
+                            const int val = base2val_dev((halo >> (8 * h)) & 0xFF, v);
+                            run = v ? run + 1 : 0;
+                            kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
+                        }
+                    }
+                    const u32 sw[4] = {sv.x, sv.y, sv.z, sv.w};
+                    const u32 qw[4] = {qv.x, qv.y, qv.z, qv.w};
+                    if (itemL >= tile_start + CS_T) { /* wave-uniform: the item covers the whole tile */
+#pragma unroll
+                        for (int k = 0; k < 16; k++) FPL_CS_BYTE(k)
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            if (k < nvalid) FPL_CS_BYTE(k)
                     }
                 }
-                const u32 sw[4] = {sv.x, sv.y, sv.z, sv.w};
-                const u32 qw[4] = {qv.x, qv.y, qv.z, qv.w};
-                if (itemL >= tile_start + CS_T) { /* wave-uniform: the item covers the whole tile */
-#pragma unroll
-                    for (int k = 0; k < 16; k++) FPL_CS_BYTE(k)
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        if (k < nvalid) FPL_CS_BYTE(k)
-                }
-            }
 #undef FPL_CS_BYTE
-            if (!more) break;
+            }
         }
     }
     __syncthreads();
     /* flush: slot -> cycle, unpack, one global atomic per non-zero counter */
-    if (dbg & 32) return;
+    if (FPL_DBG(dbg, 32)) return;
     for (u32 slot = threadIdx.x; slot < CS_T; slot += blockDim.x) {
         const u32 c = tile_start + 16 * (slot & 63) + (slot >> 6);
         if (c < C) {
@@ -1099,15 +1271,15 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
         prev_tile_last = shfl_u32(s[7], ACTIVE - 1);
         if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
         if (nstat == SC_CHUNK) {
-            if (!(dbg & 1)) {
+            if (!FPL_DBG(dbg, 1)) {
 #pragma unroll
                 for (int k = 0; k < SC_CHUNK; k++) {
                     const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0x7Fu;
                     atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
                 }
             }
-            if (SUMS && !(dbg & 2)) sums32(s, q, prevd, qqrep, lowq, nn, totq, diff);
-            if (dbg & 4) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
+            if (SUMS && !FPL_DBG(dbg, 2)) sums32(s, q, prevd, qqrep, lowq, nn, totq, diff);
+            if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
         } else if (nstat > 0) { /* ragged last chunk */
             u32 pb = prevd >> 24;
             for (int k = 0; k < nstat; k++) {
