@@ -118,27 +118,96 @@ __device__ __forceinline__ int lev_bp64(const uint64_t (*__restrict__ peq)[PEQ_W
     return score;
 }
 
-/* Same distance, computed by the whole wave: lanes fetch text bytes and their Peq words in
- * parallel (64 columns per round), then every lane runs the identical recurrence on
- * v_readlane-broadcast words -- no serial chain of dependent memory loads, result wave-uniform. */
-__device__ inline int lev_wave(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
-                               const u8* __restrict__ text, int n) {
+/* Column loop of the wave-cooperative Levenshtein (see lev_wave): `pub` holds, per 64-column round,
+ * the Peq words of the text bytes.  Returns the exact distance when it is <= thr, and some value
+ * > thr otherwise: along the last DP row the value drops by at most 1 per column, so once
+ * score - (columns left) > thr the answer is known and the loop stops.  Patterns of <= 32 columns
+ * run on one 32-bit word (half the instructions of the 64-bit form). */
+__device__ __forceinline__ bool lev_round32(const WaveVals64& pub, int cnt, int left_after, u32& Pv, u32& Mv, int& score,
+                                            u32 top, int thr) {
+    for (int t = 0; t < cnt; t++) {
+        const u32 Eq = (u32)pub.get(t);
+        const u32 Xv = Eq | Mv;
+        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        u32 Ph = Mv | ~(Xh | Pv);
+        u32 Mh = Pv & Xh;
+        score += (Ph & top) ? 1 : ((Mh & top) ? -1 : 0);
+        Ph = (Ph << 1) | 1u;
+        Mh <<= 1;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+        if (score - (left_after + cnt - 1 - t) > thr) return true; /* wave-uniform */
+    }
+    return false;
+}
+__device__ __forceinline__ bool lev_round64(const WaveVals64 (&pub)[PEQ_WORDS], int W, int cnt, int left_after,
+                                            u64 (&Pv)[PEQ_WORDS], u64 (&Mv)[PEQ_WORDS], int& score, u64 last_top, int thr) {
+    for (int t = 0; t < cnt; t++) {
+        int hin = 1; /* D[0][j] - D[0][j-1] */
+#pragma unroll
+        for (int b = 0; b < PEQ_WORDS; b++) {
+            if (b < W) {
+                u64 Eq = pub[b].get(t);
+                const u64 pv = Pv[b], mv = Mv[b];
+                const u64 Xv = Eq | mv;
+                if (hin < 0) Eq |= 1ull;
+                const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                u64 Ph = mv | ~(Xh | pv);
+                u64 Mh = pv & Xh;
+                const u64 hb = (b == W - 1) ? last_top : (1ull << 63);
+                int hout = 0;
+                if (Ph & hb) hout = 1;
+                else if (Mh & hb) hout = -1;
+                Ph <<= 1;
+                Mh <<= 1;
+                if (hin < 0) Mh |= 1ull;
+                else if (hin > 0) Ph |= 1ull;
+                Pv[b] = Mh | ~(Xv | Ph);
+                Mv[b] = Ph & Xv;
+                hin = hout;
+            }
+        }
+        score += hin;
+        if (score - (left_after + cnt - 1 - t) > thr) return true;
+    }
+    return false;
+}
+
+/* Global Levenshtein distance computed by the whole wave: lanes fetch text bytes and their Peq
+ * words in parallel (64 columns per round), then every lane runs the identical recurrence on
+ * v_readlane-broadcast words -- no serial chain of dependent memory loads, result wave-uniform.
+ * BYTE(j) yields text byte j.  Exact when the distance is <= thr, otherwise some value > thr. */
+template <class ByteFn>
+__device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m, int n,
+                                             int thr, ByteFn&& BYTE) {
     if (m == 0) return n;
     if (n == 0) return m;
     const int W = (m + 63) >> 6;
     const int lane = lane_id();
+    int score = m;
+    if (m <= 32) {
+        u32 Pv = ~0u, Mv = 0;
+        const u32 top = 1u << (m - 1);
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            u64 eq = 0;
+            if (j0 + lane < n) eq = peq_word(peq, (int)BYTE(j0 + lane), shift, 0);
+            const WaveVals64 pub = wave_publish(eq);
+            const int cnt = min(64, n - j0);
+            if (lev_round32(pub, cnt, n - j0 - cnt, Pv, Mv, score, top, thr)) return thr + 1;
+        }
+        return score;
+    }
     u64 Pv[PEQ_WORDS], Mv[PEQ_WORDS];
 #pragma unroll
     for (int b = 0; b < PEQ_WORDS; b++) {
         Pv[b] = ~0ull;
         Mv[b] = 0;
     }
-    int score = m;
     const u64 last_top = 1ull << ((m - 1) & 63);
     for (int j0 = 0; j0 < n; j0 += 64) {
         u64 eqw[PEQ_WORDS] = {0, 0, 0, 0};
         if (j0 + lane < n) {
-            const int c = text[j0 + lane];
+            const int c = (int)BYTE(j0 + lane);
 #pragma unroll
             for (int b = 0; b < PEQ_WORDS; b++)
                 if (b < W) eqw[b] = peq_word(peq, c, shift, b);
@@ -148,35 +217,13 @@ __device__ inline int lev_wave(const uint64_t (*__restrict__ peq)[PEQ_WORDS], in
         for (int b = 0; b < PEQ_WORDS; b++)
             if (b < W) pub[b] = wave_publish(eqw[b]);
         const int cnt = min(64, n - j0);
-        for (int t = 0; t < cnt; t++) {
-            int hin = 1; /* D[0][j] - D[0][j-1] */
-#pragma unroll
-            for (int b = 0; b < PEQ_WORDS; b++) {
-                if (b < W) {
-                    u64 Eq = pub[b].get(t);
-                    const u64 pv = Pv[b], mv = Mv[b];
-                    const u64 Xv = Eq | mv;
-                    if (hin < 0) Eq |= 1ull;
-                    const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
-                    u64 Ph = mv | ~(Xh | pv);
-                    u64 Mh = pv & Xh;
-                    const u64 hb = (b == W - 1) ? last_top : (1ull << 63);
-                    int hout = 0;
-                    if (Ph & hb) hout = 1;
-                    else if (Mh & hb) hout = -1;
-                    Ph <<= 1;
-                    Mh <<= 1;
-                    if (hin < 0) Mh |= 1ull;
-                    else if (hin > 0) Ph |= 1ull;
-                    Pv[b] = Mh | ~(Xv | Ph);
-                    Mv[b] = Ph & Xv;
-                    hin = hout;
-                }
-            }
-            score += hin;
-        }
+        if (lev_round64(pub, W, cnt, n - j0 - cnt, Pv, Mv, score, last_top, thr)) return thr + 1;
     }
     return score;
+}
+__device__ __forceinline__ int lev_wave(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
+                                        const u8* __restrict__ text, int n, int thr) {
+    return lev_wave_core(peq, shift, m, n, thr, [&](int j) { return (u32)text[j]; });
 }
 
 /* run f() on lane 0 only and hand its int result to every lane */
@@ -441,64 +488,11 @@ __device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const u3
     return score;
 }
 
-/* lev_wave (above) with the text taken from a Win */
+/* lev_wave with the text taken from a Win */
 template <bool LDSWIN>
 __device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
-                                            const Win<LDSWIN>& win, int p, int n) {
-    if (m == 0) return n;
-    if (n == 0) return m;
-    const int W = (m + 63) >> 6;
-    const int lane = lane_id();
-    u64 Pv[PEQ_WORDS], Mv[PEQ_WORDS];
-#pragma unroll
-    for (int b = 0; b < PEQ_WORDS; b++) {
-        Pv[b] = ~0ull;
-        Mv[b] = 0;
-    }
-    int score = m;
-    const u64 last_top = 1ull << ((m - 1) & 63);
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        u64 eqw[PEQ_WORDS] = {0, 0, 0, 0};
-        if (j0 + lane < n) {
-            const int c = (int)win.byte(p + j0 + lane);
-#pragma unroll
-            for (int b = 0; b < PEQ_WORDS; b++)
-                if (b < W) eqw[b] = peq_word(peq, c, shift, b);
-        }
-        WaveVals64 pub[PEQ_WORDS];
-#pragma unroll
-        for (int b = 0; b < PEQ_WORDS; b++)
-            if (b < W) pub[b] = wave_publish(eqw[b]);
-        const int cnt = min(64, n - j0);
-        for (int t = 0; t < cnt; t++) {
-            int hin = 1;
-#pragma unroll
-            for (int b = 0; b < PEQ_WORDS; b++) {
-                if (b < W) {
-                    u64 Eq = pub[b].get(t);
-                    const u64 pv = Pv[b], mv = Mv[b];
-                    const u64 Xv = Eq | mv;
-                    if (hin < 0) Eq |= 1ull;
-                    const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
-                    u64 Ph = mv | ~(Xh | pv);
-                    u64 Mh = pv & Xh;
-                    const u64 hb = (b == W - 1) ? last_top : (1ull << 63);
-                    int hout = 0;
-                    if (Ph & hb) hout = 1;
-                    else if (Mh & hb) hout = -1;
-                    Ph <<= 1;
-                    Mh <<= 1;
-                    if (hin < 0) Mh |= 1ull;
-                    else if (hin > 0) Ph |= 1ull;
-                    Pv[b] = Mh | ~(Xv | Ph);
-                    Mv[b] = Ph & Xv;
-                    hin = hout;
-                }
-            }
-            score += hin;
-        }
-    }
-    return score;
+                                            const Win<LDSWIN>& win, int p, int n, int thr) {
+    return lev_wave_core(peq, shift, m, n, thr, [&](int j) { return win.byte(p + j); });
 }
 
 /* AdapterTrimmer::trimBySequenceStart, src/adaptertrimmer.cpp:168-236 (searchAdapter in its
@@ -539,7 +533,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(u32)best;
-                const int ed = FPL_DBG(cfg->dbg, 64) ? 999 : lev_wave_win(peqf, 0, alen, win, pos, alen);
+                const int ed = FPL_DBG(cfg->dbg, 64) ? 999 : lev_wave_win(peqf, 0, alen, win, pos, alen, thrA);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -568,7 +562,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
     if (best != ~0ull) { /* :218-233 */
         int pos = (int)(u32)best;
         const int cmplen = min(pos + plen, alen);
-        const int ed = lev_wave_win(peqf, alen - cmplen, cmplen, win, pos + plen - cmplen, cmplen);
+        const int ed = lev_wave_win(peqf, alen - cmplen, cmplen, win, pos + plen - cmplen, cmplen, cfg->thr[cmplen]);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - alen);
             keylen = cmplen;
@@ -621,7 +615,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(0xFFFFFFFFu - (u32)best);
-                const int ed = lev_wave_win(peqf, 0, alen, win, pos, alen);
+                const int ed = lev_wave_win(peqf, 0, alen, win, pos, alen, thrA);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -660,7 +654,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     }
     if (pos > 0) { /* :288 strict */
         const int cmplen = min(pos + plen, alen);
-        const int ed = lev_wave_win(peqf, 0, cmplen, win, rlen - plen - pos, cmplen);
+        const int ed = lev_wave_win(peqf, 0, cmplen, win, rlen - plen - pos, cmplen, cfg->thr[cmplen]);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - plen);
             keylen = cmplen;
@@ -1192,12 +1186,11 @@ __device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane,
 __device__ __forceinline__ void sliced_max(const u32 B[7], u32 cand, int& val, int& first) {
     val = 0;
 #pragma unroll
-    for (int b = 6; b >= 0; b--) {
+    for (int b = 6; b >= 0; b--) { /* branch-free: selects, no exec-mask juggling */
         const u32 t = cand & B[b];
-        if (t) {
-            cand = t;
-            val |= 1 << b;
-        }
+        const bool nz = t != 0;
+        cand = nz ? t : cand;
+        val |= nz ? (1 << b) : 0;
     }
     first = __ffs(cand) - 1;
 }
@@ -1474,15 +1467,15 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             if (ham) {
                 const int al0 = ads[0].len, al1 = ads[1].len;
                 int sp = -1, ep = -1;
-                if (key0 != ~0ull) {
-                    const int p = (int)(u32)key0;
-                    const int ed = lev_wave(ads[0].peq_full, 0, al0, rb + s + p, al0);
-                    if (ed <= cfg->thr[al0]) sp = p;
+                if (key0 != ~0ull) { /* edit distance <= Hamming distance: only a worse argmin needs the confirm */
+                    const int p = (int)(u32)key0, thr0 = cfg->thr[al0];
+                    const int ed = (int)(key0 >> 32) <= thr0 ? 0 : lev_wave(ads[0].peq_full, 0, al0, rb + s + p, al0, thr0);
+                    if (ed <= thr0) sp = p;
                 }
                 if (key1 != ~0ull) {
-                    const int p = (int)(u32)key1;
-                    const int ed = lev_wave(ads[1].peq_full, 0, al1, rb + s + p, al1);
-                    if (ed <= cfg->thr[al1]) ep = p;
+                    const int p = (int)(u32)key1, thr1 = cfg->thr[al1];
+                    const int ed = (int)(key1 >> 32) <= thr1 ? 0 : lev_wave(ads[1].peq_full, 0, al1, rb + s + p, al1, thr1);
+                    if (ed <= thr1) ep = p;
                 }
                 const int ext = cfg->ext;
                 if (sp >= 0 && ep >= 0) {

@@ -36,6 +36,8 @@ def lib():
                                         C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.emu_lev_bp64.restype = C.c_int
         L.emu_lev_bp64.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.emu_lev_wave.restype = C.c_int
+        L.emu_lev_wave.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int]
         for f in (L.emu_lev_bp32_start, L.emu_lev_bp32_end):
             f.restype = C.c_int
             f.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]

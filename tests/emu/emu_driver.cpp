@@ -65,6 +65,18 @@ extern "C" int emu_lev_bp64(const char* adapter, int alen, int shift, int m, con
     build_adapter(&ad, adapter, alen);
     return lev_bp64(ad.peq_full, shift, m, (const u8*)text, n);
 }
+/* the wave-cooperative, thresholded form: one 64-thread block, result from lane 0 */
+static DevAdapter g_ad;
+static int g_res;
+static void k_lev_wave(int shift, int m, const u8* text, int n, int thr) {
+    int r = lev_wave(g_ad.peq_full, shift, m, text, n, thr);
+    if (lane_id() == 0) g_res = r;
+}
+extern "C" int emu_lev_wave(const char* adapter, int alen, int shift, int m, const char* text, int n, int thr) {
+    build_adapter(&g_ad, adapter, alen);
+    emu_launch(k_lev_wave, dim3(1), dim3(64), shift, m, (const u8*)text, n, thr);
+    return g_res;
+}
 extern "C" int emu_lev_bp32_start(const char* adapter, int alen, const char* text, int n) {
     static DevAdapter ad;
     build_adapter(&ad, adapter, alen);

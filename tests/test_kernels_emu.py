@@ -38,6 +38,10 @@ def test_bitparallel_levenshtein_matches_oracle(orc):
             want = orc.edit_distance(pat, text)
             got = L.emu_lev_bp64(adb, alen, shift, m, text.encode(), n)
             assert got == want, (ad, shift, m, text)
+            # wave-cooperative thresholded form: exact when <= thr, otherwise anything > thr
+            for thr in (want, max(0, want - 1), want + 3, 0):
+                gw = L.emu_lev_wave(adb, alen, shift, m, text.encode(), n, thr)
+                assert (gw == want) if want <= thr else (gw > thr), (ad, shift, m, text, thr, gw, want)
         plen = min(16, alen)
         for _ in range(4):
             text = "".join("ACGTN"[i] for i in rng.integers(0, 5, plen))
