@@ -160,6 +160,17 @@ def main():
         dom = max(ktimes, key=ktimes.get)
         dom_ms = ktimes[dom] / max(1, nbatches)
         achieved = ALGO_BYTES_PER_BASE * n_bases / (dom_ms * 1e-3) / 1e9
+        # HBM bytes per launch of the dominant kernel: PMC counters come from separate rocprofv3 --pmc
+        # passes of this same command (profiles/hbm_traffic.json records bytes per base, corrected as
+        # MI355X_MICROARCH.md prescribes); --hbm-traffic overrides, otherwise null when nothing is recorded
+        traffic, traffic_src = args.hbm_traffic, "--hbm-traffic"
+        if traffic is None:
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+                if rec.get("workload") == args.workload and not args.set and dom in rec["hbm_bytes_per_base"]:
+                    traffic, traffic_src = rec["hbm_bytes_per_base"][dom] * n_bases, rec["source"]
+            except (OSError, ValueError, KeyError):
+                traffic = None
         out = {
             "metric": "Gbases/s processed (trim+cut+filter)",
             "value": total_bases * args.steps / dt / 1e9,
@@ -184,7 +195,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": args.hbm_traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BASE * n_bases,
                 "kernel_ms": {k: ktimes[k] / max(1, nbatches) for k in ktimes},
             },
