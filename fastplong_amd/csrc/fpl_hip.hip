@@ -30,6 +30,9 @@ struct fpl_ctx {
     uint64_t* d_frag_off = nullptr;
     u32* d_frag_len = nullptr;
     u32* d_work_ctr = nullptr;
+    size_t scratch_slabs = 0;
+    u64* d_stats_scratch = nullptr;
+    u8* d_stats_flags = nullptr;
     /* staging for the host-pointer entry point */
     uint64_t st_bytes = 0;
     u32 st_reads = 0;
@@ -136,7 +139,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         FPL_HIP(hipMemcpy(ctx->d_cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
         FPL_HIP(hipMalloc((void**)&ctx->d_ads, sizeof(DevAdapter) * ads.size()));
         FPL_HIP(hipMemcpy(ctx->d_ads, ads.data(), sizeof(DevAdapter) * ads.size(), hipMemcpyHostToDevice));
-        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, sizeof(u32)));
+        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, 2 * sizeof(u32)));
         ctx->C = max_cycles ? max_cycles : 1;
         int r = alloc_counters(ctx, ctx->C, &ctx->d_counters);
         if (r != FPL_OK) return r;
@@ -158,7 +161,8 @@ void fpl_destroy(fpl_ctx* ctx) {
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->d_cfg, ctx->d_ads, ctx->d_counters, ctx->d_state, ctx->d_frag_off, ctx->d_frag_len,
-                    ctx->d_work_ctr, ctx->d_seq, ctx->d_qual, ctx->d_off, ctx->d_results};
+                    ctx->d_work_ctr, ctx->d_seq, ctx->d_qual, ctx->d_off, ctx->d_results, ctx->d_stats_scratch,
+                    ctx->d_stats_flags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int r = 0; r < fpl_ctx::EV_RING; r++)
@@ -221,6 +225,22 @@ int fpl_reset_counters(fpl_ctx* ctx) {
     return FPL_OK;
 }
 
+static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_read_len) {
+    const size_t slabs = stats_scratch_slabs(n_reads, n_bytes, max_read_len, ctx->n_cu);
+    if (slabs <= ctx->scratch_slabs) return FPL_OK;
+    FPL_HIP(hipDeviceSynchronize());
+    if (ctx->d_stats_scratch) (void)hipFree(ctx->d_stats_scratch);
+    if (ctx->d_stats_flags) (void)hipFree(ctx->d_stats_flags);
+    ctx->d_stats_scratch = nullptr;
+    ctx->d_stats_flags = nullptr;
+    ctx->scratch_slabs = 0;
+    const size_t cap = slabs + slabs / 4;
+    FPL_HIP(hipMalloc((void**)&ctx->d_stats_scratch, cap * (size_t)(8 * CS_T) * sizeof(u64)));
+    FPL_HIP(hipMalloc((void**)&ctx->d_stats_flags, cap));
+    ctx->scratch_slabs = cap;
+    return FPL_OK;
+}
+
 static int ensure_workspace(fpl_ctx* ctx, u32 n_reads) {
     if (n_reads <= ctx->ws_reads) return FPL_OK;
     FPL_HIP(hipDeviceSynchronize());
@@ -253,7 +273,9 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     if (n_reads) {
         int r = ensure_workspace(ctx, n_reads);
         if (r != FPL_OK) return r;
-        FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, sizeof(u32), stream));
+        r = ensure_scratch(ctx, n_reads, n_bytes, max_read_len);
+        if (r != FPL_OK) return r;
+        FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, 2 * sizeof(u32), stream));
     }
     BatchArgs a;
     a.seq = d_seq;
@@ -271,6 +293,8 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.counters = ctx->d_counters;
     a.C = ctx->C;
     a.work_ctr = ctx->d_work_ctr;
+    a.stats_scratch = ctx->d_stats_scratch;
+    a.stats_flags = ctx->d_stats_flags;
     a.n_cu = ctx->n_cu;
     a.dbg = ctx->dbg;
     const bool timing = ctx->timing != 0;

@@ -821,17 +821,38 @@ template <int WAVES, bool PRE>
 __global__ void __launch_bounds__(WAVES * 64)
 k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_bytes,
               const uint64_t* __restrict__ item_off, const u32* __restrict__ item_len, u32 n_items,
-              u32 items_per_slice, long long* __restrict__ stats, u32 C, int dbg) {
+              const u32* __restrict__ n_items_dev, u32 items_per_slice, long long* __restrict__ stats,
+              u64* __restrict__ scratch, u8* __restrict__ flags, u32 C, int dbg) {
+    /* PRE: items are the reads (CSR offsets).  POST: items are the compacted passing-fragment list
+       k_scan built (count in n_items_dev), cycles re-based to the fragment start. */
+    constexpr bool KMER = true;
+    if (!PRE) n_items = *n_items_dev;
     __shared__ u64 cyc[8 * CS_T];
     __shared__ u32 kmer[1024];
+    __shared__ u32 any_work;
     const int lane = lane_id();
+    const u32 tile_start = blockIdx.y * CS_T;
+    const u32 i_begin = blockIdx.x * items_per_slice;
+    if (i_begin >= n_items) return;
+    const u32 i_end = min(n_items, i_begin + items_per_slice);
+    /* most (slice, tile) blocks beyond the typical item length have nothing to count: find out before
+       paying for the 68 KiB table */
+    if (threadIdx.x == 0) any_work = 0;
+    __syncthreads();
+    {
+        bool mine = false;
+        for (u32 it = i_begin + threadIdx.x; it < i_end; it += blockDim.x) {
+            const u32 L = PRE ? (u32)(item_off[it + 1] - item_off[it]) : item_len[it];
+            mine = mine || (L > tile_start);
+        }
+        if (wave_ballot(mine) && lane == 0) any_work = 1;
+    }
+    __syncthreads();
+    if (!any_work) return;
     for (u32 i = threadIdx.x; i < 8 * CS_T; i += blockDim.x) cyc[i] = 0;
     for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) kmer[i] = 0;
     __syncthreads();
 
-    const u32 tile_start = blockIdx.y * CS_T;
-    const u32 i_begin = blockIdx.x * items_per_slice;
-    const u32 i_end = min(n_items, i_begin + items_per_slice);
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
     const u32 c0 = tile_start + 16 * lane; /* cycle of this lane's first byte */
@@ -889,16 +910,18 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
         const u32 q = (qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                               \
         const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);          \
         if (!FPL_DBG(dbg, 8)) atomicAdd(&cyc[(bb & 7u) * CS_T + (k)*64 + lane], inc);                             \
-        bool v;                                                                                             \
-        const int val = base2val_dev(bb, v);                                                                \
-        run = v ? run + 1 : 0;                                                                              \
-        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;                                                           \
-        if (run >= 5 && !FPL_DBG(dbg, 16)) atomicAdd(&kmer[kidx], 1u);                                            \
+        if (KMER) {                                                                                         \
+            bool v;                                                                                         \
+            const int val = base2val_dev(bb, v);                                                            \
+            run = v ? run + 1 : 0;                                                                          \
+            kidx = ((kidx << 2) & 0x3FCu) | (u32)val;                                                       \
+            if (run >= 5 && !FPL_DBG(dbg, 16)) atomicAdd(&kmer[kidx], 1u);                                  \
+        }                                                                                                   \
     }
                 if (nvalid > 0) {
                     int run = 0;
                     u32 kidx = 0;
-                    if (have_halo) {
+                    if (KMER && have_halo) {
 #pragma unroll
                         for (int h = 0; h < 4; h++) {
                             bool v;
@@ -923,28 +946,50 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
         }
     }
     __syncthreads();
-    /* flush: slot -> cycle, unpack, one global atomic per non-zero counter */
+    /* hand the packed table over as is: plain coalesced stores into this block's 64 KiB slab of the
+       scratch buffer; k_cycle_reduce sums the slabs of a tile and unpacks them.  (Flushing with global
+       atomics instead -- ~17 k per heavy block -- cost more than the counting itself.) */
     if (FPL_DBG(dbg, 32)) return;
-    for (u32 slot = threadIdx.x; slot < CS_T; slot += blockDim.x) {
-        const u32 c = tile_start + 16 * (slot & 63) + (slot >> 6);
-        if (c < C) {
-#pragma unroll
-            for (int cls = 0; cls < 8; cls++) {
-                const u64 v = cyc[cls * CS_T + slot];
-                if (v) {
-                    const u64 cnt = (v >> 22) & 0x3FFF, q20 = (v >> 36) & 0x3FFF, q30 = v >> 50;
-                    const long long qsum = (long long)(v & 0x3FFFFF) - 33ll * (long long)cnt; /* += qual-33 */
-                    atomicAdd((u64*)&stats[FPL_ST_CYC(c, 0, cls)], cnt);
-                    atomicAdd((u64*)&stats[FPL_ST_CYC(c, 1, cls)], (u64)qsum);
-                    if (q20) atomicAdd((u64*)&stats[FPL_ST_CYC(c, 2, cls)], q20);
-                    if (q30) atomicAdd((u64*)&stats[FPL_ST_CYC(c, 3, cls)], q30);
-                }
-            }
-        }
+    {
+        const size_t slab = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        u64* dst = scratch + slab * (8 * CS_T);
+        for (u32 i = threadIdx.x; i < 8 * CS_T; i += blockDim.x) dst[i] = cyc[i];
+        if (threadIdx.x == 0) flags[slab] = 1;
     }
-    long long* kg = stats + FPL_ST_KMER(C);
-    for (u32 i = threadIdx.x; i < 1024; i += blockDim.x)
-        if (kmer[i]) atomicAdd((u64*)&kg[i], (u64)kmer[i]);
+    if (KMER) {
+        long long* kg = stats + FPL_ST_KMER(C);
+        for (u32 i = threadIdx.x; i < 1024; i += blockDim.x)
+            if (kmer[i]) atomicAdd((u64*)&kg[i], (u64)kmer[i]);
+    }
+}
+
+/* Sum the per-(tile, slice) packed tables of one statistics pass and add them to the per-cycle
+ * counters.  Block (x = 256-cell chunk of the tile's 8 x 1024 table, y = tile); a thread owns one
+ * (class, slot) cell, walks the slices that wrote a slab and unpacks into 64-bit sums; every
+ * counter has exactly one owner, so the update is a plain read-modify-write. */
+__global__ void __launch_bounds__(256)
+k_cycle_reduce(const u64* __restrict__ scratch, const u8* __restrict__ flags, u32 n_slices,
+               long long* __restrict__ stats, u32 C) {
+    const u32 tile = blockIdx.y;
+    const u32 cell = blockIdx.x * 256 + threadIdx.x; /* cls * CS_T + slot */
+    const u32 cls = cell / CS_T, slot = cell % CS_T;
+    const u32 c = tile * CS_T + 16 * (slot & 63) + (slot >> 6);
+    u64 qsum = 0, cnt = 0, q20 = 0, q30 = 0;
+    for (u32 sl = 0; sl < n_slices; sl++) {
+        const size_t slab = (size_t)tile * n_slices + sl;
+        if (!flags[slab]) continue; /* block-uniform */
+        const u64 v = scratch[slab * (8 * CS_T) + cell];
+        qsum += v & 0x3FFFFF;
+        cnt += (v >> 22) & 0x3FFF;
+        q20 += (v >> 36) & 0x3FFF;
+        q30 += v >> 50;
+    }
+    if (cnt && c < C) {
+        stats[FPL_ST_CYC(c, 0, cls)] += (long long)cnt;
+        stats[FPL_ST_CYC(c, 1, cls)] += (long long)qsum - 33ll * (long long)cnt; /* += qual - 33 */
+        stats[FPL_ST_CYC(c, 2, cls)] += (long long)q20;
+        stats[FPL_ST_CYC(c, 3, cls)] += (long long)q30;
+    }
 }
 
 /* =========================================================================================
@@ -952,12 +997,15 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
  * ======================================================================================= */
 constexpr int HIST_COPIES = 16; /* per-wave quality histogram: 128 bins x 16 lane-copies */
 constexpr int SC_CHUNK = 32;    /* bases per lane per tile in the bit-sliced scan */
+constexpr int SC_FBUF = 32;     /* fragments a wave gathers per reservation in the global fragment list */
 constexpr int SC_LANES_HAM = 62; /* lanes 62/63 only provide the plane words the last windows reach into */
 
 /* per-wave LDS of k_scan */
 struct ScanWaveLds {
     u32 planes[5][64];            /* letter bit-planes of the current tile: [A,C,T,G][chunk]; row 4 stays zero */
     u32 hist[128 * HIST_COPIES];
+    uint64_t fbuf_off[SC_FBUF];   /* passing fragments waiting for a slot in the global list */
+    u32 fbuf_len[SC_FBUF];
 };
 
 struct ScanBlockAcc {
@@ -1365,13 +1413,14 @@ __device__ __forceinline__ int filter_code(const DevConfig* __restrict__ cfg, in
     return FPL_PASS_FILTER;
 }
 
+
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
        uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
        const ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
        uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, long long* __restrict__ counters, u32 C,
-       u32* __restrict__ work_ctr, u32 chunk) {
+       u32* __restrict__ work_ctr, u32 chunk, u32* __restrict__ frag_count) {
     __shared__ ScanWaveLds wlds[WAVES];
     __shared__ ScanBlockAcc acc;
     const int lane = lane_id();
@@ -1390,6 +1439,21 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     /* dynamic work distribution in chunks: one device-scope atomic serves `chunk` reads (a single
        hot counter sustains only ~80 atomics/us, which a per-read dequeue would saturate) */
     u32 chunk_next = 0, chunk_end = 0;
+    u32 nbuf = 0; /* entries in this wave's fragment buffer (wave-uniform) */
+    /* hand the buffered fragments to the global list: one atomic per <= SC_FBUF fragments */
+    auto flush_frags = [&]() {
+        if (nbuf == 0) return;
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(frag_count, nbuf);
+        base = shfl_u32(base, 0);
+        wave_sync();
+        if ((u32)lane < nbuf) {
+            frag_off[base + lane] = wl->fbuf_off[lane];
+            frag_len[base + lane] = wl->fbuf_len[lane];
+        }
+        wave_sync();
+        nbuf = 0;
+    };
     for (;;) {
         if (chunk_next >= chunk_end) {
             u32 base = 0;
@@ -1445,24 +1509,14 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             atomicAdd(&acc.lensum[0], (u64)l);
         }
 
-        fpl_read_result res;
-        res.r1_start = dropped ? 0 : (u32)s;
-        res.r1_len = dropped ? 0 : (u32)blen;
-        res.frag_start[0] = res.frag_start[1] = 0;
-        res.frag_len[0] = res.frag_len[1] = 0;
-        res.n_frag = 0;
-        res.dropped = dropped ? 1 : 0;
-        res.code[0] = res.code[1] = 0;
-        res.kind[0] = res.kind[1] = 0;
-        res.median_q_pre = (u8)med_pre;
-        res.median_q_post[0] = res.median_q_post[1] = 0;
-        res.reserved[0] = res.reserved[1] = res.reserved[2] = 0;
-        uint64_t fo[2] = {0, 0};
-        u32 fl[2] = {0, 0};
+        /* per-fragment outcome in scalars (an indexed struct would be demoted to LDS) */
+        int nf = 0;
+        u32 r_fs0 = 0, r_fs1 = 0, r_fl0 = 0, r_fl1 = 0, r_code0 = 0, r_code1 = 0, r_kind0 = 0, r_kind1 = 0, r_med0 = 0, r_med1 = 0;
+        bool pass0 = false, pass1 = false;
+        bool split = false;
 
         if (!dropped) {
             /* ---- findMiddleAdapters, src/adaptertrimmer.cpp:13-40 */
-            bool split = false;
             int gs = 0, glen = 0;
             if (ham) {
                 const int al0 = ads[0].len, al1 = ads[1].len;
@@ -1498,7 +1552,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 }
             }
             /* ---- fragments: Read::breakByGap, src/read.cpp:192-215 */
-            int nf = 0, fa[2] = {0, 0}, fb[2] = {0, 0}, fk[2] = {0, 0};
+            int fa[2] = {0, 0}, fb[2] = {0, 0}, fk[2] = {0, 0};
             if (split) {
                 const int len1 = gs, len2 = blen - gs - glen;
                 if (len1 > 0) {
@@ -1517,7 +1571,6 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 fk[0] = 0;
                 nf = 1;
             }
-            res.n_frag = (u8)nf;
             /* ---- passFilter per fragment, counters, post-filter Stats scalars (src/seprocessor.cpp:265-281) */
             for (int f = 0; f < nf; f++) {
                 const int flen = fb[f] - fa[f];
@@ -1530,14 +1583,17 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                     hist_totals(h, t0, t1);
                 }
                 const int code = filter_code(cfg, flen, fs);
-                res.frag_start[f] = (u32)fa[f];
-                res.frag_len[f] = (u32)flen;
-                res.code[f] = (u8)code;
-                res.kind[f] = (u8)fk[f];
+                int med = 0;
+                if (code == FPL_PASS_FILTER) med = hist_median(t0, t1, (u32)flen); /* flen > 0 when passing */
+                if (f == 0) {
+                    r_fs0 = (u32)fa[0]; r_fl0 = (u32)flen; r_code0 = (u32)code; r_kind0 = (u32)fk[0]; r_med0 = (u32)med;
+                    pass0 = code == FPL_PASS_FILTER;
+                } else {
+                    r_fs1 = (u32)fa[1]; r_fl1 = (u32)flen; r_code1 = (u32)code; r_kind1 = (u32)fk[1]; r_med1 = (u32)med;
+                    pass1 = code == FPL_PASS_FILTER;
+                }
                 if (lane == 0) atomicAdd(&acc.fr[code], (u64)1);
                 if (code == FPL_PASS_FILTER) {
-                    const int med = hist_median(t0, t1, (u32)flen); /* flen > 0 when passing */
-                    res.median_q_post[f] = (u8)med;
                     if (t0) atomicAdd(&acc.bqh[1][2 * lane], (u64)t0);
                     if (t1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)t1);
                     if (lane == 0) {
@@ -1546,19 +1602,40 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                         atomicAdd(&acc.reads[1], (u64)1);
                         atomicAdd(&acc.lensum[1], (u64)flen);
                     }
-                    fo[f] = o0 + (uint64_t)fa[f];
-                    fl[f] = (u32)flen;
                 }
             }
         }
         if (lane == 0) {
+            fpl_read_result res;
+            res.r1_start = dropped ? 0 : (u32)s;
+            res.r1_len = dropped ? 0 : (u32)blen;
+            res.frag_start[0] = r_fs0; res.frag_start[1] = r_fs1;
+            res.frag_len[0] = r_fl0; res.frag_len[1] = r_fl1;
+            res.n_frag = (u8)nf;
+            res.dropped = dropped ? 1 : 0;
+            res.code[0] = (u8)r_code0; res.code[1] = (u8)r_code1;
+            res.kind[0] = (u8)r_kind0; res.kind[1] = (u8)r_kind1;
+            res.median_q_pre = (u8)med_pre;
+            res.median_q_post[0] = (u8)r_med0; res.median_q_post[1] = (u8)r_med1;
+            res.reserved[0] = res.reserved[1] = res.reserved[2] = 0;
             results[ri] = res;
-            frag_off[2 * ri] = fo[0];
-            frag_off[2 * ri + 1] = fo[1];
-            frag_len[2 * ri] = fl[0];
-            frag_len[2 * ri + 1] = fl[1];
+            /* passing fragments -> this wave's buffer (compact list for the post-filter statistics pass;
+               the order is irrelevant) */
+            u32 slot = nbuf;
+            if (pass0) {
+                wl->fbuf_off[slot] = o0 + r_fs0;
+                wl->fbuf_len[slot] = r_fl0;
+                slot++;
+            }
+            if (pass1) {
+                wl->fbuf_off[slot] = o0 + r_fs1;
+                wl->fbuf_len[slot] = r_fl1;
+            }
         }
+        nbuf += (pass0 ? 1u : 0u) + (pass1 ? 1u : 0u);
+        if (nbuf > SC_FBUF - 2) flush_frags();
     }
+    flush_frags();
     __syncthreads();
     /* flush the block accumulators */
     for (int k = 0; k < 2; k++) {

@@ -12,6 +12,9 @@
 #ifndef FPL_PIPELINE_H
 #define FPL_PIPELINE_H
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "kernels.h"
 
 namespace fpl {
@@ -20,11 +23,13 @@ namespace fpl {
 constexpr int KWAVES = 2; /* two waves per block keep the emulator's thread count low */
 constexpr int SWAVES = 2;
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
+#define FPL_MEMSET(ptr, bytes, stream) memset(ptr, 0, bytes)
 typedef void* fpl_stream_t;
 #else
 constexpr int KWAVES = 4;
 constexpr int SWAVES = 8; /* k_cycle_stats: 8 waves share one 68 KiB LDS table -> 16 waves per CU */
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+#define FPL_MEMSET(ptr, bytes, stream) (void)hipMemsetAsync(ptr, 0, bytes, stream)
 typedef hipStream_t fpl_stream_t;
 #endif
 
@@ -43,7 +48,9 @@ struct BatchArgs {
     u32* frag_len;      /* 2 * n_reads */
     long long* counters;
     u32 C;
-    u32* work_ctr; /* zeroed before the batch */
+    u32* work_ctr; /* two words zeroed before the batch: [0] k_scan work counter, [1] passing-fragment count */
+    u64* stats_scratch;   /* stats_scratch_slabs() x 64 KiB */
+    u8* stats_flags;      /* one byte per slab, zeroed before each statistics pass */
     u32 n_cu;      /* compute units of the device (grid sizing) */
     int dbg = 0;   /* FPL_DEBUG_FLAGS ablation switches (profiling only) */
 };
@@ -53,17 +60,28 @@ static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_cycle_stats_
 
 inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
-/* slices of the item list for k_cycle_stats: enough blocks to fill the chip, bounded by the
- * 14-bit counter fields */
-inline u32 stats_items_per_slice(u32 n_items, u32 n_tiles, u32 n_cu) {
-    u32 want_blocks = 8 * n_cu;
-    u32 slices = n_tiles ? cdiv(want_blocks, n_tiles) : 1;
-    if (slices < 1) slices = 1;
-    u32 per = cdiv(n_items ? n_items : 1, slices);
+/* Slices of the item list for k_cycle_stats.  A (slice, tile) block is heavy only while its tile lies
+ * below the typical item length, so the number of HEAVY blocks is about slices x (mean length / tile):
+ * aim for a few of them per block slot of the chip (2 blocks/CU) for load balance -- the table hand-over
+ * is a plain 64 KiB store now, so extra slices are cheap -- bounded above by the 14-bit counter fields. */
+inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu) {
+    if (n_items == 0) return 64;
+    const char* e = getenv("FPL_STATS_PER"); /* tuning hook */
+    if (e && atoi(e) > 0) return (u32)atoi(e);
+    const u32 heavy_tiles = mean_len / CS_T + 1;
+    const u32 slices = cdiv(6 * n_cu, heavy_tiles);
+    u32 per = cdiv(n_items, slices);
     per = (per + 63) / 64 * 64;
+    if (per < 1024) per = 1024;
     if (per > CS_MAX_ITEMS_PER_SLICE / 64 * 64) per = CS_MAX_ITEMS_PER_SLICE / 64 * 64;
-    if (per < 64) per = 64;
     return per;
+}
+/* slabs (tiles x slices) the scratch buffer must hold for a batch: the post pass may see up to 2 n items */
+inline size_t stats_scratch_slabs(u32 n_reads, uint64_t n_bytes, u32 max_read_len, u32 n_cu) {
+    const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, CS_T);
+    const u32 mean_len = n_reads ? (u32)(n_bytes / n_reads) : 0;
+    const u32 per = stats_items_per_slice(n_reads, mean_len, n_cu);
+    return (size_t)cdiv(2 * (n_reads ? n_reads : 1), per) * n_tiles;
 }
 
 template <class Mark>
@@ -87,9 +105,14 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     mark(1);
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, CS_T);
     {
-        const u32 per = stats_items_per_slice(n, n_tiles, a.n_cu);
-        FPL_LAUNCH((k_cycle_stats<SWAVES, true>), dim3(cdiv(n, per), n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
-                   a.off, (const u32*)nullptr, n, per, a.counters + FPL_OFF_PRE(a.C), a.C, a.dbg);
+        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu);
+        const u32 n_slices = cdiv(n, per);
+        FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles, stream);
+        FPL_LAUNCH((k_cycle_stats<SWAVES, true>), dim3(n_slices, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
+                   a.off, (const u32*)nullptr, n, (const u32*)nullptr, per, a.counters + FPL_OFF_PRE(a.C),
+                   a.stats_scratch, a.stats_flags, a.C, a.dbg);
+        FPL_LAUNCH(k_cycle_reduce, dim3(8 * CS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
+                   (const u8*)a.stats_flags, n_slices, a.counters + FPL_OFF_PRE(a.C), a.C);
     }
     mark(2);
     {
@@ -100,15 +123,20 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         if (chunk < 1) chunk = 1;
         if (chunk > 64) chunk = 64;
         FPL_LAUNCH((k_scan<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
-                   (const ReadState*)a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk);
+                   (const ReadState*)a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk,
+                   a.work_ctr + 1);
     }
     mark(3);
     {
-        const u32 items = 2 * n;
-        const u32 per = stats_items_per_slice(items, n_tiles, a.n_cu);
-        FPL_LAUNCH((k_cycle_stats<SWAVES, false>), dim3(cdiv(items, per), n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual,
-                   a.n_bytes, (const uint64_t*)a.frag_off, (const u32*)a.frag_len, items, per,
-                   a.counters + FPL_OFF_POST(a.C), a.C, a.dbg);
+        const u32 items = 2 * n; /* upper bound; the kernel reads the compacted count from the device */
+        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu);
+        const u32 n_slices = cdiv(items, per);
+        FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles, stream);
+        FPL_LAUNCH((k_cycle_stats<SWAVES, false>), dim3(n_slices, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual,
+                   a.n_bytes, (const uint64_t*)a.frag_off, (const u32*)a.frag_len, items, (const u32*)(a.work_ctr + 1), per,
+                   a.counters + FPL_OFF_POST(a.C), a.stats_scratch, a.stats_flags, a.C, a.dbg);
+        FPL_LAUNCH(k_cycle_reduce, dim3(8 * CS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
+                   (const u8*)a.stats_flags, n_slices, a.counters + FPL_OFF_POST(a.C), a.C);
     }
     mark(4);
 }

@@ -36,7 +36,7 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     std::vector<ReadState> state(n_reads ? n_reads : 1);
     std::vector<uint64_t> frag_off(2 * (size_t)n_reads + 2, 0);
     std::vector<uint32_t> frag_len(2 * (size_t)n_reads + 2, 0);
-    uint32_t work_ctr = 0;
+    uint32_t work_ctr[2] = {0, 0};
     /* the kernels never read past n_bytes, but give the buffers an end guard anyway */
     BatchArgs a;
     a.seq = seq;
@@ -53,8 +53,13 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.frag_len = frag_len.data();
     a.counters = (long long*)counters;
     a.C = C;
-    a.work_ctr = &work_ctr;
+    a.work_ctr = work_ctr;
     a.n_cu = n_cu ? n_cu : 2;
+    const size_t slabs = stats_scratch_slabs(n_reads, n_bytes, max_len, a.n_cu);
+    std::vector<u64> scratch(slabs * (size_t)(8 * CS_T) + 1);
+    std::vector<u8> sflags(slabs + 1);
+    a.stats_scratch = scratch.data();
+    a.stats_flags = sflags.data();
     enqueue_batch(a, nullptr, [](int) {});
     return 0;
 }
