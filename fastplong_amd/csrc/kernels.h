@@ -548,15 +548,20 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
     const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
     const int thrP = cfg->thr[plen];
     u64 best = ~0ull;
-    for (int p0 = 0; p0 < lim && !FPL_DBG(cfg->dbg, 128); p0 += 64) {
-        const int p = p0 + lane;
-        if (p < lim) {
-            const int ed = lev16_win(win, p, peq16, plen, plen);
-            if (ed <= thrP) {
-                const u64 k = ((u64)(u32)ed << 32) | (u32)p;
+    /* lim <= 184: three positions per lane, evaluated as three independent chains in one straight-line
+       block (positions past lim are clamped for the loads and masked afterwards) */
+    for (int p0 = 0; p0 < lim && !FPL_DBG(cfg->dbg, 128); p0 += 192) {
+        int pp[3], ed[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) pp[u] = p0 + 64 * u + lane;
+#pragma unroll
+        for (int u = 0; u < 3; u++) ed[u] = lev16_win(win, min(pp[u], lim - 1), peq16, plen, plen);
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            if (pp[u] < lim && ed[u] <= thrP) {
+                const u64 k = ((u64)(u32)ed[u] << 32) | (u32)pp[u];
                 best = k < best ? k : best;
             }
-        }
     }
     best = wave_min_u64(best);
     if (best != ~0ull) { /* :218-233 */
@@ -632,10 +637,14 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     const int thrP = cfg->thr[plen];
     int pos = -1, mined = -1;
     bool stop = false;
+    int ed3[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) /* lim <= 184 = three rounds; independent chains, one straight-line block */
+        ed3[u] = lim > 0 ? lev16_win(win, rlen - plen - min(64 * u + lane, lim - 1), peq16, plen, plen) : 0x7fffffff;
     for (int p0 = 0; p0 < lim && !stop; p0 += 64) {
         const int p = p0 + lane;
-        int ed = 0x7fffffff;
-        if (p < lim) ed = lev16_win(win, rlen - plen - p, peq16, plen, plen);
+        const int edr = p0 == 0 ? ed3[0] : (p0 == 64 ? ed3[1] : ed3[2]);
+        const int ed = p < lim ? edr : 0x7fffffff;
         u64 q = wave_ballot(p < lim && ed <= thrP);
         while (q && !stop) {
             const int b = __ffsll(q) - 1;
@@ -915,7 +924,7 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
             const int val = base2val_dev(bb, v);                                                            \
             run = v ? run + 1 : 0;                                                                          \
             kidx = ((kidx << 2) & 0x3FCu) | (u32)val;                                                       \
-            if (run >= 5 && !FPL_DBG(dbg, 16)) atomicAdd(&kmer[kidx], 1u);                                  \
+            if (!FPL_DBG(dbg, 16)) atomicAdd(&kmer[kidx], run >= 5 ? 1u : 0u);                              \
         }                                                                                                   \
     }
                 if (nvalid > 0) {
