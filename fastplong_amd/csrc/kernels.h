@@ -702,7 +702,7 @@ __device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __
 }
 
 template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
+__global__ void __launch_bounds__(WAVES * 64, 5)
 k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
             uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
             ReadState* __restrict__ state, long long* __restrict__ counters, u32 C) {

@@ -27,7 +27,7 @@ constexpr int SWAVES = 2;
 typedef void* fpl_stream_t;
 #else
 constexpr int KWAVES = 4;
-constexpr int SWAVES = 8; /* k_cycle_stats: 8 waves share one 68 KiB LDS table -> 16 waves per CU */
+constexpr int SWAVES = 12; /* k_cycle_stats: 12 waves share one 68 KiB LDS table -> 24 waves per CU */
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #define FPL_MEMSET(ptr, bytes, stream) (void)hipMemsetAsync(ptr, 0, bytes, stream)
 typedef hipStream_t fpl_stream_t;
