@@ -1048,6 +1048,7 @@ __device__ __forceinline__ void hist_totals(const u32* __restrict__ h, u32& t0, 
         t0 += h[(2 * lane) * HIST_COPIES + cc];
         t1 += h[(2 * lane + 1) * HIST_COPIES + cc];
     }
+    wave_sync(); /* later atomics of other lanes must not overtake these reads */
 }
 
 /* median as Stats::statRead computes it, src/stats.cpp:352-363: smallest q with
@@ -1423,6 +1424,29 @@ __device__ __forceinline__ int filter_code(const DevConfig* __restrict__ cfg, in
 }
 
 
+/* First tile (32 bytes per lane) of the quality bytes of [a, b), loaded early so that the trip to
+ * HBM overlaps other work; hist_apply_tile later adds them to the wave's histogram. */
+__device__ __forceinline__ int hist_prefetch_tile(const u8* __restrict__ qb, int a, int b, const u8* __restrict__ qual_end,
+                                                  u32 (&q)[8]) {
+    const int j0 = a + SC_CHUNK * lane_id();
+    const int n = b > j0 ? min(SC_CHUNK, b - j0) : 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) q[k] = 0;
+    if (n > 0) {
+        const u32x4 q0 = load16_guard(qb + j0, qual_end), q1 = load16_guard(qb + j0 + 16, qual_end);
+        q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
+        q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+    }
+    return n;
+}
+__device__ __forceinline__ void hist_apply_tile(u32* __restrict__ h, const u32 (&q)[8], int n) {
+    const int lane = lane_id();
+    for (int k = 0; k < n; k++) {
+        const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0x7Fu;
+        atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
+    }
+}
+
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
@@ -1448,6 +1472,9 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     /* dynamic work distribution in chunks: one device-scope atomic serves `chunk` reads (a single
        hot counter sustains only ~80 atomics/us, which a per-read dequeue would saturate) */
     u32 chunk_next = 0, chunk_end = 0;
+    bool have_next = false;
+    uint64_t nx_o0 = 0, nx_o1 = 0;
+    ReadState nx_st = {0, 0, 0, 0};
     u32 nbuf = 0; /* entries in this wave's fragment buffer (wave-uniform) */
     /* hand the buffered fragments to the global list: one atomic per <= SC_FBUF fragments */
     auto flush_frags = [&]() {
@@ -1471,16 +1498,38 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             if (base >= n_reads) break;
             chunk_next = base;
             chunk_end = min(n_reads, base + chunk);
+            have_next = false;
         }
         const u32 ri = chunk_next++;
-        const uint64_t o0 = off[ri];
-        const int l = (int)(off[ri + 1] - o0);
+        /* this read's metadata: loaded while the previous read was being processed, when possible */
+        uint64_t o0, o1;
+        ReadState st;
+        if (have_next) {
+            o0 = nx_o0;
+            o1 = nx_o1;
+            st = nx_st;
+        } else {
+            o0 = off[ri];
+            o1 = off[ri + 1];
+            st = state[ri];
+        }
+        have_next = chunk_next < chunk_end;
+        if (have_next) { /* the next read of the chunk */
+            nx_o0 = o1;
+            nx_o1 = off[ri + 2];
+            nx_st = state[ri + 1];
+        }
+        const int l = (int)(o1 - o0);
         const u8* rb = seq + o0;
         const u8* qb = qual + o0;
-        const ReadState st = state[ri];
         const int s = (int)st.s, e = (int)st.e;
         const bool dropped = st.dropped != 0;
         const int blen = e - s;
+        /* the trimmed-off ends only feed the pre-filter histogram: start their loads now, use them
+           after the body scan */
+        u32 qhead[8], qtail[8];
+        const int nhead = hist_prefetch_tile(qb, 0, s, qual_end, qhead);
+        const int ntail = hist_prefetch_tile(qb, e, l, qual_end, qtail);
 
         /* ---- r1 body: histogram + filter sums + (adapters enabled) both Hamming scans */
         hist_zero(h);
@@ -1495,12 +1544,15 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, nullptr, nullptr, key0, key1);
         u32 hb0, hb1;
         hist_totals(h, hb0, hb1);
-        /* ---- the trimmed-off ends only feed the pre-filter histogram */
+        /* ---- the ends: first 2 KiB of each from the prefetched registers, any rest (rare) by a scan */
         {
+            hist_apply_tile(h, qhead, nhead);
+            hist_apply_tile(h, qtail, ntail);
+            constexpr int PF = 64 * SC_CHUNK;
             RangeSums dummy;
             u64 d0, d1;
-            if (s > 0) range_scan_fast<false, false>(rb, qb, 0, s, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
-            if (l > e) range_scan_fast<false, false>(rb, qb, e, l, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+            if (s > PF) range_scan_fast<false, false>(rb, qb, PF, s, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+            if (l - e > PF) range_scan_fast<false, false>(rb, qb, e + PF, l, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
         }
         u32 ht0, ht1;
         hist_totals(h, ht0, ht1);
