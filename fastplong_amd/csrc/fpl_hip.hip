@@ -235,8 +235,8 @@ static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_r
     ctx->d_stats_flags = nullptr;
     ctx->scratch_slabs = 0;
     const size_t cap = slabs + slabs / 4;
-    FPL_HIP(hipMalloc((void**)&ctx->d_stats_scratch, cap * (size_t)(8 * CS_T) * sizeof(u64)));
-    FPL_HIP(hipMalloc((void**)&ctx->d_stats_flags, cap));
+    FPL_HIP(hipMalloc((void**)&ctx->d_stats_scratch, cap * (size_t)FS_SLAB * sizeof(u64)));
+    FPL_HIP(hipMalloc((void**)&ctx->d_stats_flags, cap + cap / 8 + 4096)); /* slab flags + tile flags */
     ctx->scratch_slabs = cap;
     return FPL_OK;
 }

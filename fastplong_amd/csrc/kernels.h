@@ -3,8 +3,8 @@
  *
  *   k_trim_ends   : Filter::trimAndCut -> PolyX::trimPolyX -> trimBySequenceStart/End ->
  *                   trimByMultiSequences.  One wave per read, lanes = candidate positions.
- *   k_cycle_stats : the per-cycle / k-mer part of Stats::statRead.  Block = (cycle tile,
- *                   slice of reads); counters privatised in LDS, one flush per block.
+ *   k_stats       : the per-cycle / k-mer part of Stats::statRead, pre- and post-filter tables in one
+ *                   pass.  Block = (cycle tile, slice of reads); counters privatised in LDS.
  *   k_scan        : whole-read pass on r1: both middle-adapter Hamming scans
  *                   (findMiddleAdapters), the passFilter sums, the per-read quality histogram
  *                   (median, base-quality histogram); then resolves the read: Levenshtein
@@ -803,20 +803,32 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
 }
 
 /* =========================================================================================
- * k_cycle_stats: the per-cycle tables and the 5-mer counts of Stats::statRead
- * (src/stats.cpp:265-347) for a list of items (original reads, or passing fragments with the
- * cycle re-based to the fragment start, src/seprocessor.cpp:277).
+ * k_stats: the per-cycle tables and the 5-mer counts of Stats::statRead (src/stats.cpp:265-347),
+ * PRE-filter and POST-filter in ONE pass over the batch.
  *
- * Block (x = slice of items, y = tile of T cycles).  A wave takes one item at a time and reads
- * its T-byte tile with one 16-byte load per lane.  Per (cycle, base class) one packed 64-bit
- * LDS counter: bits 0..21 sum of raw quality bytes, 22..35 count, 36..49 count(q>='5'),
- * 50..63 count(q>='?'); a slice holds <= 16383 items so no field overflows.  The LDS slot of
- * cycle c is (c%16)*64 + c/16 within the tile, so the 64 lanes of one ds_add_u64 touch 64
- * consecutive slots (no bank conflicts).
+ * The post-filter statistics of a read that survives unsplit are the statistics of its window
+ * r1 = [s, e) with the cycle re-based to s (src/seprocessor.cpp:277); k_scan has already decided
+ * s, e and pass/fail, so a single walk over the original read can feed both tables: a base at
+ * position c goes to pre cycle c and, when s <= c < e, to post cycle c - s; a 5-mer window ending
+ * at c goes to the pre table and, when it lies inside r1 (c - 4 >= s, c < e), to the post table.
+ * Class / quality extraction, the packed increment and the k-mer index are computed once.
+ *
+ * Block (x = slice of items, y = tile of FS_T pre cycles).  LDS holds the packed 64-bit counters
+ * (bits 0..21 sum of raw quality bytes, 22..35 count, 36..49 count(q>='5'), 50..63 count(q>='?');
+ * a slice has <= 16383 items so no field overflows) of FS_T pre cycles and of the FS_T + FS_SMAX post
+ * cycles [tile_start - FS_SMAX, tile_start + FS_T) they can map to (reads whose front trim exceeds
+ * FS_SMAX, and the fragments of split reads, come through the EXTRA list instead: post only, cycle =
+ * position).  A lane takes 8 consecutive bytes; the LDS slot of local cycle x is (x%8)*(n/8) + x/8, so
+ * the 64 lanes of one ds_add_u64 hit 64 consecutive slots.  At the end the block stores its tables as
+ * one slab of the scratch buffer (plain coalesced stores); k_stats_reduce sums the slabs per tile.
  * ======================================================================================= */
-constexpr int CS_T = 1024;
+constexpr int FS_T = 512;
+constexpr int FS_SMAX = 128;
+constexpr int FS_PT = FS_T + FS_SMAX;          /* post cycles per slab */
+constexpr int FS_SLAB = 8 * FS_T + 8 * FS_PT;  /* u64 per slab: pre table, then post table */
 constexpr u32 CS_MAX_ITEMS_PER_SLICE = 16383;
 constexpr int CS_GROUP = 4; /* items whose loads are in flight together, per wave */
+constexpr u32 PLAN_TO_POST = 1u; /* ReadState::pad bit: r1 passes unsplit and s <= FS_SMAX */
 
 __device__ __forceinline__ int base2val_dev(u32 b, bool& valid) {
     /* Stats::base2val, src/stats.cpp:411-425: A0 T/U1 C2 G3 else invalid */
@@ -826,77 +838,174 @@ __device__ __forceinline__ int base2val_dev(u32 b, bool& valid) {
     return (int)(((c & 1u) << 1) | (c >> 1));
 }
 
-template <int WAVES, bool PRE>
-__global__ void __launch_bounds__(WAVES * 64)
-k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_bytes,
-              const uint64_t* __restrict__ item_off, const u32* __restrict__ item_len, u32 n_items,
-              const u32* __restrict__ n_items_dev, u32 items_per_slice, long long* __restrict__ stats,
-              u64* __restrict__ scratch, u8* __restrict__ flags, u32 C, int dbg) {
-    /* PRE: items are the reads (CSR offsets).  POST: items are the compacted passing-fragment list
-       k_scan built (count in n_items_dev), cycles re-based to the fragment start. */
-    constexpr bool KMER = true;
-    if (!PRE) n_items = *n_items_dev;
-    __shared__ u64 cyc[8 * CS_T];
-    __shared__ u32 kmer[1024];
-    __shared__ u32 any_work;
+struct u32x2 {
+    u32 x, y;
+};
+__device__ __forceinline__ u32x2 load8_guard(const u8* p, const u8* end) {
+    u32x2 v = {0, 0};
+    if (p + 8 <= end) {
+        __builtin_memcpy(&v, p, 8);
+        return v;
+    }
+    v.x = load4_guard(p, end);
+    v.y = load4_guard(p + 4, end);
+    return v;
+}
+
+/* (two blocks of 12 waves per CU need <= 80 VGPRs: 6 waves per SIMD) */
+/* packed counter -> its four fields */
+__device__ __forceinline__ void fs_unpack_add(u64 v, u64& qsum, u64& cnt, u64& q20, u64& q30) {
+    qsum += v & 0x3FFFFF;
+    cnt += (v >> 22) & 0x3FFF;
+    q20 += (v >> 36) & 0x3FFF;
+    q30 += v >> 50;
+}
+/* Hand the packed tables over as they are: plain coalesced stores into one slab of the scratch buffer;
+   k_stats_reduce sums the slabs of a tile and unpacks them.  (Flushing with global atomics instead cost
+   more than the counting itself.)  The 5-mer counts are few: atomics. */
+template <bool EXTRA>
+__device__ __forceinline__ void fs_hand_over(const u64* tpre, const u64* tpost, const u32* kpre, const u32* kpost,
+                                             u64* __restrict__ scratch, u8* __restrict__ flags, size_t slab,
+                                             long long* kg0, long long* kg1) {
+    u64* dst = scratch + slab * FS_SLAB;
+    if (!EXTRA)
+        for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) dst[i] = tpre[i];
+    for (u32 i = threadIdx.x; i < 8 * FS_PT; i += blockDim.x) dst[8 * FS_T + i] = tpost[i];
+    if (threadIdx.x == 0) {
+        flags[gridDim.y + slab] = 1;
+        flags[blockIdx.y] = 1; /* this tile has at least one slab */
+    }
+    for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) {
+        if (!EXTRA && kpre[i]) atomicAdd((u64*)&kg0[i], (u64)kpre[i]);
+        if (kpost[i]) atomicAdd((u64*)&kg1[i], (u64)kpost[i]);
+    }
+}
+
+template <int WAVES, bool EXTRA>
+__global__ void __launch_bounds__(WAVES * 64, (2 * WAVES + 3) / 4)
+k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_bytes,
+        const uint64_t* __restrict__ item_off, const u32* __restrict__ item_len, const ReadState* __restrict__ plan,
+        u32 n_items, const u32* __restrict__ n_items_dev, u32 items_per_slice, u32 n_slices, u32 max_acc,
+        long long* __restrict__ counters, u64* __restrict__ scratch, u8* __restrict__ flags, u32 C) {
+    /* main pass: items are the reads (CSR offsets + plan).  EXTRA: items are the post-only fragment list
+       k_scan built (count in n_items_dev), cycle = position in the fragment. */
+    __shared__ u64 tpre[8 * FS_T];
+    __shared__ u64 tpost[8 * FS_PT];
+    __shared__ u32 kpre[1024];
+    __shared__ u32 kpost[1024];
+    u32& any_work = kpost[0]; /* (2 x 81920 bytes of LDS per CU: no room for one more word) */
     const int lane = lane_id();
-    const u32 tile_start = blockIdx.y * CS_T;
-    const u32 i_begin = blockIdx.x * items_per_slice;
-    if (i_begin >= n_items) return;
+    if (EXTRA) n_items = *n_items_dev;
+    const u32 tile_start = blockIdx.y * FS_T;
+    const u8* seq_end = seq + n_bytes;
+    const u8* qual_end = qual + n_bytes;
+    const u32 c0 = tile_start + 8 * lane; /* position of this lane's first byte */
+    /* main pass: one slice per block (gridDim.x == n_slices), one slab per (tile, slice).
+       EXTRA pass: the list is usually tiny and its length is only known on the device, so a fixed grid of
+       blocks walks short slices, keeps accumulating in the same tables (while the 14-bit fields allow:
+       max_acc items) and hands over ONE slab per (tile, blockIdx.x) at the end. */
+    long long* kg0 = counters + FPL_OFF_PRE(C) + FPL_ST_KMER(C);
+    long long* kg1 = counters + FPL_OFF_POST(C) + FPL_ST_KMER(C);
+    bool ready = false; /* tables zeroed and in use (block-uniform) */
+    u32 acc = 0;        /* items the tables may already hold */
+    for (u32 slice = blockIdx.x; EXTRA || slice < n_slices; slice += gridDim.x) {
+    const u32 i_begin = slice * items_per_slice;
+    if (i_begin >= n_items) break;
     const u32 i_end = min(n_items, i_begin + items_per_slice);
     /* most (slice, tile) blocks beyond the typical item length have nothing to count: find out before
-       paying for the 68 KiB table */
-    if (threadIdx.x == 0) any_work = 0;
-    __syncthreads();
-    {
+       paying for the tables */
+    u32 aw;
+    if (EXTRA && ready) {
+        aw = 1; /* any_work aliases a live counter now; the tables are paid for anyway */
+    } else {
+        if (threadIdx.x == 0) any_work = 0;
+        __syncthreads();
         bool mine = false;
         for (u32 it = i_begin + threadIdx.x; it < i_end; it += blockDim.x) {
-            const u32 L = PRE ? (u32)(item_off[it + 1] - item_off[it]) : item_len[it];
+            const u32 L = EXTRA ? item_len[it] : (u32)(item_off[it + 1] - item_off[it]);
             mine = mine || (L > tile_start);
         }
         if (wave_ballot(mine) && lane == 0) any_work = 1;
+        __syncthreads();
+        aw = any_work; /* the word is about to be reused as a counter: read, then barrier */
+        __syncthreads();
     }
-    __syncthreads();
-    if (!any_work) return;
-    for (u32 i = threadIdx.x; i < 8 * CS_T; i += blockDim.x) cyc[i] = 0;
-    for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) kmer[i] = 0;
-    __syncthreads();
+    if (!aw) continue;
+    if (EXTRA && ready && acc + items_per_slice > max_acc) {
+        /* the packed fields could overflow: empty the tables with atomics (never seen outside tests) */
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < 8 * FS_PT; i += blockDim.x) {
+            const u64 v = tpost[i];
+            if (!v) continue;
+            const u32 cls = i / FS_PT, slot = i % FS_PT;
+            const u32 pl = (slot % (FS_PT / 8)) * 8 + slot / (FS_PT / 8);
+            const u32 c = tile_start + pl - FS_SMAX; /* EXTRA items start at cycle 0: pl >= FS_SMAX */
+            if (c >= C) continue;
+            u64 qsum = 0, cnt = 0, q20 = 0, q30 = 0;
+            fs_unpack_add(v, qsum, cnt, q20, q30);
+            long long* st = counters + FPL_OFF_POST(C);
+            atomicAdd((u64*)&st[FPL_ST_CYC(c, 0, cls)], cnt);
+            atomicAdd((u64*)&st[FPL_ST_CYC(c, 1, cls)], qsum - 33 * cnt);
+            atomicAdd((u64*)&st[FPL_ST_CYC(c, 2, cls)], q20);
+            atomicAdd((u64*)&st[FPL_ST_CYC(c, 3, cls)], q30);
+        }
+        for (u32 i = threadIdx.x; i < 1024; i += blockDim.x)
+            if (kpost[i]) atomicAdd((u64*)&kg1[i], (u64)kpost[i]);
+        __syncthreads();
+        ready = false;
+    }
+    if (!ready) {
+        if (!EXTRA)
+            for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) tpre[i] = 0;
+        for (u32 i = threadIdx.x; i < 8 * FS_PT; i += blockDim.x) tpost[i] = 0;
+        for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) kpre[i] = kpost[i] = 0;
+        __syncthreads();
+        ready = true;
+        acc = 0;
+    }
+    acc += items_per_slice;
 
-    const u8* seq_end = seq + n_bytes;
-    const u8* qual_end = qual + n_bytes;
-    const u32 c0 = tile_start + 16 * lane; /* cycle of this lane's first byte */
-
-    /* One wave = 64 candidate items per round: offsets and lengths arrive with one coalesced load,
-       the items that reach this tile are walked from the ballot mask, and the 16-byte loads of the
-       NEXT item are in flight while the current one is counted (two-deep software pipeline). */
     for (u32 ib = i_begin + 64 * wave_in_block(); ib < i_end; ib += 64 * WAVES) {
         const u32 it = ib + lane;
-        u32 L = 0;
+        u32 L = 0, S = 0, E = 0, TP = 0;
         uint64_t st = 0;
         if (it < i_end) {
             st = item_off[it];
-            L = PRE ? (u32)(item_off[it + 1] - st) : item_len[it];
+            if (EXTRA) {
+                L = item_len[it];
+                S = 0;
+                E = L;
+                TP = 1;
+            } else {
+                L = (u32)(item_off[it + 1] - st);
+                const ReadState ps = plan[it];
+                S = ps.s;
+                E = ps.e;
+                TP = ps.pad & PLAN_TO_POST;
+            }
         }
         u64 m = wave_ballot(L > tile_start);
-        /* groups of CS_GROUP items: all their 16-byte loads are issued before the first one is
-           counted, so each wave keeps CS_GROUP x 2 KiB of HBM reads in flight */
+        /* groups of CS_GROUP items: all their loads are issued before the first one is counted */
         while (m) {
-            u32x4 svG[CS_GROUP], qvG[CS_GROUP];
-            u32 haloG[CS_GROUP], LG[CS_GROUP];
+            u32x2 svG[CS_GROUP], qvG[CS_GROUP];
+            u32 haloG[CS_GROUP], LG[CS_GROUP], SG[CS_GROUP], EG[CS_GROUP], TG[CS_GROUP];
 #pragma unroll
             for (int g = 0; g < CS_GROUP; g++) {
-                svG[g] = {0, 0, 0, 0};
-                qvG[g] = {0, 0, 0, 0};
+                svG[g] = {0, 0};
+                qvG[g] = {0, 0};
                 haloG[g] = 0;
-                LG[g] = 0;
+                LG[g] = SG[g] = EG[g] = TG[g] = 0;
                 if (m) { /* wave-uniform */
                     const int bit = __ffsll(m) - 1;
                     m &= m - 1;
                     LG[g] = shfl_u32(L, bit);
+                    SG[g] = shfl_u32(S, bit);
+                    EG[g] = shfl_u32(E, bit);
+                    TG[g] = shfl_u32(TP, bit);
                     const uint64_t start = shfl_u64(st, bit);
                     if (LG[g] > c0) {
-                        svG[g] = load16_guard(seq + start + c0, seq_end);
-                        qvG[g] = load16_guard(qual + start + c0, qual_end);
+                        svG[g] = load8_guard(seq + start + c0, seq_end);
+                        qvG[g] = load8_guard(qual + start + c0, qual_end);
                     }
                     if (lane == 0 && tile_start >= 4) haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
                 }
@@ -905,99 +1014,146 @@ k_cycle_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t 
             for (int g = 0; g < CS_GROUP; g++) {
                 const u32 itemL = LG[g];
                 if (itemL <= tile_start) continue; /* wave-uniform: empty slot of the last group */
-                const u32x4 sv = svG[g], qv = qvG[g];
+                const u32 sw[2] = {svG[g].x, svG[g].y};
+                const u32 qw[2] = {qvG[g].x, qvG[g].y};
+                const int s = (int)SG[g], e = (int)EG[g];
+                const bool tp = TG[g] != 0;
                 u32 halo = haloG[g];
-                const int nvalid = itemL > c0 ? (int)min(16u, itemL - c0) : 0;
+                const int nvalid = itemL > c0 ? (int)min(8u, itemL - c0) : 0;
                 /* the four bases in front of this lane's chunk: previous lane's last dword */
-                const u32 up = shfl_up_u32(sv.w, 1);
+                const u32 up = shfl_up_u32(sw[1], 1);
                 const bool have_halo = lane > 0 || tile_start >= 4;
                 if (lane > 0) halo = up;
-    /* one byte of the tile: packed per-cycle counter + rolling 5-mer */
-#define FPL_CS_BYTE(k)                                                                                      \
-    {                                                                                                       \
-        const u32 bb = (sw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                              \
-        const u32 q = (qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                               \
-        const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);          \
-        if (!FPL_DBG(dbg, 8)) atomicAdd(&cyc[(bb & 7u) * CS_T + (k)*64 + lane], inc);                             \
-        if (KMER) {                                                                                         \
-            bool v;                                                                                         \
-            const int val = base2val_dev(bb, v);                                                            \
-            run = v ? run + 1 : 0;                                                                          \
-            kidx = ((kidx << 2) & 0x3FCu) | (u32)val;                                                       \
-            if (!FPL_DBG(dbg, 16)) atomicAdd(&kmer[kidx], run >= 5 ? 1u : 0u);                              \
-        }                                                                                                   \
-    }
-                if (nvalid > 0) {
-                    int run = 0;
-                    u32 kidx = 0;
-                    if (KMER && have_halo) {
+                if (nvalid <= 0) continue; /* (per lane; no wave-level primitive below) */
+                int run = 0;
+                u32 kidx = 0;
+                if (have_halo) {
 #pragma unroll
-                        for (int h = 0; h < 4; h++) {
-                            bool v;
-                            const int val = base2val_dev((halo >> (8 * h)) & 0xFF, v);
-                            run = v ? run + 1 : 0;
-                            kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
-                        }
-                    }
-                    const u32 sw[4] = {sv.x, sv.y, sv.z, sv.w};
-                    const u32 qw[4] = {qv.x, qv.y, qv.z, qv.w};
-                    if (itemL >= tile_start + CS_T) { /* wave-uniform: the item covers the whole tile */
-#pragma unroll
-                        for (int k = 0; k < 16; k++) FPL_CS_BYTE(k)
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 16; k++)
-                            if (k < nvalid) FPL_CS_BYTE(k)
+                    for (int h = 0; h < 4; h++) {
+                        bool v;
+                        const int val = base2val_dev((halo >> (8 * h)) & 0xFF, v);
+                        run = v ? run + 1 : 0;
+                        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
                     }
                 }
-#undef FPL_CS_BYTE
+                /* post cell of local byte k: x = 8*lane + k + (FS_SMAX - s); slot(x) = (x%8)*(FS_PT/8) + x/8 */
+                const int u0 = FS_SMAX - s;
+                /* one byte: DO_PRE / DO_POST are compile-time, BODY / KBODY say whether this byte (its 5-mer
+                   window) lies inside r1 */
+#define FPL_FS_BYTE(k, DO_PRE, DO_POST, BODY, KBODY)                                                              \
+    {                                                                                                             \
+        const u32 bb = (sw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                    \
+        const u32 q = (qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                     \
+        const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);                \
+        const u32 cls = bb & 7u;                                                                                  \
+        if (DO_PRE) atomicAdd(&tpre[cls * FS_T + (k)*64 + lane], inc);                                            \
+        if (DO_POST) {                                                                                            \
+            const int uu = u0 + (k); /* wave-uniform */                                                           \
+            if (BODY) atomicAdd(&tpost[cls * FS_PT + (uu & 7) * (FS_PT / 8) + (uu >> 3) + lane], inc);           \
+        }                                                                                                         \
+        bool v;                                                                                                   \
+        const int val = base2val_dev(bb, v);                                                                      \
+        run = v ? run + 1 : 0;                                                                                    \
+        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;                                                                 \
+        if (DO_PRE) atomicAdd(&kpre[kidx], run >= 5 ? 1u : 0u);                                                   \
+        if (DO_POST) atomicAdd(&kpost[kidx], (run >= 5 && (KBODY)) ? 1u : 0u);                                    \
+    }
+                const int p0 = (int)c0; /* position of byte 0 of this lane */
+                if (EXTRA) {
+                    /* post only; cycle = position; a window needs 4 predecessors inside the fragment */
+                    if (itemL >= tile_start + FS_T) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, false, true, true, p0 + k >= 4)
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (k < nvalid) FPL_FS_BYTE(k, false, true, true, p0 + k >= 4)
+                    }
+                } else if (tp && (int)tile_start >= s + 4 && (int)(tile_start + FS_T) <= e) {
+                    /* wave-uniform: the whole tile lies inside r1 (and inside the read) */
+#pragma unroll
+                    for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, true, true, true)
+                } else if (tp) { /* a tile that straddles an end of r1 */
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (k < nvalid)
+                            FPL_FS_BYTE(k, true, true, (p0 + k >= s && p0 + k < e), (p0 + k >= s + 4 && p0 + k < e))
+                } else if (itemL >= tile_start + FS_T) { /* pre only (dropped, failed, split or far-trimmed read) */
+#pragma unroll
+                    for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, false, false, false)
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (k < nvalid) FPL_FS_BYTE(k, true, false, false, false)
+                }
+#undef FPL_FS_BYTE
             }
         }
     }
+    if (EXTRA) continue;
     __syncthreads();
-    /* hand the packed table over as is: plain coalesced stores into this block's 64 KiB slab of the
-       scratch buffer; k_cycle_reduce sums the slabs of a tile and unpacks them.  (Flushing with global
-       atomics instead -- ~17 k per heavy block -- cost more than the counting itself.) */
-    if (FPL_DBG(dbg, 32)) return;
-    {
-        const size_t slab = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        u64* dst = scratch + slab * (8 * CS_T);
-        for (u32 i = threadIdx.x; i < 8 * CS_T; i += blockDim.x) dst[i] = cyc[i];
-        if (threadIdx.x == 0) flags[slab] = 1;
+    fs_hand_over<EXTRA>(tpre, tpost, kpre, kpost, scratch, flags, (size_t)blockIdx.y * n_slices + slice, kg0, kg1);
+    __syncthreads(); /* (the tables would be reused by a next slice) */
+    ready = false;
     }
-    if (KMER) {
-        long long* kg = stats + FPL_ST_KMER(C);
-        for (u32 i = threadIdx.x; i < 1024; i += blockDim.x)
-            if (kmer[i]) atomicAdd((u64*)&kg[i], (u64)kmer[i]);
+    if (EXTRA && ready) {
+        __syncthreads();
+        fs_hand_over<EXTRA>(tpre, tpost, kpre, kpost, scratch, flags, (size_t)blockIdx.y * n_slices + blockIdx.x, kg0,
+                            kg1);
     }
 }
 
-/* Sum the per-(tile, slice) packed tables of one statistics pass and add them to the per-cycle
- * counters.  Block (x = 256-cell chunk of the tile's 8 x 1024 table, y = tile); a thread owns one
- * (class, slot) cell, walks the slices that wrote a slab and unpacks into 64-bit sums; every
- * counter has exactly one owner, so the update is a plain read-modify-write. */
+/* Sum the per-(tile, slice) slabs of one k_stats launch into the per-cycle counters.  Block (x = chunk
+ * of 256 cells, y = tile); cells 0 .. 8*FS_T-1 are the tile's pre cycles, the next 8*FS_T its post cycles
+ * [tile*FS_T, (tile+1)*FS_T) -- which receive contributions from this tile's slabs and from the next
+ * tile's (whose post window starts FS_SMAX cycles earlier).  Every counter has exactly one owner, so
+ * the update is a plain read-modify-write. */
 __global__ void __launch_bounds__(256)
-k_cycle_reduce(const u64* __restrict__ scratch, const u8* __restrict__ flags, u32 n_slices,
-               long long* __restrict__ stats, u32 C) {
+k_stats_reduce(const u64* __restrict__ scratch, const u8* __restrict__ flags, u32 n_slices, u32 n_tiles,
+               long long* __restrict__ counters, u32 C, int with_pre) {
     const u32 tile = blockIdx.y;
-    const u32 cell = blockIdx.x * 256 + threadIdx.x; /* cls * CS_T + slot */
-    const u32 cls = cell / CS_T, slot = cell % CS_T;
-    const u32 c = tile * CS_T + 16 * (slot & 63) + (slot >> 6);
+    const u32 cell = blockIdx.x * 256 + threadIdx.x; /* [0, 8*FS_T): pre, [8*FS_T, 16*FS_T): post */
+    const bool is_post = cell >= 8 * FS_T;
+    const u8* slab_flags = flags + n_tiles;
+    const bool here = flags[tile] != 0, next = tile + 1 < n_tiles && flags[tile + 1] != 0;
+    if (!here && !next) return; /* block-uniform */
+    const u32 cc = is_post ? cell - 8 * FS_T : cell;
+    const u32 cls = cc / FS_T, x = cc % FS_T; /* x = cycle within the tile */
     u64 qsum = 0, cnt = 0, q20 = 0, q30 = 0;
-    for (u32 sl = 0; sl < n_slices; sl++) {
-        const size_t slab = (size_t)tile * n_slices + sl;
-        if (!flags[slab]) continue; /* block-uniform */
-        const u64 v = scratch[slab * (8 * CS_T) + cell];
-        qsum += v & 0x3FFFFF;
-        cnt += (v >> 22) & 0x3FFF;
-        q20 += (v >> 36) & 0x3FFF;
-        q30 += v >> 50;
+    if (!is_post) {
+        if (!with_pre || !here) return;
+        const u32 slot = (x & 7) * 64 + (x >> 3);
+        for (u32 sl = 0; sl < n_slices; sl++) {
+            const size_t slab = (size_t)tile * n_slices + sl;
+            if (!slab_flags[slab]) continue;
+            fs_unpack_add(scratch[slab * FS_SLAB + cls * FS_T + slot], qsum, cnt, q20, q30);
+        }
+    } else {
+        /* post cycle p = tile*FS_T + x: local index x + FS_SMAX in this tile's slabs, x + FS_SMAX - FS_T in the next tile's */
+        const u32 pl0 = x + FS_SMAX;
+        const u32 slot0 = (pl0 & 7) * (FS_PT / 8) + (pl0 >> 3);
+        for (u32 sl = 0; here && sl < n_slices; sl++) {
+            const size_t slab = (size_t)tile * n_slices + sl;
+            if (!slab_flags[slab]) continue;
+            fs_unpack_add(scratch[slab * FS_SLAB + 8 * FS_T + cls * FS_PT + slot0], qsum, cnt, q20, q30);
+        }
+        if (x + FS_SMAX >= FS_T && next) {
+            const u32 pl1 = x + FS_SMAX - FS_T;
+            const u32 slot1 = (pl1 & 7) * (FS_PT / 8) + (pl1 >> 3);
+            for (u32 sl = 0; sl < n_slices; sl++) {
+                const size_t slab = (size_t)(tile + 1) * n_slices + sl;
+                if (!slab_flags[slab]) continue;
+                fs_unpack_add(scratch[slab * FS_SLAB + 8 * FS_T + cls * FS_PT + slot1], qsum, cnt, q20, q30);
+            }
+        }
     }
+    const u32 c = tile * FS_T + x;
     if (cnt && c < C) {
-        stats[FPL_ST_CYC(c, 0, cls)] += (long long)cnt;
-        stats[FPL_ST_CYC(c, 1, cls)] += (long long)qsum - 33ll * (long long)cnt; /* += qual - 33 */
-        stats[FPL_ST_CYC(c, 2, cls)] += (long long)q20;
-        stats[FPL_ST_CYC(c, 3, cls)] += (long long)q30;
+        long long* st = counters + (is_post ? FPL_OFF_POST(C) : FPL_OFF_PRE(C));
+        st[FPL_ST_CYC(c, 0, cls)] += (long long)cnt;
+        st[FPL_ST_CYC(c, 1, cls)] += (long long)qsum - 33ll * (long long)cnt; /* += qual - 33 */
+        st[FPL_ST_CYC(c, 2, cls)] += (long long)q20;
+        st[FPL_ST_CYC(c, 3, cls)] += (long long)q30;
     }
 }
 
@@ -1451,7 +1607,7 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
        uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
-       const ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
+       ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
        uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, long long* __restrict__ counters, u32 C,
        u32* __restrict__ work_ctr, u32 chunk, u32* __restrict__ frag_count) {
     __shared__ ScanWaveLds wlds[WAVES];
@@ -1666,6 +1822,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 }
             }
         }
+        const bool to_post = !dropped && !split && pass0 && s <= FS_SMAX;
         if (lane == 0) {
             fpl_read_result res;
             res.r1_start = dropped ? 0 : (u32)s;
@@ -1680,10 +1837,12 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             res.median_q_post[0] = (u8)r_med0; res.median_q_post[1] = (u8)r_med1;
             res.reserved[0] = res.reserved[1] = res.reserved[2] = 0;
             results[ri] = res;
-            /* passing fragments -> this wave's buffer (compact list for the post-filter statistics pass;
-               the order is irrelevant) */
+            /* plan for k_stats: a read that passes unsplit with a small front trim feeds the post-filter
+               tables straight from the single statistics pass; every other passing fragment goes to the
+               post-only EXTRA list (through this wave's buffer; the order is irrelevant) */
+            state[ri].pad = to_post ? PLAN_TO_POST : 0u;
             u32 slot = nbuf;
-            if (pass0) {
+            if (pass0 && !to_post) {
                 wl->fbuf_off[slot] = o0 + r_fs0;
                 wl->fbuf_len[slot] = r_fl0;
                 slot++;
@@ -1693,7 +1852,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 wl->fbuf_len[slot] = r_fl1;
             }
         }
-        nbuf += (pass0 ? 1u : 0u) + (pass1 ? 1u : 0u);
+        nbuf += ((pass0 && !to_post) ? 1u : 0u) + (pass1 ? 1u : 0u);
         if (nbuf > SC_FBUF - 2) flush_frags();
     }
     flush_frags();

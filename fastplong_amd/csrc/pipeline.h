@@ -4,10 +4,10 @@
  * kernel order are exercised on the CPU too.
  *
  *   1 k_trim_ends              reads  -> r1 window per read (+ polyX / adapter counters)
- *   2 k_cycle_stats<PRE>       original reads -> pre-filter per-cycle tables + k-mers
- *   3 k_scan                   r1 -> middle-adapter split, filter code, result records,
- *                              quality histograms / medians, passing-fragment list
- *   4 k_cycle_stats<POST>      passing fragments -> post-filter per-cycle tables + k-mers
+ *   2 k_scan                   r1 -> middle-adapter split, filter code, result records,
+ *                              quality histograms / medians, statistics plan + EXTRA fragment list
+ *   3 k_stats + k_stats_reduce reads -> pre- AND post-filter per-cycle tables + k-mers in one pass
+ *   4 k_stats<EXTRA> + reduce  post-only fragments (split reads, far-trimmed reads)
  */
 #ifndef FPL_PIPELINE_H
 #define FPL_PIPELINE_H
@@ -27,7 +27,7 @@ constexpr int SWAVES = 2;
 typedef void* fpl_stream_t;
 #else
 constexpr int KWAVES = 4;
-constexpr int SWAVES = 12; /* k_cycle_stats: 12 waves share one 68 KiB LDS table -> 24 waves per CU */
+constexpr int SWAVES = 12; /* k_stats: 12 waves share one 80 KiB LDS table set -> 24 waves per CU */
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #define FPL_MEMSET(ptr, bytes, stream) (void)hipMemsetAsync(ptr, 0, bytes, stream)
 typedef hipStream_t fpl_stream_t;
@@ -48,15 +48,15 @@ struct BatchArgs {
     u32* frag_len;      /* 2 * n_reads */
     long long* counters;
     u32 C;
-    u32* work_ctr; /* two words zeroed before the batch: [0] k_scan work counter, [1] passing-fragment count */
-    u64* stats_scratch;   /* stats_scratch_slabs() x 64 KiB */
-    u8* stats_flags;      /* one byte per slab, zeroed before each statistics pass */
+    u32* work_ctr; /* two words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count */
+    u64* stats_scratch;   /* stats_scratch_slabs() x FS_SLAB u64 */
+    u8* stats_flags;      /* n_tiles tile flags + one byte per slab, zeroed before each statistics pass */
     u32 n_cu;      /* compute units of the device (grid sizing) */
     int dbg = 0;   /* FPL_DEBUG_FLAGS ablation switches (profiling only) */
 };
 
 constexpr int N_STAGES = 4;
-static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_cycle_stats_pre", "k_scan", "k_cycle_stats_post"};
+static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_stats", "k_stats_extra"};
 
 inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
@@ -68,7 +68,7 @@ inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu) {
     if (n_items == 0) return 64;
     const char* e = getenv("FPL_STATS_PER"); /* tuning hook */
     if (e && atoi(e) > 0) return (u32)atoi(e);
-    const u32 heavy_tiles = mean_len / CS_T + 1;
+    const u32 heavy_tiles = mean_len / FS_T + 1;
     const u32 slices = cdiv(6 * n_cu, heavy_tiles);
     u32 per = cdiv(n_items, slices);
     per = (per + 63) / 64 * 64;
@@ -76,12 +76,30 @@ inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu) {
     if (per > CS_MAX_ITEMS_PER_SLICE / 64 * 64) per = CS_MAX_ITEMS_PER_SLICE / 64 * 64;
     return per;
 }
-/* slabs (tiles x slices) the scratch buffer must hold for a batch: the post pass may see up to 2 n items */
+/* EXTRA pass (post-only fragments; count known only on the device): a fixed number of blocks per tile walk
+ * slices of FS_EXTRA_PER items and hand over one slab each. */
+constexpr u32 FS_EXTRA_PER = 1024;
+constexpr u32 FS_EXTRA_BLOCKS = 64;
+inline u32 env_u32(const char* name, u32 dflt) { /* tuning / test hooks */
+    const char* e = getenv(name);
+    return (e && atoi(e) > 0) ? (u32)atoi(e) : dflt;
+}
+inline u32 stats_extra_per() { return env_u32("FPL_STATS_EXTRA_PER", FS_EXTRA_PER); }
+inline u32 stats_extra_blocks(u32 n_reads) {
+    const u32 b = cdiv(2 * (n_reads ? n_reads : 1), stats_extra_per());
+    const u32 cap = env_u32("FPL_STATS_EXTRA_BLOCKS", FS_EXTRA_BLOCKS);
+    return b < cap ? b : (cap < FS_EXTRA_BLOCKS ? cap : FS_EXTRA_BLOCKS);
+}
+/* items a block may accumulate before it must empty its tables (test hook: force that path) */
+inline u32 stats_extra_max_acc() { return env_u32("FPL_STATS_EXTRA_ACC", CS_MAX_ITEMS_PER_SLICE); }
+/* slabs (tiles x slices) the scratch buffer must hold for a batch */
 inline size_t stats_scratch_slabs(u32 n_reads, uint64_t n_bytes, u32 max_read_len, u32 n_cu) {
-    const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, CS_T);
+    const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, FS_T);
     const u32 mean_len = n_reads ? (u32)(n_bytes / n_reads) : 0;
     const u32 per = stats_items_per_slice(n_reads, mean_len, n_cu);
-    return (size_t)cdiv(2 * (n_reads ? n_reads : 1), per) * n_tiles;
+    u32 slices = cdiv(n_reads ? n_reads : 1, per);
+    if (slices < FS_EXTRA_BLOCKS) slices = FS_EXTRA_BLOCKS;
+    return (size_t)slices * n_tiles;
 }
 
 template <class Mark>
@@ -103,18 +121,6 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                    a.state, a.counters, a.C);
     }
     mark(1);
-    const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, CS_T);
-    {
-        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu);
-        const u32 n_slices = cdiv(n, per);
-        FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles, stream);
-        FPL_LAUNCH((k_cycle_stats<SWAVES, true>), dim3(n_slices, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
-                   a.off, (const u32*)nullptr, n, (const u32*)nullptr, per, a.counters + FPL_OFF_PRE(a.C),
-                   a.stats_scratch, a.stats_flags, a.C, a.dbg);
-        FPL_LAUNCH(k_cycle_reduce, dim3(8 * CS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
-                   (const u8*)a.stats_flags, n_slices, a.counters + FPL_OFF_PRE(a.C), a.C);
-    }
-    mark(2);
     {
         u32 blocks = cdiv(n, KWAVES);
         const u32 cap = 3 * a.n_cu; /* registers / LDS admit three blocks per CU */
@@ -123,20 +129,30 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         if (chunk < 1) chunk = 1;
         if (chunk > 64) chunk = 64;
         FPL_LAUNCH((k_scan<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
-                   (const ReadState*)a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk,
-                   a.work_ctr + 1);
+                   a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk, a.work_ctr + 1);
+    }
+    mark(2);
+    const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
+    {
+        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu);
+        const u32 n_slices = cdiv(n, per);
+        FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles + n_tiles, stream);
+        FPL_LAUNCH((k_stats<SWAVES, false>), dim3(n_slices, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
+                   a.off, (const u32*)nullptr, (const ReadState*)a.state, n, (const u32*)nullptr, per, n_slices,
+                   CS_MAX_ITEMS_PER_SLICE, a.counters, a.stats_scratch, a.stats_flags, a.C);
+        FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
+                   (const u8*)a.stats_flags, n_slices, n_tiles, a.counters, a.C, 1);
     }
     mark(3);
     {
-        const u32 items = 2 * n; /* upper bound; the kernel reads the compacted count from the device */
-        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu);
-        const u32 n_slices = cdiv(items, per);
-        FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles, stream);
-        FPL_LAUNCH((k_cycle_stats<SWAVES, false>), dim3(n_slices, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual,
-                   a.n_bytes, (const uint64_t*)a.frag_off, (const u32*)a.frag_len, items, (const u32*)(a.work_ctr + 1), per,
-                   a.counters + FPL_OFF_POST(a.C), a.stats_scratch, a.stats_flags, a.C, a.dbg);
-        FPL_LAUNCH(k_cycle_reduce, dim3(8 * CS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
-                   (const u8*)a.stats_flags, n_slices, a.counters + FPL_OFF_POST(a.C), a.C);
+        const u32 gx = stats_extra_blocks(n); /* slabs per tile */
+        FPL_MEMSET(a.stats_flags, (size_t)gx * n_tiles + n_tiles, stream);
+        FPL_LAUNCH((k_stats<SWAVES, true>), dim3(gx, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
+                   (const uint64_t*)a.frag_off, (const u32*)a.frag_len, (const ReadState*)nullptr, 2 * n,
+                   (const u32*)(a.work_ctr + 1), stats_extra_per(), gx, stats_extra_max_acc(), a.counters, a.stats_scratch,
+                   a.stats_flags, a.C);
+        FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
+                   (const u8*)a.stats_flags, gx, n_tiles, a.counters, a.C, 0);
     }
     mark(4);
 }

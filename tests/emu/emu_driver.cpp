@@ -56,8 +56,8 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.work_ctr = work_ctr;
     a.n_cu = n_cu ? n_cu : 2;
     const size_t slabs = stats_scratch_slabs(n_reads, n_bytes, max_len, a.n_cu);
-    std::vector<u64> scratch(slabs * (size_t)(8 * CS_T) + 1);
-    std::vector<u8> sflags(slabs + 1);
+    std::vector<u64> scratch(slabs * (size_t)FS_SLAB + 1);
+    std::vector<u8> sflags(slabs + slabs / 8 + 4096);
     a.stats_scratch = scratch.data();
     a.stats_flags = sflags.data();
     enqueue_batch(a, nullptr, [](int) {});
