@@ -197,6 +197,41 @@ __device__ __forceinline__ u32 perm_lo(u32 tbl, u32 sel) {
     return __builtin_amdgcn_perm(0u, tbl, sel);
 #endif
 }
+/* v_perm_b32: result byte i = byte sel.byte[i] of the 8 bytes hi:lo (0..3 lo, 4..7 hi), 0x0c = constant 0 */
+__device__ __forceinline__ u32 perm_b32(u32 hi, u32 lo, u32 sel) {
+#ifdef FPL_EMU
+    const u64 v = ((u64)hi << 32) | lo;
+    u32 r = 0;
+    for (int i = 0; i < 4; i++) {
+        const u32 k = (sel >> (8 * i)) & 0xFF;
+        r |= (u32)((k < 8 ? (v >> (8 * k)) : 0) & 0xFF) << (8 * i);
+    }
+    return r;
+#else
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+/* a value the program knows to be wave-uniform, moved to a scalar register so that everything derived from
+   it runs on the scalar unit */
+__device__ __forceinline__ u32 uniform_u32(u32 v) {
+#ifdef FPL_EMU
+    return v;
+#else
+    return (u32)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+/* (a << n) | b in one VALU op (v_lshl_or_b32; spelled out so that the compiler does not turn a chain of
+   them into a quarter-rate 32-bit multiply) */
+template <int N>
+__device__ __forceinline__ u32 lshl_or(u32 a, u32 b) {
+#ifdef FPL_EMU
+    return (a << N) | b;
+#else
+    u32 r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(N), "v"(b));
+    return r;
+#endif
+}
 __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__popc(x); }
 
 /* 0x01 in every byte of x that is non-zero */

@@ -827,6 +827,9 @@ constexpr int FS_SMAX = 128;
 constexpr int FS_PT = FS_T + FS_SMAX;          /* post cycles per slab */
 constexpr int FS_SLAB = 8 * FS_T + 8 * FS_PT;  /* u64 per slab: pre table, then post table */
 constexpr u32 CS_MAX_ITEMS_PER_SLICE = 16383;
+#ifndef FPL_ABL
+#define FPL_ABL 0 /* profiling only (-DFPL_ABL=bits): 1 no pre-table, 2 no post-table, 4 no 5-mer updates in k_stats */
+#endif
 constexpr int CS_GROUP = 4; /* items whose loads are in flight together, per wave */
 constexpr u32 PLAN_TO_POST = 1u; /* ReadState::pad bit: r1 passes unsplit and s <= FS_SMAX */
 
@@ -836,6 +839,21 @@ __device__ __forceinline__ int base2val_dev(u32 b, bool& valid) {
     valid = d < 32u && ((0x00180045u >> d) & 1u);
     const u32 c = (b >> 1) & 3u; /* A0 C1 T/U2 G3 */
     return (int)(((c & 1u) << 1) | (c >> 1));
+}
+
+/* 2-bit base codes of the four bytes of d, one per byte (Stats::base2val: A0 T/U1 C2 G3; other letters give
+   some code and are caught by the validity mask) */
+__device__ __forceinline__ u32 kmer_codes(u32 d) { return (d & 0x02020202u) | ((d >> 2) & 0x01010101u); }
+/* byte 3 of the result = the four codes packed v0<<6 | v1<<4 | v2<<2 | v3 (v0 = lowest byte = earliest base) */
+__device__ __forceinline__ u32 kmer_pack(u32 v) {
+    const u32 x = lshl_or<10>(v, v);
+    return lshl_or<20>(x, x);
+}
+/* bits [lo, hi) of a byte, lo/hi clamped to 0..8 */
+__device__ __forceinline__ u32 range_mask8(int lo, int hi) {
+    lo = lo < 0 ? 0 : (lo > 8 ? 8 : lo);
+    hi = hi < 0 ? 0 : (hi > 8 ? 8 : hi);
+    return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
 }
 
 struct u32x2 {
@@ -876,8 +894,9 @@ __device__ __forceinline__ void fs_hand_over(const u64* tpre, const u64* tpost, 
         flags[blockIdx.y] = 1; /* this tile has at least one slab */
     }
     for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) {
-        if (!EXTRA && kpre[i]) atomicAdd((u64*)&kg0[i], (u64)kpre[i]);
-        if (kpost[i]) atomicAdd((u64*)&kg1[i], (u64)kpost[i]);
+        const u32 both = kpost[i], pre_only = EXTRA ? 0u : kpre[i]; /* (EXTRA: kpost is post-only) */
+        if (!EXTRA && both + pre_only) atomicAdd((u64*)&kg0[i], (u64)both + pre_only);
+        if (both) atomicAdd((u64*)&kg1[i], (u64)both);
     }
 }
 
@@ -889,10 +908,14 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
         long long* __restrict__ counters, u64* __restrict__ scratch, u8* __restrict__ flags, u32 C) {
     /* main pass: items are the reads (CSR offsets + plan).  EXTRA: items are the post-only fragment list
        k_scan built (count in n_items_dev), cycle = position in the fragment. */
-    __shared__ u64 tpre[8 * FS_T];
-    __shared__ u64 tpost[8 * FS_PT];
-    __shared__ u32 kpre[1024];
-    __shared__ u32 kpost[1024];
+    /* one LDS array carved by hand: the 5-mer tables come first so that their (data-dependent) addresses
+       take the table choice as an instruction offset */
+    __shared__ u64 lds_all[1024 + 8 * FS_T + 8 * FS_PT];
+    u32* const kmer = (u32*)lds_all; /* [0,1024): 5-mers counted pre-filter only; [1024,2048): pre- AND post-filter */
+    u64* const tpre = lds_all + 1024;
+    u64* const tpost = tpre + 8 * FS_T;
+    u32* const kpre = kmer;
+    u32* const kpost = kmer + 1024;
     u32& any_work = kpost[0]; /* (2 x 81920 bytes of LDS per CU: no room for one more word) */
     const int lane = lane_id();
     if (EXTRA) n_items = *n_items_dev;
@@ -995,14 +1018,14 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                 qvG[g] = {0, 0};
                 haloG[g] = 0;
                 LG[g] = SG[g] = EG[g] = TG[g] = 0;
-                if (m) { /* wave-uniform */
+                if (m) { /* wave-uniform; readlane keeps the item's fields in scalar registers */
                     const int bit = __ffsll(m) - 1;
                     m &= m - 1;
-                    LG[g] = shfl_u32(L, bit);
-                    SG[g] = shfl_u32(S, bit);
-                    EG[g] = shfl_u32(E, bit);
-                    TG[g] = shfl_u32(TP, bit);
-                    const uint64_t start = shfl_u64(st, bit);
+                    LG[g] = readlane_u32(L, bit);
+                    SG[g] = readlane_u32(S, bit);
+                    EG[g] = readlane_u32(E, bit);
+                    TG[g] = readlane_u32(TP, bit);
+                    const uint64_t start = readlane_u64(st, bit);
                     if (LG[g] > c0) {
                         svG[g] = load8_guard(seq + start + c0, seq_end);
                         qvG[g] = load8_guard(qual + start + c0, qual_end);
@@ -1012,79 +1035,114 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
             }
 #pragma unroll
             for (int g = 0; g < CS_GROUP; g++) {
-                const u32 itemL = LG[g];
+                const u32 itemL = uniform_u32(LG[g]);
                 if (itemL <= tile_start) continue; /* wave-uniform: empty slot of the last group */
                 const u32 sw[2] = {svG[g].x, svG[g].y};
                 const u32 qw[2] = {qvG[g].x, qvG[g].y};
-                const int s = (int)SG[g], e = (int)EG[g];
-                const bool tp = TG[g] != 0;
-                u32 halo = haloG[g];
-                const int nvalid = itemL > c0 ? (int)min(8u, itemL - c0) : 0;
+                const int s = (int)uniform_u32(SG[g]), e = (int)uniform_u32(EG[g]);
+                const bool tp = uniform_u32(TG[g]) != 0;
+                const int nvalid = itemL > c0 ? (int)min(8u, itemL - c0) : 0; /* bytes of the item in this lane */
                 /* the four bases in front of this lane's chunk: previous lane's last dword */
                 const u32 up = shfl_up_u32(sw[1], 1);
                 const bool have_halo = lane > 0 || tile_start >= 4;
-                if (lane > 0) halo = up;
-                if (nvalid <= 0) continue; /* (per lane; no wave-level primitive below) */
-                int run = 0;
-                u32 kidx = 0;
-                if (have_halo) {
+                const u32 halo = lane > 0 ? up : haloG[g];
+                /* 5-mers, twelve bases at once: 2-bit codes (Stats::base2val: A0 T1 C2 G3) packed earliest base
+                   highest, so the window that ends at byte k is a 10-bit field of W */
+                const u32 vh = kmer_codes(halo), v0 = kmer_codes(sw[0]), v1 = kmer_codes(sw[1]);
+                const u32 W = perm_b32(kmer_pack(vh), perm_b32(kmer_pack(v0), kmer_pack(v1), 0x0c0c0703u), 0x0c070100u);
+                /* okmask bit k: the window ending at byte k holds five valid bases.  All-ACGT rows (the rule)
+                   are recognised by mapping the codes back to letters; anything else takes the exact count */
+                u32 okmask;
+                {
+                    u32 bad = (perm_lo(0x47435441u, v0) ^ sw[0]) | (perm_lo(0x47435441u, v1) ^ sw[1]);
+                    if (have_halo) bad |= perm_lo(0x47435441u, vh) ^ halo;
+                    if (!wave_ballot(nvalid > 0 && bad != 0)) {
+                        okmask = have_halo ? 0xFFu : 0xF0u;
+                    } else {
+                        int run = 0;
+                        okmask = 0;
+                        if (have_halo) {
 #pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        bool v;
-                        const int val = base2val_dev((halo >> (8 * h)) & 0xFF, v);
-                        run = v ? run + 1 : 0;
-                        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;
+                            for (int h = 0; h < 4; h++) {
+                                bool v;
+                                (void)base2val_dev((halo >> (8 * h)) & 0xFF, v);
+                                run = v ? run + 1 : 0;
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            bool v;
+                            (void)base2val_dev((sw[k >> 2] >> (8 * (k & 3))) & 0xFF, v);
+                            run = v ? run + 1 : 0;
+                            okmask |= (run >= 5 ? 1u : 0u) << k;
+                        }
                     }
+                    okmask &= (1u << nvalid) - 1u;
                 }
                 /* post cell of local byte k: x = 8*lane + k + (FS_SMAX - s); slot(x) = (x%8)*(FS_PT/8) + x/8 */
                 const int u0 = FS_SMAX - s;
-                /* one byte: DO_PRE / DO_POST are compile-time, BODY / KBODY say whether this byte (its 5-mer
-                   window) lies inside r1 */
-#define FPL_FS_BYTE(k, DO_PRE, DO_POST, BODY, KBODY)                                                              \
-    {                                                                                                             \
+                const int p0 = (int)c0; /* position of byte 0 of this lane */
+                /* one byte.  DO_PRE / DO_POST / FULL are compile-time; FULL: all 8 bytes of every lane belong to
+                   the item and (with DO_POST) to r1, 5-mer windows included.  Otherwise bit k of bodymask /
+                   kbodymask says whether byte k (its window) lies inside r1. */
+#define FPL_FS_BYTE(k, DO_PRE, DO_POST, FULL)                                                                     \
+    if (FULL || (k) < nvalid) {                                                                                   \
         const u32 bb = (sw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                    \
         const u32 q = (qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                     \
         const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);                \
         const u32 cls = bb & 7u;                                                                                  \
-        if (DO_PRE) atomicAdd(&tpre[cls * FS_T + (k)*64 + lane], inc);                                            \
-        if (DO_POST) {                                                                                            \
+        if (DO_PRE && !(FPL_ABL & 1)) atomicAdd(&tpre[cls * FS_T + (k)*64 + lane], inc);                          \
+        if (DO_POST && !(FPL_ABL & 2)) {                                                                          \
             const int uu = u0 + (k); /* wave-uniform */                                                           \
-            if (BODY) atomicAdd(&tpost[cls * FS_PT + (uu & 7) * (FS_PT / 8) + (uu >> 3) + lane], inc);           \
+            if (FULL || ((bodymask >> (k)) & 1u))                                                                 \
+                atomicAdd(&tpost[cls * FS_PT + (uu & 7) * (FS_PT / 8) + (uu >> 3) + lane], inc);                  \
         }                                                                                                         \
-        bool v;                                                                                                   \
-        const int val = base2val_dev(bb, v);                                                                      \
-        run = v ? run + 1 : 0;                                                                                    \
-        kidx = ((kidx << 2) & 0x3FCu) | (u32)val;                                                                 \
-        if (DO_PRE) atomicAdd(&kpre[kidx], run >= 5 ? 1u : 0u);                                                   \
-        if (DO_POST) atomicAdd(&kpost[kidx], (run >= 5 && (KBODY)) ? 1u : 0u);                                    \
+        /* ONE 5-mer update per byte: a window counted post-filter is also counted pre-filter, so kpost   \
+           holds the windows inside r1 (both tables) and kpre the pre-only rest */                              \
+        const u32 kidx = (W >> (2 * (7 - (k)))) & 0x3FFu;                                                         \
+        const u32 kval = (okmask >> (k)) & 1u;                                                                    \
+        if (FPL_ABL & 4) {                                                                                        \
+        } else if (DO_PRE && DO_POST)                                                                             \
+            atomicAdd(&kmer[(FULL ? 1024u : (((kbodymask >> (k)) & 1u) << 10)) + kidx], kval);                    \
+        else if (DO_PRE)                                                                                          \
+            atomicAdd(&kmer[kidx], kval);                                                                         \
+        else                                                                                                      \
+            atomicAdd(&kmer[1024u + kidx], kval);                                                                 \
     }
-                const int p0 = (int)c0; /* position of byte 0 of this lane */
                 if (EXTRA) {
-                    /* post only; cycle = position; a window needs 4 predecessors inside the fragment */
+                    /* post only; cycle = position; a window needs 4 predecessors inside the fragment, which the
+                       missing halo of (tile 0, lane 0) already says */
+                    const u32 bodymask = 0xFFu, kbodymask = 0xFFu;
+                    (void)kbodymask;
                     if (itemL >= tile_start + FS_T) {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, false, true, true, p0 + k >= 4)
+                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, false, true, true)
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 8; k++)
-                            if (k < nvalid) FPL_FS_BYTE(k, false, true, true, p0 + k >= 4)
+                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, false, true, false)
                     }
                 } else if (tp && (int)tile_start >= s + 4 && (int)(tile_start + FS_T) <= e) {
                     /* wave-uniform: the whole tile lies inside r1 (and inside the read) */
+                    const u32 bodymask = 0xFFu, kbodymask = 0xFFu;
+                    (void)bodymask;
+                    (void)kbodymask;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, true, true, true)
+                    for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, true, true)
                 } else if (tp) { /* a tile that straddles an end of r1 */
+                    const u32 bodymask = range_mask8(s - p0, e - p0), kbodymask = range_mask8(s + 4 - p0, e - p0);
 #pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        if (k < nvalid)
-                            FPL_FS_BYTE(k, true, true, (p0 + k >= s && p0 + k < e), (p0 + k >= s + 4 && p0 + k < e))
-                } else if (itemL >= tile_start + FS_T) { /* pre only (dropped, failed, split or far-trimmed read) */
+                    for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, true, false)
+                } else { /* pre only (dropped, failed, split or far-trimmed read) */
+                    const u32 bodymask = 0, kbodymask = 0;
+                    (void)bodymask;
+                    (void)kbodymask;
+                    if (itemL >= tile_start + FS_T) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, false, false, false)
-                } else {
+                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, false, true)
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        if (k < nvalid) FPL_FS_BYTE(k, true, false, false, false)
+                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, false, false)
+                    }
                 }
 #undef FPL_FS_BYTE
             }
