@@ -33,7 +33,14 @@ struct u32x4 {
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
+/* index of this wave in its block, in a scalar register (every lane of a wave has the same value) */
+__device__ __forceinline__ int wave_in_block() {
+#ifdef FPL_EMU
+    return (int)(threadIdx.x >> 6);
+#else
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+}
 
 __device__ __forceinline__ u64 wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
 
@@ -94,37 +101,83 @@ __device__ __forceinline__ WaveVals64 wave_publish(u64 v) {
     return w;
 }
 
-/* wave-wide reductions / scans (all 64 lanes must call) */
-__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u32(v, m);
-    return v;
+/* wave-wide reductions / scans (all 64 lanes must call, in wave-uniform control flow).
+ * Device: DPP row shifts and row broadcasts (one VALU op per step, no LDS crossbar trip like
+ * ds_bpermute): row_shr 1,2,4,8 scan each row of 16 lanes, row_bcast:15 / row_bcast:31 carry the row
+ * totals forward; lane 63 ends up with the reduction of the whole wave.  Lanes without a source keep
+ * `old`, the identity of the operation. */
+#ifndef FPL_EMU
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_u32(u32 old, u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        u64 o = shfl_xor_u64(v, m);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ u32 wave_max_u32(u32 v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        u32 o = shfl_xor_u32(v, m);
-        v = o > v ? o : v;
-    }
-    return v;
-}
+#define FPL_DPP_SCAN(OP, ID, v)                          \
+    v = OP(v, (dpp_u32<0x111, 0xf>(ID, v)));             \
+    v = OP(v, (dpp_u32<0x112, 0xf>(ID, v)));             \
+    v = OP(v, (dpp_u32<0x114, 0xf>(ID, v)));             \
+    v = OP(v, (dpp_u32<0x118, 0xf>(ID, v)));             \
+    v = OP(v, (dpp_u32<0x142, 0xa>(ID, v)));             \
+    v = OP(v, (dpp_u32<0x143, 0xc>(ID, v)));
+__device__ __forceinline__ u32 op_add_u32(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 op_max_u32(u32 a, u32 b) { return a > b ? a : b; }
+#endif
 /* inclusive prefix sum across lanes */
 __device__ __forceinline__ u32 wave_scan_incl_u32(u32 v) {
+#ifdef FPL_EMU
     int l = lane_id();
-#pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         u32 o = shfl_up_u32(v, d);
         if (l >= d) v += o;
     }
     return v;
+#else
+    FPL_DPP_SCAN(op_add_u32, 0u, v)
+    return v;
+#endif
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#ifdef FPL_EMU
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u32(v, m);
+    return v;
+#else
+    FPL_DPP_SCAN(op_add_u32, 0u, v)
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#ifdef FPL_EMU
+    for (int m = 32; m >= 1; m >>= 1) {
+        u32 o = shfl_xor_u32(v, m);
+        v = o > v ? o : v;
+    }
+    return v;
+#else
+    FPL_DPP_SCAN(op_max_u32, 0u, v)
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#ifdef FPL_EMU
+    for (int m = 32; m >= 1; m >>= 1) {
+        u64 o = shfl_xor_u64(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+#else
+#define FPL_DPP_MIN64(CTRL, MASK)                                                                       \
+    {                                                                                                   \
+        const u64 o = ((u64)dpp_u32<CTRL, MASK>(~0u, (u32)(v >> 32)) << 32) | dpp_u32<CTRL, MASK>(~0u, (u32)v); \
+        v = o < v ? o : v;                                                                              \
+    }
+    FPL_DPP_MIN64(0x111, 0xf)
+    FPL_DPP_MIN64(0x112, 0xf)
+    FPL_DPP_MIN64(0x114, 0xf)
+    FPL_DPP_MIN64(0x118, 0xf)
+    FPL_DPP_MIN64(0x142, 0xa)
+    FPL_DPP_MIN64(0x143, 0xc)
+#undef FPL_DPP_MIN64
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 63);
+#endif
 }
 
 /* bytes [n, n+4) of the 8-byte little-endian value hi:lo, n in 0..3 */
@@ -220,6 +273,11 @@ __device__ __forceinline__ u32 uniform_u32(u32 v) {
     return (u32)__builtin_amdgcn_readfirstlane((int)v);
 #endif
 }
+__device__ __forceinline__ int uniform_i32(int v) { return (int)uniform_u32((u32)v); }
+__device__ __forceinline__ u64 uniform_u64(u64 v) {
+    return ((u64)uniform_u32((u32)(v >> 32)) << 32) | uniform_u32((u32)v);
+}
+__device__ __forceinline__ int readlane_i32(int v, int src) { return (int)readlane_u32((u32)v, src); }
 /* (a << n) | b in one VALU op (v_lshl_or_b32; spelled out so that the compiler does not turn a chain of
    them into a quarter-rate 32-bit multiply) */
 template <int N>

@@ -392,3 +392,15 @@ int fpl_get_kernel_times(fpl_ctx* ctx, float* ms, const char** names, int* n, in
 }
 
 } /* extern "C" */
+
+#ifdef FPL_PROF
+/* profiling builds only: read (and clear) the section timers the kernels accumulate */
+extern "C" int fpl_debug_prof(unsigned long long* out, int n) {
+    unsigned long long tmp[64];
+    if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(fpl::g_fpl_prof), sizeof(tmp)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 64; i++) out[i] = tmp[i];
+    memset(tmp, 0, sizeof(tmp));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fpl::g_fpl_prof), tmp, sizeof(tmp)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

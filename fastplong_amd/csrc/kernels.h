@@ -22,6 +22,29 @@
 
 namespace fpl {
 
+/* Section timers, profiling builds only (-DFPL_PROF, tools/prof_sections.sh): every wave sums the cycles
+   (s_memtime) it spends between PROF marks; fpl_debug_prof() reads the totals back. */
+#if defined(FPL_PROF) && !defined(FPL_EMU)
+__device__ unsigned long long g_fpl_prof[64];
+#define PROF_INIT()                                     \
+    unsigned long long prof_a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    unsigned long long prof_t = __builtin_amdgcn_s_memtime()
+#define PROF(i)                                                     \
+    {                                                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        prof_a[i] += t_ - prof_t;                                   \
+        prof_t = t_;                                                \
+    }
+#define PROF_FLUSH(base)                                                                      \
+    if (lane_id() == 0)                                                                       \
+        for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_fpl_prof[(base) + i_], prof_a[i_])
+#else
+#define PROF_INIT()
+#define PROF(i)
+#define PROF_FLUSH(base)
+#endif
+
+
 /* profiling-only ablation switches (FPL_DEBUG_FLAGS); compiled out unless -DFPL_ABLATE */
 #ifdef FPL_ABLATE
 #define FPL_DBG(x, bit) ((x) & (bit))
@@ -227,7 +250,7 @@ __device__ __forceinline__ int lev_wave(const uint64_t (*__restrict__ peq)[PEQ_W
 }
 
 /* run f() on lane 0 only and hand its int result to every lane */
-#define FPL_LANE0_INT(expr) shfl_i32((lane_id() == 0) ? (expr) : 0, 0)
+#define FPL_LANE0_INT(expr) readlane_i32((lane_id() == 0) ? (expr) : 0, 0)
 
 /* =========================================================================================
  * k_trim_ends
@@ -344,10 +367,10 @@ __device__ inline int trim_polyx_wave(const u8* __restrict__ r, int rlen, int co
         const u64 m = wave_ballot(brk);
         const int src = m ? (__ffsll(m) - 1) : 63;
         /* counts at the break lane, or the running totals when the round ends without one */
-        cnt[0] = shfl_i32(nA, src);
-        cnt[1] = shfl_i32(nT, src);
-        cnt[2] = shfl_i32(nC, src);
-        cnt[3] = shfl_i32(nG, src);
+        cnt[0] = readlane_i32(nA, src);
+        cnt[1] = readlane_i32(nT, src);
+        cnt[2] = readlane_i32(nC, src);
+        cnt[3] = readlane_i32(nG, src);
         if (m) {
             P = p0 + src;
             broke = true;
@@ -649,7 +672,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
         while (q && !stop) {
             const int b = __ffsll(q) - 1;
             q &= q - 1;
-            const int edb = shfl_i32(ed, b);
+            const int edb = readlane_i32(ed, b);
             if (pos < 0) {
                 pos = p0 + b;
                 mined = edb;
@@ -728,13 +751,16 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     const u32 wave_global = blockIdx.x * WAVES + wave_in_block();
     const u32 n_waves = gridDim.x * WAVES;
     long long* keyh = counters + FPL_OFF_KEYHIST(C);
+    PROF_INIT();
     for (u32 ri = wave_global; ri < n_reads; ri += n_waves) {
         const uint64_t o0 = off[ri];
         const int l = (int)(off[ri + 1] - o0);
         const u8* sq = seq + o0;
         const u8* ql = qual + o0;
         int s, e;
+        PROF(0)
         bool alive = trim_and_cut_wave(sq, ql, l, cfg, s, e);
+        PROF(1)
         if (alive && cfg->polyx) { /* src/seprocessor.cpp:198-201 */
             int poly, tl;
             const int nl = trim_polyx_wave(sq + s, e - s, cfg->polyx_min_len, poly, tl);
@@ -744,6 +770,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 atomicAdd(&acc.fr[FPL_FR_POLYX_BASES + poly], (u64)tl);
             }
         }
+        PROF(2) /* polyX */
         if (alive && cfg->adapter_enabled) { /* src/seprocessor.cpp:205-216 */
             int trimmed = 0, kl;
             if (cfg->has_start && ads[0].len <= FPL_END_WINDOW) {
@@ -757,6 +784,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 trimmed += trim_start_wave(wn, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             }
+            PROF(3) /* start adapter */
             if (cfg->has_end && ads[1].len <= FPL_END_WINDOW) {
                 /* the end trim only looks at the last 200 bases of r1 */
                 const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
@@ -769,6 +797,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 trimmed += trim_end_wave(wn, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             }
+            PROF(4) /* end adapter */
             for (int a = 0; a < cfg->n_fasta; a++) { /* trimByMultiSequences, src/adaptertrimmer.cpp:42-57 */
                 const DevAdapter* ad = &ads[2 + a];
                 const Win<false> ws = {sq + s, nullptr, 0, e - s};
@@ -793,7 +822,9 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
             st.pad = 0;
             state[ri] = st;
         }
+        PROF(5)
     }
+    PROF_FLUSH(16);
     __syncthreads();
     long long* fr = counters + FPL_OFF_FR(C);
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x)
@@ -1218,15 +1249,21 @@ k_stats_reduce(const u64* __restrict__ scratch, const u8* __restrict__ flags, u3
 /* =========================================================================================
  * k_scan
  * ======================================================================================= */
-constexpr int HIST_COPIES = 16; /* per-wave quality histogram: 128 bins x 16 lane-copies */
+#ifndef FPL_HIST_COPIES
+#define FPL_HIST_COPIES 8
+#endif
+constexpr int HIST_COPIES = FPL_HIST_COPIES; /* per-wave quality histogram: 128 bins x this many lane-copies */
+/* k_scan blocks (4 waves) a CU holds: LDS-bound, 10 KiB (16 copies) or 6 KiB (8 copies) per wave */
+constexpr int SCAN_BLOCKS_PER_CU = HIST_COPIES == 16 ? 3 : 5;
 constexpr int SC_CHUNK = 32;    /* bases per lane per tile in the bit-sliced scan */
 constexpr int SC_FBUF = 32;     /* fragments a wave gathers per reservation in the global fragment list */
 constexpr int SC_LANES_HAM = 62; /* lanes 62/63 only provide the plane words the last windows reach into */
 
 /* per-wave LDS of k_scan */
-struct ScanWaveLds {
+struct alignas(16) ScanWaveLds {
     u32 planes[5][64];            /* letter bit-planes of the current tile: [A,C,T,G][chunk]; row 4 stays zero */
-    u32 hist[128 * HIST_COPIES];
+    u32 hist[128 * HIST_COPIES];  /* quality histogram of the range being scanned; all zero between uses */
+    u32 ehist[128];               /* quality histogram of the trimmed-off ends of the read; all zero between uses */
     uint64_t fbuf_off[SC_FBUF];   /* passing fragments waiting for a slot in the global list */
     u32 fbuf_len[SC_FBUF];
 };
@@ -1250,19 +1287,28 @@ __device__ __forceinline__ void hist_zero(u32* __restrict__ h) {
     wave_sync();
 }
 
-/* totals of bins 2*lane and 2*lane+1 over the lane copies */
-__device__ __forceinline__ void hist_totals(const u32* __restrict__ h, u32& t0, u32& t1) {
+/* totals of bins 2*lane and 2*lane+1 over the lane copies; leaves the histogram zeroed for its next
+ * user.  A lane owns 2 * HIST_COPIES consecutive words = HIST_COPIES / 2 slots of 16 bytes and visits them in
+ * an order rotated by its lane number, so the 64 lanes of one ds_read_b128 / ds_write_b128 spread over the banks. */
+__device__ __forceinline__ void hist_totals(u32* __restrict__ h, u32& t0, u32& t1) {
+    static_assert(HIST_COPIES == 8 || HIST_COPIES == 16, "slot arithmetic below");
+    constexpr int NSLOT = HIST_COPIES / 2; /* 16-byte slots per lane: the first half is bin 2*lane, the rest 2*lane+1 */
     const int lane = lane_id();
     t0 = 0;
     t1 = 0;
     wave_sync();
-#pragma unroll 8
-    for (int c = 0; c < HIST_COPIES; c++) {
-        const int cc = (c + lane) & (HIST_COPIES - 1); /* rotate so that lanes hit different banks */
-        t0 += h[(2 * lane) * HIST_COPIES + cc];
-        t1 += h[(2 * lane + 1) * HIST_COPIES + cc];
+    u32x4* row = (u32x4*)(h + 2 * HIST_COPIES * lane);
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+        const int slot = (k + lane) & (NSLOT - 1);
+        const u32x4 v = row[slot];
+        const u32x4 z = {0, 0, 0, 0};
+        row[slot] = z;
+        const u32 sum = v.x + v.y + v.z + v.w;
+        t0 += slot < NSLOT / 2 ? sum : 0u;
+        t1 += slot < NSLOT / 2 ? 0u : sum;
     }
-    wave_sync(); /* later atomics of other lanes must not overtake these reads */
+    wave_sync(); /* later atomics of other lanes must not overtake these accesses */
 }
 
 /* median as Stats::statRead computes it, src/stats.cpp:352-363: smallest q with
@@ -1275,7 +1321,7 @@ __device__ __forceinline__ int hist_median(u32 t0, u32 t1, u32 len) {
     const u64 m = wave_ballot(incl > half);
     const int L = __ffsll(m) - 1; /* m != 0 because the total is len > half */
     const int mine = 2 * lane_id() + ((excl + t0 > half) ? 0 : 1);
-    return shfl_i32(mine, L);
+    return readlane_i32(mine, L);
 }
 
 /* Hamming distances between the adapter and the 16 windows starting at this lane's 16 bytes.
@@ -1331,7 +1377,7 @@ __device__ inline void range_scan_bytes(const u8* __restrict__ rb, const u8* __r
         }
         u32 prevb = shfl_up_u32(sv.w >> 24, 1);
         if (lane == 0) prevb = prev_last;
-        prev_last = shfl_u32(sv.w >> 24, 63);
+        prev_last = readlane_u32(sv.w >> 24, 63);
         const u32 sw[4] = {sv.x, sv.y, sv.z, sv.w};
         const u32 qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
@@ -1533,7 +1579,7 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
         /* predecessor of this chunk's first byte: last dword of the previous lane / previous tile */
         u32 prevd = shfl_up_u32(s[7], 1);
         if (lane == 0) prevd = prev_tile_last;
-        prev_tile_last = shfl_u32(s[7], ACTIVE - 1);
+        prev_tile_last = readlane_u32(s[7], ACTIVE - 1);
         if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
         if (nstat == SC_CHUNK) {
             if (!FPL_DBG(dbg, 1)) {
@@ -1638,27 +1684,93 @@ __device__ __forceinline__ int filter_code(const DevConfig* __restrict__ cfg, in
 }
 
 
-/* First tile (32 bytes per lane) of the quality bytes of [a, b), loaded early so that the trip to
- * HBM overlaps other work; hist_apply_tile later adds them to the wave's histogram. */
-__device__ __forceinline__ int hist_prefetch_tile(const u8* __restrict__ qb, int a, int b, const u8* __restrict__ qual_end,
-                                                  u32 (&q)[8]) {
-    const int j0 = a + SC_CHUNK * lane_id();
-    const int n = b > j0 ? min(SC_CHUNK, b - j0) : 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) q[k] = 0;
-    if (n > 0) {
-        const u32x4 q0 = load16_guard(qb + j0, qual_end), q1 = load16_guard(qb + j0 + 16, qual_end);
-        q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
-        q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
-    }
-    return n;
-}
-__device__ __forceinline__ void hist_apply_tile(u32* __restrict__ h, const u32 (&q)[8], int n) {
+/* The trimmed-off ends of a read (head [0, s), tail [e, l)) only feed the pre-filter quality histogram and
+ * are short: one byte per lane, two rounds each (SC_END_PF bytes), loaded early so that the trip to HBM
+ * overlaps the body scan; anything longer (rare) goes through a range scan. */
+constexpr int SC_END_PF = 128;
+struct EndBytes {
+    u32 q[4]; /* head round 0 / 1, tail round 0 / 1 */
+};
+__device__ __forceinline__ EndBytes ends_prefetch(const u8* __restrict__ qb, int s, int e, int l) {
     const int lane = lane_id();
-    for (int k = 0; k < n; k++) {
-        const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0x7Fu;
-        atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
+    EndBytes eb;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int jh = 64 * r + lane, jt = e + 64 * r + lane;
+        eb.q[r] = jh < s ? (u32)qb[jh] : 0u;
+        eb.q[2 + r] = jt < l ? (u32)qb[jt] : 0u;
     }
+    return eb;
+}
+__device__ __forceinline__ void ends_apply(u32* __restrict__ eh, const EndBytes& eb, int s, int e, int l) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (64 * r + lane < s) atomicAdd(&eh[eb.q[r] & 127u], 1u);
+        if (e + 64 * r + lane < l) atomicAdd(&eh[eb.q[2 + r] & 127u], 1u);
+    }
+}
+
+/* Levenshtein confirmation of both middle-adapter candidates at once (ACGT-only adapters of <= 32 bases).
+ * The two text windows are fetched early (lev_pair32_fetch, right after the scan that found them, so the
+ * trip to memory overlaps the histogram work); their Peq words come from a 4-entry LDS table per adapter;
+ * lane 0 runs the column recurrence of adapter 0 and lane 1 that of adapter 1 in the same VALU
+ * instructions (lane j holds the Peq word of column j of both windows; v_readlane + one select feed the
+ * two lanes).  edX = the distance when it is <= thrX, some value > thrX otherwise (see lev_round32);
+ * windows that need no confirmation (needX false) are skipped. */
+struct LevPairText {
+    u32 b0, b1;
+};
+__device__ __forceinline__ LevPairText lev_pair32_fetch(const u8* __restrict__ t0, int m0, bool need0,
+                                                        const u8* __restrict__ t1, int m1, bool need1) {
+    const int lane = lane_id();
+    LevPairText x;
+    x.b0 = (need0 && lane < m0) ? (u32)t0[lane] : 0u;
+    x.b1 = (need1 && lane < m1) ? (u32)t1[lane] : 0u;
+    return x;
+}
+__device__ __forceinline__ u32 peq4_lookup(const u32* __restrict__ tbl, u32 b) {
+    const u32 code = (b >> 1) & 3u; /* A0 C1 T2 G3 */
+    return ((0x47544341u >> (8 * code)) & 0xFFu) == b ? tbl[code] : 0u;
+}
+__device__ __forceinline__ void lev_pair32_run(const u32 (*__restrict__ peq4)[4], const LevPairText& x, int m0, int thr0,
+                                               bool need0, int m1, int thr1, bool need1, int& ed0, int& ed1) {
+    const int lane = lane_id();
+    const WaveVals64 pub0 = wave_publish((u64)peq4_lookup(peq4[0], x.b0));
+    const WaveVals64 pub1 = wave_publish((u64)peq4_lookup(peq4[1], x.b1));
+    const bool second = lane == 1;
+    const int m = second ? m1 : m0, thr = second ? thr1 : thr0;
+    bool done = !((lane == 0 && need0 && m0 > 0) || (second && need1 && m1 > 0));
+    int res = (lane == 0 && need0) ? m0 : ((second && need1) ? m1 : 0); /* (m == 0: the distance is the text length) */
+    u32 Pv = ~0u, Mv = 0;
+    int score = m;
+    const u32 top = m > 0 ? 1u << (m - 1) : 0u;
+    const int mmax = max(need0 ? m0 : 0, need1 ? m1 : 0);
+    for (int t = 0; t < mmax; t++) {
+        const u32 e0 = (u32)pub0.get(t), e1 = (u32)pub1.get(t);
+        const u32 Eq = second ? e1 : e0;
+        const u32 Xv = Eq | Mv;
+        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        u32 Ph = Mv | ~(Xh | Pv);
+        u32 Mh = Pv & Xh;
+        score += (Ph & top) ? 1 : ((Mh & top) ? -1 : 0);
+        Ph = (Ph << 1) | 1u;
+        Mh <<= 1;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+        if (!done) {
+            if (score - (m - 1 - t) > thr) {
+                res = thr + 1;
+                done = true;
+            } else if (t + 1 == m) {
+                res = score;
+                done = true;
+            }
+        }
+        if (!(wave_ballot(!done) & 3ull)) break; /* wave-uniform */
+    }
+    ed0 = readlane_i32(res, 0);
+    ed1 = readlane_i32(res, 1);
 }
 
 template <int WAVES>
@@ -1670,10 +1782,16 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
        u32* __restrict__ work_ctr, u32 chunk, u32* __restrict__ frag_count) {
     __shared__ ScanWaveLds wlds[WAVES];
     __shared__ ScanBlockAcc acc;
+    __shared__ u32 peq4[2][4]; /* Peq words of A, C, T, G for the two command-line adapters (lev_pair32) */
     const int lane = lane_id();
     ScanWaveLds* const wl = &wlds[wave_in_block()];
     u32* h = wl->hist;
     wl->planes[4][lane] = 0;
+    hist_zero(h); /* from here on every user of the histograms leaves them zeroed */
+    wl->ehist[lane] = 0;
+    wl->ehist[64 + lane] = 0;
+    if (threadIdx.x < 8) peq4[threadIdx.x >> 2][threadIdx.x & 3] =
+        (u32)ads[threadIdx.x >> 2].peq_full[(0x47544341u >> (8 * (threadIdx.x & 3))) & 0xFFu][0];
     {
         u64* z = (u64*)&acc;
         for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
@@ -1687,6 +1805,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
        hot counter sustains only ~80 atomics/us, which a per-read dequeue would saturate) */
     u32 chunk_next = 0, chunk_end = 0;
     bool have_next = false;
+    PROF_INIT();
     uint64_t nx_o0 = 0, nx_o1 = 0;
     ReadState nx_st = {0, 0, 0, 0};
     u32 nbuf = 0; /* entries in this wave's fragment buffer (wave-uniform) */
@@ -1695,7 +1814,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         if (nbuf == 0) return;
         u32 base = 0;
         if (lane == 0) base = atomicAdd(frag_count, nbuf);
-        base = shfl_u32(base, 0);
+        base = readlane_u32(base, 0);
         wave_sync();
         if ((u32)lane < nbuf) {
             frag_off[base + lane] = wl->fbuf_off[lane];
@@ -1708,7 +1827,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         if (chunk_next >= chunk_end) {
             u32 base = 0;
             if (lane == 0) base = atomicAdd(work_ctr, chunk);
-            base = shfl_u32(base, 0);
+            base = readlane_u32(base, 0);
             if (base >= n_reads) break;
             chunk_next = base;
             chunk_end = min(n_reads, base + chunk);
@@ -1727,6 +1846,13 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             o1 = off[ri + 1];
             st = state[ri];
         }
+        /* every lane holds the same values: keep them (and all the range arithmetic and branching derived
+           from them) on the scalar unit */
+        o0 = uniform_u64(o0);
+        o1 = uniform_u64(o1);
+        st.s = uniform_u32(st.s);
+        st.e = uniform_u32(st.e);
+        st.dropped = uniform_u32(st.dropped);
         have_next = chunk_next < chunk_end;
         if (have_next) { /* the next read of the chunk */
             nx_o0 = o1;
@@ -1741,12 +1867,10 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         const int blen = e - s;
         /* the trimmed-off ends only feed the pre-filter histogram: start their loads now, use them
            after the body scan */
-        u32 qhead[8], qtail[8];
-        const int nhead = hist_prefetch_tile(qb, 0, s, qual_end, qhead);
-        const int ntail = hist_prefetch_tile(qb, e, l, qual_end, qtail);
+        const EndBytes eb = ends_prefetch(qb, s, e, l);
+        PROF(0) /* dequeue, metadata, prefetch issue */
 
         /* ---- r1 body: histogram + filter sums + (adapters enabled) both Hamming scans */
-        hist_zero(h);
         RangeSums sm = {0, 0, 0, 0};
         u64 key0 = ~0ull, key1 = ~0ull;
         const bool ham = !dropped && cfg->adapter_enabled;
@@ -1756,20 +1880,47 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             range_scan_bytes<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
         else
             range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, nullptr, nullptr, key0, key1);
+        /* candidates of the middle-adapter search that still need their edit distance: fetch the two text
+           windows now, confirm after the histogram work (edit distance <= Hamming distance, so only an argmin
+           worse than the threshold needs it) */
+        const bool pair32 = ham && cfg->ham_fast && ads[0].len <= 32 && ads[1].len <= 32;
+        const int thr0 = ham ? cfg->thr[ads[0].len] : 0, thr1 = ham ? cfg->thr[ads[1].len] : 0;
+        const bool need0 = ham && key0 != ~0ull && (int)(key0 >> 32) > thr0;
+        const bool need1 = ham && key1 != ~0ull && (int)(key1 >> 32) > thr1;
+        LevPairText ltxt = {0, 0};
+        if (pair32 && (need0 || need1))
+            ltxt = lev_pair32_fetch(rb + s + (int)(u32)key0, ads[0].len, need0, rb + s + (int)(u32)key1, ads[1].len, need1);
+        PROF(2) /* body scan */
         u32 hb0, hb1;
         hist_totals(h, hb0, hb1);
-        /* ---- the ends: first 2 KiB of each from the prefetched registers, any rest (rare) by a scan */
+        PROF(3)
+        /* ---- the ends: their first SC_END_PF bytes from the prefetched registers into the small histogram,
+           any rest (rare) by a scan; pre-filter totals = body + ends */
+        u32 ht0 = hb0, ht1 = hb1;
         {
-            hist_apply_tile(h, qhead, nhead);
-            hist_apply_tile(h, qtail, ntail);
-            constexpr int PF = 64 * SC_CHUNK;
-            RangeSums dummy;
-            u64 d0, d1;
-            if (s > PF) range_scan_fast<false, false>(rb, qb, PF, s, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
-            if (l - e > PF) range_scan_fast<false, false>(rb, qb, e + PF, l, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+            u32* const eh = wl->ehist;
+            ends_apply(eh, eb, s, e, l);
+            if (s > SC_END_PF || l - e > SC_END_PF) { /* wave-uniform */
+                RangeSums dummy;
+                u64 d0, d1;
+                if (s > SC_END_PF)
+                    range_scan_fast<false, false>(rb, qb, SC_END_PF, s, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+                if (l - e > SC_END_PF)
+                    range_scan_fast<false, false>(rb, qb, e + SC_END_PF, l, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+                u32 x0, x1;
+                hist_totals(h, x0, x1);
+                ht0 += x0;
+                ht1 += x1;
+            }
+            wave_sync();
+            ht0 += eh[2 * lane];
+            ht1 += eh[2 * lane + 1];
+            eh[2 * lane] = 0;
+            eh[2 * lane + 1] = 0;
+            wave_sync();
         }
-        u32 ht0, ht1;
-        hist_totals(h, ht0, ht1);
+        PROF(4) /* ends */
+        PROF(5)
         int med_pre = 0;
         if (l > 0) med_pre = hist_median(ht0, ht1, (u32)l);
         /* pre-filter Stats scalars, src/stats.cpp:265-271,352-374 */
@@ -1784,6 +1935,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             atomicAdd(&acc.lensum[0], (u64)l);
         }
 
+        PROF(6) /* median + block accumulators */
         /* per-fragment outcome in scalars (an indexed struct would be demoted to LDS) */
         int nf = 0;
         u32 r_fs0 = 0, r_fs1 = 0, r_fl0 = 0, r_fl1 = 0, r_code0 = 0, r_code1 = 0, r_kind0 = 0, r_kind1 = 0, r_med0 = 0, r_med1 = 0;
@@ -1796,16 +1948,18 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             if (ham) {
                 const int al0 = ads[0].len, al1 = ads[1].len;
                 int sp = -1, ep = -1;
-                if (key0 != ~0ull) { /* edit distance <= Hamming distance: only a worse argmin needs the confirm */
-                    const int p = (int)(u32)key0, thr0 = cfg->thr[al0];
-                    const int ed = (int)(key0 >> 32) <= thr0 ? 0 : lev_wave(ads[0].peq_full, 0, al0, rb + s + p, al0, thr0);
-                    if (ed <= thr0) sp = p;
+                const int p0 = (int)(u32)key0, p1 = (int)(u32)key1;
+                int ed0 = 0, ed1 = 0;
+                PROF(10)
+                if (pair32) {
+                    if (need0 || need1) lev_pair32_run(peq4, ltxt, al0, thr0, need0, al1, thr1, need1, ed0, ed1);
+                    PROF(11)
+                } else {
+                    if (need0) ed0 = lev_wave(ads[0].peq_full, 0, al0, rb + s + p0, al0, thr0);
+                    if (need1) ed1 = lev_wave(ads[1].peq_full, 0, al1, rb + s + p1, al1, thr1);
                 }
-                if (key1 != ~0ull) {
-                    const int p = (int)(u32)key1, thr1 = cfg->thr[al1];
-                    const int ed = (int)(key1 >> 32) <= thr1 ? 0 : lev_wave(ads[1].peq_full, 0, al1, rb + s + p, al1, thr1);
-                    if (ed <= thr1) ep = p;
-                }
+                if (key0 != ~0ull && ed0 <= thr0) sp = p0;
+                if (key1 != ~0ull && ed1 <= thr1) ep = p1;
                 const int ext = cfg->ext;
                 if (sp >= 0 && ep >= 0) {
                     int gstart = min(sp, ep), gend = max(sp + al0, ep + al1);
@@ -1826,6 +1980,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                     split = true;
                 }
             }
+            PROF(7) /* Levenshtein confirmation of the two Hamming argmins */
             /* ---- fragments: Read::breakByGap, src/read.cpp:192-215 */
             int fa[2] = {0, 0}, fb[2] = {0, 0}, fk[2] = {0, 0};
             if (split) {
@@ -1852,7 +2007,6 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 u32 t0 = hb0, t1 = hb1;
                 RangeSums fs = sm;
                 if (split) { /* rare: re-derive sums and histogram for this fragment */
-                    hist_zero(h);
                     u64 d0, d1;
                     range_scan_fast<true, false>(rb, qb, fa[f], fb[f], seq_end, qual_end, wl, qq, fs, nullptr, nullptr, d0, d1);
                     hist_totals(h, t0, t1);
@@ -1880,6 +2034,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 }
             }
         }
+        PROF(8) /* filter + fragment statistics */
         const bool to_post = !dropped && !split && pass0 && s <= FS_SMAX;
         if (lane == 0) {
             fpl_read_result res;
@@ -1912,7 +2067,9 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         }
         nbuf += ((pass0 && !to_post) ? 1u : 0u) + (pass1 ? 1u : 0u);
         if (nbuf > SC_FBUF - 2) flush_frags();
+        PROF(9) /* result record, plan, fragment buffer */
     }
+    PROF_FLUSH(0);
     flush_frags();
     __syncthreads();
     /* flush the block accumulators */

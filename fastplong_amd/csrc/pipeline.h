@@ -123,10 +123,13 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     mark(1);
     {
         u32 blocks = cdiv(n, KWAVES);
-        const u32 cap = 3 * a.n_cu; /* registers / LDS admit three blocks per CU */
+        const u32 cap = SCAN_BLOCKS_PER_CU * a.n_cu; /* what registers / LDS admit */
         if (blocks > cap) blocks = cap;
-        u32 chunk = n / (blocks * KWAVES * 32u); /* ~32 dequeues per wave keep the tail short */
-        if (chunk < 1) chunk = 1;
+        /* ~32 dequeues per wave keep the tail short, but never fewer than 4 reads per dequeue once there is
+           that much work: the single work counter sustains only ~80 atomics/us */
+        const u32 waves = blocks * KWAVES;
+        u32 chunk = n / (waves * 32u);
+        if (chunk < 4) chunk = n >= 8 * waves ? 4 : (n >= 2 * waves ? 2 : 1);
         if (chunk > 64) chunk = 64;
         FPL_LAUNCH((k_scan<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
                    a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk, a.work_ctr + 1);
