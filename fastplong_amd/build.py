@@ -35,7 +35,10 @@ def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> fastplong_amd/libfastplong_amd.so (cross-compiles without a GPU)"""
     srcs = hip_sources()
     if force or _newer(LIB, srcs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB, srcs[0]]
+        # the atomic optimizer rewrites every single-lane LDS accumulator update into a wave reduction: pure
+        # overhead for the per-read bookkeeping of k_scan / k_trim_ends
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+               "-amdgpu-atomic-optimizer-strategy=None", "-o", LIB, srcs[0]]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

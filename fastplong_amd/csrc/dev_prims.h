@@ -121,6 +121,15 @@ __device__ __forceinline__ u32 dpp_u32(u32 old, u32 v) {
 __device__ __forceinline__ u32 op_add_u32(u32 a, u32 b) { return a + b; }
 __device__ __forceinline__ u32 op_max_u32(u32 a, u32 b) { return a > b ? a : b; }
 #endif
+/* the value of the next lane (lane 63 gets 0): DPP wave_shl:1, no LDS */
+__device__ __forceinline__ u32 wave_next_u32(u32 v) {
+#ifdef FPL_EMU
+    const u32 o = shfl_down_u32(v, 1);
+    return lane_id() == 63 ? 0u : o;
+#else
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+#endif
+}
 /* inclusive prefix sum across lanes */
 __device__ __forceinline__ u32 wave_scan_incl_u32(u32 v) {
 #ifdef FPL_EMU

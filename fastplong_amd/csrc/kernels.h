@@ -1262,7 +1262,8 @@ constexpr int SC_LANES_HAM = 62; /* lanes 62/63 only provide the plane words the
 /* per-wave LDS of k_scan */
 struct alignas(16) ScanWaveLds {
     u32 planes[5][64];            /* letter bit-planes of the current tile: [A,C,T,G][chunk]; row 4 stays zero */
-    u32 hist[128 * HIST_COPIES];  /* quality histogram of the range being scanned; all zero between uses */
+    u32 hist[129 * HIST_COPIES];  /* quality histogram of the range being scanned; all zero between uses
+                                     (bin 128 swallows the bytes past the end of a ragged tile; never read) */
     u32 ehist[128];               /* quality histogram of the trimmed-off ends of the read; all zero between uses */
     uint64_t fbuf_off[SC_FBUF];   /* passing fragments waiting for a slot in the global list */
     u32 fbuf_len[SC_FBUF];
@@ -1515,22 +1516,49 @@ __device__ __forceinline__ void sliced_max(const u32 B[7], u32 cand, int& val, i
 
 /* passFilter sums over 32 bytes with SWAR byte tricks (quality and base bytes < 128):
  *   lowq: bytes with q < qq          totq: sum of q (v_sad_u8)
- *   nn  : bytes == 'N'               diff: bytes that differ from their predecessor (pw = byte before s[0]) */
-__device__ __forceinline__ void sums32(const u32 s[8], const u32 q[8], u32 prev_dword, u32 qqrep, u32& lowq, u32& nn,
-                                       u32& totq, u32& diff) {
+ *   nn  : bytes == 'N'               diff: bytes that differ from their predecessor (pw = byte before s[0])
+ * MASKED: only the first nvalid bytes count (the ragged last tile of a range). */
+template <bool MASKED>
+__device__ __forceinline__ void sums32(const u32 s[8], const u32 q[8], int nvalid, u32 prev_dword, u32 qqrep, u32& lowq,
+                                       u32& nn, u32& totq, u32& diff) {
     u32 pd = prev_dword;
 #pragma unroll
     for (int d = 0; d < 8; d++) {
+        u32 bm = ~0u, fm = 0x80808080u; /* bytes / flag bits of this dword that count */
+        if (MASKED) {
+            const int c = nvalid - 4 * d;
+            bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
+            fm &= bm;
+        }
         const u32 t = (q[d] | 0x80808080u) - qqrep; /* per byte, no borrow: bit 7 survives iff q >= qq */
-        lowq += popc32(~t & 0x80808080u);
-        totq = sum_bytes(q[d], totq);
+        lowq += popc32(~t & fm);
+        totq = sum_bytes(q[d] & bm, totq);
         const u32 x = s[d] ^ 0x4E4E4E4Eu;
         const u32 zx = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
-        nn += popc32(~zx & 0x80808080u);
+        nn += popc32(~zx & fm);
         const u32 y = s[d] ^ alignbyte(s[d], pd, 3);
         const u32 zy = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
-        diff += popc32(zy & 0x80808080u);
+        diff += popc32(zy & fm);
         pd = s[d];
+    }
+}
+/* the 32 quality bytes of a lane into the wave's histogram; MASKED: bytes past nvalid go to the dump bin */
+template <bool MASKED>
+__device__ __forceinline__ void hist32(u32* __restrict__ h, const u32 q[8], int nvalid) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        u32 qd = q[d];
+        if (MASKED) {
+            const int c = nvalid - 4 * d;
+            const u32 bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
+            qd = (qd & bm & 0x7F7F7F7Fu) | (~bm & 0x80808080u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 qq = (qd >> (8 * k)) & (MASKED ? 0xFFu : 0x7Fu);
+            atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
+        }
     }
 }
 
@@ -1581,33 +1609,20 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
         if (lane == 0) prevd = prev_tile_last;
         prev_tile_last = readlane_u32(s[7], ACTIVE - 1);
         if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
-        if (nstat == SC_CHUNK) {
-            if (!FPL_DBG(dbg, 1)) {
-#pragma unroll
-                for (int k = 0; k < SC_CHUNK; k++) {
-                    const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0x7Fu;
-                    atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
-                }
+        /* the last tile of a range is ragged (some lane holds fewer than 32 bytes): the whole wave then takes
+           the byte-masked variants, so that no lane falls back to a byte-by-byte loop */
+        if (!wave_ballot(nstat > 0 && nstat < SC_CHUNK)) {
+            if (nstat == SC_CHUNK) {
+                if (!FPL_DBG(dbg, 1)) hist32<false>(h, q, SC_CHUNK);
+                if (SUMS && !FPL_DBG(dbg, 2)) sums32<false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
+                if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
             }
-            if (SUMS && !FPL_DBG(dbg, 2)) sums32(s, q, prevd, qqrep, lowq, nn, totq, diff);
-            if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
-        } else if (nstat > 0) { /* ragged last chunk */
-            u32 pb = prevd >> 24;
-            for (int k = 0; k < nstat; k++) {
-                const u32 bb = (s[k >> 2] >> (8 * (k & 3))) & 0xFF;
-                const u32 qq = (q[k >> 2] >> (8 * (k & 3))) & 0xFF;
-                atomicAdd(&h[(qq & 127u) * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
-                if (SUMS) {
-                    lowq += ((int)qq < qualified_qual);
-                    nn += (bb == 'N');
-                    totq += qq;
-                    diff += (bb != pb) && (j0 + k > 0);
-                    pb = bb;
-                }
-            }
+        } else if (nstat > 0) {
+            hist32<true>(h, q, nstat);
+            if (SUMS) sums32<true>(s, q, nstat, prevd, qqrep, lowq, nn, totq, diff);
         }
         if (HAM) {
-            if (npos0 > t0 || npos1 > t0) { /* wave-uniform: some window of this tile is tested */
+            if ((npos0 > t0 || npos1 > t0) && !FPL_DBG(dbg, 16)) { /* wave-uniform: some window of this tile is tested */
                 u32 PA, PC, PT, PG;
                 build_planes(s, PA, PC, PT, PG);
                 wave_sync(); /* previous tile's plane reads are done */
@@ -1619,7 +1634,7 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
                 /* lanes 62/63 hold halo words only; their (clamped) plane reads are never used */
                 const u32* plane_lane = &w->planes[0][lane < ACTIVE ? lane : 0];
                 u32 B[7];
-                if (npos0 > t0) {
+                if (npos0 > t0 && !FPL_DBG(dbg, 8)) {
                     match_counts(plane_lane, ad0, B);
                     const int nv = npos0 - j0;
                     const u32 vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
@@ -1632,7 +1647,7 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
                         }
                     }
                 }
-                if (npos1 > t0) {
+                if (npos1 > t0 && !FPL_DBG(dbg, 8)) {
                     match_counts(plane_lane, ad1, B);
                     const int nv = npos1 - j0;
                     const u32 vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
@@ -1774,7 +1789,7 @@ __device__ __forceinline__ void lev_pair32_run(const u32 (*__restrict__ peq4)[4]
 }
 
 template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
+__global__ void __launch_bounds__(WAVES * 64, SCAN_BLOCKS_PER_CU * WAVES / 4)
 k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
        uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
        ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
