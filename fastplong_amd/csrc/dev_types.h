@@ -24,8 +24,8 @@ struct DevAdapter {
     uint32_t peq16_start[256];   /* Myers Peq of the LAST plen bytes  (start trim, :203)  */
     uint32_t peq16_end[256];     /* Myers Peq of the FIRST plen bytes (end trim,   :274)  */
     uint64_t peq_full[256][PEQ_WORDS]; /* Myers Peq of the whole adapter, bit j <-> seq[j]  */
-    /* bit-sliced middle-adapter scan (k_scan): for adapter offset i, (plane word offset << 8) | shift,
-       plane word offset = code(seq[i]) * 64 + (i >> 5), shift = i & 31, code A0 C1 T2 G3 */
+    /* bit-sliced middle-adapter scan (k_scan): for adapter offset i, (plane BYTE offset << 8) | shift,
+       plane byte offset = 4 * (code(seq[i]) * 64 + (i >> 5)), shift = i & 31, code A0 C1 T2 G3 */
     uint32_t term[64];
     int32_t acgt_only; /* every byte is one of A C G T and len <= 64 */
 };
@@ -65,12 +65,12 @@ inline void build_adapter(DevAdapter* a, const char* seq, int len) {
         a->peq_full[c][i >> 6] |= 1ull << (i & 63);
     }
     a->acgt_only = len <= 64;
-    for (int i = 0; i < 64; i++) a->term[i] = (4u * 64u) << 8; /* padding: the all-zero plane row */
+    for (int i = 0; i < 64; i++) a->term[i] = (4u * 4u * 64u) << 8; /* padding: the all-zero plane row */
     for (int i = 0; i < len && i < 64; i++) {
         const uint8_t c = (uint8_t)seq[i];
         if (c != 'A' && c != 'C' && c != 'G' && c != 'T') a->acgt_only = 0;
         const uint32_t code = (c >> 1) & 3u; /* A0 C1 T2 G3 */
-        a->term[i] = ((code * 64u + (uint32_t)(i >> 5)) << 8) | (uint32_t)(i & 31);
+        a->term[i] = ((4u * (code * 64u + (uint32_t)(i >> 5))) << 8) | (uint32_t)(i & 31);
     }
     for (int j = 0; j < a->plen; j++) {
         a->peq16_start[(uint8_t)seq[len - a->plen + j]] |= 1u << j;

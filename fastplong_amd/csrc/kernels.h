@@ -1473,16 +1473,43 @@ __device__ __forceinline__ void build_planes(const u32 s[8], u32& PA, u32& PC, u
  * (v_bitop3 majority / parity) sum eight 1-bit planes with seven CSAs. */
 __device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane, const DevAdapter* __restrict__ ad, u32 B[7]) {
     const int alen = ad->len;
+#ifndef FPL_EMU
+    /* LDS byte address of lane 0's plane word, minus what the instruction adds for this lane */
+    const u32 planes_m0 = uniform_u32((u32)(size_t)plane_lane - 4u * (u32)lane_id());
+#endif
 #pragma unroll
     for (int b = 0; b < 7; b++) B[b] = 0;
     for (int i0 = 0; i0 < alen; i0 += 8) {
-        u32 m[8];
+        u32 m[8], tw[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { /* terms past alen point at the all-zero plane row */
-            const u32 tw = ad->term[i0 + k];
-            const u32* p = plane_lane + (tw >> 8);
-            m[k] = alignbit(p[1], p[0], tw & 31u);
+        for (int k = 0; k < 8; k++) tw[k] = ad->term[i0 + k]; /* terms past alen point at the all-zero plane row */
+#ifdef FPL_EMU
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32* p = plane_lane + (tw[k] >> 10);
+            m[k] = alignbit(p[1], p[0], tw[k] & 31u);
         }
+#else
+        /* ds_read_addtid_b32: LDS address = M0 + offset + 4 * lane, so a term costs two scalar ops and no
+           address arithmetic on the vector unit (the compiler has no intrinsic for it) */
+        u32 lo[8], hi[8];
+        asm volatile(
+            "s_lshr_b32 m0, %16, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %0 offset:0\n ds_read_addtid_b32 %8 offset:4\n"
+            "s_lshr_b32 m0, %17, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %1 offset:0\n ds_read_addtid_b32 %9 offset:4\n"
+            "s_lshr_b32 m0, %18, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %2 offset:0\n ds_read_addtid_b32 %10 offset:4\n"
+            "s_lshr_b32 m0, %19, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %3 offset:0\n ds_read_addtid_b32 %11 offset:4\n"
+            "s_lshr_b32 m0, %20, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %4 offset:0\n ds_read_addtid_b32 %12 offset:4\n"
+            "s_lshr_b32 m0, %21, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %5 offset:0\n ds_read_addtid_b32 %13 offset:4\n"
+            "s_lshr_b32 m0, %22, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %6 offset:0\n ds_read_addtid_b32 %14 offset:4\n"
+            "s_lshr_b32 m0, %23, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %7 offset:0\n ds_read_addtid_b32 %15 offset:4\n"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(lo[6]), "=&v"(lo[7]),
+              "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7])
+            : "s"(tw[0]), "s"(tw[1]), "s"(tw[2]), "s"(tw[3]), "s"(tw[4]), "s"(tw[5]), "s"(tw[6]), "s"(tw[7]), "s"(planes_m0)
+            : "m0", "scc", "memory");
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[k] = alignbit(hi[k], lo[k], tw[k]);
+#endif
         u32 t1, t2, t3, t4, f1, f2, e;
         csa(t1, B[0], B[0], m[0], m[1]);
         csa(t2, B[0], B[0], m[2], m[3]);
