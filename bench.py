@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (1 M x ~10 kb N50)")
     ap.add_argument("--median-len", type=int, default=8000)
     ap.add_argument("--workload", default="c3_full_pipeline", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-bases", type=float, default=1e9, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-bases", type=float, default=6e9, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--set", default="", help="ablation only: comma separated fpl_options overrides, e.g. adapter_enabled=0")
     ap.add_argument("--hbm-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
