@@ -27,6 +27,10 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -170,10 +174,39 @@ static vector<string> load_fasta_adapters(const string& path) {
 
 struct Device {
     fpl_ctx* ctx = nullptr;
+};
+
+/* One batch on its way through the host pipeline:
+ *   reader thread (parse into CSR) -> one thread per device (fpl_process_batch, then the output text on a few
+ *   helper threads) -> the main thread (writes the pieces in input order).
+ * Where the reference's workers hand strings to WriterThread (src/seprocessor.cpp:283-313), the stages here
+ * hand whole batches; a small pool of Work objects bounds what is in flight. */
+struct Work {
+    uint64_t seq_no = 0;
     fplh::Batch batch;
     vector<fpl_read_result> res;
-    string out, failed;
+    vector<string> outs, faileds;
     int rc = 0;
+    string err;
+};
+template <class T>
+class Channel {
+   public:
+    void push(T v) {
+        { lock_guard<mutex> g(m_); q_.push_back(v); }
+        cv_.notify_one();
+    }
+    T pop() { /* blocks */
+        unique_lock<mutex> g(m_);
+        cv_.wait(g, [&] { return !q_.empty(); });
+        T v = q_.front();
+        q_.pop_front();
+        return v;
+    }
+   private:
+    mutex m_;
+    condition_variable cv_;
+    deque<T> q_;
 };
 
 int main(int argc, char* argv[]) {
@@ -314,6 +347,7 @@ int main(int argc, char* argv[]) {
 
     fplh::FastqReader reader(in);
     if (!reader.ok()) error_exit("Failed to open file: " + in);
+    reader.set_copy_threads(max(1, min(8, (int)thread::hardware_concurrency() / 2)));
     auto open_out = [](const string& path) -> gzFile {
         if (path.empty()) return nullptr;
         const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
@@ -325,39 +359,95 @@ int main(int argc, char* argv[]) {
     gzFile ffail = open_out(failedOut);
 
     long readsLeft = readsToProcess > 0 ? readsToProcess : -1;
-    bool done = false;
-    while (!done) {
-        int used = 0;
-        for (int d = 0; d < nGpus && !done; d++) { /* cut the next nGpus batches in input order */
-            Device& D = dev[d];
-            D.batch.clear();
+    const int fmtThreads = max(1, min(16, (int)thread::hardware_concurrency() / max(1, nGpus) - 1));
+    const int nWork = 2 * nGpus + 1;
+    vector<Work> pool(nWork);
+    Channel<Work*> freeq, doneq;
+    vector<Channel<Work*>> devq(nGpus);
+    for (auto& w : pool) freeq.push(&w);
+    uint64_t nBatches = 0;
+    /* --verbose: where the wall time of the host pipeline goes (busy seconds per stage) */
+    auto now = []() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tStart = now();
+    double tParse = 0, tWrite = 0;
+    vector<double> tGpu(nGpus, 0), tFormat(nGpus, 0);
+    thread readerThread([&]() {
+        for (;;) {
             uint32_t maxReads = batchReads;
             if (readsLeft >= 0) maxReads = (uint32_t)min<long>(readsLeft, maxReads);
-            if (maxReads == 0 || reader.fill(D.batch, batchBases, maxReads) == 0) {
-                done = true;
+            if (maxReads == 0) break;
+            Work* w = freeq.pop();
+            w->batch.clear();
+            const double t0 = now();
+            const uint32_t got = reader.fill(w->batch, batchBases, maxReads);
+            tParse += now() - t0;
+            if (got == 0) {
+                freeq.push(w);
                 break;
             }
-            if (readsLeft >= 0) readsLeft -= D.batch.n();
-            used++;
+            if (readsLeft >= 0) readsLeft -= w->batch.n();
+            w->seq_no = nBatches++;
+            devq[w->seq_no % nGpus].push(w); /* batches are dealt round-robin in input order */
         }
-        vector<thread> th;
-        for (int d = 0; d < used; d++)
-            th.emplace_back([&, d]() {
-                Device& D = dev[d];
-                D.res.resize(D.batch.n());
-                D.rc = fpl_process_batch(D.ctx, D.batch.seq.data(), D.batch.qual.data(), D.batch.off.data(), D.batch.n(),
-                                         D.res.data());
-                D.out.clear();
-                D.failed.clear();
-                if (D.rc == FPL_OK) fplh::format_batch(D.batch, D.res.data(), D.out, ffail ? &D.failed : nullptr);
-            });
-        for (auto& t : th) t.join();
-        for (int d = 0; d < used; d++) { /* in input order */
-            Device& D = dev[d];
-            if (D.rc != FPL_OK) error_exit(string("fpl_process_batch: ") + fpl_strerror(D.rc) + " " + fpl_last_error(D.ctx));
-            if (fout && !D.out.empty()) gzwrite(fout, D.out.data(), (unsigned)D.out.size());
-            if (ffail && !D.failed.empty()) gzwrite(ffail, D.failed.data(), (unsigned)D.failed.size());
+        for (int d = 0; d < nGpus; d++) devq[d].push(nullptr);
+    });
+    vector<thread> devThreads;
+    for (int d = 0; d < nGpus; d++)
+        devThreads.emplace_back([&, d]() {
+            for (;;) {
+                Work* w = devq[d].pop();
+                if (!w) break;
+                w->res.resize(w->batch.n());
+                const double t0 = now();
+                w->rc = fpl_process_batch(dev[d].ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(),
+                                          w->batch.n(), w->res.data());
+                const double t1 = now();
+                if (w->rc != FPL_OK) w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
+                else fplh::format_batch_parallel(w->batch, w->res.data(), fmtThreads, w->outs, ffail ? &w->faileds : nullptr);
+                tGpu[d] += t1 - t0;
+                tFormat[d] += now() - t1;
+                doneq.push(w);
+            }
+            doneq.push(nullptr);
+        });
+    { /* writer: this thread, in input order */
+        map<uint64_t, Work*> ready;
+        uint64_t next = 0;
+        int live = nGpus;
+        while (live > 0) {
+            Work* w = doneq.pop();
+            if (!w) {
+                live--;
+                continue;
+            }
+            ready[w->seq_no] = w;
+            while (!ready.empty() && ready.begin()->first == next) {
+                Work* r = ready.begin()->second;
+                ready.erase(ready.begin());
+                if (r->rc != FPL_OK) error_exit("fpl_process_batch: " + r->err);
+                const double t0 = now();
+                if (fout)
+                    for (auto& piece : r->outs)
+                        for (size_t o = 0; o < piece.size(); o += 1u << 30)
+                            gzwrite(fout, piece.data() + o, (unsigned)min<size_t>(piece.size() - o, 1u << 30));
+                if (ffail)
+                    for (auto& piece : r->faileds)
+                        for (size_t o = 0; o < piece.size(); o += 1u << 30)
+                            gzwrite(ffail, piece.data() + o, (unsigned)min<size_t>(piece.size() - o, 1u << 30));
+                tWrite += now() - t0;
+                next++;
+                freeq.push(r);
+            }
         }
+    }
+    readerThread.join();
+    for (auto& t : devThreads) t.join();
+    if (cmd.exist("verbose")) {
+        double g = 0, f = 0;
+        for (int d = 0; d < nGpus; d++) g = max(g, tGpu[d]), f = max(f, tFormat[d]);
+        cerr << "host pipeline: " << nBatches << " batches, wall " << now() - tStart << " s; busy: parse " << tParse
+             << " s, fpl_process_batch " << g << " s, format (" << fmtThreads << " threads) " << f << " s, write " << tWrite
+             << " s" << endl;
     }
     if (fout) gzclose(fout);
     if (ffail) gzclose(ffail);

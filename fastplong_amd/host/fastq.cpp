@@ -1,10 +1,17 @@
 #include "fastq.h"
 
+#include <fcntl.h>
+#include <immintrin.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <iostream>
+#include <thread>
 
 using namespace std;
 
@@ -35,47 +42,167 @@ void Batch::clear() {
     strand_len.clear();
 }
 
+/* index of the first '\n' or '\r' in p[0, n), or n: one pass for both terminators */
+static size_t find_eol_sse2(const char* p, size_t n) {
+    const __m128i nl = _mm_set1_epi8('\n'), cr = _mm_set1_epi8('\r');
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m128i v = _mm_loadu_si128((const __m128i*)(p + i));
+        const int m = _mm_movemask_epi8(_mm_or_si128(_mm_cmpeq_epi8(v, nl), _mm_cmpeq_epi8(v, cr)));
+        if (m) return i + (size_t)__builtin_ctz((unsigned)m);
+    }
+    for (; i < n; i++)
+        if (p[i] == '\n' || p[i] == '\r') return i;
+    return n;
+}
+__attribute__((target("avx2"))) static size_t find_eol_avx2(const char* p, size_t n) {
+    const __m256i nl = _mm256_set1_epi8('\n'), cr = _mm256_set1_epi8('\r');
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m256i a = _mm256_loadu_si256((const __m256i*)(p + i)), b = _mm256_loadu_si256((const __m256i*)(p + i + 32));
+        const unsigned ma = (unsigned)_mm256_movemask_epi8(_mm256_or_si256(_mm256_cmpeq_epi8(a, nl), _mm256_cmpeq_epi8(a, cr)));
+        const unsigned mb = (unsigned)_mm256_movemask_epi8(_mm256_or_si256(_mm256_cmpeq_epi8(b, nl), _mm256_cmpeq_epi8(b, cr)));
+        if (ma | mb) return i + (size_t)__builtin_ctzll((unsigned long long)ma | ((unsigned long long)mb << 32));
+    }
+    return i + find_eol_sse2(p + i, n - i);
+}
+static size_t find_eol(const char* p, size_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? find_eol_avx2(p, n) : find_eol_sse2(p, n);
+}
+
 FastqReader::FastqReader(const string& path) {
-    /* gzopen reads plain files transparently */
-    fp_ = path == "/dev/stdin" ? (void*)gzdopen(0, "rb") : (void*)gzopen(path.c_str(), "rb");
-    if (fp_) gzbuffer((gzFile)fp_, 1 << 20);
-    buf_.resize(8 << 20); /* FQ_BUF_SIZE of the reference is 8 MiB as well */
+    size_t cap = 32u << 20;
+    bool allow_map = true;
+    if (const char* e = getenv("FPLH_READ_WINDOW")) /* test hook: tiny windows exercise the refill paths */
+        if (atol(e) > 0) {
+            cap = (size_t)atol(e);
+            allow_map = false;
+        }
+    if (path != "/dev/stdin" && allow_map) { /* a regular file that is not gzip: map it, no copies into a window */
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd >= 0) {
+            struct stat st;
+            unsigned char magic[2] = {0, 0};
+            if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 &&
+                !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                    madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+                    map_ = m;
+                    map_len_ = (size_t)st.st_size;
+                    win_ = (const char*)m;
+                    len_ = map_len_;
+                    eof_ = true;
+                    fp_ = this;
+                }
+            }
+            close(fd);
+        }
+    }
+    if (!map_) {
+        /* gzopen reads plain files transparently */
+        fp_ = path == "/dev/stdin" ? (void*)gzdopen(0, "rb") : (void*)gzopen(path.c_str(), "rb");
+        if (fp_) gzbuffer((gzFile)fp_, 1 << 20);
+        buf_.resize(cap);
+        win_ = buf_.data();
+    }
 }
 
 FastqReader::~FastqReader() {
-    if (fp_) gzclose((gzFile)fp_);
+    if (map_) munmap(map_, map_len_);
+    else if (fp_) gzclose((gzFile)fp_);
 }
 
-bool FastqReader::refill() {
-    if (eof_ || !fp_) return false;
-    int n = gzread((gzFile)fp_, buf_.data(), (unsigned)buf_.size());
-    pos_ = 0;
-    len_ = n > 0 ? (size_t)n : 0;
-    if (n <= 0) eof_ = true;
-    return n > 0;
-}
-
-/* one line without its terminator; false at end of input with nothing read */
-bool FastqReader::getline(string& line) {
-    line.clear();
-    bool any = false;
-    for (;;) {
-        if (pos_ >= len_ && !refill()) return any;
-        any = true;
-        size_t e = pos_;
-        while (e < len_ && buf_[e] != '\r' && buf_[e] != '\n') e++;
-        line.append(buf_.data() + pos_, e - pos_);
-        if (e < len_) {
-            const char term = buf_[e];
-            pos_ = e + 1;
-            if (term == '\r') { /* swallow the '\n' of "\r\n" */
-                if (pos_ >= len_) refill();
-                if (pos_ < len_ && buf_[pos_] == '\n') pos_++;
-            }
-            return true;
-        }
-        pos_ = len_;
+bool FastqReader::pull() {
+    if (eof_ || !fp_ || map_) return false;
+    if (pos_ > 0) {
+        memmove(buf_.data(), buf_.data() + pos_, len_ - pos_);
+        len_ -= pos_;
+        pos_ = 0;
+    } else if (len_ == buf_.size()) {
+        buf_.resize(buf_.size() * 2); /* one record is larger than the window */
     }
+    win_ = buf_.data();
+    while (len_ < buf_.size()) { /* gzread returns short counts on pipes */
+        const size_t want = min<size_t>(buf_.size() - len_, 1u << 30);
+        const int n = gzread((gzFile)fp_, buf_.data() + len_, (unsigned)want);
+        if (n <= 0) {
+            eof_ = true;
+            break;
+        }
+        len_ += (size_t)n;
+    }
+    return true;
+}
+
+/* FastqReader::getLine, src/fastqreader.cpp:219-312: a line ends at '\r' or '\n', "\r\n" counts once */
+int FastqReader::scan_line(size_t& pos, Line& ln) const {
+    if (pos >= len_) return eof_ ? -1 : 0;
+    const char* b = win_ + pos;
+    const size_t avail = len_ - pos;
+    const size_t e = find_eol(b, avail);
+    if (e == avail) { /* no terminator in the window */
+        if (!eof_) return 0;
+        ln = Line{b, avail};
+        pos = len_;
+        return 1;
+    }
+    size_t next = pos + e + 1;
+    if (b[e] == '\r') { /* swallow the '\n' of "\r\n": needs the byte after it */
+        if (next >= len_ && !eof_) return 0;
+        if (next < len_ && win_[next] == '\n') next++;
+    }
+    ln = Line{b, e};
+    pos = next;
+    return 1;
+}
+
+/* append the located records to the batch: offsets first, then the line copies on copy_threads_ threads */
+void FastqReader::copy_records(Batch& b, const vector<Rec>& recs) const {
+    const size_t n0 = b.n(), nr = recs.size();
+    if (nr == 0) return;
+    const size_t base0 = b.seq.size(), text0 = b.text.size();
+    uint64_t bases = base0, text = text0;
+    b.off.reserve(n0 + nr + 1);
+    for (const Rec& r : recs) {
+        bases += r.seq.n;
+        text += r.name.n + r.strand.n;
+        b.off.push_back(bases);
+        b.name_off.push_back(text);
+        b.name_len.push_back((uint32_t)r.name.n);
+        b.strand_len.push_back((uint32_t)r.strand.n);
+    }
+    b.seq.resize_uninit(bases);
+    b.qual.resize_uninit(bases);
+    b.text.resize(text);
+    auto work = [&](size_t first, size_t last) {
+        for (size_t i = first; i < last; i++) {
+            const Rec& r = recs[i];
+            const uint64_t o = b.off[n0 + i], t = b.name_off[n0 + i];
+            memcpy(b.seq.data() + o, r.seq.p, r.seq.n);
+            memcpy(b.qual.data() + o, r.qual.p, r.qual.n);
+            memcpy(b.text.data() + t, r.name.p, r.name.n);
+            memcpy(b.text.data() + t + r.name.n, r.strand.p, r.strand.n);
+        }
+    };
+    const int T = (bases - base0) < (8u << 20) ? 1 : copy_threads_;
+    if (T <= 1) {
+        work(0, nr);
+        return;
+    }
+    vector<std::thread> th;
+    size_t first = 0;
+    for (int t = 0; t < T; t++) { /* slices of about equal numbers of bases */
+        const uint64_t want = base0 + (bases - base0) / T * (t + 1);
+        size_t last = t == T - 1 ? nr : (size_t)(std::lower_bound(b.off.begin() + n0 + 1, b.off.begin() + n0 + 1 + nr, want) -
+                                                 (b.off.begin() + n0 + 1)) + 1;
+        last = min(max(last, first), nr);
+        th.emplace_back(work, first, last);
+        first = last;
+    }
+    for (auto& x : th) x.join();
 }
 
 uint32_t FastqReader::fill(Batch& b, uint64_t max_bases, uint32_t max_reads) {
@@ -84,44 +211,100 @@ uint32_t FastqReader::fill(Batch& b, uint64_t max_bases, uint32_t max_reads) {
         b.name_off.push_back(0);
     }
     uint32_t added = 0;
-    string name, seq, strand, qual;
-    while (!malformed_ && b.seq.size() < max_bases && b.n() < max_reads) {
-        bool got = getline(name);
-        while (got && (name.empty() || name[0] != '@')) got = getline(name); /* src/fastqreader.cpp:316-319 */
-        if (!got) break;
-        getline(seq);
-        getline(strand);
-        getline(qual);
-        if (strand.empty() || strand[0] != '+') {
-            cerr << name << endl << "Expected '+', got " << strand << endl
-                 << "Your FASTQ may be invalid, please check the tail of your FASTQ file" << endl;
-            malformed_ = true;
-            break;
+    const Line none = {nullptr, 0};
+    vector<Rec> recs;
+    uint64_t bases = b.seq.size();
+    uint32_t reads = b.n();
+    bool end = false;
+    while (!end && !malformed_ && bases < max_bases && reads < max_reads) {
+        /* locate the records of the current window (mapped file: of the next stretch of it) */
+        recs.clear();
+        bool need_more = false;
+        while (bases < max_bases && reads < max_reads) {
+            /* one record = the next line that starts with '@' (src/fastqreader.cpp:316-319) and the three lines
+               after it; lines missing at the end of the input read as empty, as getLine() does */
+            Rec rc = {none, none, none, none};
+            size_t p = pos_;
+            int r;
+            for (;;) {
+                r = scan_line(p, rc.name);
+                if (r <= 0) break;
+                if (rc.name.n > 0 && rc.name.p[0] == '@') break;
+                pos_ = p; /* a skipped line is consumed for good */
+            }
+            if (r == 0) {
+                need_more = true;
+                break;
+            }
+            if (r < 0) {
+                end = true;
+                break;
+            }
+            Line* rest[3] = {&rc.seq, &rc.strand, &rc.qual};
+            for (int k = 0; k < 3 && !need_more; k++) {
+                r = scan_line(p, *rest[k]);
+                if (r == 0) need_more = true;
+                else if (r < 0) *rest[k] = none;
+            }
+            if (need_more) break; /* the record continues beyond the window: restart it after reading more */
+            if (rc.strand.n == 0 || rc.strand.p[0] != '+') {
+                cerr << string(rc.name.p, rc.name.n) << endl
+                     << "Expected '+', got " << string(rc.strand.p ? rc.strand.p : "", rc.strand.n) << endl
+                     << "Your FASTQ may be invalid, please check the tail of your FASTQ file" << endl;
+                malformed_ = true;
+                break;
+            }
+            if (rc.qual.n != rc.seq.n) {
+                cerr << "ERROR: sequence and quality have different length:" << endl << string(rc.name.p, rc.name.n) << endl
+                     << string(rc.seq.p ? rc.seq.p : "", rc.seq.n) << endl << string(rc.strand.p, rc.strand.n) << endl
+                     << string(rc.qual.p ? rc.qual.p : "", rc.qual.n) << endl
+                     << "Your FASTQ may be invalid, please check the tail of your FASTQ file" << endl;
+                malformed_ = true;
+                break;
+            }
+            pos_ = p;
+            recs.push_back(rc);
+            bases += rc.seq.n;
+            reads++;
         }
-        if (qual.length() != seq.length()) {
-            cerr << "ERROR: sequence and quality have different length:" << endl << name << endl << seq << endl
-                 << strand << endl << qual << endl
-                 << "Your FASTQ may be invalid, please check the tail of your FASTQ file" << endl;
-            malformed_ = true;
-            break;
-        }
-        b.seq.insert(b.seq.end(), seq.begin(), seq.end());
-        b.qual.insert(b.qual.end(), qual.begin(), qual.end());
-        b.off.push_back(b.seq.size());
-        b.text.insert(b.text.end(), name.begin(), name.end());
-        b.text.insert(b.text.end(), strand.begin(), strand.end());
-        b.name_off.push_back(b.text.size());
-        b.name_len.push_back((uint32_t)name.size());
-        b.strand_len.push_back((uint32_t)strand.size());
-        added++;
+        copy_records(b, recs); /* before the window moves */
+        added += (uint32_t)recs.size();
+        if (need_more && !pull()) end = true;
     }
     return added;
 }
 
 void format_batch(const Batch& b, const fpl_read_result* res, string& out, string* failed) {
-    static const char* prefix[3] = {"", "split-by-adapter-left-", "split-by-adapter-right-"}; /* src/read.cpp:199,208 */
+    format_range(b, res, 0, b.n(), out, failed);
+}
+
+void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threads, vector<string>& outs,
+                           vector<string>* faileds) {
     const uint32_t n = b.n();
-    for (uint32_t i = 0; i < n; i++) {
+    if (threads < 1) threads = 1;
+    outs.assign(threads, string());
+    if (faileds) faileds->assign(threads, string());
+    /* slices of about equal numbers of bases */
+    vector<uint32_t> cut(threads + 1, n);
+    cut[0] = 0;
+    const uint64_t total = n ? b.off[n] : 0;
+    for (int t = 1; t < threads; t++) {
+        const uint64_t want = total / threads * t;
+        cut[t] = (uint32_t)(std::lower_bound(b.off.begin(), b.off.begin() + n, want) - b.off.begin());
+    }
+    vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t]() {
+            outs[t].reserve((size_t)((b.off[cut[t + 1]] - b.off[cut[t]]) * 2 + (uint64_t)(cut[t + 1] - cut[t]) * 128 + 64));
+            format_range(b, res, cut[t], cut[t + 1], outs[t], faileds ? &(*faileds)[t] : nullptr);
+        });
+    for (auto& x : th) x.join();
+}
+
+void format_range(const Batch& b, const fpl_read_result* res, uint32_t first, uint32_t last, string& out,
+                  string* failed) {
+    static const char* prefix[3] = {"", "split-by-adapter-left-", "split-by-adapter-right-"}; /* src/read.cpp:199,208 */
+    for (uint32_t i = first; i < last; i++) {
         const fpl_read_result& r = res[i];
         if (r.dropped) continue;
         const char* name = b.text.data() + b.name_off[i];
@@ -194,6 +377,24 @@ int fplh_format_batch(void* bv, const fpl_read_result* res, char** out, uint64_t
         *failed = (char*)malloc(f.size() + 1);
         memcpy(*failed, f.data(), f.size());
         *failed_len = f.size();
+    }
+    return 0;
+}
+int fplh_format_batch_parallel(void* bv, const fpl_read_result* res, int threads, char** out, uint64_t* out_len,
+                               char** failed, uint64_t* failed_len) {
+    fplh::Batch* b = (fplh::Batch*)bv;
+    std::vector<std::string> o, f;
+    fplh::format_batch_parallel(*b, res, threads, o, failed ? &f : nullptr);
+    std::string oo, ff;
+    for (auto& x : o) oo += x;
+    for (auto& x : f) ff += x;
+    *out = (char*)malloc(oo.size() + 1);
+    memcpy(*out, oo.data(), oo.size());
+    *out_len = oo.size();
+    if (failed) {
+        *failed = (char*)malloc(ff.size() + 1);
+        memcpy(*failed, ff.data(), ff.size());
+        *failed_len = ff.size();
     }
     return 0;
 }

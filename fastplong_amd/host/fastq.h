@@ -10,6 +10,7 @@
 
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -18,8 +19,39 @@
 
 namespace fplh {
 
+/* growable byte array without the zero fill of std::vector::resize (batches are hundreds of megabytes and
+ * every byte is overwritten by the parser's copy threads) */
+class ByteBuf {
+   public:
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf&) = delete;
+    ByteBuf& operator=(const ByteBuf&) = delete;
+    ~ByteBuf() { free(p_); }
+    uint8_t* data() { return p_; }
+    const uint8_t* data() const { return p_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    void clear() { n_ = 0; }
+    const uint8_t* begin() const { return p_; }
+    const uint8_t* end() const { return p_ + n_; }
+    void reserve(size_t c) {
+        if (c <= cap_) return;
+        size_t nc = cap_ ? cap_ : 4096;
+        while (nc < c) nc *= 2;
+        p_ = (uint8_t*)realloc(p_, nc);
+        cap_ = nc;
+    }
+    void resize_uninit(size_t n) {
+        reserve(n);
+        n_ = n;
+    }
+   private:
+    uint8_t* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 struct Batch {
-    std::vector<uint8_t> seq, qual;   /* CSR payload handed to fpl_process_batch */
+    ByteBuf seq, qual;                /* CSR payload handed to fpl_process_batch */
     std::vector<uint64_t> off;        /* n + 1 */
     std::vector<char> text;           /* name and strand lines, back to back */
     std::vector<uint64_t> name_off;   /* n + 1 offsets into text for names   */
@@ -41,12 +73,31 @@ class FastqReader {
     uint32_t fill(Batch& b, uint64_t max_bases, uint32_t max_reads);
     bool malformed() const { return malformed_; }
 
+    void set_copy_threads(int t) { copy_threads_ = t < 1 ? 1 : t; }
+
    private:
-    bool getline(std::string& line);
-    bool refill();
-    void* fp_ = nullptr; /* gzFile */
+    struct Line {
+        const char* p;
+        size_t n;
+    };
+    struct Rec {
+        Line name, seq, strand, qual;
+    };
+    /* The input is scanned in place (one SIMD pass for both terminators): a regular uncompressed file is mapped
+     * whole, anything else (gzip, pipes) streams through one large window that is refilled behind the
+     * unconsumed tail.  fill() first only LOCATES the records of a stretch of the window, then copies their
+     * lines into the batch on copy_threads_ threads.  scan_line: 1 = a line, 0 = the window ends inside the
+     * line and more input exists, -1 = end of input with nothing left. */
+    int scan_line(size_t& pos, Line& ln) const;
+    bool pull(); /* stream mode: keep [pos_, len_), read more behind it (growing the window when a record fills it) */
+    void copy_records(Batch& b, const std::vector<Rec>& recs) const;
+    void* fp_ = nullptr;       /* gzFile (stream mode) or a non-null token (mapped mode) */
+    const char* win_ = nullptr; /* the window: buf_.data() or the mapping */
     std::vector<char> buf_;
+    void* map_ = nullptr;
+    size_t map_len_ = 0;
     size_t pos_ = 0, len_ = 0;
+    int copy_threads_ = 1;
     bool eof_ = false, malformed_ = false;
 };
 
@@ -54,6 +105,13 @@ class FastqReader {
  * (name with the split prefix when the read was broken), and -- when failed != nullptr -- the
  * trimmed read with its tag for reads that produced exactly one fragment and failed. */
 void format_batch(const Batch& b, const fpl_read_result* res, std::string& out, std::string* failed);
+/* the same for reads [first, last) only (appends) */
+void format_range(const Batch& b, const fpl_read_result* res, uint32_t first, uint32_t last, std::string& out,
+                  std::string* failed);
+/* the same on `threads` host threads: piece t of outs / faileds holds the text of the t-th slice of the
+ * batch, so writing the pieces in order gives format_batch's output */
+void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threads, std::vector<std::string>& outs,
+                           std::vector<std::string>* faileds);
 
 }  // namespace fplh
 
@@ -69,6 +127,8 @@ void fplh_batch_free(void* b);
 /* returns malloc'ed buffers the caller frees with fplh_free */
 int fplh_format_batch(void* b, const fpl_read_result* res, char** out, uint64_t* out_len, char** failed,
                       uint64_t* failed_len);
+int fplh_format_batch_parallel(void* b, const fpl_read_result* res, int threads, char** out, uint64_t* out_len,
+                               char** failed, uint64_t* failed_len);
 void fplh_free(void* p);
 }
 #endif

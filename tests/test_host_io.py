@@ -28,6 +28,9 @@ def hostlib():
     L.fplh_format_batch.restype = C.c_int
     L.fplh_format_batch.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.fplh_format_batch_parallel.restype = C.c_int
+    L.fplh_format_batch_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.fplh_free.argtypes = [C.c_void_p]
     return L
 
@@ -66,6 +69,27 @@ def test_fastq_to_csr(hostlib, tmp_path, variant):
     assert np.array_equal(o2, off) and np.array_equal(s2, seq) and np.array_equal(q2, qual)
 
 
+@pytest.mark.parametrize("window", [16, 100, 4096])
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n", b"\r"])
+def test_fastq_reader_refills_anywhere(hostlib, tmp_path, monkeypatch, window, eol):
+    """the reader scans one window of the input in place: records that straddle, or exceed, the window and
+    terminators split across two refills ("\\r" | "\\n") must parse exactly like the whole file; a lone
+    "\\r" ends a line as in the reference's getLine"""
+    monkeypatch.setenv("FPLH_READ_WINDOW", str(window))
+    seq, qual, off = synth.adversarial(60, seed=12)
+    keep = np.nonzero(np.diff(off.astype(np.int64)) > 0)[0]
+    seq, qual, off = synth.pack([(seq[int(off[i]):int(off[i + 1])], qual[int(off[i]):int(off[i + 1])]) for i in keep])
+    text, names, strands = hostio.make_fastq(seq, qual, off, strand_names=True)
+    text = b"\n" + text.replace(b"\n", eol)
+    if eol != b"\r":
+        text = text[:-len(eol)]  # no terminator after the last line
+    p = tmp_path / "in.fq"
+    p.write_bytes(text)
+    b, s2, q2, o2 = read_batch(hostlib, p)
+    hostlib.fplh_batch_free(b)
+    assert np.array_equal(o2, off) and np.array_equal(s2, seq) and np.array_equal(q2, qual)
+
+
 def test_format_batch_matches_python_composition(orc, hostlib, tmp_path):
     cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1, complexity_filter=1),
                      synth.START_ADAPTER, synth.END_ADAPTER)
@@ -84,6 +108,12 @@ def test_format_batch_matches_python_composition(orc, hostlib, tmp_path):
     got_out, got_failed = C.string_at(out, ol.value), C.string_at(failed, fl.value)
     hostlib.fplh_free(out)
     hostlib.fplh_free(failed)
+    for threads in (1, 3, 16):  # the sliced formatter the CLI uses writes the same bytes
+        assert hostlib.fplh_format_batch_parallel(b, res.ctypes.data, threads, C.byref(out), C.byref(ol), C.byref(failed),
+                                                  C.byref(fl)) == 0
+        assert C.string_at(out, ol.value) == got_out and C.string_at(failed, fl.value) == got_failed
+        hostlib.fplh_free(out)
+        hostlib.fplh_free(failed)
     hostlib.fplh_batch_free(b)
     want_out, want_failed = hostio.expected_outputs(seq, qual, off, names, strands, res)
     assert got_out == want_out
