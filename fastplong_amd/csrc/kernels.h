@@ -1492,21 +1492,24 @@ __device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane,
 #else
         /* ds_read_addtid_b32: LDS address = M0 + offset + 4 * lane, so a term costs two scalar ops and no
            address arithmetic on the vector unit (the compiler has no intrinsic for it) */
-        u32 lo[8], hi[8];
+        u32 lo[8], hi[8], m0_keep;
         asm volatile(
-            "s_lshr_b32 m0, %16, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %0 offset:0\n ds_read_addtid_b32 %8 offset:4\n"
-            "s_lshr_b32 m0, %17, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %1 offset:0\n ds_read_addtid_b32 %9 offset:4\n"
-            "s_lshr_b32 m0, %18, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %2 offset:0\n ds_read_addtid_b32 %10 offset:4\n"
-            "s_lshr_b32 m0, %19, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %3 offset:0\n ds_read_addtid_b32 %11 offset:4\n"
-            "s_lshr_b32 m0, %20, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %4 offset:0\n ds_read_addtid_b32 %12 offset:4\n"
-            "s_lshr_b32 m0, %21, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %5 offset:0\n ds_read_addtid_b32 %13 offset:4\n"
-            "s_lshr_b32 m0, %22, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %6 offset:0\n ds_read_addtid_b32 %14 offset:4\n"
-            "s_lshr_b32 m0, %23, 8\n s_add_u32 m0, m0, %24\n s_nop 0\n ds_read_addtid_b32 %7 offset:0\n ds_read_addtid_b32 %15 offset:4\n"
-            "s_waitcnt lgkmcnt(0)"
+            "s_mov_b32 %16, m0\n"
+            "s_lshr_b32 m0, %17, 8\n s_add_u32 m0, m0, %25\n s_nop 0\n ds_read_addtid_b32 %0 offset:0\n ds_read_addtid_b32 %8 offset:4\n"
+            "s_lshr_b32 m0, %18, 8\n s_add_u32 m0, m0, %25\n s_nop 0\n ds_read_addtid_b32 %1 offset:0\n ds_read_addtid_b32 %9 offset:4\n"
+            "s_lshr_b32 m0, %19, 8\n s_add_u32 m0, m0, %25\n s_nop 0\n ds_read_addtid_b32 %2 offset:0\n ds_read_addtid_b32 %10 offset:4\n"
+            "s_lshr_b32 m0, %20, 8\n s_add_u32 m0, m0, %25\n s_nop 0\n ds_read_addtid_b32 %3 offset:0\n ds_read_addtid_b32 %11 offset:4\n"
+            "s_lshr_b32 m0, %21, 8\n s_add_u32 m0, m0, %25\n s_nop 0\n ds_read_addtid_b32 %4 offset:0\n ds_read_addtid_b32 %12 offset:4\n"
+            "s_lshr_b32 m0, %22, 8\n s_add_u32 m0, m0, %25\n s_nop 0\n ds_read_addtid_b32 %5 offset:0\n ds_read_addtid_b32 %13 offset:4\n"
+            "s_lshr_b32 m0, %23, 8\n s_add_u32 m0, m0, %25\n s_nop 0\n ds_read_addtid_b32 %6 offset:0\n ds_read_addtid_b32 %14 offset:4\n"
+            "s_lshr_b32 m0, %24, 8\n s_add_u32 m0, m0, %25\n s_nop 0\n ds_read_addtid_b32 %7 offset:0\n ds_read_addtid_b32 %15 offset:4\n"
+            "s_waitcnt lgkmcnt(0)\n s_mov_b32 m0, %16"
             : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(lo[6]), "=&v"(lo[7]),
-              "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7])
+              "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7]),
+              "=&s"(m0_keep)
             : "s"(tw[0]), "s"(tw[1]), "s"(tw[2]), "s"(tw[3]), "s"(tw[4]), "s"(tw[5]), "s"(tw[6]), "s"(tw[7]), "s"(planes_m0)
-            : "m0", "scc", "memory");
+            : "scc", "memory"); /* M0 is restored: the compiler does not know it was touched */
+        (void)m0_keep;
 #pragma unroll
         for (int k = 0; k < 8; k++) m[k] = alignbit(hi[k], lo[k], tw[k]);
 #endif
