@@ -65,6 +65,12 @@ class FplOptions(C.Structure):
         ("max_length", C.c_int32),
         ("complexity_filter", C.c_int32),
         ("complexity_percent", C.c_int32),
+        ("break_enabled", C.c_int32),
+        ("break_window", C.c_int32),
+        ("break_quality", C.c_int32),
+        ("mask_enabled", C.c_int32),
+        ("mask_window", C.c_int32),
+        ("mask_quality", C.c_int32),
     ]
 
     @classmethod
@@ -77,6 +83,7 @@ class FplOptions(C.Structure):
             n_base_limit=1000000, n_base_percent_limit=10, avg_qual_req=0,
             length_filter=1, required_length=20, max_length=0,
             complexity_filter=0, complexity_percent=30,
+            break_enabled=0, break_window=100, break_quality=10, mask_enabled=0, mask_window=50, mask_quality=10,
         )
         for k, v in kw.items():
             if not hasattr(o, k):
@@ -118,6 +125,14 @@ RESULT_DTYPE = [
     ("n_frag", "u1"), ("dropped", "u1"), ("code", "u1", (2,)), ("kind", "u1", (2,)),
     ("median_q_pre", "u1"), ("median_q_post", "u1", (2,)), ("reserved", "u1", (3,)),
 ]
+
+# struct fpl_fragment (32 bytes) / fpl_region (8 bytes): the --break / --mask outcome list
+FRAGMENT_DTYPE = [
+    ("read", "<u4"), ("seq_no", "<u4"), ("start", "<u4"), ("len", "<u4"), ("region_first", "<u4"),
+    ("region_count", "<u4"), ("break_no", "<u2"), ("code", "u1"), ("kind", "u1"), ("median_q", "u1"),
+    ("reserved", "u1", (3,)),
+]
+REGION_DTYPE = [("start", "<u4"), ("len", "<u4")]
 
 # ---- flat int64 counter layout (see the header) -------------------------------------------
 FPL_CYC_STRIDE = 32

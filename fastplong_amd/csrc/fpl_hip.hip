@@ -94,6 +94,10 @@ void fpl_options_default(fpl_options* o) {
     o->length_filter = 1;
     o->required_length = 20;
     o->complexity_percent = 30;
+    o->break_window = 100; /* src/main.cpp:72-73 */
+    o->break_quality = 10;
+    o->mask_window = 50;   /* src/main.cpp:67-68 */
+    o->mask_quality = 10;
 }
 
 static int alloc_counters(fpl_ctx* ctx, u32 C, long long** out) {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 1
+#define FPL_ABI_VERSION 2
 
 /* limits */
 #define FPL_MAX_ADAPTER_LEN 255 /* longest adapter the device path accepts            */
@@ -95,6 +95,15 @@ typedef struct fpl_options {
        the reference stores percent/100.0 and compares doubles -- equivalent) */
     int32_t complexity_filter;
     int32_t complexity_percent;
+    /* LowQualityBreakOptions / MaskOptions, src/options.h:20-44: -b --break_window_size --break_mean_quality,
+       -N --mask_window_size --mask_mean_quality (src/main.cpp:65-73,207-215); qualities are phred (not +33).
+       With either enabled the per-read record cannot hold the outcome any more: see fpl_fragment. */
+    int32_t break_enabled;
+    int32_t break_window;
+    int32_t break_quality;
+    int32_t mask_enabled;
+    int32_t mask_window;
+    int32_t mask_quality;
 } fpl_options;
 
 typedef struct fpl_adapter {
@@ -133,6 +142,42 @@ typedef struct fpl_read_result {
     uint8_t median_q_post[2];
     uint8_t reserved[3];
 } fpl_read_result;
+
+/*
+ * --break / --mask (src/seprocessor.cpp:234-262) turn a read into any number of output reads, some of whose
+ * bases are replaced by N.  When fpl_options.break_enabled or mask_enabled is set, fpl_read_result keeps
+ * r1_start / r1_len / dropped / median_q_pre, n_frag saturates at 255 and its fragment fields are zero;
+ * the fragments come as a list of these records (fpl_fragment_counts / fpl_get_fragments after each batch),
+ * sorted by (read, seq_no) = the order the reference writes them.  32 bytes.
+ *
+ *  start/len    : window on the ORIGINAL read.
+ *  kind         : 0 r1 itself or cut from r1, 1 / 2 the left / right part of a middle-adapter split.
+ *  break_no     : 0 = not a product of Read::breakByRegions; i >= 1: that function named it by inserting
+ *                 "r<i>-" after the first character of the (possibly split-prefixed) name (src/read.cpp:244,256).
+ *  region_first/count : slice of the fpl_region list: stretches of the fragment that Read::maskRegionWithN
+ *                 overwrote with 'N' (original-read coordinates, ascending, disjoint).
+ *  code         : Filter::passFilter of the fragment (after masking); median_q valid when code == FPL_PASS_FILTER.
+ * The reference writes --failed_out only for a read with exactly one fragment that fails; it then prints r1,
+ * masked only if that fragment IS r1 (kind == 0 and break_no == 0: masking was done in place).
+ */
+typedef struct fpl_fragment {
+    uint32_t read;
+    uint32_t seq_no;
+    uint32_t start;
+    uint32_t len;
+    uint32_t region_first;
+    uint32_t region_count;
+    uint16_t break_no;
+    uint8_t code;
+    uint8_t kind;
+    uint8_t median_q;
+    uint8_t reserved[3];
+} fpl_fragment;
+
+typedef struct fpl_region {
+    uint32_t start;
+    uint32_t len;
+} fpl_region;
 
 /*
  * Flat int64 counter buffer ("what the RCCL all-reduce sums").  C = max_cycles capacity.
@@ -226,6 +271,14 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
  */
 int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint64_t* off,
                       uint32_t n_reads, fpl_read_result* results);
+
+/*
+ * Fragment list of the LAST batch (contexts created with break_enabled or mask_enabled; otherwise the counts
+ * are zero).  fpl_get_fragments synchronizes, copies the records to the host and sorts them by (read, seq_no).
+ */
+int fpl_fragment_counts(fpl_ctx* ctx, uint32_t* n_fragments, uint32_t* n_regions);
+int fpl_get_fragments(fpl_ctx* ctx, fpl_fragment* fragments, uint32_t n_fragments, fpl_region* regions,
+                      uint32_t n_regions);
 
 /* Counter buffer: capacity, number of adapter slots, length, device pointer, host copy. */
 uint32_t fpl_max_cycles(const fpl_ctx* ctx);

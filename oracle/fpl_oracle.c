@@ -494,8 +494,124 @@ void orc_stat_read(int64_t* st, uint32_t C, const orc_read* r, uint8_t* median_o
  * SingleEndProcessor::processSingleEnd, one read -- reference src/seprocessor.cpp:186-295
  * (--break / --mask, :234-262, are not part of this path yet).
  * ---------------------------------------------------------------------------------------- */
-void orc_process_read(const orc_config* cfg, const char* seq, const char* qual, int len,
-                      int64_t* counters, uint32_t C, fpl_read_result* res) {
+/* Filter::detectLowQualityRegions, src/filter.cpp:83-128, restated literally -- including the warm-up loop
+ * `for (i = start; i < windowSize - 1 && i < l; i++)` whose bound is absolute, so that only the first search
+ * starts from a (w-1)-element sum and every later one from zero. */
+int orc_detect_low_quality_regions(const orc_read* r, int window, int quality, int* first, int* last, int cap) {
+    int n = 0;
+    if (r == NULL || r->len == 0 || window <= 0) return 0;
+    const int l = r->len;
+    const char* q = r->qual + r->start;
+    int start = 0;
+    while (start + window <= l) {
+        int total = 0;
+        for (int i = start; i < window - 1 && i < l; i++) total += q[i];
+        int ws = -1;
+        for (int s = start; s + window < l; s++) {
+            if (total < (33 + quality) * window) {
+                ws = s;
+                break;
+            }
+            total += q[s + window];
+            total -= q[s];
+        }
+        if (ws == -1) break;
+        int e;
+        for (e = ws; e + window < l; e++) {
+            total += q[e + window];
+            total -= q[e];
+            if (total >= (33 + quality) * window) break;
+        }
+        if (n < cap) {
+            first[n] = ws;
+            last[n] = e + window - 1;
+        }
+        n++;
+        start = e + window;
+    }
+    return n;
+}
+
+void orc_fraglist_free(orc_fraglist* l) {
+    free(l->frag);
+    free(l->reg);
+    memset(l, 0, sizeof(*l));
+}
+static fpl_fragment* fraglist_add(orc_fraglist* l) {
+    if (l->n_frag == l->cap_frag) {
+        l->cap_frag = l->cap_frag ? 2 * l->cap_frag : 1024;
+        l->frag = (fpl_fragment*)realloc(l->frag, l->cap_frag * sizeof(fpl_fragment));
+    }
+    fpl_fragment* f = &l->frag[l->n_frag++];
+    memset(f, 0, sizeof(*f));
+    return f;
+}
+static void fraglist_add_region(orc_fraglist* l, uint32_t start, uint32_t len) {
+    if (l->n_reg == l->cap_reg) {
+        l->cap_reg = l->cap_reg ? 2 * l->cap_reg : 1024;
+        l->reg = (fpl_region*)realloc(l->reg, l->cap_reg * sizeof(fpl_region));
+    }
+    l->reg[l->n_reg].start = start;
+    l->reg[l->n_reg].len = len;
+    l->n_reg++;
+}
+
+/* One output read of the --break / --mask stage (src/seprocessor.cpp:234-281): a window on the original read
+ * plus how it got its name. */
+typedef struct out_read {
+    orc_read r;
+    int kind;     /* 0 / 1 / 2, see fpl_fragment */
+    int break_no; /* i of the "r<i>-" prefix, 0 = none */
+} out_read;
+
+/* passFilter + counters + statRead for the output reads of one input read; masking (Read::maskRegionWithN,
+ * src/read.cpp:217-225) happens on a private copy of the fragment's bases, as the reference's strings are. */
+static void finish_break_mask(const orc_config* cfg, out_read* outs, int n_out, int64_t* counters, uint32_t C,
+                              uint32_t read_index, orc_fraglist* list) {
+    const fpl_options* o = &cfg->opt;
+    int64_t* post = counters + FPL_OFF_POST(C);
+    int64_t* fr = counters + FPL_OFF_FR(C);
+    for (int i = 0; i < n_out; i++) {
+        orc_read fr_read = outs[i].r;
+        char* masked = NULL;
+        fpl_fragment* f = fraglist_add(list);
+        f->read = read_index;
+        f->seq_no = (uint32_t)i;
+        f->start = (uint32_t)outs[i].r.start;
+        f->len = (uint32_t)outs[i].r.len;
+        f->kind = (uint8_t)outs[i].kind;
+        f->break_no = (uint16_t)outs[i].break_no;
+        f->region_first = list->n_reg;
+        if (o->mask_enabled && outs[i].r.len > 0) { /* :254-262 */
+            int cap = outs[i].r.len / 2 + 2;
+            int* a = (int*)malloc(sizeof(int) * 2 * (size_t)cap);
+            int* b = a + cap;
+            int nr = orc_detect_low_quality_regions(&outs[i].r, o->mask_window, o->mask_quality, a, b, cap);
+            if (nr > 0) {
+                masked = (char*)malloc((size_t)outs[i].r.len);
+                memcpy(masked, outs[i].r.seq + outs[i].r.start, (size_t)outs[i].r.len);
+                for (int j = 0; j < nr; j++) { /* maskRegionWithN(first, last - first + 1) */
+                    int st = a[j], ln = b[j] - a[j] + 1;
+                    if (st < 0 || ln <= 0 || st >= outs[i].r.len) continue;
+                    if (st + ln > outs[i].r.len) ln = outs[i].r.len - st;
+                    memset(masked + st, 'N', (size_t)ln);
+                    fraglist_add_region(list, (uint32_t)(outs[i].r.start + st), (uint32_t)ln);
+                }
+                fr_read.seq = masked - outs[i].r.start; /* same window coordinates, private bases */
+            }
+            free(a);
+        }
+        f->region_count = list->n_reg - f->region_first;
+        int result = orc_pass_filter(&fr_read, o);
+        fr[FPL_FR_FILTER + result] += 1;
+        f->code = (uint8_t)result;
+        if (result == FPL_PASS_FILTER) orc_stat_read(post, C, &fr_read, &f->median_q);
+        free(masked);
+    }
+}
+
+void orc_process_read_ex(const orc_config* cfg, const char* seq, const char* qual, int len,
+                         int64_t* counters, uint32_t C, fpl_read_result* res, uint32_t read_index, orc_fraglist* list) {
     const fpl_options* o = &cfg->opt;
     int nad = 2 + cfg->n_fasta;
     int64_t* pre = counters + FPL_OFF_PRE(C);
@@ -573,6 +689,60 @@ void orc_process_read(const orc_config* cfg, const char* seq, const char* qual, 
     }
     res->r1_start = (uint32_t)r1.start;
     res->r1_len = (uint32_t)r1.len;
+    if (o->break_enabled || o->mask_enabled) { /* :234-262, then :265-281 over however many reads result */
+        int n_out = 0, cap_out = 8;
+        out_read* outs = (out_read*)malloc(sizeof(out_read) * (size_t)cap_out);
+        for (int i = 0; i < nfrag; i++) {
+            int nr = 0, *ra = NULL, *rb = NULL;
+            if (o->break_enabled) {
+                int cap = frags[i].len / 2 + 2;
+                ra = (int*)malloc(sizeof(int) * 2 * (size_t)cap);
+                rb = ra + cap;
+                nr = orc_detect_low_quality_regions(&frags[i], o->break_window, o->break_quality, ra, rb, cap);
+            }
+            if (n_out + nr + 2 > cap_out) {
+                cap_out = 2 * (n_out + nr + 2);
+                outs = (out_read*)realloc(outs, sizeof(out_read) * (size_t)cap_out);
+            }
+            if (nr > 0) { /* Read::breakByRegions, src/read.cpp:227-262 */
+                const int L = frags[i].len;
+                int lastEnd = -1;
+                for (int j = 0; j < nr; j++) {
+                    int st = ra[j], en = rb[j];
+                    if (st < 0) st = 0;
+                    if (en >= L) en = L - 1;
+                    if (st > en || st >= L) continue;
+                    if (st > lastEnd + 1) {
+                        out_read* x = &outs[n_out++];
+                        x->r = frags[i];
+                        x->r.start = frags[i].start + lastEnd + 1;
+                        x->r.len = st - lastEnd - 1;
+                        x->kind = kinds[i];
+                        x->break_no = j + 1;
+                    }
+                    lastEnd = en;
+                }
+                if (lastEnd < L - 1) {
+                    out_read* x = &outs[n_out++];
+                    x->r = frags[i];
+                    x->r.start = frags[i].start + lastEnd + 1;
+                    x->r.len = L - lastEnd - 1;
+                    x->kind = kinds[i];
+                    x->break_no = nr + 1;
+                }
+            } else {
+                out_read* x = &outs[n_out++];
+                x->r = frags[i];
+                x->kind = kinds[i];
+                x->break_no = 0;
+            }
+            free(ra);
+        }
+        res->n_frag = (uint8_t)(n_out > 255 ? 255 : n_out);
+        finish_break_mask(cfg, outs, n_out, counters, C, read_index, list);
+        free(outs);
+        return;
+    }
     res->n_frag = (uint8_t)nfrag;
     for (int i = 0; i < nfrag; i++) { /* :265-281 */
         int result = orc_pass_filter(&frags[i], o);
@@ -585,10 +755,21 @@ void orc_process_read(const orc_config* cfg, const char* seq, const char* qual, 
     }
 }
 
+void orc_process_read(const orc_config* cfg, const char* seq, const char* qual, int len,
+                      int64_t* counters, uint32_t C, fpl_read_result* res) {
+    orc_process_read_ex(cfg, seq, qual, len, counters, C, res, 0, NULL);
+}
+
+void orc_process_batch_ex(const orc_config* cfg, const uint8_t* seq, const uint8_t* qual,
+                          const uint64_t* off, uint32_t n_reads, int64_t* counters, uint32_t C,
+                          fpl_read_result* res, orc_fraglist* list) {
+    for (uint32_t i = 0; i < n_reads; i++)
+        orc_process_read_ex(cfg, (const char*)seq + off[i], (const char*)qual + off[i],
+                            (int)(off[i + 1] - off[i]), counters, C, &res[i], i, list);
+}
+
 void orc_process_batch(const orc_config* cfg, const uint8_t* seq, const uint8_t* qual,
                        const uint64_t* off, uint32_t n_reads, int64_t* counters, uint32_t C,
                        fpl_read_result* res) {
-    for (uint32_t i = 0; i < n_reads; i++)
-        orc_process_read(cfg, (const char*)seq + off[i], (const char*)qual + off[i],
-                         (int)(off[i + 1] - off[i]), counters, C, &res[i]);
+    orc_process_batch_ex(cfg, seq, qual, off, n_reads, counters, C, res, NULL);
 }

@@ -65,6 +65,27 @@ int orc_pass_filter(const orc_read* r, const fpl_options* opt);
 /* stats: int64 block laid out as FPL_STATS_LEN(C) of include/fastplong_amd.h */
 void orc_stat_read(int64_t* stats, uint32_t C, const orc_read* r, uint8_t* median_out);
 
+/* Filter::detectLowQualityRegions, src/filter.cpp:83-128, on the window of r: writes up to cap (first, last)
+ * pairs (positions relative to the window, last inclusive) and returns how many the reference finds. */
+int orc_detect_low_quality_regions(const orc_read* r, int window, int quality, int* first, int* last, int cap);
+
+/* Growing lists the extended flow appends to (plain realloc; test infrastructure) */
+typedef struct orc_fraglist {
+    fpl_fragment* frag;
+    uint32_t n_frag, cap_frag;
+    fpl_region* reg;
+    uint32_t n_reg, cap_reg;
+} orc_fraglist;
+void orc_fraglist_free(orc_fraglist* l);
+
+/* The whole of processSingleEnd for one read.  counters: FPL_COUNTERS_LEN(C, nad) int64.
+ * With opt.break_enabled / mask_enabled the fragments are appended to `list` (must not be NULL then) with
+ * read = read_index, and res follows the convention of fpl_fragment in include/fastplong_amd.h. */
+void orc_process_read_ex(const orc_config* cfg, const char* seq, const char* qual, int len,
+                         int64_t* counters, uint32_t C, fpl_read_result* res, uint32_t read_index, orc_fraglist* list);
+void orc_process_batch_ex(const orc_config* cfg, const uint8_t* seq, const uint8_t* qual,
+                          const uint64_t* off, uint32_t n_reads, int64_t* counters, uint32_t C,
+                          fpl_read_result* res, orc_fraglist* list);
 /* The whole of processSingleEnd for one read.  counters: FPL_COUNTERS_LEN(C, nad) int64. */
 void orc_process_read(const orc_config* cfg, const char* seq, const char* qual, int len,
                       int64_t* counters, uint32_t C, fpl_read_result* res);

@@ -68,6 +68,14 @@ def lib():
         L.orc_process_batch.restype = None
         L.orc_process_batch.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_process_batch_ex.restype = None
+        L.orc_process_batch_ex.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_detect_low_quality_regions.restype = C.c_int
+        L.orc_detect_low_quality_regions.argtypes = [C.POINTER(OrcRead), C.c_int, C.c_int, C.POINTER(C.c_int),
+                                                     C.POINTER(C.c_int), C.c_int]
+        L.orc_fraglist_free.restype = None
+        L.orc_fraglist_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -199,6 +207,47 @@ def process_batch(cfg, seq, qual, off, max_cycles=None, counters=None):
     lib().orc_process_batch(C.byref(c), seq_p, qual_p, off.ctypes.data, n, counters.ctypes.data,
                             max_cycles, res.ctypes.data if n else None)
     return res, counters
+
+
+class OrcFragList(C.Structure):
+    _fields_ = [("frag", C.c_void_p), ("n_frag", C.c_uint32), ("cap_frag", C.c_uint32), ("reg", C.c_void_p),
+                ("n_reg", C.c_uint32), ("cap_reg", C.c_uint32)]
+
+
+def process_batch_ex(cfg, seq, qual, off, max_cycles=None):
+    """process_batch for option sets with --break / --mask:
+    -> (results, counters, fragments [FRAGMENT_DTYPE, in output order], regions [REGION_DTYPE])"""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    qual = np.ascontiguousarray(qual, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    n = len(off) - 1
+    need = int(np.diff(off.astype(np.int64)).max()) if n > 0 else 0
+    if max_cycles is None:
+        max_cycles = max(need, 1)
+    counters = np.zeros(abi.counters_len(max_cycles, cfg.n_adapters), dtype=np.int64)
+    res = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    c = cfg._c()
+    fl = OrcFragList()
+    L = lib()
+    L.orc_process_batch_ex(C.byref(c), seq.ctypes.data if seq.size else None, qual.ctypes.data if qual.size else None,
+                           off.ctypes.data, n, counters.ctypes.data, max_cycles, res.ctypes.data if n else None,
+                           C.byref(fl))
+    frags = np.frombuffer(C.string_at(fl.frag, fl.n_frag * 32), dtype=abi.FRAGMENT_DTYPE).copy() if fl.n_frag else \
+        np.zeros(0, dtype=abi.FRAGMENT_DTYPE)
+    regs = np.frombuffer(C.string_at(fl.reg, fl.n_reg * 8), dtype=abi.REGION_DTYPE).copy() if fl.n_reg else \
+        np.zeros(0, dtype=abi.REGION_DTYPE)
+    L.orc_fraglist_free(C.byref(fl))
+    return res, counters, frags, regs
+
+
+def detect_low_quality_regions(qual, window, quality):
+    """-> list of (first, last) like Filter::detectLowQualityRegions"""
+    q = _b(qual)
+    r = _read(b"A" * len(q), q)
+    cap = len(q) // 2 + 2
+    a, b = (C.c_int * cap)(), (C.c_int * cap)()
+    n = lib().orc_detect_low_quality_regions(C.byref(r), window, quality, a, b, cap)
+    return [(a[i], b[i]) for i in range(n)]
 
 
 # ---- client of the real-reference harness ---------------------------------------------------

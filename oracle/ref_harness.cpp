@@ -17,6 +17,9 @@
  *   TF n =seq =qual / RS n =seq =qual           -> Read::trimFront / Read::resize
  *   BG start len =name =seq =strand =qual       -> Read::breakByGap + appendToString
  *   TAG code =name =seq =strand =qual           -> Read::appendToStringWithTag(FAILED_TYPES[code])
+ *   LQR window quality =seq =qual               -> Filter::detectLowQualityRegions
+ *   BRK be bw bq me mw mq =name =seq =strand =qual -> the --break / --mask stage (detect, breakByRegions,
+ *                                                  maskRegionWithN) + appendToString of what comes out
  *   JSON block: J_BEGIN threads seqlen isrna adapter_enabled polyx complexity =start =end
  *               J_PRE =seq =qual | J_POST =seq =qual | J_FR code | J_AD =key | J_ART bases
  *               | J_PXT base len | J_END =path   -> Stats/FilterResult/JsonReporter::report
@@ -139,6 +142,48 @@ int main() {
                 delete out[i];
             }
             cout << out.size() << " " << s.size() << "\n" << s;
+        } else if (op == "LQR") { /* Filter::detectLowQualityRegions(window, quality) */
+            Options opt;
+            Filter filter(&opt);
+            Read r("@n", str(t[3]).c_str(), "+", str(t[4]).c_str());
+            vector<pair<int, int>> regions = filter.detectLowQualityRegions(&r, atoi(t[1].c_str()), atoi(t[2].c_str()));
+            cout << regions.size();
+            for (auto& rg : regions) cout << " " << rg.first << " " << rg.second;
+            cout << "\n";
+        } else if (op == "BRK") { /* the --break / --mask stage of processSingleEnd (src/seprocessor.cpp:234-262) on
+                                     one read: detect + breakByRegions, detect + maskRegionWithN, appendToString */
+            Options opt;
+            Filter filter(&opt);
+            const int be = atoi(t[1].c_str()), bw = atoi(t[2].c_str()), bq = atoi(t[3].c_str());
+            const int me = atoi(t[4].c_str()), mw = atoi(t[5].c_str()), mq = atoi(t[6].c_str());
+            Read* r1 = new Read(str(t[7]).c_str(), str(t[8]).c_str(), str(t[9]).c_str(), str(t[10]).c_str());
+            vector<Read*> outReads;
+            outReads.push_back(r1);
+            if (be) {
+                vector<Read*> tmpReads;
+                for (size_t i = 0; i < outReads.size(); i++) {
+                    Read* rr = outReads[i];
+                    vector<pair<int, int>> regions = filter.detectLowQualityRegions(rr, bw, bq);
+                    if (regions.size() > 0) {
+                        vector<Read*> brs = rr->breakByRegions(regions);
+                        for (size_t j = 0; j < brs.size(); j++) tmpReads.push_back(brs[j]);
+                    } else {
+                        tmpReads.push_back(rr);
+                    }
+                }
+                outReads = tmpReads;
+            }
+            if (me) {
+                for (size_t i = 0; i < outReads.size(); i++) {
+                    Read* rr = outReads[i];
+                    vector<pair<int, int>> regions = filter.detectLowQualityRegions(rr, mw, mq);
+                    for (size_t j = 0; j < regions.size(); j++)
+                        rr->maskRegionWithN(regions[j].first, regions[j].second - regions[j].first + 1);
+                }
+            }
+            string s;
+            for (size_t i = 0; i < outReads.size(); i++) outReads[i]->appendToString(&s);
+            cout << outReads.size() << " " << s.size() << "\n" << s;
         } else if (op == "TAG") {
             Read r(str(t[2]).c_str(), str(t[3]).c_str(), str(t[4]).c_str(), str(t[5]).c_str());
             string s;

@@ -6,7 +6,7 @@ Read::trimFront/resize."""
 import numpy as np
 import pytest
 
-from fastplong_amd import abi
+from fastplong_amd import abi, synth
 
 
 def rand_seq(rng, n, alphabet="ACGT", p_n=0.0):
@@ -198,3 +198,72 @@ def test_read_offset_ops_vs_reference(ref):
         else:
             exp = (s, q) if (n > L or n < 0) else (s[:n], q[:n])
         assert (ws[1:], wq[1:]) == exp, (op, n, s)
+
+
+# ---- --break / --mask (src/seprocessor.cpp:234-262) -----------------------------------------------
+def _lowq_read(rng, n, p_low=0.3):
+    """qualities with stretches far below the threshold, so that regions start, stop and chain"""
+    q = np.clip(np.round(rng.normal(30, 4, n)), 5, 50)
+    pos = 0
+    while pos < n:
+        run = int(rng.integers(5, 120))
+        if rng.random() < p_low:
+            q[pos:pos + run] = np.clip(np.round(rng.normal(6, 3, min(run, n - pos))), 2, 40)
+        pos += run
+    return (q + 33).astype(np.uint8)
+
+
+@pytest.mark.parametrize("window,quality", [(5, 10), (20, 15), (50, 10), (100, 10), (7, 30)])
+def test_detect_low_quality_regions_matches_reference(orc, ref, window, quality):
+    rng = np.random.default_rng(window * 100 + quality)
+    quals = [_lowq_read(rng, int(n)) for n in list(rng.integers(1, 400, 40)) + [window - 1, window, window + 1, 2 * window]]
+    lines = ["LQR %d %d %s %s" % (window, quality, ref.s(b"A" * len(q)), ref.s(q.tobytes())) for q in quals]
+    out = ref.run(lines).splitlines()
+    n_regions = 0
+    for q, line in zip(quals, out):
+        t = [int(x) for x in line.split()]
+        want = list(zip(t[1::2], t[2::2]))
+        assert len(want) == t[0]
+        assert orc.detect_low_quality_regions(q.tobytes(), window, quality) == want
+        n_regions += len(want)
+    assert n_regions > 10
+
+
+@pytest.mark.parametrize("be,me", [(1, 0), (0, 1), (1, 1)])
+def test_break_mask_stage_matches_reference(orc, ref, be, me):
+    """the oracle's fragment list, rendered the way the host formats it, against the real
+    detectLowQualityRegions + breakByRegions + maskRegionWithN + appendToString"""
+    rng = np.random.default_rng(7 + 2 * be + me)
+    bw, bq, mw, mq = 20, 12, 8, 14
+    opt = abi.FplOptions.default(adapter_enabled=0, qual_filter=0, length_filter=0, break_enabled=be, break_window=bw,
+                                 break_quality=bq, mask_enabled=me, mask_window=mw, mask_quality=mq)
+    cfg = orc.Config(opt)
+    reads = []
+    for n in list(rng.integers(1, 500, 60)):
+        reads.append((synth._ACGT[rng.integers(0, 4, int(n))].astype(np.uint8), _lowq_read(rng, int(n))))
+    seq, qual, off = synth.pack(reads)
+    res, cnt, frags, regs = orc.process_batch_ex(cfg, seq, qual, off)
+    lines = ["BRK %d %d %d %d %d %d %s %s %s %s" % (be, bw, bq, me, mw, mq, ref.s(b"@read%d" % i), ref.s(s.tobytes()),
+                                                    ref.s(b"+"), ref.s(q.tobytes())) for i, (s, q) in enumerate(reads)]
+    raw = ref.run(lines).encode("latin-1")
+    pos, total_frag, total_masked = 0, 0, 0
+    for i, (s, q) in enumerate(reads):
+        nl = raw.index(b"\n", pos)
+        n_out, nbytes = [int(x) for x in raw[pos:nl].split()]
+        want = raw[nl + 1:nl + 1 + nbytes]
+        pos = nl + 1 + nbytes
+        mine = frags[frags["read"] == i]
+        assert len(mine) == n_out and list(mine["seq_no"]) == list(range(n_out))
+        got = []
+        for f in mine:
+            sb = bytearray(s[f["start"]:f["start"] + f["len"]].tobytes())
+            for r in regs[f["region_first"]:f["region_first"] + f["region_count"]]:
+                a = int(r["start"]) - int(f["start"])
+                sb[a:a + int(r["len"])] = b"N" * int(r["len"])
+                total_masked += int(r["len"])
+            name = b"@" + (b"r%d-" % f["break_no"] if f["break_no"] else b"") + b"read%d" % i
+            got += [name, b"\n", bytes(sb), b"\n+\n", q[f["start"]:f["start"] + f["len"]].tobytes(), b"\n"]
+        assert b"".join(got) == want
+        total_frag += n_out
+    assert (frags["break_no"] > 0).any() if be else total_frag == len(reads)
+    assert (total_masked > 0) == bool(me)
