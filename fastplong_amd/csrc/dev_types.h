@@ -42,6 +42,9 @@ struct DevConfig {
     int32_t qual_filter, qualified_qual, unqual_pct, n_base_limit, n_pct_limit, avg_qual_req;
     int32_t length_filter, required_length, max_length;
     int32_t complexity, complexity_pct;
+    /* --break / --mask (src/seprocessor.cpp:234-262): window and (33 + quality) * window; with either one on,
+       k_scan leaves the fragments' fate to k_break_mask (defer) */
+    int32_t brk, brk_w, brk_thr, msk, msk_w, msk_thr, defer;
     int32_t dbg;      /* FPL_DEBUG_FLAGS: ablation switches for profiling (wrong results when set) */
     int32_t ham_fast; /* both command-line adapters are ACGT-only and <= 64 long: bit-sliced scan */
     int32_t thr[FPL_MAX_ADAPTER_LEN + 1]; /* (int)round(ed_max * len), computed in double on the host */
@@ -107,6 +110,13 @@ inline void build_config(DevConfig* c, const fpl_options* o, int start_len, int 
     c->complexity = o->complexity_filter != 0;
     int y = o->complexity_percent; /* src/main.cpp:219 clamps -Y to 0..100 */
     c->complexity_pct = y < 0 ? 0 : (y > 100 ? 100 : y);
+    c->brk = o->break_enabled != 0;
+    c->brk_w = o->break_window;
+    c->brk_thr = (33 + o->break_quality) * o->break_window;
+    c->msk = o->mask_enabled != 0;
+    c->msk_w = o->mask_window;
+    c->msk_thr = (33 + o->mask_quality) * o->mask_window;
+    c->defer = c->brk || c->msk;
     for (int l = 0; l <= FPL_MAX_ADAPTER_LEN; l++) c->thr[l] = (int)round(o->ed_max * l);
 }
 

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,12 @@ struct fpl_ctx {
     uint64_t* d_frag_off = nullptr;
     u32* d_frag_len = nullptr;
     u32* d_work_ctr = nullptr;
+    /* --break / --mask (DevConfig::defer): lists k_break_mask appends to, sized per batch */
+    DevConfig hcfg;
+    u32* d_frag_cyc = nullptr;
+    BmLists bm = {nullptr, nullptr, 0, 0, 0, nullptr};
+    uint64_t bm_bytes = 0; /* n_bytes the lists are sized for */
+    u32 bm_reads = 0;
     size_t scratch_slabs = 0;
     u64* d_stats_scratch = nullptr;
     u8* d_stats_flags = nullptr;
@@ -139,6 +146,12 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
         if (const char* e = getenv("FPL_DEBUG_FLAGS")) cfg.dbg = atoi(e);
         ctx->dbg = cfg.dbg;
+        if ((cfg.brk && cfg.brk_w <= 0) || (cfg.msk && cfg.msk_w <= 0)) {
+            ctx->err = "break / mask window size must be positive";
+            delete ctx;
+            return FPL_ERR_ARG;
+        }
+        ctx->hcfg = cfg;
         FPL_HIP(hipMalloc((void**)&ctx->d_cfg, sizeof(DevConfig)));
         FPL_HIP(hipMemcpy(ctx->d_cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
         FPL_HIP(hipMalloc((void**)&ctx->d_ads, sizeof(DevAdapter) * ads.size()));
@@ -166,7 +179,7 @@ void fpl_destroy(fpl_ctx* ctx) {
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->d_cfg, ctx->d_ads, ctx->d_counters, ctx->d_state, ctx->d_frag_off, ctx->d_frag_len,
                     ctx->d_work_ctr, ctx->d_seq, ctx->d_qual, ctx->d_off, ctx->d_results, ctx->d_stats_scratch,
-                    ctx->d_stats_flags};
+                    ctx->d_stats_flags, ctx->d_frag_cyc, ctx->bm.frags, ctx->bm.regs, ctx->bm.counts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int r = 0; r < fpl_ctx::EV_RING; r++)
@@ -245,19 +258,49 @@ static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_r
     return FPL_OK;
 }
 
+/* the fragment / region / piece lists of k_break_mask for a batch of this size */
+static int ensure_break_mask(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes) {
+    if (!ctx->hcfg.defer) return FPL_OK;
+    if (!ctx->bm.counts) FPL_HIP(hipMalloc((void**)&ctx->bm.counts, 4 * sizeof(u32)));
+    if (n_reads <= ctx->bm_reads && n_bytes <= ctx->bm_bytes && ctx->bm.frags) return FPL_OK;
+    FPL_HIP(hipDeviceSynchronize());
+    if (ctx->bm.frags) (void)hipFree(ctx->bm.frags);
+    if (ctx->bm.regs) (void)hipFree(ctx->bm.regs);
+    if (ctx->d_frag_cyc) (void)hipFree(ctx->d_frag_cyc);
+    if (ctx->d_frag_off) (void)hipFree(ctx->d_frag_off);
+    if (ctx->d_frag_len) (void)hipFree(ctx->d_frag_len);
+    ctx->bm.frags = nullptr;
+    ctx->bm.regs = nullptr;
+    ctx->d_frag_cyc = nullptr;
+    ctx->d_frag_off = nullptr;
+    ctx->d_frag_len = nullptr;
+    break_mask_caps(n_reads, n_bytes, ctx->hcfg.brk, ctx->hcfg.brk_w, ctx->hcfg.msk, ctx->hcfg.msk_w, ctx->bm.frag_cap,
+                    ctx->bm.reg_cap, ctx->bm.item_cap);
+    FPL_HIP(hipMalloc((void**)&ctx->bm.frags, sizeof(fpl_fragment) * (size_t)ctx->bm.frag_cap));
+    FPL_HIP(hipMalloc((void**)&ctx->bm.regs, sizeof(fpl_region) * (size_t)ctx->bm.reg_cap));
+    FPL_HIP(hipMalloc((void**)&ctx->d_frag_off, sizeof(uint64_t) * (size_t)ctx->bm.item_cap));
+    FPL_HIP(hipMalloc((void**)&ctx->d_frag_len, sizeof(u32) * (size_t)ctx->bm.item_cap));
+    FPL_HIP(hipMalloc((void**)&ctx->d_frag_cyc, sizeof(u32) * (size_t)ctx->bm.item_cap));
+    ctx->bm_reads = n_reads;
+    ctx->bm_bytes = n_bytes;
+    return FPL_OK;
+}
+
 static int ensure_workspace(fpl_ctx* ctx, u32 n_reads) {
     if (n_reads <= ctx->ws_reads) return FPL_OK;
     FPL_HIP(hipDeviceSynchronize());
     if (ctx->d_state) (void)hipFree(ctx->d_state);
-    if (ctx->d_frag_off) (void)hipFree(ctx->d_frag_off);
-    if (ctx->d_frag_len) (void)hipFree(ctx->d_frag_len);
     ctx->d_state = nullptr;
-    ctx->d_frag_off = nullptr;
-    ctx->d_frag_len = nullptr;
     ctx->ws_reads = 0;
     FPL_HIP(hipMalloc((void**)&ctx->d_state, sizeof(ReadState) * (size_t)n_reads));
-    FPL_HIP(hipMalloc((void**)&ctx->d_frag_off, sizeof(uint64_t) * 2 * (size_t)n_reads));
-    FPL_HIP(hipMalloc((void**)&ctx->d_frag_len, sizeof(u32) * 2 * (size_t)n_reads));
+    if (!ctx->hcfg.defer) { /* (with --break / --mask the item list is sized by ensure_break_mask) */
+        if (ctx->d_frag_off) (void)hipFree(ctx->d_frag_off);
+        if (ctx->d_frag_len) (void)hipFree(ctx->d_frag_len);
+        ctx->d_frag_off = nullptr;
+        ctx->d_frag_len = nullptr;
+        FPL_HIP(hipMalloc((void**)&ctx->d_frag_off, sizeof(uint64_t) * 2 * (size_t)n_reads));
+        FPL_HIP(hipMalloc((void**)&ctx->d_frag_len, sizeof(u32) * 2 * (size_t)n_reads));
+    }
     ctx->ws_reads = n_reads;
     return FPL_OK;
 }
@@ -279,8 +322,11 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         if (r != FPL_OK) return r;
         r = ensure_scratch(ctx, n_reads, n_bytes, max_read_len);
         if (r != FPL_OK) return r;
+        r = ensure_break_mask(ctx, n_reads, n_bytes);
+        if (r != FPL_OK) return r;
         FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, 2 * sizeof(u32), stream));
     }
+    if (ctx->hcfg.defer && ctx->bm.counts) FPL_HIP(hipMemsetAsync(ctx->bm.counts, 0, 4 * sizeof(u32), stream));
     BatchArgs a;
     a.seq = d_seq;
     a.qual = d_qual;
@@ -294,6 +340,9 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.results = d_results;
     a.frag_off = ctx->d_frag_off;
     a.frag_len = ctx->d_frag_len;
+    a.frag_cyc = ctx->d_frag_cyc;
+    a.bm = ctx->bm;
+    a.defer = ctx->hcfg.defer != 0;
     a.counters = ctx->d_counters;
     a.C = ctx->C;
     a.work_ctr = ctx->d_work_ctr;
@@ -396,6 +445,38 @@ int fpl_get_kernel_times(fpl_ctx* ctx, float* ms, const char** names, int* n, in
 }
 
 } /* extern "C" */
+
+extern "C" int fpl_fragment_counts(fpl_ctx* ctx, uint32_t* n_fragments, uint32_t* n_regions) {
+    if (!ctx || !n_fragments || !n_regions) return FPL_ERR_ARG;
+    *n_fragments = *n_regions = 0;
+    if (!ctx->hcfg.defer || !ctx->bm.counts) return FPL_OK;
+    FPL_HIP(hipSetDevice(ctx->device));
+    FPL_HIP(hipDeviceSynchronize());
+    u32 c[4] = {0, 0, 0, 0};
+    FPL_HIP(hipMemcpy(c, ctx->bm.counts, sizeof(c), hipMemcpyDeviceToHost));
+    if (c[2]) {
+        ctx->err = "break/mask lists overflowed their capacity";
+        return FPL_ERR_CAPACITY;
+    }
+    *n_fragments = c[0];
+    *n_regions = c[1];
+    return FPL_OK;
+}
+
+extern "C" int fpl_get_fragments(fpl_ctx* ctx, fpl_fragment* fragments, uint32_t n_fragments, fpl_region* regions,
+                                 uint32_t n_regions) {
+    if (!ctx || (n_fragments && !fragments) || (n_regions && !regions)) return FPL_ERR_ARG;
+    uint32_t nf = 0, nr = 0;
+    int r = fpl_fragment_counts(ctx, &nf, &nr);
+    if (r != FPL_OK) return r;
+    if (n_fragments < nf || n_regions < nr) return FPL_ERR_ARG;
+    if (nf) FPL_HIP(hipMemcpy(fragments, ctx->bm.frags, sizeof(fpl_fragment) * (size_t)nf, hipMemcpyDeviceToHost));
+    if (nr) FPL_HIP(hipMemcpy(regions, ctx->bm.regs, sizeof(fpl_region) * (size_t)nr, hipMemcpyDeviceToHost));
+    std::sort(fragments, fragments + nf, [](const fpl_fragment& a, const fpl_fragment& b) {
+        return a.read != b.read ? a.read < b.read : a.seq_no < b.seq_no;
+    });
+    return FPL_OK;
+}
 
 #ifdef FPL_PROF
 /* profiling builds only: read (and clear) the section timers the kernels accumulate */

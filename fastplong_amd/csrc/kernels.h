@@ -934,7 +934,8 @@ __device__ __forceinline__ void fs_hand_over(const u64* tpre, const u64* tpost, 
 template <int WAVES, bool EXTRA>
 __global__ void __launch_bounds__(WAVES * 64, (2 * WAVES + 3) / 4)
 k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_bytes,
-        const uint64_t* __restrict__ item_off, const u32* __restrict__ item_len, const ReadState* __restrict__ plan,
+        const uint64_t* __restrict__ item_off, const u32* __restrict__ item_len, const u32* __restrict__ item_cyc,
+        const ReadState* __restrict__ plan,
         u32 n_items, const u32* __restrict__ n_items_dev, u32 items_per_slice, u32 n_slices, u32 max_acc,
         long long* __restrict__ counters, u64* __restrict__ scratch, u8* __restrict__ flags, u32 C) {
     /* main pass: items are the reads (CSR offsets + plan).  EXTRA: items are the post-only fragment list
@@ -976,7 +977,8 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
         __syncthreads();
         bool mine = false;
         for (u32 it = i_begin + threadIdx.x; it < i_end; it += blockDim.x) {
-            const u32 L = EXTRA ? item_len[it] : (u32)(item_off[it + 1] - item_off[it]);
+            u32 L = EXTRA ? item_len[it] : (u32)(item_off[it + 1] - item_off[it]);
+            if (EXTRA && item_cyc) L += item_cyc[it] & 0x7FFFFFFFu;
             mine = mine || (L > tile_start);
         }
         if (wave_ballot(mine) && lane == 0) any_work = 1;
@@ -1026,10 +1028,15 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
         if (it < i_end) {
             st = item_off[it];
             if (EXTRA) {
-                L = item_len[it];
-                S = 0;
+                /* a post-only item starts at cycle cyc0 (non-zero for the pieces of a --mask'ed fragment): treat it
+                   as a virtual read that begins cyc0 bytes earlier and whose body is [cyc0, cyc0 + len); TP bit 1
+                   marks a piece whose bases were overwritten with N */
+                const u32 cy = item_cyc ? item_cyc[it] : 0u;
+                S = cy & 0x7FFFFFFFu;
+                L = item_len[it] + S;
                 E = L;
-                TP = 1;
+                TP = 1u | ((cy >> 31) << 1);
+                st -= S;
             } else {
                 L = (u32)(item_off[it + 1] - st);
                 const ReadState ps = plan[it];
@@ -1038,7 +1045,7 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                 TP = ps.pad & PLAN_TO_POST;
             }
         }
-        u64 m = wave_ballot(L > tile_start);
+        u64 m = wave_ballot(L > tile_start && (!EXTRA || S < tile_start + FS_T));
         /* groups of CS_GROUP items: all their loads are issued before the first one is counted */
         while (m) {
             u32x2 svG[CS_GROUP], qvG[CS_GROUP];
@@ -1057,26 +1064,29 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                     EG[g] = readlane_u32(E, bit);
                     TG[g] = readlane_u32(TP, bit);
                     const uint64_t start = readlane_u64(st, bit);
-                    if (LG[g] > c0) {
+                    if (LG[g] > c0 && (!EXTRA || c0 + 8 > SG[g])) {
                         svG[g] = load8_guard(seq + start + c0, seq_end);
                         qvG[g] = load8_guard(qual + start + c0, qual_end);
                     }
-                    if (lane == 0 && tile_start >= 4) haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
+                    if (lane == 0 && tile_start >= 4 && (!EXTRA || tile_start >= SG[g] + 4))
+                        haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
                 }
             }
 #pragma unroll
             for (int g = 0; g < CS_GROUP; g++) {
                 const u32 itemL = uniform_u32(LG[g]);
                 if (itemL <= tile_start) continue; /* wave-uniform: empty slot of the last group */
-                const u32 sw[2] = {svG[g].x, svG[g].y};
+                const u32 tflags = uniform_u32(TG[g]);
+                const bool tp = (tflags & 1u) != 0;
+                const bool allN = EXTRA && (tflags & 2u); /* Read::maskRegionWithN: the bases read as N, qualities stay */
+                const u32 sw[2] = {allN ? 0x4E4E4E4Eu : svG[g].x, allN ? 0x4E4E4E4Eu : svG[g].y};
                 const u32 qw[2] = {qvG[g].x, qvG[g].y};
                 const int s = (int)uniform_u32(SG[g]), e = (int)uniform_u32(EG[g]);
-                const bool tp = uniform_u32(TG[g]) != 0;
                 const int nvalid = itemL > c0 ? (int)min(8u, itemL - c0) : 0; /* bytes of the item in this lane */
                 /* the four bases in front of this lane's chunk: previous lane's last dword */
                 const u32 up = shfl_up_u32(sw[1], 1);
                 const bool have_halo = lane > 0 || tile_start >= 4;
-                const u32 halo = lane > 0 ? up : haloG[g];
+                const u32 halo = allN ? 0x4E4E4E4Eu : (lane > 0 ? up : haloG[g]);
                 /* 5-mers, twelve bases at once: 2-bit codes (Stats::base2val: A0 T1 C2 G3) packed earliest base
                    highest, so the window that ends at byte k is a 10-bit field of W */
                 const u32 vh = kmer_codes(halo), v0 = kmer_codes(sw[0]), v1 = kmer_codes(sw[1]);
@@ -1110,8 +1120,9 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                     }
                     okmask &= (1u << nvalid) - 1u;
                 }
-                /* post cell of local byte k: x = 8*lane + k + (FS_SMAX - s); slot(x) = (x%8)*(FS_PT/8) + x/8 */
-                const int u0 = FS_SMAX - s;
+                /* post cell of local byte k: x = 8*lane + k + (FS_SMAX - s); slot(x) = (x%8)*(FS_PT/8) + x/8
+                   (EXTRA items keep their cycle: the body starts at s but is not re-based) */
+                const int u0 = EXTRA ? FS_SMAX : FS_SMAX - s;
                 const int p0 = (int)c0; /* position of byte 0 of this lane */
                 /* one byte.  DO_PRE / DO_POST / FULL are compile-time; FULL: all 8 bytes of every lane belong to
                    the item and (with DO_POST) to r1, 5-mer windows included.  Otherwise bit k of bodymask /
@@ -1138,14 +1149,13 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
         else if (DO_PRE)                                                                                          \
             atomicAdd(&kmer[kidx], kval);                                                                         \
         else                                                                                                      \
-            atomicAdd(&kmer[1024u + kidx], kval);                                                                 \
+            atomicAdd(&kmer[1024u + kidx], FULL ? kval : (kval & (kbodymask >> (k))));                            \
     }
                 if (EXTRA) {
-                    /* post only; cycle = position; a window needs 4 predecessors inside the fragment, which the
-                       missing halo of (tile 0, lane 0) already says */
-                    const u32 bodymask = 0xFFu, kbodymask = 0xFFu;
-                    (void)kbodymask;
-                    if (itemL >= tile_start + FS_T) {
+                    /* post only; cycle = position in the (virtual) item; a window needs 4 predecessors inside
+                       the body [s, itemL) */
+                    const u32 bodymask = range_mask8(s - p0, e - p0), kbodymask = range_mask8(s + 4 - p0, e - p0);
+                    if ((int)tile_start >= s + 4 && itemL >= tile_start + FS_T) {
 #pragma unroll
                         for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, false, true, true)
                     } else {
@@ -1729,6 +1739,25 @@ __device__ __forceinline__ int filter_code(const DevConfig* __restrict__ cfg, in
 }
 
 
+/* add a block's accumulators to the counter buffer (block-wide; call after a __syncthreads) */
+__device__ __forceinline__ void scan_acc_flush(ScanBlockAcc& acc, long long* __restrict__ counters, u32 C) {
+    for (int k = 0; k < 2; k++) {
+        long long* st = counters + (k == 0 ? FPL_OFF_PRE(C) : FPL_OFF_POST(C));
+        for (u32 i = threadIdx.x; i < 128; i += blockDim.x) {
+            if (acc.bqh[k][i]) atomicAdd((u64*)&st[FPL_ST_BASE_QUAL_HIST(C) + i], acc.bqh[k][i]);
+            if (acc.medh[k][i]) atomicAdd((u64*)&st[FPL_ST_MEDIAN_HIST(C) + i], acc.medh[k][i]);
+            if (acc.medb[k][i]) atomicAdd((u64*)&st[FPL_ST_MEDIAN_BASES(C) + i], acc.medb[k][i]);
+        }
+        if (threadIdx.x == 0) {
+            if (acc.reads[k]) atomicAdd((u64*)&st[FPL_ST_READS(C)], acc.reads[k]);
+            if (acc.lensum[k]) atomicAdd((u64*)&st[FPL_ST_LENGTH_SUM(C)], acc.lensum[k]);
+        }
+    }
+    long long* fr = counters + FPL_OFF_FR(C);
+    for (u32 i = threadIdx.x; i < FPL_FILTER_RESULT_TYPES; i += blockDim.x)
+        if (acc.fr[i]) atomicAdd((u64*)&fr[FPL_FR_FILTER + i], acc.fr[i]);
+}
+
 /* The trimmed-off ends of a read (head [0, s), tail [e, l)) only feed the pre-filter quality histogram and
  * are short: one byte per lane, two rounds each (SC_END_PF bytes), loaded early so that the trip to HBM
  * overlaps the body scan; anything longer (rare) goes through a range scan. */
@@ -2049,6 +2078,11 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             /* ---- passFilter per fragment, counters, post-filter Stats scalars (src/seprocessor.cpp:265-281) */
             for (int f = 0; f < nf; f++) {
                 const int flen = fb[f] - fa[f];
+                if (cfg->defer) { /* --break / --mask: k_break_mask decides what becomes of the fragment */
+                    if (f == 0) { r_fs0 = (u32)fa[0]; r_fl0 = (u32)flen; r_kind0 = (u32)fk[0]; }
+                    else { r_fs1 = (u32)fa[1]; r_fl1 = (u32)flen; r_kind1 = (u32)fk[1]; }
+                    continue;
+                }
                 u32 t0 = hb0, t1 = hb1;
                 RangeSums fs = sm;
                 if (split) { /* rare: re-derive sums and histogram for this fragment */
@@ -2117,22 +2151,272 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     PROF_FLUSH(0);
     flush_frags();
     __syncthreads();
-    /* flush the block accumulators */
-    for (int k = 0; k < 2; k++) {
-        long long* st = counters + (k == 0 ? FPL_OFF_PRE(C) : FPL_OFF_POST(C));
-        for (u32 i = threadIdx.x; i < 128; i += blockDim.x) {
-            if (acc.bqh[k][i]) atomicAdd((u64*)&st[FPL_ST_BASE_QUAL_HIST(C) + i], acc.bqh[k][i]);
-            if (acc.medh[k][i]) atomicAdd((u64*)&st[FPL_ST_MEDIAN_HIST(C) + i], acc.medh[k][i]);
-            if (acc.medb[k][i]) atomicAdd((u64*)&st[FPL_ST_MEDIAN_BASES(C) + i], acc.medb[k][i]);
+    scan_acc_flush(acc, counters, C);
+}
+
+/* =========================================================================================
+ * k_break_mask: --break and --mask, src/seprocessor.cpp:234-281.
+ *
+ * Runs only when one of the two options is on (DevConfig::defer); k_scan then stops after the
+ * middle-adapter split and leaves <= 2 preliminary fragments per read in the result record.  One
+ * wave per read walks them:
+ *   --break: Filter::detectLowQualityRegions (src/filter.cpp:83-128) on the fragment, then
+ *            Read::breakByRegions (src/read.cpp:227-262): the stretches between regions become the
+ *            output reads, numbered "r<i>-";
+ *   --mask : detectLowQualityRegions on every output read, Read::maskRegionWithN over each region;
+ *   then Filter::passFilter on the (masked) output read, the FilterResult / post-Stats scalars, a
+ *   fpl_fragment record, its fpl_region list, and -- when it passes -- its pieces (unmasked / masked,
+ *   each with the cycle it starts at) on the post-only list that k_stats<EXTRA> counts.
+ *
+ * The reference's region detector rolls a window sum along the read with two sequential scans per
+ * region ("first window below the threshold", then "first window back above it").  Its rolling sum
+ * is, at every step, a window sum W(s) = q[s] + .. + q[s+w-1] plus a constant that only depends on
+ * where the scan started (the warm-up loop's absolute bound makes the first scan start from
+ * W(0) - q[w-1] and all later ones from 0), so both scans are "first s with W(s) + bias </>= thr":
+ * 64 candidate positions per round from one prefix scan of q[s+w] - q[s], ballot + ffs.
+ * ======================================================================================= */
+struct BmLists {
+    fpl_fragment* frags;
+    fpl_region* regs;
+    u32 frag_cap, reg_cap, item_cap;
+    u32* counts; /* [0] fragments, [1] regions, [2] set when a list was too small */
+};
+struct BmWaveLds {
+    u32 hist[129 * HIST_COPIES];
+};
+
+__device__ __forceinline__ int bm_window_sum(const u8* __restrict__ q, int s, int w) {
+    u32 acc = 0;
+    for (int j = lane_id(); j < w; j += 64) acc += q[s + j];
+    return (int)wave_sum_u32(acc);
+}
+/* first s in [s0, s1) with W(s) + bias < thr (LT) or >= thr, -1 when there is none; s1 + w <= L + 1 */
+template <bool LT>
+__device__ __forceinline__ int bm_search(const u8* __restrict__ q, int L, int w, int s0, int s1, int bias, int thr) {
+    if (s0 >= s1) return -1;
+    const int lane = lane_id();
+    int wbase = bm_window_sum(q, s0, w); /* W(b) of the round's first position */
+    for (int b = s0; b < s1; b += 64) {
+        const int s = b + lane;
+        u32 d = 0; /* W(s + 1) - W(s) */
+        if (s + w < L) d = (u32)q[s + w] - (u32)q[s];
+        const u32 incl = wave_scan_incl_u32(d);
+        const int ws = wbase + (int)(incl - d);
+        const bool hit = s < s1 && (LT ? (ws + bias < thr) : (ws + bias >= thr));
+        const u64 m = wave_ballot(hit);
+        if (m) return b + (int)__ffsll((long long)m) - 1;
+        wbase += (int)readlane_u32(incl, 63);
+    }
+    return -1;
+}
+struct BmGen {
+    int start;
+    bool first;
+};
+/* the next region (first, last inclusive) detectLowQualityRegions reports on q[0, L) */
+__device__ __forceinline__ bool bm_next_region(const u8* __restrict__ q, int L, int w, int thr, BmGen& g, int& r_first,
+                                               int& r_last) {
+    if (w <= 0 || g.start + w > L) return false;
+    /* the rolling sum at scan position s is W(s) + bias */
+    const int bias = g.first ? -(int)q[w - 1] : -bm_window_sum(q, g.start, w);
+    const int ws = bm_search<true>(q, L, w, g.start, L - w, bias, thr);
+    if (ws < 0) return false;
+    const int hit = bm_search<false>(q, L, w, ws + 1, L - w + 1, bias, thr); /* the update at e looks at W(e + 1) */
+    const int e = hit < 0 ? L - w : hit - 1;
+    r_first = ws;
+    r_last = e + w - 1;
+    g.start = e + w;
+    g.first = false;
+    return true;
+}
+
+/* passFilter sums and quality histogram of bytes [a, b) of the read, masked (every base reads as N) or not;
+   prev = the effective base in front of a, 256 when a starts the output read.  Per-lane partial sums. */
+__device__ __forceinline__ void bm_accumulate(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b, bool masked,
+                                              u32 prev, int qualified_qual, u32* __restrict__ h, RangeSums& part) {
+    const int lane = lane_id();
+    for (int j = a + lane; j < b; j += 64) {
+        const u32 q = qb[j];
+        const u32 cur = masked ? (u32)'N' : (u32)rb[j];
+        const u32 pv = j == a ? prev : (masked ? (u32)'N' : (u32)rb[j - 1]);
+        atomicAdd(&h[(q & 127u) * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
+        part.lowq += ((int)q < qualified_qual);
+        part.totq += q;
+        part.nn += (cur == 'N');
+        part.diff += (pv != 256u && cur != pv);
+    }
+}
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_break_mask(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
+             const DevConfig* __restrict__ cfg, fpl_read_result* __restrict__ results, BmLists lists,
+             uint64_t* __restrict__ item_off, u32* __restrict__ item_len, u32* __restrict__ item_cyc,
+             u32* __restrict__ item_count, long long* __restrict__ counters, u32 C) {
+    __shared__ BmWaveLds wlds[WAVES];
+    __shared__ ScanBlockAcc acc;
+    const int lane = lane_id();
+    u32* const h = wlds[wave_in_block()].hist;
+    hist_zero(h);
+    {
+        u64* z = (u64*)&acc;
+        for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
+    }
+    __syncthreads();
+    const int qq = cfg->qualified_qual;
+    const u32 wave_global = blockIdx.x * WAVES + wave_in_block(), n_waves = gridDim.x * WAVES;
+    for (u32 ri = wave_global; ri < n_reads; ri += n_waves) {
+        const uint64_t o0 = off[ri];
+        const u8* rb = seq + o0;
+        const u8* qb = qual + o0;
+        const fpl_read_result pre = results[ri];
+        const int npre = pre.dropped ? 0 : (int)pre.n_frag;
+        u32 n_out = 0; /* output reads of this read so far (= seq_no of the next one) */
+
+        /* one output read [os, os + ol) of the original read: mask, passFilter, counters, records */
+        auto emit = [&](int os, int ol, u32 kind, u32 break_no) {
+            const u32 seq_no = n_out++;
+            RangeSums part = {0, 0, 0, 0};
+            u32 n_reg = 0, n_piece = 0;
+            /* pass 1: walk the pieces (unmasked stretch, masked region, ...) for the sums */
+            {
+                BmGen g = {0, true};
+                int pos = 0, rf, rl;
+                u32 prev = 256u;
+                while (cfg->msk && bm_next_region(qb + os, ol, cfg->msk_w, cfg->msk_thr, g, rf, rl)) {
+                    int st = rf, ln = rl - rf + 1; /* maskRegionWithN(first, last - first + 1), src/read.cpp:217-225 */
+                    if (st < 0 || ln <= 0 || st >= ol) continue;
+                    if (st + ln > ol) ln = ol - st;
+                    if (st > pos) {
+                        bm_accumulate(rb, qb, os + pos, os + st, false, prev, qq, h, part);
+                        prev = rb[os + st - 1];
+                        n_piece++;
+                    }
+                    bm_accumulate(rb, qb, os + st, os + st + ln, true, prev, qq, h, part);
+                    prev = 'N';
+                    n_piece++;
+                    n_reg++;
+                    pos = st + ln;
+                }
+                if (pos < ol) {
+                    bm_accumulate(rb, qb, os + pos, os + ol, false, prev, qq, h, part);
+                    n_piece++;
+                }
+            }
+            RangeSums sm;
+            sm.lowq = wave_sum_u32(part.lowq);
+            sm.nn = wave_sum_u32(part.nn);
+            sm.totq = wave_sum_u32(part.totq);
+            sm.diff = wave_sum_u32(part.diff);
+            u32 t0, t1;
+            hist_totals(h, t0, t1);
+            const int code = filter_code(cfg, ol, sm);
+            const bool pass = code == FPL_PASS_FILTER;
+            int med = 0;
+            if (pass) med = hist_median(t0, t1, (u32)ol);
+            if (lane == 0) atomicAdd(&acc.fr[code], (u64)1);
+            if (pass) {
+                if (t0) atomicAdd(&acc.bqh[1][2 * lane], (u64)t0);
+                if (t1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)t1);
+                if (lane == 0) {
+                    atomicAdd(&acc.medh[1][med], (u64)1);
+                    atomicAdd(&acc.medb[1][med], (u64)ol);
+                    atomicAdd(&acc.reads[1], (u64)1);
+                    atomicAdd(&acc.lensum[1], (u64)ol);
+                }
+            }
+            /* reserve the record, its regions and (when it passes) its pieces */
+            u32 fi = 0, rbase = 0, ibase = 0;
+            if (lane == 0) {
+                fi = atomicAdd(&lists.counts[0], 1u);
+                if (n_reg) rbase = atomicAdd(&lists.counts[1], n_reg);
+                if (pass && n_piece) ibase = atomicAdd(item_count, n_piece);
+            }
+            fi = readlane_u32(fi, 0);
+            rbase = readlane_u32(rbase, 0);
+            ibase = readlane_u32(ibase, 0);
+            const bool fits = fi < lists.frag_cap && rbase + n_reg <= lists.reg_cap && (!pass || ibase + n_piece <= lists.item_cap);
+            if (!fits) {
+                if (lane == 0) lists.counts[2] = 1u;
+                return;
+            }
+            if (lane == 0) {
+                fpl_fragment f;
+                f.read = ri;
+                f.seq_no = seq_no;
+                f.start = (u32)os;
+                f.len = (u32)ol;
+                f.region_first = rbase;
+                f.region_count = n_reg;
+                f.break_no = (uint16_t)break_no;
+                f.code = (u8)code;
+                f.kind = (u8)kind;
+                f.median_q = (u8)med;
+                f.reserved[0] = f.reserved[1] = f.reserved[2] = 0;
+                lists.frags[fi] = f;
+            }
+            if (n_reg == 0 && !pass) return;
+            /* pass 2: the same walk writes the regions and the pieces */
+            {
+                BmGen g = {0, true};
+                int pos = 0, rf, rl;
+                u32 ir = rbase, ii = ibase;
+                auto piece = [&](int a, int b, bool masked) {
+                    if (pass && lane == 0) {
+                        item_off[ii] = o0 + (uint64_t)(os + a);
+                        item_len[ii] = (u32)(b - a);
+                        item_cyc[ii] = (u32)a | (masked ? 0x80000000u : 0u);
+                    }
+                    ii++;
+                };
+                while (cfg->msk && bm_next_region(qb + os, ol, cfg->msk_w, cfg->msk_thr, g, rf, rl)) {
+                    int st = rf, ln = rl - rf + 1;
+                    if (st < 0 || ln <= 0 || st >= ol) continue;
+                    if (st + ln > ol) ln = ol - st;
+                    if (st > pos) piece(pos, st, false);
+                    piece(st, st + ln, true);
+                    if (lane == 0) {
+                        lists.regs[ir].start = (u32)(os + st);
+                        lists.regs[ir].len = (u32)ln;
+                    }
+                    ir++;
+                    pos = st + ln;
+                }
+                if (pos < ol) piece(pos, ol, false);
+            }
+        };
+
+        for (int f = 0; f < npre; f++) {
+            const int fs = (int)pre.frag_start[f], fl = (int)pre.frag_len[f];
+            const u32 kind = pre.kind[f];
+            bool broken = false;
+            if (cfg->brk) { /* :235-252 */
+                BmGen g = {0, true};
+                int rf, rl, last_end = -1, j = 0;
+                while (bm_next_region(qb + fs, fl, cfg->brk_w, cfg->brk_thr, g, rf, rl)) {
+                    broken = true;
+                    j++; /* Read::breakByRegions, src/read.cpp:230-250: i + 1 */
+                    int st = rf, en = rl;
+                    if (st < 0) st = 0;
+                    if (en >= fl) en = fl - 1;
+                    if (st > en || st >= fl) continue;
+                    if (st > last_end + 1) emit(fs + last_end + 1, st - last_end - 1, kind, (u32)j);
+                    last_end = en;
+                }
+                if (broken && last_end < fl - 1) emit(fs + last_end + 1, fl - last_end - 1, kind, (u32)(j + 1));
+            }
+            if (!broken) emit(fs, fl, kind, 0u);
         }
-        if (threadIdx.x == 0) {
-            if (acc.reads[k]) atomicAdd((u64*)&st[FPL_ST_READS(C)], acc.reads[k]);
-            if (acc.lensum[k]) atomicAdd((u64*)&st[FPL_ST_LENGTH_SUM(C)], acc.lensum[k]);
+        if (lane == 0) { /* the per-read record keeps r1 / dropped / median_q_pre; fragments are in the list */
+            fpl_read_result r = pre;
+            r.n_frag = (u8)(n_out > 255u ? 255u : n_out);
+            r.frag_start[0] = r.frag_start[1] = r.frag_len[0] = r.frag_len[1] = 0;
+            r.code[0] = r.code[1] = r.kind[0] = r.kind[1] = r.median_q_post[0] = r.median_q_post[1] = 0;
+            results[ri] = r;
         }
     }
-    long long* fr = counters + FPL_OFF_FR(C);
-    for (u32 i = threadIdx.x; i < FPL_FILTER_RESULT_TYPES; i += blockDim.x)
-        if (acc.fr[i]) atomicAdd((u64*)&fr[FPL_FR_FILTER + i], acc.fr[i]);
+    __syncthreads();
+    scan_acc_flush(acc, counters, C);
 }
 
 }  // namespace fpl

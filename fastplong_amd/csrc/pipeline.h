@@ -44,8 +44,11 @@ struct BatchArgs {
     const DevAdapter* ads;
     ReadState* state;
     fpl_read_result* results;
-    uint64_t* frag_off; /* 2 * n_reads */
-    u32* frag_len;      /* 2 * n_reads */
+    uint64_t* frag_off; /* the post-only (EXTRA) item list: 2 * n_reads entries, bm.item_cap with --break / --mask */
+    u32* frag_len;
+    u32* frag_cyc = nullptr; /* with --break / --mask: first cycle of the item | masked << 31 */
+    BmLists bm = {nullptr, nullptr, 0, 0, 0, nullptr}; /* fragment / region lists of k_break_mask */
+    bool defer = false;      /* DevConfig::defer on the host side */
     long long* counters;
     u32 C;
     u32* work_ctr; /* two words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count */
@@ -57,6 +60,21 @@ struct BatchArgs {
 
 constexpr int N_STAGES = 4;
 static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_stats", "k_stats_extra"};
+/* with --break / --mask, k_break_mask runs between k_scan and k_stats and is timed with k_scan */
+
+/* capacities of the lists k_break_mask appends to: every region is at least one window long, so an output
+   read or a piece costs at least window + 1 bytes of input beyond the two fragments a read starts with */
+inline void break_mask_caps(u32 n_reads, uint64_t n_bytes, int brk, int brk_w, int msk, int msk_w, u32& frags, u32& regs,
+                            u32& items) {
+    const uint64_t bw = brk && brk_w > 0 ? (uint64_t)brk_w : ~0ull >> 1, mw = msk && msk_w > 0 ? (uint64_t)msk_w : ~0ull >> 1;
+    const uint64_t f = 2ull * n_reads + n_bytes / (bw + 1) + 16;
+    const uint64_t r = f + n_bytes / (mw + 1) + 16; /* <= one region per window of a read, plus one per output read */
+    const uint64_t i = f + 2 * r;
+    const uint64_t cap = 0x7FFFFFF0ull;
+    frags = (u32)(f < cap ? f : cap);
+    regs = (u32)(r < cap ? r : cap);
+    items = (u32)(i < cap ? i : cap);
+}
 
 inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
@@ -134,6 +152,14 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_LAUNCH((k_scan<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
                    a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk, a.work_ctr + 1);
     }
+    if (a.defer) {
+        u32 blocks = cdiv(n, KWAVES);
+        const u32 cap = 8 * a.n_cu;
+        if (blocks > cap) blocks = cap;
+        FPL_MEMSET(a.bm.counts, 3 * sizeof(u32), stream);
+        FPL_LAUNCH((k_break_mask<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.cfg, a.results, a.bm,
+                   a.frag_off, a.frag_len, a.frag_cyc, a.work_ctr + 1, a.counters, a.C);
+    }
     mark(2);
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
     {
@@ -141,17 +167,19 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         const u32 n_slices = cdiv(n, per);
         FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles + n_tiles, stream);
         FPL_LAUNCH((k_stats<SWAVES, false>), dim3(n_slices, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
-                   a.off, (const u32*)nullptr, (const ReadState*)a.state, n, (const u32*)nullptr, per, n_slices,
+                   a.off, (const u32*)nullptr, (const u32*)nullptr, (const ReadState*)a.state, n, (const u32*)nullptr, per,
+                   n_slices,
                    CS_MAX_ITEMS_PER_SLICE, a.counters, a.stats_scratch, a.stats_flags, a.C);
         FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, n_slices, n_tiles, a.counters, a.C, 1);
     }
     mark(3);
     {
-        const u32 gx = stats_extra_blocks(n); /* slabs per tile */
+        const u32 n_items = a.defer ? a.bm.item_cap : 2 * n; /* upper bound; the kernel reads the real count */
+        const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n); /* slabs per tile */
         FPL_MEMSET(a.stats_flags, (size_t)gx * n_tiles + n_tiles, stream);
         FPL_LAUNCH((k_stats<SWAVES, true>), dim3(gx, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
-                   (const uint64_t*)a.frag_off, (const u32*)a.frag_len, (const ReadState*)nullptr, 2 * n,
+                   (const uint64_t*)a.frag_off, (const u32*)a.frag_len, (const u32*)a.frag_cyc, (const ReadState*)nullptr, n_items,
                    (const u32*)(a.work_ctr + 1), stats_extra_per(), gx, stats_extra_max_acc(), a.counters, a.stats_scratch,
                    a.stats_flags, a.C);
         FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,

@@ -81,6 +81,10 @@ def load_library():
     L.fpl_get_kernel_times.restype = C.c_int
     L.fpl_get_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                        C.POINTER(C.c_int)]
+    L.fpl_fragment_counts.restype = C.c_int
+    L.fpl_fragment_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.fpl_get_fragments.restype = C.c_int
+    L.fpl_get_fragments.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     if L.fpl_abi_version() != abi.FPL_ABI_VERSION:
         raise FplError("ABI version mismatch")
     _lib = L
@@ -150,6 +154,16 @@ class Engine:
         self._check(self.L.fpl_process_batch(self.h, seq.ctypes.data, qual.ctypes.data, off.ctypes.data, n,
                                              res.ctypes.data), "fpl_process_batch")
         return res[:n]
+
+    def fragments(self):
+        """--break / --mask outcome of the LAST batch: (fpl_fragment records sorted by (read, seq_no), fpl_region list)"""
+        nf, nr = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.L.fpl_fragment_counts(self.h, C.byref(nf), C.byref(nr)), "fpl_fragment_counts")
+        frags = np.zeros(max(nf.value, 1), dtype=abi.FRAGMENT_DTYPE)
+        regs = np.zeros(max(nr.value, 1), dtype=abi.REGION_DTYPE)
+        self._check(self.L.fpl_get_fragments(self.h, frags.ctypes.data, nf.value, regs.ctypes.data, nr.value),
+                    "fpl_get_fragments")
+        return frags[:nf.value], regs[:nr.value]
 
     def process_device(self, seq_t, qual_t, off_t, max_read_len, results_t=None, stream=None):
         """fpl_process_batch_device on torch CUDA tensors (uint8, uint8, int64 offsets).

@@ -45,7 +45,7 @@ def lib():
     return _lib
 
 
-def process_batch(cfg, seq, qual, off, max_cycles, n_cu=2):
+def process_batch(cfg, seq, qual, off, max_cycles, n_cu=2, with_fragments=False):
     """cfg: oracle.Config-like object with .opt, .start, .end, .fasta (bytes)."""
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     qual = np.ascontiguousarray(qual, dtype=np.uint8)
@@ -66,4 +66,13 @@ def process_batch(cfg, seq, qual, off, max_cycles, n_cu=2):
                                  counters.ctypes.data, max_cycles, res.ctypes.data, n_cu)
     if rc != 0:
         raise RuntimeError("emu_process_batch rc=%d" % rc)
+    if with_fragments:
+        L = lib()
+        L.emu_fragment_count.restype = C.c_uint32
+        L.emu_region_count.restype = C.c_uint32
+        nf, nr = L.emu_fragment_count(), L.emu_region_count()
+        frags = np.zeros(max(nf, 1), dtype=abi.FRAGMENT_DTYPE)
+        regs = np.zeros(max(nr, 1), dtype=abi.REGION_DTYPE)
+        L.emu_get_fragments(C.c_void_p(frags.ctypes.data), C.c_void_p(regs.ctypes.data))
+        return res[:n], counters, frags[:nf], regs[:nr]
     return res[:n], counters

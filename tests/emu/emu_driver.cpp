@@ -5,6 +5,7 @@
  * Built as tests/emu/libfpl_emu.so by tests/emu/build.py; loaded only by tests.
  */
 #define FPL_EMU 1
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -12,6 +13,16 @@
 #include "../../fastplong_amd/csrc/pipeline.h"
 
 using namespace fpl;
+
+/* fragments / regions of the last emu_process_batch call with --break / --mask (sorted like fpl_get_fragments) */
+static std::vector<fpl_fragment> g_frags;
+static std::vector<fpl_region> g_regs;
+extern "C" uint32_t emu_fragment_count() { return (uint32_t)g_frags.size(); }
+extern "C" uint32_t emu_region_count() { return (uint32_t)g_regs.size(); }
+extern "C" void emu_get_fragments(fpl_fragment* f, fpl_region* r) {
+    if (!g_frags.empty()) memcpy(f, g_frags.data(), g_frags.size() * sizeof(fpl_fragment));
+    if (!g_regs.empty()) memcpy(r, g_regs.data(), g_regs.size() * sizeof(fpl_region));
+}
 
 extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int start_len, const char* end,
                                  int end_len, const fpl_adapter* fasta, int n_fasta, const uint8_t* seq,
@@ -34,8 +45,13 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     }
     if (max_len > C) return FPL_ERR_CAPACITY;
     std::vector<ReadState> state(n_reads ? n_reads : 1);
-    std::vector<uint64_t> frag_off(2 * (size_t)n_reads + 2, 0);
-    std::vector<uint32_t> frag_len(2 * (size_t)n_reads + 2, 0);
+    u32 frag_cap = 0, reg_cap = 0, item_cap = 2 * n_reads + 2;
+    if (cfg.defer) break_mask_caps(n_reads, n_bytes, cfg.brk, cfg.brk_w, cfg.msk, cfg.msk_w, frag_cap, reg_cap, item_cap);
+    std::vector<uint64_t> frag_off((size_t)item_cap + 2, 0);
+    std::vector<uint32_t> frag_len((size_t)item_cap + 2, 0), frag_cyc((size_t)item_cap + 2, 0);
+    std::vector<fpl_fragment> frags((size_t)frag_cap + 1);
+    std::vector<fpl_region> regs((size_t)reg_cap + 1);
+    u32 bm_counts[4] = {0, 0, 0, 0};
     uint32_t work_ctr[2] = {0, 0};
     /* the kernels never read past n_bytes, but give the buffers an end guard anyway */
     BatchArgs a;
@@ -51,6 +67,9 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.results = results;
     a.frag_off = frag_off.data();
     a.frag_len = frag_len.data();
+    a.frag_cyc = frag_cyc.data();
+    a.bm = BmLists{frags.data(), regs.data(), frag_cap, reg_cap, item_cap, bm_counts};
+    a.defer = cfg.defer != 0;
     a.counters = (long long*)counters;
     a.C = C;
     a.work_ctr = work_ctr;
@@ -61,6 +80,16 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.stats_scratch = scratch.data();
     a.stats_flags = sflags.data();
     enqueue_batch(a, nullptr, [](int) {});
+    g_frags.clear();
+    g_regs.clear();
+    if (cfg.defer) {
+        if (bm_counts[2]) return FPL_ERR_CAPACITY;
+        g_frags.assign(frags.begin(), frags.begin() + bm_counts[0]);
+        g_regs.assign(regs.begin(), regs.begin() + bm_counts[1]);
+        std::sort(g_frags.begin(), g_frags.end(), [](const fpl_fragment& x, const fpl_fragment& y) {
+            return x.read != y.read ? x.read < y.read : x.seq_no < y.seq_no;
+        });
+    }
     return 0;
 }
 

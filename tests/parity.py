@@ -58,3 +58,19 @@ def assert_counters_equal(got, want, c, nad):
             idx = np.argwhere(a != b)[:5]
             raise AssertionError("%s differs, first %s: got %s want %s" % (f, idx.tolist(), a[a != b][:5], b[a != b][:5]))
     raise AssertionError("counter buffers differ outside the named views")
+
+
+def assert_fragments_equal(got_f, got_r, want_f, want_r):
+    """--break / --mask outcome lists: records in (read, seq_no) order; the region list may be laid out
+    differently, so regions are compared per fragment"""
+    assert len(got_f) == len(want_f), (len(got_f), len(want_f))
+    for name in ("read", "seq_no", "start", "len", "region_count", "break_no", "code", "kind"):
+        if not np.array_equal(got_f[name], want_f[name]):
+            i = int(np.nonzero(got_f[name] != want_f[name])[0][0])
+            raise AssertionError("fragment field %s differs first at record %d: got %s want %s" % (name, i, got_f[i], want_f[i]))
+    ok = want_f["code"] == abi.FPL_PASS_FILTER
+    assert np.array_equal(got_f["median_q"][ok], want_f["median_q"][ok])
+    for i in range(len(want_f)):
+        a, b = int(got_f["region_first"][i]), int(want_f["region_first"][i])
+        n = int(want_f["region_count"][i])
+        assert np.array_equal(got_r[a:a + n], want_r[b:b + n]), ("regions of fragment", i, got_r[a:a + n], want_r[b:b + n])

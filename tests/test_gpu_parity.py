@@ -92,6 +92,50 @@ def test_hifi_like_64_adapters_bit_exact(orc, engine_mod):
     _run_both(orc, engine_mod, cfgd, seq, qual, off, fasta=sorted(ads))
 
 
+def _lowq_ont_like(n, seed, median_len=3000):
+    """ONT-like reads whose qualities dip far below the --break / --mask thresholds in stretches"""
+    rng = np.random.default_rng(seed)
+    seq, qual, off = synth.ont_like(n, seed=seed, median_len=median_len, p_middle=0.2, p_polya=0.1)
+    qual = qual.copy()
+    for i in range(n):
+        a, b = int(off[i]), int(off[i + 1])
+        pos = a + int(rng.integers(0, max(1, (b - a) // 2)))
+        while pos < b:
+            run = int(rng.integers(10, 400))
+            if rng.random() < 0.4:
+                qual[pos:min(b, pos + run)] = np.clip(np.round(rng.normal(6, 3, min(b, pos + run) - pos)), 2, 40) + 33
+            pos += run + int(rng.integers(50, 2000))
+    return seq, qual, off
+
+
+@pytest.mark.parametrize("be,me,bw,mw", [(1, 0, 100, 50), (0, 1, 100, 50), (1, 1, 100, 50), (1, 1, 5, 7), (1, 1, 1000, 300)])
+def test_break_and_mask_bit_exact(orc, engine_mod, be, me, bw, mw):
+    """--break / --mask (src/seprocessor.cpp:234-262): fragment records, N regions, FilterResult and both Stats"""
+    opt = abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1, complexity_filter=1, break_enabled=be, break_window=bw,
+                                 break_quality=12, mask_enabled=me, mask_window=mw, mask_quality=13,
+                                 n_base_percent_limit=95, unqualified_percent_limit=90, complexity_percent=5)
+    cfg = orc.Config(opt, synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = _lowq_ont_like(300, seed=41 + bw)
+    C = int(np.diff(off.astype(np.int64)).max())
+    want_res, want_cnt, want_f, want_r = orc.process_batch_ex(cfg, seq, qual, off, max_cycles=C)
+    eng = engine_mod.Engine(cfg.opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=C)
+    got_res = eng.process_host(seq, qual, off)
+    got_f, got_r = eng.fragments()
+    got_cnt = eng.counters()
+    # a second, smaller batch through the same context: the lists describe the LAST batch only
+    eng.process_host(seq[:int(off[50])], qual[:int(off[50])], off[:51])
+    f2, r2 = eng.fragments()
+    eng.close()
+    parity.assert_fragments_equal(got_f, got_r, want_f, want_r)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    keep = want_f["read"] < 50
+    parity.assert_fragments_equal(f2, r2, want_f[keep], want_r)
+    if bw == 100:  # (the other window sizes are there for the search arithmetic, not for a particular mix)
+        assert (want_f["break_no"] > 0).any() == bool(be) and (want_f["region_count"] > 0).any() == bool(me)
+        assert (want_f["code"] == abi.FPL_PASS_FILTER).any()
+
+
 def test_edge_batches(orc, engine_mod):
     cfgd = CASES["full_pipeline"]
     # empty batch

@@ -134,3 +134,41 @@ def test_emulated_stats_extra_pass_accumulates_and_overflows(orc, monkeypatch, a
     got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
     parity.assert_results_equal(got_res, want_res, seq, off)
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
+def _lowq_batch(n, seed, with_adapters=True):
+    """reads whose qualities dip far below the --break / --mask thresholds in stretches"""
+    rng = np.random.default_rng(seed)
+    seq, qual, off = synth.ont_like(n, seed=seed, median_len=900, p_middle=0.3, p_polya=0.1)
+    qual = qual.copy()
+    for i in range(n):
+        a, b = int(off[i]), int(off[i + 1])
+        pos = a + int(rng.integers(0, 200))
+        while pos < b:
+            run = int(rng.integers(10, 150))
+            if rng.random() < 0.4:
+                qual[pos:min(b, pos + run)] = np.clip(np.round(rng.normal(6, 3, min(b, pos + run) - pos)), 2, 40) + 33
+            pos += run + int(rng.integers(20, 300))
+    return seq, qual, off
+
+
+@pytest.mark.parametrize("be,me", [(1, 0), (0, 1), (1, 1)])
+def test_emulated_break_mask(orc, be, me):
+    """--break / --mask: k_break_mask + the cycle-offset / masked items of k_stats<EXTRA> against the oracle"""
+    # (the reference masks from the first low-quality window to the end of the read, see orc_detect_low_quality_regions:
+    #  generous N / quality limits keep some masked reads passing, so that their pieces reach the post-filter tables)
+    opt = abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1, complexity_filter=1, break_enabled=be, break_window=30,
+                                 break_quality=12, mask_enabled=me, mask_window=15, mask_quality=13,
+                                 n_base_percent_limit=95, unqualified_percent_limit=90, complexity_percent=5)
+    cfg = orc.Config(opt, synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = _lowq_batch(40, seed=31 + 2 * be + me)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt, want_f, want_r = orc.process_batch_ex(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt, got_f, got_r = emu.process_batch(cfg, seq, qual, off, C, with_fragments=True)
+    parity.assert_fragments_equal(got_f, got_r, want_f, want_r)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    assert (want_f["break_no"] > 0).any() == bool(be) and (want_f["region_count"] > 0).any() == bool(me)
+    assert (want_f["code"] == abi.FPL_PASS_FILTER).any() and (want_f["kind"] > 0).any()
+    if me:  # a masked read that passes: its unmasked / all-N pieces feed the post-filter tables at their own cycles
+        assert ((want_f["region_count"] > 0) & (want_f["code"] == abi.FPL_PASS_FILTER)).any()
