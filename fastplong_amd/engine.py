@@ -16,7 +16,7 @@ EXPORTS = [
     "fpl_abi_version", "fpl_strerror", "fpl_last_error", "fpl_options_default", "fpl_create", "fpl_destroy",
     "fpl_process_batch_device", "fpl_process_batch", "fpl_max_cycles", "fpl_n_adapters", "fpl_counters_len",
     "fpl_reserve_cycles", "fpl_counters_device_ptr", "fpl_get_counters", "fpl_reset_counters", "fpl_synchronize",
-    "fpl_enable_timing", "fpl_get_kernel_times",
+    "fpl_enable_timing", "fpl_get_kernel_times", "fpl_fragment_counts", "fpl_get_fragments",
 ]
 
 
