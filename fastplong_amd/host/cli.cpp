@@ -11,8 +11,7 @@
  * FilterResult::merge, src/seprocessor.cpp:108-121) and rank 0's copy feeds the reports.
  *
  * Not implemented (SURVEY.md section 8f "next" rows): adapter auto-detection (an undetected
- * "auto" is used literally, as the reference does when detection fails), --break / --mask,
- * --split*, the HTML report.
+ * "auto" is used literally, as the reference does when detection fails), --split*, the HTML report.
  */
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -185,6 +184,7 @@ struct Work {
     uint64_t seq_no = 0;
     fplh::Batch batch;
     vector<fpl_read_result> res;
+    fplh::FragmentList frags; /* --break / --mask */
     vector<string> outs, faileds;
     int rc = 0;
     string err;
@@ -261,7 +261,15 @@ int main(int argc, char* argv[]) {
     o.max_length = cmd.i("length_limit");
     o.complexity_filter = cmd.exist("low_complexity_filter");
     o.complexity_percent = min(100, max(0, cmd.i("complexity_threshold")));
-    if (cmd.exist("mask") || cmd.exist("break")) error_exit("--mask / --break are not implemented in fastplong_amd yet");
+    o.mask_enabled = cmd.exist("mask"); /* src/main.cpp:207-215 */
+    o.mask_window = cmd.i("mask_window_size");
+    o.mask_quality = cmd.i("mask_mean_quality");
+    o.break_enabled = cmd.exist("break");
+    o.break_window = cmd.i("break_window_size");
+    o.break_quality = cmd.i("break_mean_quality");
+    if ((o.mask_enabled && o.mask_window <= 0) || (o.break_enabled && o.break_window <= 0))
+        error_exit("the window size of --mask / --break must be positive");
+    const bool fragmentMode = o.mask_enabled || o.break_enabled;
     if (cmd.exist("split") || cmd.exist("split_by_lines")) error_exit("--split / --split_by_lines are not implemented in fastplong_amd");
     const string jsonFile = cmd.str("json");
     const int nGpus = max(1, cmd.i("gpus"));
@@ -402,8 +410,19 @@ int main(int argc, char* argv[]) {
                 w->rc = fpl_process_batch(dev[d].ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(),
                                           w->batch.n(), w->res.data());
                 const double t1 = now();
+                if (w->rc == FPL_OK && fragmentMode) { /* any number of output reads per read: fetch the list */
+                    uint32_t nf = 0, nr = 0;
+                    w->rc = fpl_fragment_counts(dev[d].ctx, &nf, &nr);
+                    if (w->rc == FPL_OK) {
+                        w->frags.frags.resize(nf);
+                        w->frags.regs.resize(nr);
+                        w->rc = fpl_get_fragments(dev[d].ctx, w->frags.frags.data(), nf, w->frags.regs.data(), nr);
+                        w->frags.index(w->batch.n());
+                    }
+                }
                 if (w->rc != FPL_OK) w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
-                else fplh::format_batch_parallel(w->batch, w->res.data(), fmtThreads, w->outs, ffail ? &w->faileds : nullptr);
+                else fplh::format_batch_parallel(w->batch, w->res.data(), fmtThreads, w->outs, ffail ? &w->faileds : nullptr,
+                                                 fragmentMode ? &w->frags : nullptr);
                 tGpu[d] += t1 - t0;
                 tFormat[d] += now() - t1;
                 doneq.push(w);

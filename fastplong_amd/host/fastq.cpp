@@ -278,8 +278,15 @@ void format_batch(const Batch& b, const fpl_read_result* res, string& out, strin
     format_range(b, res, 0, b.n(), out, failed);
 }
 
+void FragmentList::index(uint32_t n_reads) {
+    first.assign((size_t)n_reads + 1, 0);
+    for (const fpl_fragment& f : frags)
+        if (f.read < n_reads) first[f.read + 1]++;
+    for (uint32_t i = 0; i < n_reads; i++) first[i + 1] += first[i];
+}
+
 void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threads, vector<string>& outs,
-                           vector<string>* faileds) {
+                           vector<string>* faileds, const FragmentList* fl) {
     const uint32_t n = b.n();
     if (threads < 1) threads = 1;
     outs.assign(threads, string());
@@ -296,13 +303,24 @@ void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threa
     for (int t = 0; t < threads; t++)
         th.emplace_back([&, t]() {
             outs[t].reserve((size_t)((b.off[cut[t + 1]] - b.off[cut[t]]) * 2 + (uint64_t)(cut[t + 1] - cut[t]) * 128 + 64));
-            format_range(b, res, cut[t], cut[t + 1], outs[t], faileds ? &(*faileds)[t] : nullptr);
+            format_range(b, res, cut[t], cut[t + 1], outs[t], faileds ? &(*faileds)[t] : nullptr, fl);
         });
     for (auto& x : th) x.join();
 }
 
+/* bases [start, start + len) of a read with the regions Read::maskRegionWithN overwrote (src/read.cpp:217-225) */
+static void append_masked(string& out, const uint8_t* s, uint32_t start, uint32_t len, const fpl_region* regs, uint32_t n_regs) {
+    const size_t at = out.size();
+    out.append((const char*)s + start, len);
+    for (uint32_t k = 0; k < n_regs; k++) {
+        if (regs[k].start < start || regs[k].start - start >= len) continue;
+        const uint32_t a = regs[k].start - start, l = std::min(regs[k].len, len - a);
+        memset(&out[at + a], 'N', l);
+    }
+}
+
 void format_range(const Batch& b, const fpl_read_result* res, uint32_t first, uint32_t last, string& out,
-                  string* failed) {
+                  string* failed, const FragmentList* fl) {
     static const char* prefix[3] = {"", "split-by-adapter-left-", "split-by-adapter-right-"}; /* src/read.cpp:199,208 */
     for (uint32_t i = first; i < last; i++) {
         const fpl_read_result& r = res[i];
@@ -312,6 +330,46 @@ void format_range(const Batch& b, const fpl_read_result* res, uint32_t first, ui
         const char* strand = name + nl;
         const uint8_t* s = b.seq.data() + b.off[i];
         const uint8_t* q = b.qual.data() + b.off[i];
+        if (fl) { /* --break / --mask: any number of output reads, src/seprocessor.cpp:234-281 */
+            const uint32_t f0 = fl->first[i], f1 = fl->first[i + 1];
+            for (uint32_t k = f0; k < f1; k++) {
+                const fpl_fragment& f = fl->frags[k];
+                const fpl_region* rg = fl->regs.data() + f.region_first;
+                if (f.code == FPL_PASS_FILTER) {
+                    /* the name went through breakByGap's insert(1, "split-..") and then breakByRegions'
+                       insert(1, "r<i>-") (src/read.cpp:199,208,244,256) */
+                    if (nl > 0) out.append(name, 1);
+                    if (f.break_no) {
+                        out.push_back('r');
+                        out.append(std::to_string(f.break_no));
+                        out.push_back('-');
+                    }
+                    out.append(prefix[f.kind <= 2 ? f.kind : 0]);
+                    if (nl > 1) out.append(name + 1, nl - 1);
+                    out.push_back('\n');
+                    append_masked(out, s, f.start, f.len, rg, f.region_count);
+                    out.push_back('\n');
+                    out.append(strand, sl);
+                    out.push_back('\n');
+                    out.append((const char*)q + f.start, f.len);
+                    out.push_back('\n');
+                } else if (failed && f1 - f0 == 1) {
+                    /* or1 with its tag; it shows the N only when the one output read IS r1 (masked in place) */
+                    const bool in_place = f.kind == 0 && f.break_no == 0;
+                    failed->append(name, nl);
+                    failed->push_back(' ');
+                    failed->append(failed_type(f.code));
+                    failed->push_back('\n');
+                    append_masked(*failed, s, r.r1_start, r.r1_len, rg, in_place ? f.region_count : 0);
+                    failed->push_back('\n');
+                    failed->append(strand, sl);
+                    failed->push_back('\n');
+                    failed->append((const char*)q + r.r1_start, r.r1_len);
+                    failed->push_back('\n');
+                }
+            }
+            continue;
+        }
         for (int f = 0; f < r.n_frag; f++) {
             if (r.code[f] == FPL_PASS_FILTER) { /* Read::appendToString, src/read.cpp:119-143 */
                 const char* pf = prefix[r.kind[f] <= 2 ? r.kind[f] : 0];
@@ -377,6 +435,29 @@ int fplh_format_batch(void* bv, const fpl_read_result* res, char** out, uint64_t
         *failed = (char*)malloc(f.size() + 1);
         memcpy(*failed, f.data(), f.size());
         *failed_len = f.size();
+    }
+    return 0;
+}
+int fplh_format_batch_fragments(void* bv, const fpl_read_result* res, const fpl_fragment* frags, uint32_t n_frags,
+                                const fpl_region* regs, uint32_t n_regs, int threads, char** out, uint64_t* out_len,
+                                char** failed, uint64_t* failed_len) {
+    fplh::Batch* b = (fplh::Batch*)bv;
+    fplh::FragmentList fl;
+    fl.frags.assign(frags, frags + n_frags);
+    fl.regs.assign(regs, regs + n_regs);
+    fl.index(b->n());
+    std::vector<std::string> o, f;
+    fplh::format_batch_parallel(*b, res, threads, o, failed ? &f : nullptr, &fl);
+    std::string oo, ff;
+    for (auto& x : o) oo += x;
+    for (auto& x : f) ff += x;
+    *out = (char*)malloc(oo.size() + 1);
+    memcpy(*out, oo.data(), oo.size());
+    *out_len = oo.size();
+    if (failed) {
+        *failed = (char*)malloc(ff.size() + 1);
+        memcpy(*failed, ff.data(), ff.size());
+        *failed_len = ff.size();
     }
     return 0;
 }

@@ -101,17 +101,26 @@ class FastqReader {
     bool eof_ = false, malformed_ = false;
 };
 
+/* --break / --mask: the outcome list of a batch (fpl_get_fragments: sorted by read, then seq_no) and where
+ * each read's records start */
+struct FragmentList {
+    std::vector<fpl_fragment> frags;
+    std::vector<fpl_region> regs;
+    std::vector<uint32_t> first; /* n + 1: fragments of read i are [first[i], first[i+1]) */
+    void index(uint32_t n_reads);
+};
+
 /* Serialize what src/seprocessor.cpp:265-281 writes for one batch: passing fragments to `out`
  * (name with the split prefix when the read was broken), and -- when failed != nullptr -- the
  * trimmed read with its tag for reads that produced exactly one fragment and failed. */
 void format_batch(const Batch& b, const fpl_read_result* res, std::string& out, std::string* failed);
 /* the same for reads [first, last) only (appends) */
 void format_range(const Batch& b, const fpl_read_result* res, uint32_t first, uint32_t last, std::string& out,
-                  std::string* failed);
+                  std::string* failed, const FragmentList* fl = nullptr);
 /* the same on `threads` host threads: piece t of outs / faileds holds the text of the t-th slice of the
  * batch, so writing the pieces in order gives format_batch's output */
 void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threads, std::vector<std::string>& outs,
-                           std::vector<std::string>* faileds);
+                           std::vector<std::string>* faileds, const FragmentList* fl = nullptr);
 
 }  // namespace fplh
 
@@ -127,6 +136,10 @@ void fplh_batch_free(void* b);
 /* returns malloc'ed buffers the caller frees with fplh_free */
 int fplh_format_batch(void* b, const fpl_read_result* res, char** out, uint64_t* out_len, char** failed,
                       uint64_t* failed_len);
+/* the same with a --break / --mask fragment list (n_frags records sorted by read / seq_no, their regions) */
+int fplh_format_batch_fragments(void* b, const fpl_read_result* res, const fpl_fragment* frags, uint32_t n_frags,
+                                const fpl_region* regs, uint32_t n_regs, int threads, char** out, uint64_t* out_len,
+                                char** failed, uint64_t* failed_len);
 int fplh_format_batch_parallel(void* b, const fpl_read_result* res, int threads, char** out, uint64_t* out_len,
                                char** failed, uint64_t* failed_len);
 void fplh_free(void* p);

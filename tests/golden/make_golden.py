@@ -38,6 +38,15 @@ CASES = {
                             "-l", "30", "-n", "5", "-m", "12"],
                      opt=dict(ed_max=0.3, trimming_extension=5, required_length=30, n_base_percent_limit=5, avg_qual_req=12),
                      start=synth.START_ADAPTER, end=synth.revcomp(synth.START_ADAPTER), fasta=FASTA, n=150, seed=43),
+    # --break / --mask on top of the full pipeline (generous -n / -u so that masked reads pass)
+    "c3_break_mask": dict(flags=["-s", synth.START_ADAPTER, "-e", synth.END_ADAPTER, "--cut_front", "--cut_tail", "-W", "5",
+                                 "-x", "-y", "-b", "--break_window_size", "40", "--break_mean_quality", "12", "-N",
+                                 "--mask_window_size", "15", "--mask_mean_quality", "14", "-n", "95", "-u", "90", "-Y", "5"],
+                          opt=dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1,
+                                   break_enabled=1, break_window=40, break_quality=12, mask_enabled=1, mask_window=15,
+                                   mask_quality=14, n_base_percent_limit=95, unqualified_percent_limit=90,
+                                   complexity_percent=5),
+                          start=synth.START_ADAPTER, end=synth.END_ADAPTER, fasta=None, n=150, seed=44, lowq=True),
 }
 
 
@@ -58,12 +67,27 @@ def main():
         for (s, q, o) in (a, b):
             reads += [(s[int(o[i]):int(o[i + 1])], q[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1) if o[i + 1] > o[i]]
         seq, qual, off = synth.pack(reads)
+        if c.get("lowq"):  # stretches far below the --break / --mask thresholds
+            rng = np.random.default_rng(c["seed"])
+            for i in range(len(off) - 1):
+                lo, hi = int(off[i]), int(off[i + 1])
+                pos = lo + int(rng.integers(0, max(1, (hi - lo) // 2)))
+                while pos < hi:
+                    run = int(rng.integers(10, 200))
+                    if rng.random() < 0.4:
+                        qual[pos:min(hi, pos + run)] = np.clip(np.round(rng.normal(6, 3, min(hi, pos + run) - pos)), 2, 40) + 33
+                    pos += run + int(rng.integers(30, 600))
         seq[seq == ord("U")] = ord("R")  # a file with both U and T is rejected up front (src/evaluator.cpp:50-52)
         text, names, strands = hostio.make_fastq(seq, qual, off, strand_names=True)
         cfg = oracle.Config(abi.FplOptions.default(**c["opt"]), c["start"], c["end"], fasta)
         C = int(np.diff(off.astype(np.int64)).max())
-        res, counters = oracle.process_batch(cfg, seq, qual, off, max_cycles=C)
-        out, failed = hostio.expected_outputs(seq, qual, off, names, strands, res)
+        frags = regs = None
+        if cfg.opt.break_enabled or cfg.opt.mask_enabled:
+            res, counters, frags, regs = oracle.process_batch_ex(cfg, seq, qual, off, max_cycles=C)
+            out, failed = hostio.expected_outputs_fragments(seq, qual, off, names, strands, res, frags, regs)
+        else:
+            res, counters = oracle.process_batch(cfg, seq, qual, off, max_cycles=C)
+            out, failed = hostio.expected_outputs(seq, qual, off, names, strands, res)
         d = os.path.join(HERE, name)
         os.makedirs(d, exist_ok=True)
         with gzip.GzipFile(os.path.join(d, "in.fq.gz"), "wb", mtime=0) as f:
@@ -77,7 +101,7 @@ def main():
                 for k in c["fasta"]:  # file order differs from sorted order on purpose
                     f.write(">%s\n%s\n" % (k, c["fasta"][k]))
         tmp = os.path.join(d, "ref.json.tmp")
-        refjson.reference_json(ref, tmp, cfg, seq, qual, off, res, counters, C, threads=3)
+        refjson.reference_json(ref, tmp, cfg, seq, qual, off, res, counters, C, threads=3, frags=frags, regs=regs)
         lines = [l for l in open(tmp, "rb").read().split(b"\n") if not l.startswith(b'\t"command":')]
         os.remove(tmp)
         with gzip.GzipFile(os.path.join(d, "expected.json.gz"), "wb", mtime=0) as f:

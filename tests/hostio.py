@@ -40,3 +40,36 @@ def expected_outputs(seq, qual, off, names, strands, res, with_failed=True):
                 failed += [names[i], b" ", abi.FAILED_TYPES[int(r["code"][f])].encode(), b"\n", s[ra:ra + rl], b"\n",
                            strands[i], b"\n", q[ra:ra + rl], b"\n"]
     return b"".join(out), b"".join(failed)
+
+
+def expected_outputs_fragments(seq, qual, off, names, strands, res, frags, regs, with_failed=True):
+    """the same for a --break / --mask run (src/seprocessor.cpp:234-281): output reads from the fragment list,
+    names through breakByGap's and breakByRegions' insert(1, ..), bases with the N of maskRegionWithN"""
+    out, failed = [], []
+    for i in range(len(off) - 1):
+        r = res[i]
+        if r["dropped"]:
+            continue
+        a = int(off[i])
+        s, q = seq[a:int(off[i + 1])].tobytes(), qual[a:int(off[i + 1])].tobytes()
+        mine = frags[frags["read"] == i]
+
+        def masked(start, length, fr, apply):
+            sb = bytearray(s[start:start + length])
+            if apply:
+                for g in regs[fr["region_first"]:fr["region_first"] + fr["region_count"]]:
+                    x = int(g["start"]) - start
+                    sb[x:x + int(g["len"])] = b"N" * int(g["len"])
+            return bytes(sb)
+
+        for fr in mine:
+            fa, fl = int(fr["start"]), int(fr["len"])
+            if fr["code"] == abi.FPL_PASS_FILTER:
+                name = names[i][:1] + (b"r%d-" % fr["break_no"] if fr["break_no"] else b"") + PREFIX[int(fr["kind"])] + names[i][1:]
+                out += [name, b"\n", masked(fa, fl, fr, True), b"\n", strands[i], b"\n", q[fa:fa + fl], b"\n"]
+            elif with_failed and len(mine) == 1:
+                ra, rl = int(r["r1_start"]), int(r["r1_len"])
+                in_place = fr["kind"] == 0 and fr["break_no"] == 0
+                failed += [names[i], b" ", abi.FAILED_TYPES[int(fr["code"])].encode(), b"\n", masked(ra, rl, fr, in_place), b"\n",
+                           strands[i], b"\n", q[ra:ra + rl], b"\n"]
+    return b"".join(out), b"".join(failed)

@@ -5,7 +5,7 @@ import numpy as np
 from fastplong_amd import abi
 
 
-def reference_json(ref, path, cfg, seq, qual, off, res, counters, c, threads, is_rna=False):
+def reference_json(ref, path, cfg, seq, qual, off, res, counters, c, threads, is_rna=False, frags=None, regs=None):
     """replay the oracle's per-read outcome into the reference's own Stats / FilterResult objects
     (pre reads, passing fragments, filter codes, adapter keys, polyX) and let the reference write
     the JSON."""
@@ -35,6 +35,17 @@ def reference_json(ref, path, cfg, seq, qual, off, res, counters, c, threads, is
                 lines += ["J_ART 0"] * (int(v.adapter_reads) - 1)
             first = False
         r = res[i]
+        if frags is not None:  # --break / --mask: the output reads come from the fragment list
+            for fr in frags[frags["read"] == i]:
+                lines.append("J_FR %d" % fr["code"])
+                if fr["code"] == 0:
+                    fa, fb = int(fr["start"]), int(fr["start"]) + int(fr["len"])
+                    sb = bytearray(rs[fa:fb].encode("latin-1"))
+                    for g in regs[fr["region_first"]:fr["region_first"] + fr["region_count"]]:
+                        x = int(g["start"]) - fa
+                        sb[x:x + int(g["len"])] = b"N" * int(g["len"])
+                    lines.append("J_POST %s %s" % (s(bytes(sb)), s(rq[fa:fb])))
+            continue
         for f in range(r["n_frag"]):
             lines.append("J_FR %d" % r["code"][f])
             if r["code"][f] == 0:

@@ -23,6 +23,10 @@ OPTS = {
                 synth.START_ADAPTER, synth.END_ADAPTER),
     "c5_fasta": (dict(ed_max=0.3, trimming_extension=5, required_length=30, n_base_percent_limit=5, avg_qual_req=12),
                  synth.START_ADAPTER, synth.revcomp(synth.START_ADAPTER)),
+    "c3_break_mask": (dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1,
+                           break_enabled=1, break_window=40, break_quality=12, mask_enabled=1, mask_window=15,
+                           mask_quality=14, n_base_percent_limit=95, unqualified_percent_limit=90, complexity_percent=5),
+                      synth.START_ADAPTER, synth.END_ADAPTER),
 }
 
 
@@ -63,8 +67,13 @@ def test_oracle_reproduces_golden(orc, case):
     okw, start, end = OPTS[case]
     seq, qual, off, names, strands = parse_fastq(gz(os.path.join(GOLD, case, "in.fq.gz")))
     cfg = orc.Config(abi.FplOptions.default(**okw), start, end, fasta_list(case))
-    res, counters = orc.process_batch(cfg, seq, qual, off)
-    out, failed = hostio.expected_outputs(seq, qual, off, names, strands, res)
+    if cfg.opt.break_enabled or cfg.opt.mask_enabled:
+        res, counters, frags, regs = orc.process_batch_ex(cfg, seq, qual, off)
+        out, failed = hostio.expected_outputs_fragments(seq, qual, off, names, strands, res, frags, regs)
+        assert (frags["break_no"] > 0).any() and ((frags["region_count"] > 0) & (frags["code"] == 0)).any() and len(failed)
+    else:
+        res, counters = orc.process_batch(cfg, seq, qual, off)
+        out, failed = hostio.expected_outputs(seq, qual, off, names, strands, res)
     assert out == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
     assert failed == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
     meta = json.load(open(os.path.join(GOLD, case, "case.json")))

@@ -121,6 +121,43 @@ def test_format_batch_matches_python_composition(orc, hostlib, tmp_path):
     assert len(want_failed) > 0 and b"split-by-adapter-right-" in want_out
 
 
+def test_format_batch_with_fragment_list(orc, hostlib, tmp_path):
+    """--break / --mask: the formatter works from the fragment / region lists (names through both insert(1, ..),
+    N over the masked stretches, --failed_out only for single-fragment reads, masked only when it is r1 itself)"""
+    hostlib.fplh_format_batch_fragments.restype = C.c_int
+    hostlib.fplh_format_batch_fragments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                    C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                                    C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    opt = abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1, break_enabled=1, break_window=30, break_quality=12,
+                                 mask_enabled=1, mask_window=15, mask_quality=13, n_base_percent_limit=95,
+                                 unqualified_percent_limit=90)
+    cfg = orc.Config(opt, synth.START_ADAPTER, synth.END_ADAPTER)
+    rng = np.random.default_rng(5)
+    seq, qual, off = synth.ont_like(80, seed=9, median_len=700, p_middle=0.3, p_polya=0.1)
+    qual = qual.copy()
+    for i in range(len(off) - 1):
+        lo, hi = int(off[i]), int(off[i + 1])
+        if rng.random() < 0.7:
+            a = lo + int(rng.integers(0, hi - lo))
+            qual[a:min(hi, a + int(rng.integers(20, 200)))] = 36
+    text, names, strands = hostio.make_fastq(seq, qual, off, strand_names=True)
+    p = tmp_path / "in.fq"
+    p.write_bytes(text)
+    res, _, frags, regs = orc.process_batch_ex(cfg, seq, qual, off)
+    b, *_ = read_batch(hostlib, p)
+    want_out, want_failed = hostio.expected_outputs_fragments(seq, qual, off, names, strands, res, frags, regs)
+    for threads in (1, 5):
+        out, failed = C.c_void_p(), C.c_void_p()
+        ol, fl = C.c_uint64(), C.c_uint64()
+        assert hostlib.fplh_format_batch_fragments(b, res.ctypes.data, frags.ctypes.data, len(frags), regs.ctypes.data, len(regs),
+                                                   threads, C.byref(out), C.byref(ol), C.byref(failed), C.byref(fl)) == 0
+        assert C.string_at(out, ol.value) == want_out and C.string_at(failed, fl.value) == want_failed
+        hostlib.fplh_free(out)
+        hostlib.fplh_free(failed)
+    hostlib.fplh_batch_free(b)
+    assert b"@r" in want_out and b"N" * 15 in want_out and len(want_failed) > 0
+
+
 def test_record_formats_match_reference(ref):
     """names of split fragments and the failed-read tag line, from the reference's own Read code"""
     out = ref.run(["BG 3 2 =@r1_desc =ACGTACGTAC =+xyz =IIIIIJJJJJ"])
