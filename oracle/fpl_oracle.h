@@ -14,6 +14,9 @@
  *     Read::trimFront/resize/breakByGap/appendToString*, FilterResult JSON and
  *     JsonReporter::report are cross-checked against the real reference objects compiled
  *     into oracle/_ref (see oracle/Makefile) in tests/test_oracle_vs_ref.py;
+ *   - the --break / --mask stage (Filter::detectLowQualityRegions, Read::breakByRegions,
+ *     Read::maskRegionWithN as processSingleEnd chains them, src/seprocessor.cpp:234-262) is
+ *     cross-checked the same way (harness commands LQR / BRK);
  *   - AdapterTrimmer (src/adaptertrimmer.cpp) includes Google Highway, which this image
  *     does not have, so that one file is unbuildable here: for it the restatement is pinned
  *     by the reference's own four known-answer tests only (test/adaptertrimmer_test.cpp).
