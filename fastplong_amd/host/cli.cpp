@@ -356,15 +356,55 @@ int main(int argc, char* argv[]) {
     fplh::FastqReader reader(in);
     if (!reader.ok()) error_exit("Failed to open file: " + in);
     reader.set_copy_threads(max(1, min(8, (int)thread::hardware_concurrency() / 2)));
-    auto open_out = [](const string& path) -> gzFile {
-        if (path.empty()) return nullptr;
-        const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
-        gzFile f = gzopen(path.c_str(), gz ? "wb4" : "wbT"); /* "T": transparent (no compression) */
-        if (!f) error_exit("Failed to write: " + path);
-        return f;
+    /* Outputs are plain files; a name ending in .gz gets gzip members (-z level), one per formatted slice,
+       deflated on the formatter threads and concatenated by the writer: any gzip reader takes that as one stream */
+    struct OutFile {
+        FILE* f = nullptr;
+        bool gz = false;
+        bool wrote = false;
+        explicit operator bool() const { return f != nullptr; }
     };
-    gzFile fout = toStdout ? gzdopen(1, "wbT") : open_out(out);
-    gzFile ffail = open_out(failedOut);
+    auto open_out = [](const string& path) -> OutFile {
+        OutFile o;
+        if (path.empty()) return o;
+        o.gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+        o.f = fopen(path.c_str(), "wb");
+        if (!o.f) error_exit("Failed to write: " + path);
+        return o;
+    };
+    OutFile fout = open_out(out), ffail = open_out(failedOut);
+    if (toStdout) fout.f = stdout, fout.gz = false;
+    const int gzLevel = min(9, max(1, cmd.i("compression")));
+    auto gzip_member = [gzLevel](const string& in) -> string {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, gzLevel, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) error_exit("deflateInit2 failed");
+        string o;
+        o.resize(deflateBound(&zs, (uLong)in.size()) + 64);
+        zs.next_in = (Bytef*)in.data();
+        zs.avail_in = (uInt)in.size();
+        zs.next_out = (Bytef*)&o[0];
+        zs.avail_out = (uInt)o.size();
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) error_exit("deflate failed");
+        o.resize(zs.total_out);
+        deflateEnd(&zs);
+        return o;
+    };
+    auto gzip_pieces = [&](vector<string>& pieces) { /* in parallel; pieces stay below 4 GiB (one slice of a batch) */
+        vector<thread> th;
+        for (auto& piece : pieces)
+            th.emplace_back([&gzip_member, &piece]() {
+                if (!piece.empty()) piece = gzip_member(piece);
+            });
+        for (auto& t : th) t.join();
+    };
+    auto write_pieces = [](OutFile& o, const vector<string>& pieces) {
+        for (auto& piece : pieces)
+            if (!piece.empty()) {
+                if (fwrite(piece.data(), 1, piece.size(), o.f) != piece.size()) error_exit("write failed");
+                o.wrote = true;
+            }
+    };
 
     long readsLeft = readsToProcess > 0 ? readsToProcess : -1;
     const int fmtThreads = max(1, min(16, (int)thread::hardware_concurrency() / max(1, nGpus) - 1));
@@ -421,8 +461,12 @@ int main(int argc, char* argv[]) {
                     }
                 }
                 if (w->rc != FPL_OK) w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
-                else fplh::format_batch_parallel(w->batch, w->res.data(), fmtThreads, w->outs, ffail ? &w->faileds : nullptr,
-                                                 fragmentMode ? &w->frags : nullptr);
+                else {
+                    fplh::format_batch_parallel(w->batch, w->res.data(), fmtThreads, w->outs, ffail ? &w->faileds : nullptr,
+                                                fragmentMode ? &w->frags : nullptr);
+                    if (fout && fout.gz) gzip_pieces(w->outs);
+                    if (ffail && ffail.gz) gzip_pieces(w->faileds);
+                }
                 tGpu[d] += t1 - t0;
                 tFormat[d] += now() - t1;
                 doneq.push(w);
@@ -445,14 +489,8 @@ int main(int argc, char* argv[]) {
                 ready.erase(ready.begin());
                 if (r->rc != FPL_OK) error_exit("fpl_process_batch: " + r->err);
                 const double t0 = now();
-                if (fout)
-                    for (auto& piece : r->outs)
-                        for (size_t o = 0; o < piece.size(); o += 1u << 30)
-                            gzwrite(fout, piece.data() + o, (unsigned)min<size_t>(piece.size() - o, 1u << 30));
-                if (ffail)
-                    for (auto& piece : r->faileds)
-                        for (size_t o = 0; o < piece.size(); o += 1u << 30)
-                            gzwrite(ffail, piece.data() + o, (unsigned)min<size_t>(piece.size() - o, 1u << 30));
+                if (fout) write_pieces(fout, r->outs);
+                if (ffail) write_pieces(ffail, r->faileds);
                 tWrite += now() - t0;
                 next++;
                 freeq.push(r);
@@ -468,8 +506,15 @@ int main(int argc, char* argv[]) {
              << " s, fpl_process_batch " << g << " s, format (" << fmtThreads << " threads) " << f << " s, write " << tWrite
              << " s" << endl;
     }
-    if (fout) gzclose(fout);
-    if (ffail) gzclose(ffail);
+    for (OutFile* o : {&fout, &ffail})
+        if (*o) {
+            if (o->gz && !o->wrote) { /* an empty .gz still has to be a gzip stream */
+                const string e = gzip_member(string());
+                fwrite(e.data(), 1, e.size(), o->f);
+            }
+            if (o->f == stdout) fflush(stdout);
+            else fclose(o->f);
+        }
 
     /* merge: agree on the per-cycle capacity, then ONE all-reduce (sum, int64) over RCCL */
     uint32_t C = 0;

@@ -108,3 +108,18 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     want = gz(os.path.join(GOLD, case, "expected.json.gz")).split(b"\n")
     assert got == want
     assert b"reads passed filter: " in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_gzip_outputs_on_gpu(tmp_path):
+    """names ending in .gz are written as concatenated gzip members (one per formatted slice, deflated in parallel)"""
+    case = "c3_full"
+    build.build_all()
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    cmd = [build.CLI, "-i", os.path.join(GOLD, case, "in.fq.gz"), "-o", str(tmp_path / "out.fq.gz"), "--failed_out",
+           str(tmp_path / "failed.fq.gz"), "-j", str(tmp_path / "out.json"), "-z", "6", "--batch_reads", "50"] + meta["flags"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert gz(str(tmp_path / "out.fq.gz")) == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    assert gz(str(tmp_path / "failed.fq.gz")) == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
+    assert (tmp_path / "out.fq.gz").read_bytes()[:2] == b"\x1f\x8b"
