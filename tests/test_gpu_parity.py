@@ -136,6 +136,20 @@ def test_break_and_mask_bit_exact(orc, engine_mod, be, me, bw, mw):
         assert (want_f["code"] == abi.FPL_PASS_FILTER).any()
 
 
+def test_very_long_reads_bit_exact(orc, engine_mod):
+    """BASELINE configs[3] goes up to 200 kb per read: many cycle tiles, long histories in every kernel"""
+    rng = np.random.default_rng(77)
+    reads = []
+    for L in (262144, 200000, 131073, 65536, 65535, 9000, 50):
+        s, q, o = synth.ont_like(1, seed=int(L) % 1000, median_len=L, sigma_len=0.0, min_len=L, max_len=L, p_middle=1.0)
+        reads.append((s[:int(o[1])], q[:int(o[1])]))
+    for _ in range(40):
+        s, q, o = synth.ont_like(1, seed=int(rng.integers(1 << 30)), median_len=5000)
+        reads.append((s[:int(o[1])], q[:int(o[1])]))
+    seq, qual, off = synth.pack(reads)
+    _run_both(orc, engine_mod, CASES["full_pipeline"], seq, qual, off, via="device")
+
+
 def test_edge_batches(orc, engine_mod):
     cfgd = CASES["full_pipeline"]
     # empty batch
