@@ -10,8 +10,7 @@
  * counter buffers are summed with one RCCL all-reduce (the replacement of Stats::merge /
  * FilterResult::merge, src/seprocessor.cpp:108-121) and rank 0's copy feeds the reports.
  *
- * Not implemented (SURVEY.md section 8f "next" rows): adapter auto-detection (an undetected
- * "auto" is used literally, as the reference does when detection fails), --split*, the HTML report.
+ * Not implemented (SURVEY.md section 8f "next" rows): --split*, the HTML report.
  */
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -34,6 +33,7 @@
 #include <vector>
 
 #include "fastplong_amd.h"
+#include "evaluator.h"
 #include "fastq.h"
 #include "report.h"
 
@@ -317,9 +317,6 @@ int main(int argc, char* argv[]) {
     }
     if (o.ed_max < 0 || o.ed_max > 1.0) error_exit("the adapter <distance_threshold> should be 0.0 ~ 1.0, suggest 0.1 ~ 0.3");
     if (o.trimming_extension < 0 || o.trimming_extension > 100) error_exit("the adapter <trimming_extension> should be 0 ~ 100, suggest 5 ~ 30");
-    if (o.adapter_enabled && (startAd == "auto" || endAd == "auto"))
-        cerr << "NOTE: adapter auto-detection is not implemented in fastplong_amd; an undetected adapter is used "
-                "literally as \"auto\", exactly as the reference does when detection finds nothing. Pass -s/-e." << endl;
 
     /* Evaluator::evaluateSeqLenAndCheckRNA, src/evaluator.cpp:16-61: U vs T in the first 100 reads */
     bool isRNA = false;
@@ -337,6 +334,14 @@ int main(int argc, char* argv[]) {
         if (numU > 0) {
             isRNA = true;
             cerr << "RNA direct sequencing data" << endl;
+        }
+    }
+    /* adapter auto-detection, src/main.cpp:270-277 (an undetected "auto" stays literal, as in the reference) */
+    if (o.adapter_enabled && (startAd == "auto" || endAd == "auto")) {
+        if (fromStdin || in == "/dev/stdin") cerr << "Adapter auto-detection is disabled for STDIN mode" << endl;
+        else {
+            fplh::detect_adapters(in, o.trim_tail, isRNA, startAd, endAd);
+            cerr << endl;
         }
     }
 

@@ -1,0 +1,231 @@
+#include "evaluator.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <iostream>
+#include <vector>
+
+#include "fastq.h"
+
+using namespace std;
+
+namespace fplh {
+
+/* Evaluator::int2seq, src/evaluator.cpp:485-497 */
+string int2seq(unsigned int val, int seqlen, bool is_rna) {
+    char bases[4] = {'A', 'T', 'C', 'G'};
+    if (is_rna) bases[1] = 'U';
+    string ret(seqlen, 'N');
+    for (int done = 0; done < seqlen; done++) {
+        ret[seqlen - done - 1] = bases[val & 0x03];
+        val >>= 2;
+    }
+    return ret;
+}
+
+static int base_code(char b) {
+    switch (b) {
+        case 'A': return 0;
+        case 'T':
+        case 'U': return 1;
+        case 'C': return 2;
+        case 'G': return 3;
+        default: return -1; /* N or anything else */
+    }
+}
+
+/* Evaluator::seq2int, src/evaluator.cpp:503-560: rolling when the previous key is valid */
+int seq2int(const char* seq, int rlen, int pos, int keylen, int last_val) {
+    (void)rlen;
+    if (last_val >= 0) {
+        const int mask = (1 << (keylen * 2)) - 1;
+        const int c = base_code(seq[pos + keylen - 1]);
+        if (c < 0) return -1;
+        return ((last_val << 2) & mask) + c;
+    }
+    int key = 0;
+    for (int i = pos; i < keylen + pos; i++) {
+        const int c = base_code(seq[i]);
+        if (c < 0) return -1;
+        key = (key << 2) + c;
+    }
+    return key;
+}
+
+/* Evaluator::getTopKey, src/evaluator.cpp:268-326, restated literally (its diff test reads the COUNT's bits) */
+static int get_top_key(const unsigned int* counts, int keylen) {
+    const int size = 1 << (keylen * 2);
+    int topkey = -1;
+    unsigned int top_count = 0;
+    for (int k = 0; k < size; k++) {
+        const unsigned int val = counts[k];
+        int atcg[4] = {0, 0, 0, 0};
+        for (int i = 0; i < keylen; i++) atcg[(k >> (i * 2)) & 0x03]++;
+        bool low_complexity = false;
+        int zero_num = 0;
+        for (int b = 0; b < 4; b++) {
+            if (atcg[b] >= keylen - 4) low_complexity = true;
+            if (atcg[b] == 0) zero_num++;
+        }
+        if (zero_num >= 2) low_complexity = true;
+        if ((k >> keylen) == (k & ((0x01 << keylen) - 1))) low_complexity = true; /* repetitive */
+        int diff = 0;
+        for (int s = 0; s < keylen - 1; s++) {
+            const int cur = (val >> ((keylen - s) * 2)) & 0x03;
+            const int last = (val >> ((keylen - s - 1) * 2)) & 0x03;
+            if (cur != last) diff++;
+        }
+        if (diff < 3) continue;
+        if (low_complexity) continue;
+        if (atcg[2] + atcg[3] >= keylen - 2) continue; /* too many GC */
+        if ((k >> 12) == 0xff) continue;               /* starts with GGGG */
+        if (k == 0) continue;
+        if (val > top_count) {
+            top_count = val;
+            topkey = k;
+        }
+    }
+    return topkey;
+}
+
+/* Evaluator::extendKeyToAdapter, src/evaluator.cpp:328-404 */
+static string extend_key(int key, const unsigned int* counts, const unsigned long* position_acc, int keylen, bool is_rna,
+                         bool left_first) {
+    string adapter = int2seq((unsigned)key, keylen, is_rna);
+    const int mask = (1 << (keylen * 2)) - 1;
+    const int MAX_LEN = 64;
+    char bases[4] = {'A', 'T', 'C', 'G'};
+    if (is_rna) bases[1] = 'U';
+    bool left_finished = false, right_finished = false;
+    bool extending_left = left_first;
+    while (true) {
+        int curkey = key;
+        while ((int)adapter.length() < MAX_LEN) {
+            int total_count = 0;
+            bool extended = false;
+            for (int b = 0; b < 4; b++) {
+                const int newkey = extending_left ? ((b << ((keylen - 1) * 2)) | (curkey >> 2)) : (b | (mask & (curkey << 2)));
+                total_count += counts[newkey];
+            }
+            for (int b = 0; b < 4; b++) {
+                const int newkey = extending_left ? ((b << ((keylen - 1) * 2)) | (curkey >> 2)) : (b | (mask & (curkey << 2)));
+                if (counts[newkey] == 0) continue;
+                const double offset = (double)position_acc[newkey] / counts[newkey] - (double)position_acc[curkey] / counts[curkey];
+                if ((double)counts[newkey] / (double)total_count < 0.7) continue;
+                if ((double)counts[newkey] / (double)counts[key] < 0.5) continue;
+                if (offset > 2 || offset < -4) continue; /* offset should be near -1.0 */
+                curkey = newkey;
+                extended = true;
+                if (extending_left) adapter.insert(adapter.begin(), bases[b]);
+                else adapter.insert(adapter.end(), bases[b]);
+                break;
+            }
+            if (!extended) {
+                if (extending_left) left_finished = true;
+                else right_finished = true;
+                break;
+            }
+            if ((int)adapter.length() == MAX_LEN) {
+                left_finished = true;
+                right_finished = true;
+                break;
+            }
+        }
+        extending_left = !extending_left; /* finished one side, go to the other */
+        if (left_finished && right_finished) break;
+    }
+    return adapter;
+}
+
+/* Evaluator::evalAdapterAndReadNum, src/evaluator.cpp:105-266 (the read-number estimate it also produces only
+ * feeds --split, which this host does not have) */
+void detect_adapters(const string& path, int trim_tail, bool is_rna, string& start, string& end) {
+    if (start != "auto" && end != "auto") return;
+    const long READ_LIMIT = 64 * 1024;
+    const long BASE_LIMIT = 8192 * READ_LIMIT;
+    FastqReader reader(path);
+    if (!reader.ok()) return;
+    Batch b;
+    reader.fill(b, (uint64_t)BASE_LIMIT, (uint32_t)READ_LIMIT);
+    const long records = b.n();
+    if (records < 100) return; /* we need at least 100 valid records to evaluate */
+    const int shift_tail = max(1, trim_tail);
+    const double FOLD_THRESHOLD = 100.0;
+    const int keylen = 10;
+    const int size = 1 << (keylen * 2);
+    vector<unsigned int> counts(size);
+    vector<unsigned long> position_acc(size);
+    for (int side = 0; side < 2; side++) {
+        string& target = side == 0 ? start : end;
+        if (target != "auto") continue;
+        cerr << (side == 0 ? "Trying to detect adapter sequence at read start" : "Trying to detect adapter sequence at read end") << endl;
+        long total = 0;
+        int total_key = 0;
+        fill(counts.begin(), counts.end(), 0u);
+        fill(position_acc.begin(), position_acc.end(), 0ul);
+        for (long i = 0; i < records; i++) {
+            const char* data = (const char*)b.seq.data() + b.off[i];
+            const int rlen = (int)(b.off[i + 1] - b.off[i]);
+            int key = -1;
+            if (side == 0) {
+                for (int pos = 0; pos <= rlen - keylen - shift_tail && pos < 128; pos++) {
+                    key = seq2int(data, rlen, pos, keylen, key);
+                    if (key >= 0) {
+                        counts[key]++;
+                        position_acc[key] += pos;
+                        total++;
+                    }
+                }
+            } else {
+                const int startpos = max(0, rlen - keylen - shift_tail - 128);
+                for (int pos = startpos; pos <= rlen - keylen - shift_tail; pos++) {
+                    key = seq2int(data, rlen, pos, keylen, key);
+                    if (key >= 0) {
+                        counts[key]++;
+                        position_acc[key] += rlen - pos;
+                        total++;
+                    }
+                }
+            }
+        }
+        for (int k = 0; k < size; k++)
+            if (counts[k] > 0) total_key++;
+        counts[0] = 0; /* AAAAAAAAAA */
+        const int key = get_top_key(counts.data(), keylen);
+        const long count = key >= 0 ? counts[key] : 0; /* (the reference indexes counts[-1] when nothing qualifies) */
+        if (key >= 0 && count > 10 && count * total_key > total * FOLD_THRESHOLD) {
+            const string adapter = side == 0 ? extend_key(key, counts.data(), position_acc.data(), keylen, false, true)
+                                             : extend_key(key, counts.data(), position_acc.data(), keylen, is_rna, true);
+            if (adapter.length() > 16) {
+                cerr << "Detected: " << adapter << endl;
+                target = adapter;
+            } else {
+                cerr << "Found possible adapter sequence, but it's too short: " << adapter << ", specify "
+                     << (side == 0 ? "-s " : "-e ") << adapter << " to force trimming using this adapter" << endl;
+            }
+        } else {
+            cerr << "Not detected" << endl;
+        }
+    }
+}
+
+}  // namespace fplh
+
+extern "C" {
+int fplh_seq2int(const char* seq, int rlen, int pos, int keylen, int last_val) {
+    return fplh::seq2int(seq, rlen, pos, keylen, last_val);
+}
+void fplh_int2seq(unsigned int val, int seqlen, int is_rna, char* out) {
+    const std::string s = fplh::int2seq(val, seqlen, is_rna != 0);
+    memcpy(out, s.c_str(), s.size() + 1);
+}
+void fplh_detect_adapters(const char* path, int trim_tail, int is_rna, char* out_start, char* out_end) {
+    std::string s = "auto", e = "auto";
+    fplh::detect_adapters(path, trim_tail, is_rna != 0, s, e);
+    strncpy(out_start, s.c_str(), 127);
+    out_start[127] = 0;
+    strncpy(out_end, e.c_str(), 127);
+    out_end[127] = 0;
+}
+}

@@ -1,0 +1,34 @@
+/*
+ * evaluator.h -- adapter auto-detection of the reference's Evaluator (src/evaluator.cpp:105-266,
+ * getTopKey :268-326, extendKeyToAdapter :328-404, int2seq / seq2int :485-560), restated for the host.
+ * It runs once before the batches flow, on the first 64 Ki reads / 512 Mbases of the input, when
+ * --start_adapter / --end_adapter are left at "auto" (src/main.cpp:270-277).
+ *
+ * Parity status: UNPINNED beyond the reference's own known-answer test (test/evaluator_test.cpp,
+ * replayed in tests/test_host_evaluator.py): src/evaluator.cpp includes the FASTQ reader, whose ISA-L
+ * header this image lacks, so the real object cannot be built next to oracle/_ref.
+ */
+#ifndef FPLH_EVALUATOR_H
+#define FPLH_EVALUATOR_H
+
+#include <string>
+
+namespace fplh {
+
+std::string int2seq(unsigned int val, int seqlen, bool is_rna = false);
+int seq2int(const char* seq, int rlen, int pos, int keylen, int last_val = -1);
+
+/* Replaces `start` / `end` when they are "auto" and a sequence is detected; prints the reference's progress
+ * lines to stderr.  trim_tail = -t (the evaluation skips max(1, trim_tail) bases at the end of every read). */
+void detect_adapters(const std::string& path, int trim_tail, bool is_rna, std::string& start, std::string& end);
+
+}  // namespace fplh
+
+extern "C" {
+/* test hooks */
+int fplh_seq2int(const char* seq, int rlen, int pos, int keylen, int last_val);
+void fplh_int2seq(unsigned int val, int seqlen, int is_rna, char* out);
+/* out_start / out_end: buffers of >= 128 bytes, NUL-terminated results ("auto" when nothing was detected) */
+void fplh_detect_adapters(const char* path, int trim_tail, int is_rna, char* out_start, char* out_end);
+}
+#endif
