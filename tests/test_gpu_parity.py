@@ -136,6 +136,46 @@ def test_break_and_mask_bit_exact(orc, engine_mod, be, me, bw, mw):
         assert (want_f["code"] == abi.FPL_PASS_FILTER).any()
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_random_option_sets_bit_exact(orc, engine_mod, seed):
+    """seeded random corners of the option space (including --break / --mask) on adversarial + ONT-like reads"""
+    rng = np.random.default_rng(1000 + seed)
+    pick = lambda *v: v[int(rng.integers(len(v)))]  # noqa: E731
+    okw = dict(
+        trim_front=pick(0, 0, 1, 7, 40), trim_tail=pick(0, 0, 2, 9, 33), cut_front=pick(0, 1), cut_tail=pick(0, 1),
+        cut_front_window=pick(1, 4, 5, 30, 300), cut_front_quality=pick(5, 15, 20, 30), cut_tail_window=pick(1, 4, 7, 64, 500),
+        cut_tail_quality=pick(5, 15, 20, 30), polyx=pick(0, 1), polyx_min_len=pick(3, 8, 10, 25),
+        adapter_enabled=pick(0, 1, 1, 1), ed_max=pick(0.0, 0.1, 0.25, 0.4), trimming_extension=pick(0, 5, 10, 30),
+        qual_filter=pick(0, 1, 1), qualified_qual=33 + pick(5, 15, 20, 30), unqualified_percent_limit=pick(0, 20, 40, 90),
+        n_base_limit=pick(0, 3, 1000000), n_base_percent_limit=pick(0, 5, 10, 95), avg_qual_req=pick(0, 0, 10, 20),
+        length_filter=pick(0, 1, 1), required_length=pick(1, 20, 100, 400), max_length=pick(0, 0, 300, 2000),
+        complexity_filter=pick(0, 1), complexity_percent=pick(0, 5, 30, 60, 100),
+        break_enabled=pick(0, 0, 1), break_window=pick(1, 5, 40, 100, 700), break_quality=pick(5, 10, 15, 30),
+        mask_enabled=pick(0, 0, 1), mask_window=pick(1, 5, 15, 50, 400), mask_quality=pick(5, 10, 15, 30))
+    start = pick(synth.START_ADAPTER, synth.START_ADAPTER, "", "ACGTNACGTAGGCATCGATCGGCTA")
+    end = pick(synth.END_ADAPTER, synth.END_ADAPTER, "", synth.revcomp(synth.START_ADAPTER)[:18])
+    a = synth.adversarial(120, seed=seed, start_adapter=start or synth.START_ADAPTER, end_adapter=end or synth.END_ADAPTER)
+    b = _lowq_ont_like(60, seed=seed, median_len=1500)
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
+    cfg = orc.Config(abi.FplOptions.default(**okw), start, end)
+    C = max(1, int(np.diff(off.astype(np.int64)).max()))
+    eng = engine_mod.Engine(cfg.opt, start, end, device=0, max_cycles=C)
+    got_res = eng.process_host(seq, qual, off)
+    got_cnt = eng.counters()
+    if okw["break_enabled"] or okw["mask_enabled"]:
+        want_res, want_cnt, want_f, want_r = orc.process_batch_ex(cfg, seq, qual, off, max_cycles=C)
+        got_f, got_r = eng.fragments()
+        parity.assert_fragments_equal(got_f, got_r, want_f, want_r)
+    else:
+        want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    eng.close()
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
 def test_very_long_reads_bit_exact(orc, engine_mod):
     """BASELINE configs[3] goes up to 200 kb per read: many cycle tiles, long histories in every kernel"""
     rng = np.random.default_rng(77)
