@@ -148,8 +148,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         ctx->dbg = cfg.dbg;
         if ((cfg.brk && cfg.brk_w <= 0) || (cfg.msk && cfg.msk_w <= 0)) {
             ctx->err = "break / mask window size must be positive";
-            delete ctx;
-            return FPL_ERR_ARG;
+            return FPL_ERR_ARG; /* (the caller below destroys the context) */
         }
         ctx->hcfg = cfg;
         FPL_HIP(hipMalloc((void**)&ctx->d_cfg, sizeof(DevConfig)));

@@ -190,6 +190,12 @@ def test_very_long_reads_bit_exact(orc, engine_mod):
     _run_both(orc, engine_mod, CASES["full_pipeline"], seq, qual, off, via="device")
 
 
+def test_create_rejects_bad_break_mask_window(engine_mod):
+    for kw in (dict(break_enabled=1, break_window=0), dict(mask_enabled=1, mask_window=-3)):
+        with pytest.raises(engine_mod.FplError):
+            engine_mod.Engine(abi.FplOptions.default(**kw), synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=64)
+
+
 def test_edge_batches(orc, engine_mod):
     cfgd = CASES["full_pipeline"]
     # empty batch
