@@ -482,8 +482,8 @@ __device__ __forceinline__ int hamming_win(const Win<LDSWIN>& win, int p, const 
 }
 
 /* 16-column Myers run on r1[p, p + n), n <= 16 */
-template <bool LDSWIN>
-__device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const u32* __restrict__ peq, int m, int n) {
+template <bool LDSWIN, class PT>
+__device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const PT* __restrict__ peq, int m, int n) {
     if (m == 0) return n;
     u32 d[4];
     win.template get<4>(p, d);
@@ -523,9 +523,9 @@ __device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[P
  * updated; returns the reference's return value; keylen = cmplen handed to addAdapterTrimmed. */
 /* r = first base of r1 -- the global read or a copy of its first 200 bytes in LDS; peq16 / peqf = the
  * adapter's Myers tables, global or LDS copies. */
-template <bool LDSWIN>
+template <bool LDSWIN, class PT>
 __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
-                                               const u32* __restrict__ peq16,
+                                               const PT* __restrict__ peq16,
                                                const uint64_t (*__restrict__ peqf)[PEQ_WORDS],
                                                const DevConfig* __restrict__ cfg, int& keylen) {
     const int lane = lane_id();
@@ -607,9 +607,9 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
  * asLeftAsPossible mode, :84-107, inlined). */
 /* r = first base of r1 as an address: only its last 200 bytes are dereferenced, so r may point
  * 200 - rlen bytes in front of an LDS copy of that tail. */
-template <bool LDSWIN>
+template <bool LDSWIN, class PT>
 __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
-                                             const u32* __restrict__ peq16,
+                                             const PT* __restrict__ peq16,
                                              const uint64_t (*__restrict__ peqf)[PEQ_WORDS],
                                              const DevConfig* __restrict__ cfg, int& keylen) {
     const int lane = lane_id();
@@ -710,9 +710,10 @@ struct TrimBlockAcc {
 constexpr int TRIM_WIN = 256; /* FPL_END_WINDOW rounded up, plus slack for the aligned dword reads */
 template <int WAVES>
 struct TrimLds {
-    u32 peq16[2][256];             /* [0] = start adapter's peq16_start, [1] = end adapter's peq16_end */
+    uint16_t peq16[2][256];        /* [0] = start adapter's peq16_start, [1] = end adapter's peq16_end (16 columns) */
     uint64_t peqf[2][256][PEQ_WORDS];
     u32 win[WAVES][2][TRIM_WIN / 4];
+    uint16_t peq16w[WAVES][256];   /* per wave: the 16-column Peq table of the FASTA adapter being tried */
 };
 
 /* copy bytes [from, from + n) of a read (n <= TRIM_WIN) into this wave's window, 4 bytes per lane */
@@ -735,8 +736,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x) acc.fr[i] = 0;
     for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x) acc.key[i] = 0;
     for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
-        lds.peq16[0][i] = ads[0].peq16_start[i];
-        lds.peq16[1][i] = ads[1].peq16_end[i];
+        lds.peq16[0][i] = (uint16_t)ads[0].peq16_start[i];
+        lds.peq16[1][i] = (uint16_t)ads[1].peq16_end[i];
 #pragma unroll
         for (int w = 0; w < PEQ_WORDS; w++) {
             lds.peqf[0][i][w] = ads[0].peq_full[i][w];
@@ -798,16 +799,48 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(4) /* end adapter */
-            for (int a = 0; a < cfg->n_fasta; a++) { /* trimByMultiSequences, src/adaptertrimmer.cpp:42-57 */
+            /* trimByMultiSequences, src/adaptertrimmer.cpp:42-57: every FASTA adapter at both ends, in order.  The
+               two 200-base windows stay in LDS across adapters and are staged again only after a trim moved r1;
+               each adapter's 16-column Peq table is copied next to them (4 loads per lane) */
+            bool stale_s = true, stale_e = true;
+            uint16_t* const pq = lds.peq16w[wave_in_block()];
+            for (int a = 0; a < cfg->n_fasta; a++) {
                 const DevAdapter* ad = &ads[2 + a];
-                const Win<false> ws = {sq + s, nullptr, 0, e - s};
-                trimmed += trim_start_wave(ws, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
-                if (kl > 0 && lane == 0)
-                    atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
-                const Win<false> we = {sq + s, nullptr, 0, e - s};
-                trimmed += trim_end_wave(we, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
-                if (kl > 0 && lane == 0)
-                    atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
+                if (ad->len > FPL_END_WINDOW) { /* longer than the window: work on the read in global memory */
+                    const Win<false> ws = {sq + s, nullptr, 0, e - s};
+                    trimmed += trim_start_wave(ws, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
+                    if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
+                    const Win<false> we = {sq + s, nullptr, 0, e - s};
+                    trimmed += trim_end_wave(we, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
+                    if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
+                    stale_s = stale_e = true;
+                    continue;
+                }
+                {
+                    if (stale_s) stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end);
+                    stale_s = false;
+                    wave_sync();
+                    for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_start[i];
+                    wave_sync();
+                    const int s0 = s, e0 = e;
+                    const Win<true> wn = {nullptr, win_s, 0, e - s};
+                    trimmed += trim_start_wave(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
+                    if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
+                    if (s != s0 || e != e0) stale_s = stale_e = true;
+                }
+                {
+                    const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
+                    if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end);
+                    stale_e = false;
+                    wave_sync();
+                    for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_end[i];
+                    wave_sync();
+                    const int s0 = s, e0 = e;
+                    const Win<true> wn = {nullptr, win_e, rlen - wl, rlen};
+                    trimmed += trim_end_wave(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
+                    if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
+                    if (s != s0 || e != e0) stale_s = stale_e = true;
+                }
             }
             if (trimmed > 0 && lane == 0) { /* FilterResult::addReadTrimmed */
                 atomicAdd(&acc.fr[FPL_FR_ADAPTER_READS], (u64)1);
