@@ -481,21 +481,44 @@ __device__ __forceinline__ int hamming_win(const Win<LDSWIN>& win, int p, const 
     return mm;
 }
 
+/* The same for an adapter of <= 32 bases whose 8 dwords the caller keeps in registers (one scalar load per
+ * trim instead of one per dword and position round) */
+template <bool LDSWIN>
+__device__ __forceinline__ int hamming_win32(const Win<LDSWIN>& win, int p, const u32 (&adw)[8], int alen) {
+    u32 d[8];
+    win.template get<8>(p, d);
+    int mm = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int rem = alen - 4 * k; /* wave-uniform */
+        if (rem > 0) {
+            u32 x = d[k] ^ adw[k];
+            if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+            const u32 z = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+            mm += (int)popc32(z & 0x80808080u);
+        }
+    }
+    return mm;
+}
+
 /* 16-column Myers run on r1[p, p + n), n <= 16 */
-template <bool LDSWIN, class PT>
-__device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const PT* __restrict__ peq, int m, int n) {
+/* FULL: m == n == 16 (every adapter of >= 16 bases), known at compile time: no per-column tests, one
+ * straight-line block that the scheduler can interleave with the other chains of the lane */
+template <bool FULL, bool LDSWIN, class PT>
+__device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const PT* __restrict__ peq, int m_, int n_) {
+    const int m = FULL ? 16 : m_, n = FULL ? 16 : n_;
     if (m == 0) return n;
     u32 d[4];
     win.template get<4>(p, d);
     u32 eq[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) eq[j] = j < n ? peq[(d[j >> 2] >> (8 * (j & 3))) & 0xFFu] : 0u;
+    for (int j = 0; j < 16; j++) eq[j] = (FULL || j < n) ? peq[(d[j >> 2] >> (8 * (j & 3))) & 0xFFu] : 0u;
     u32 Pv = ~0u, Mv = 0;
     int score = m;
     const u32 top = 1u << (m - 1);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        if (j < n) { /* wave-uniform */
+        if (FULL || j < n) { /* wave-uniform */
             const u32 Eq = eq[j];
             const u32 Xv = Eq | Mv;
             const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
@@ -534,6 +557,9 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
     if (rlen < FPL_PATTERN_LEN) return 0;
     const int alen = ad->len, plen = ad->plen, ext = cfg->ext;
     const int thrA = cfg->thr[alen];
+    u32 adw[8]; /* the adapter's first 32 bytes (zero padded), in scalar registers */
+#pragma unroll
+    for (int k = 0; k < 8; k++) adw[k] = uniform_u32(((const u32*)ad->seq)[k]);
     int mpos = -1;
     const int searchEnd = min(rlen, FPL_END_WINDOW);
     if (alen <= rlen && searchEnd > alen) {
@@ -543,7 +569,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
         for (int p0 = 0; p0 < npos; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < npos && !FPL_DBG(cfg->dbg, 256)) mm = hamming_win(win, p, ad);
+            if (p < npos && !FPL_DBG(cfg->dbg, 256)) mm = alen <= 32 ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
             const u64 m = wave_ballot(p < npos && mm <= thrA);
             if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
             if (p < npos) {
@@ -577,8 +603,13 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
         int pp[3], ed[3];
 #pragma unroll
         for (int u = 0; u < 3; u++) pp[u] = p0 + 64 * u + lane;
+        if (plen == 16) {
 #pragma unroll
-        for (int u = 0; u < 3; u++) ed[u] = lev16_win(win, min(pp[u], lim - 1), peq16, plen, plen);
+            for (int u = 0; u < 3; u++) ed[u] = lev16_win<true>(win, min(pp[u], lim - 1), peq16, 16, 16);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 3; u++) ed[u] = lev16_win<false>(win, min(pp[u], lim - 1), peq16, plen, plen);
+        }
 #pragma unroll
         for (int u = 0; u < 3; u++)
             if (pp[u] < lim && ed[u] <= thrP) {
@@ -618,6 +649,9 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     if (rlen < FPL_PATTERN_LEN) return 0;
     const int alen = ad->len, plen = ad->plen, ext = cfg->ext;
     const int thrA = cfg->thr[alen];
+    u32 adw[8]; /* the adapter's first 32 bytes (zero padded), in scalar registers */
+#pragma unroll
+    for (int k = 0; k < 8; k++) adw[k] = uniform_u32(((const u32*)ad->seq)[k]);
     const int ss = max(0, rlen - FPL_END_WINDOW);
     int mpos = -1;
     if (ss + alen <= rlen) {
@@ -627,7 +661,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
         for (int p0 = ss; p0 < pend; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < pend) mm = hamming_win(win, p, ad);
+            if (p < pend) mm = alen <= 32 ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
             const u64 m = wave_ballot(p < pend && mm <= thrA);
             if (m) {
                 hit = p0 + __ffsll(m) - 1; /* leftmost hit, returned at once (:98-101) */
@@ -661,9 +695,15 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     int pos = -1, mined = -1;
     bool stop = false;
     int ed3[3];
+    if (plen == 16) {
 #pragma unroll
-    for (int u = 0; u < 3; u++) /* lim <= 184 = three rounds; independent chains, one straight-line block */
-        ed3[u] = lim > 0 ? lev16_win(win, rlen - plen - min(64 * u + lane, lim - 1), peq16, plen, plen) : 0x7fffffff;
+        for (int u = 0; u < 3; u++) /* lim <= 184 = three rounds; independent chains, one straight-line block */
+            ed3[u] = lim > 0 ? lev16_win<true>(win, rlen - 16 - min(64 * u + lane, lim - 1), peq16, 16, 16) : 0x7fffffff;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            ed3[u] = lim > 0 ? lev16_win<false>(win, rlen - plen - min(64 * u + lane, lim - 1), peq16, plen, plen) : 0x7fffffff;
+    }
     for (int p0 = 0; p0 < lim && !stop; p0 += 64) {
         const int p = p0 + lane;
         const int edr = p0 == 0 ? ed3[0] : (p0 == 64 ? ed3[1] : ed3[2]);
