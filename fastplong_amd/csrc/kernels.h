@@ -148,18 +148,39 @@ __device__ __forceinline__ int lev_bp64(const uint64_t (*__restrict__ peq)[PEQ_W
  * run on one 32-bit word (half the instructions of the 64-bit form). */
 __device__ __forceinline__ bool lev_round32(const WaveVals64& pub, int cnt, int left_after, u32& Pv, u32& Mv, int& score,
                                             u32 top, int thr) {
-    for (int t = 0; t < cnt; t++) {
+    /* every value here is wave-uniform, so this loop runs on the scalar unit, which all four SIMDs of a CU
+       share: keep it short -- the score moves by a bit-field of Ph / Mh, and the exit bound is tested once per
+       two columns (it only grows: the bound at column t implies the one at t + 1 or an exact result) */
+    const u32 tsh = (u32)__builtin_ctz(top);
+    int t = 0;
+    for (; t + 2 <= cnt; t += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const u32 Eq = (u32)pub.get(t + u);
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            score += (int)((Ph >> tsh) & 1u) - (int)((Mh >> tsh) & 1u);
+            Ph = (Ph << 1) | 1u;
+            Mh <<= 1;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+        }
+        if (score - (left_after + cnt - 2 - t) > thr) return true; /* wave-uniform */
+    }
+    if (t < cnt) {
         const u32 Eq = (u32)pub.get(t);
         const u32 Xv = Eq | Mv;
         const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
         u32 Ph = Mv | ~(Xh | Pv);
         u32 Mh = Pv & Xh;
-        score += (Ph & top) ? 1 : ((Mh & top) ? -1 : 0);
+        score += (int)((Ph >> tsh) & 1u) - (int)((Mh >> tsh) & 1u);
         Ph = (Ph << 1) | 1u;
         Mh <<= 1;
         Pv = Mh | ~(Xv | Ph);
         Mv = Ph & Xv;
-        if (score - (left_after + cnt - 1 - t) > thr) return true; /* wave-uniform */
+        if (score - left_after > thr) return true;
     }
     return false;
 }
