@@ -1908,35 +1908,34 @@ __device__ __forceinline__ void lev_pair32_run(const u32 (*__restrict__ peq4)[4]
     const WaveVals64 pub1 = wave_publish((u64)peq4_lookup(peq4[1], x.b1));
     const bool second = lane == 1;
     const int m = second ? m1 : m0, thr = second ? thr1 : thr0;
-    bool done = !((lane == 0 && need0 && m0 > 0) || (second && need1 && m1 > 0));
-    int res = (lane == 0 && need0) ? m0 : ((second && need1) ? m1 : 0); /* (m == 0: the distance is the text length) */
+    const bool active = (lane == 0 && need0 && m0 > 0) || (second && need1 && m1 > 0);
     u32 Pv = ~0u, Mv = 0;
-    int score = m;
-    const u32 top = m > 0 ? 1u << (m - 1) : 0u;
+    int score = m, fin = m; /* fin: the score after the lane's last column (m == 0: the distance is the text length) */
+    bool bad = false;       /* the early-exit bound fired at some column */
+    const u32 topsh = m > 0 ? (u32)(m - 1) : 0u;
     const int mmax = max(need0 ? m0 : 0, need1 ? m1 : 0);
-    for (int t = 0; t < mmax; t++) {
-        const u32 e0 = (u32)pub0.get(t), e1 = (u32)pub1.get(t);
-        const u32 Eq = second ? e1 : e0;
-        const u32 Xv = Eq | Mv;
-        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-        u32 Ph = Mv | ~(Xh | Pv);
-        u32 Mh = Pv & Xh;
-        score += (Ph & top) ? 1 : ((Mh & top) ? -1 : 0);
-        Ph = (Ph << 1) | 1u;
-        Mh <<= 1;
-        Pv = Mh | ~(Xv | Ph);
-        Mv = Ph & Xv;
-        if (!done) {
-            if (score - (m - 1 - t) > thr) {
-                res = thr + 1;
-                done = true;
-            } else if (t + 1 == m) {
-                res = score;
-                done = true;
-            }
+    for (int t0 = 0; t0 < mmax; t0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) { /* straight-line: the exit test below runs once per two columns */
+            const int t = t0 + u;
+            const u32 e0 = (u32)pub0.get(t & 63), e1 = (u32)pub1.get(t & 63);
+            const u32 Eq = second ? e1 : e0;
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            score += (int)((Ph >> topsh) & 1u) - (int)((Mh >> topsh) & 1u);
+            Ph = (Ph << 1) | 1u;
+            Mh <<= 1;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+            /* columns past the lane's own text (t >= m) change nothing that is kept */
+            bad = bad || (t < m && score - (m - 1 - t) > thr);
+            fin = t == m - 1 ? score : fin;
         }
-        if (!(wave_ballot(!done) & 3ull)) break; /* wave-uniform */
+        if (!(wave_ballot(active && !bad && t0 + 2 < m) & 3ull)) break; /* wave-uniform */
     }
+    const int res = !active ? ((lane == 0 && need0) ? m0 : ((second && need1) ? m1 : 0)) : (bad ? thr + 1 : fin);
     ed0 = readlane_i32(res, 0);
     ed1 = readlane_i32(res, 1);
 }
