@@ -6,7 +6,7 @@
  *
  * Parity status: UNPINNED beyond the reference's own known-answer test (test/evaluator_test.cpp,
  * replayed in tests/test_host_evaluator.py): src/evaluator.cpp includes the FASTQ reader, whose ISA-L
- * header this image lacks, so the real object cannot be built next to oracle/_ref.
+ * header this image lacks, so the real object cannot be built in place as a cross-check.
  */
 #ifndef FPLH_EVALUATOR_H
 #define FPLH_EVALUATOR_H
