@@ -78,16 +78,16 @@ inline void break_mask_caps(u32 n_reads, uint64_t n_bytes, int brk, int brk_w, i
 
 inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
-/* Slices of the item list for k_cycle_stats.  A (slice, tile) block is heavy only while its tile lies
- * below the typical item length, so the number of HEAVY blocks is about slices x (mean length / tile):
- * aim for a few of them per block slot of the chip (2 blocks/CU) for load balance -- the table hand-over
- * is a plain 64 KiB store now, so extra slices are cheap -- bounded above by the 14-bit counter fields. */
+/* Slices of the item list for k_stats.  A (slice, tile) block is heavy only while its tile lies below the
+ * typical item length, so the number of HEAVY blocks is about slices x (mean length / tile).  Every block pays
+ * for zeroing its tables, the 72 KiB hand-over and the 5-mer flush, so slices should be as large as the
+ * 14-bit counter fields allow; measured optimum: ~1.25 heavy blocks per block slot of the chip (2 per CU). */
 inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu) {
     if (n_items == 0) return 64;
     const char* e = getenv("FPL_STATS_PER"); /* tuning hook */
     if (e && atoi(e) > 0) return (u32)atoi(e);
     const u32 heavy_tiles = mean_len / FS_T + 1;
-    const u32 slices = cdiv(6 * n_cu, heavy_tiles);
+    const u32 slices = cdiv(5 * n_cu / 2, heavy_tiles);
     u32 per = cdiv(n_items, slices);
     per = (per + 63) / 64 * 64;
     if (per < 1024) per = 1024;
