@@ -123,3 +123,30 @@ def test_cli_gzip_outputs_on_gpu(tmp_path):
     assert gz(str(tmp_path / "out.fq.gz")) == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
     assert gz(str(tmp_path / "failed.fq.gz")) == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
     assert (tmp_path / "out.fq.gz").read_bytes()[:2] == b"\x1f\x8b"
+
+
+@pytest.mark.gpu
+def test_cli_detects_adapters_when_left_at_auto(tmp_path):
+    """-s / -e default to "auto": the host evaluator finds the adapters most reads carry and the run trims with them"""
+    build.build_all()
+    # (same seeded reads as tests/test_host_evaluator.py: the reference's top-key rule also looks at the bits of the
+    #  k-mer COUNT, so whether a key qualifies depends on how many reads happen to carry it)
+    rng = np.random.default_rng(3)
+    sa = np.frombuffer(synth.START_ADAPTER.encode(), np.uint8)
+    ea = np.frombuffer(synth.END_ADAPTER.encode(), np.uint8)
+    reads = []
+    for _ in range(400):
+        body = synth._ACGT[rng.integers(0, 4, int(rng.integers(400, 900)))]
+        s_ = np.concatenate([sa, body, ea, synth._ACGT[rng.integers(0, 4, 1)]]) if rng.random() < 0.8 else body
+        reads.append((s_.astype(np.uint8), np.full(len(s_), 33 + 20, np.uint8)))
+    seq, qual, off = synth.pack(reads)
+    text, _, _ = hostio.make_fastq(seq, qual, off)
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    p = subprocess.run([build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "-j", str(tmp_path / "out.json")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    err = p.stderr.decode()
+    assert err.count("Detected: ") == 2, err
+    js = json.loads((tmp_path / "out.json").read_text().replace("},\n}", "}\n}"))
+    assert js["adapter_cutting"]["adapter_trimmed_reads"] > 200
