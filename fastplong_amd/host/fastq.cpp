@@ -10,6 +10,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <iostream>
 #include <thread>
 
@@ -79,44 +81,41 @@ FastqReader::FastqReader(const string& path) {
             cap = (size_t)atol(e);
             allow_map = false;
         }
-    if (path != "/dev/stdin" && allow_map) { /* a regular file that is not gzip: map it, no copies into a window */
+    if (const char* e = getenv("FPLH_PARSE_MIN"))
+        if (atol(e) > 0) parse_min_ = (size_t)atol(e);
+    if (const char* e = getenv("FPLH_PARSE_THREADS"))
+        if (atol(e) > 0) copy_threads_ = (int)atol(e);
+    if (path != "/dev/stdin" && allow_map) { /* a regular file that is not gzip: parallel pread into the window */
         const int fd = open(path.c_str(), O_RDONLY);
         if (fd >= 0) {
             struct stat st;
             unsigned char magic[2] = {0, 0};
             if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 &&
                 !(magic[0] == 0x1f && magic[1] == 0x8b)) {
-                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-                if (m != MAP_FAILED) {
-                    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-                    madvise(m, (size_t)st.st_size, MADV_WILLNEED);
-                    map_ = m;
-                    map_len_ = (size_t)st.st_size;
-                    win_ = (const char*)m;
-                    len_ = map_len_;
-                    eof_ = true;
-                    fp_ = this;
-                }
+                fd_ = fd;
+                file_size_ = (uint64_t)st.st_size;
+                fp_ = this;
+            } else {
+                close(fd);
             }
-            close(fd);
         }
     }
-    if (!map_) {
+    if (fd_ < 0) {
         /* gzopen reads plain files transparently */
         fp_ = path == "/dev/stdin" ? (void*)gzdopen(0, "rb") : (void*)gzopen(path.c_str(), "rb");
         if (fp_) gzbuffer((gzFile)fp_, 1 << 20);
-        buf_.resize(cap);
-        win_ = buf_.data();
     }
+    buf_.resize(cap);
+    win_ = buf_.data();
 }
 
 FastqReader::~FastqReader() {
-    if (map_) munmap(map_, map_len_);
+    if (fd_ >= 0) close(fd_);
     else if (fp_) gzclose((gzFile)fp_);
 }
 
 bool FastqReader::pull() {
-    if (eof_ || !fp_ || map_) return false;
+    if (eof_ || !fp_) return false;
     if (pos_ > 0) {
         memmove(buf_.data(), buf_.data() + pos_, len_ - pos_);
         len_ -= pos_;
@@ -125,6 +124,33 @@ bool FastqReader::pull() {
         buf_.resize(buf_.size() * 2); /* one record is larger than the window */
     }
     win_ = buf_.data();
+    if (fd_ >= 0) { /* regular file: every thread preads its slice of the free part of the window */
+        const size_t want = (size_t)min<uint64_t>(buf_.size() - len_, file_size_ - file_pos_);
+        const int T = (int)max<size_t>(1, min<size_t>((size_t)copy_threads_, want / (4u << 20)));
+        vector<std::thread> th;
+        std::atomic<bool> ok{true};
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                size_t a = want / T * t, e = t == T - 1 ? want : want / T * (t + 1);
+                while (a < e) {
+                    const ssize_t n = pread(fd_, buf_.data() + len_ + a, e - a, (off_t)(file_pos_ + a));
+                    if (n <= 0) {
+                        ok = false;
+                        return;
+                    }
+                    a += (size_t)n;
+                }
+            });
+        for (auto& x : th) x.join();
+        if (!ok) {
+            eof_ = true; /* (truncated underneath us: stop with what was read so far) */
+            return true;
+        }
+        len_ += want;
+        file_pos_ += want;
+        if (file_pos_ >= file_size_) eof_ = true;
+        return true;
+    }
     while (len_ < buf_.size()) { /* gzread returns short counts on pipes */
         const size_t want = min<size_t>(buf_.size() - len_, 1u << 30);
         const int n = gzread((gzFile)fp_, buf_.data() + len_, (unsigned)want);
@@ -205,71 +231,202 @@ void FastqReader::copy_records(Batch& b, const vector<Rec>& recs) const {
     for (auto& x : th) x.join();
 }
 
+/* Locate records starting at `pos` (a line start) while they START before `start_limit` and the running totals
+ * stay below the caps; `pos` ends behind the last record taken (skipped non-'@' lines in front of a taken record
+ * are consumed too).  Returns 0 = stopped at a cap / the limit, 1 = the window ran out inside a record (stream
+ * mode: pull and call again), 2 = end of input, 3 = malformed record at `pos` (message in `err`). */
+int FastqReader::scan_records(size_t& pos, size_t start_limit, uint64_t& bases, uint64_t max_bases, uint32_t& reads,
+                              uint32_t max_reads, vector<Rec>& recs, string& err) const {
+    const Line none = {nullptr, 0};
+    while (bases < max_bases && reads < max_reads) {
+        /* one record = the next line that starts with '@' (src/fastqreader.cpp:316-319) and the three lines after
+           it; lines missing at the end of the input read as empty, as getLine() does */
+        Rec rc = {none, none, none, none, 0};
+        size_t p = pos, rec_start = pos;
+        int r;
+        for (;;) {
+            rec_start = p;
+            r = scan_line(p, rc.name);
+            if (r <= 0) break;
+            if (rc.name.n > 0 && rc.name.p[0] == '@') break;
+            pos = p; /* a skipped line is consumed for good */
+        }
+        if (r == 0) return 1;
+        if (r < 0) return 2;
+        if (rec_start >= start_limit) return 0; /* belongs to the next stretch */
+        Line* rest[3] = {&rc.seq, &rc.strand, &rc.qual};
+        for (int k = 0; k < 3; k++) {
+            r = scan_line(p, *rest[k]);
+            if (r == 0) return 1; /* the record continues beyond the window: restart it after reading more */
+            if (r < 0) *rest[k] = none;
+        }
+        if (rc.strand.n == 0 || rc.strand.p[0] != '+') {
+            err = string(rc.name.p, rc.name.n) + "\nExpected '+', got " + string(rc.strand.p ? rc.strand.p : "", rc.strand.n) +
+                  "\nYour FASTQ may be invalid, please check the tail of your FASTQ file\n";
+            return 3;
+        }
+        if (rc.qual.n != rc.seq.n) {
+            err = "ERROR: sequence and quality have different length:\n" + string(rc.name.p, rc.name.n) + "\n" +
+                  string(rc.seq.p ? rc.seq.p : "", rc.seq.n) + "\n" + string(rc.strand.p, rc.strand.n) + "\n" +
+                  string(rc.qual.p ? rc.qual.p : "", rc.qual.n) +
+                  "\nYour FASTQ may be invalid, please check the tail of your FASTQ file\n";
+            return 3;
+        }
+        pos = p;
+        rc.end = p;
+        recs.push_back(rc);
+        bases += rc.seq.n;
+        reads++;
+    }
+    return 0;
+}
+
+static std::atomic<uint64_t> g_parallel_records{0}; /* records taken from the multi-threaded scan (test hook) */
+
+/* first position >= from that starts a line beginning with '@' (what the sequential scan would take next) */
+size_t FastqReader::next_at_line(size_t from) const {
+    size_t p = from;
+    Line ln;
+    for (;;) {
+        const size_t at = p;
+        const int r = scan_line(p, ln);
+        if (r <= 0) return len_;
+        if (ln.n > 0 && ln.p[0] == '@') return at;
+    }
+}
+
+/* Regular files: the stretch of the window that should hold the rest of the batch is cut into one piece per thread.
+ * A thread starts at the first line in its piece that looks like a record header ('@' line whose third line
+ * starts with '+' and whose second and fourth lines are equally long) and locates the records that start in its
+ * piece.  The pieces are then joined in order, but only while thread k's first record is exactly the '@' line the
+ * sequential scan would have taken after thread k-1's last record: anything else (a quality line that passed for
+ * a header, junk between records, a malformed record) ends the join there and the sequential scan carries on, so
+ * the result never differs from the one-thread reader's. */
+void FastqReader::scan_parallel(uint64_t& bases, uint64_t max_bases, uint32_t& reads, uint32_t max_reads, vector<Rec>& recs) {
+    const uint64_t want = max_bases - bases;
+    size_t stretch = (size_t)min<uint64_t>(len_ - pos_, want * 2 + want / 8 + (1u << 20));
+    const int T = (int)min<size_t>((size_t)copy_threads_, stretch / parse_min_);
+    if (T < 2) return;
+    const size_t piece = stretch / T;
+    struct Part {
+        vector<Rec> recs;
+        size_t first = 0, end = 0; /* start of the first record, position behind the last one */
+        uint64_t bases = 0;
+        uint32_t reads = 0;
+        int rc = 0;
+    };
+    vector<Part> parts(T);
+    vector<std::thread> th;
+    for (int k = 0; k < T; k++)
+        th.emplace_back([&, k]() {
+            Part& pt = parts[k];
+            const size_t lo = pos_ + (size_t)k * piece, hi = k == T - 1 ? pos_ + stretch : lo + piece;
+            size_t p = lo;
+            if (k > 0) { /* find a header that validates */
+                Line ln;
+                size_t q = lo;
+                if (lo > 0 && win_[lo - 1] != '\n' && win_[lo - 1] != '\r') scan_line(q, ln); /* finish the line we fell into */
+                for (;;) {
+                    const size_t cand = next_at_line(q);
+                    if (cand >= hi) {
+                        pt.first = pt.end = hi;
+                        pt.rc = -1; /* no record starts in this piece */
+                        return;
+                    }
+                    size_t t = cand;
+                    Line l0, l1, l2, l3;
+                    const bool ok = scan_line(t, l0) == 1 && scan_line(t, l1) == 1 && scan_line(t, l2) == 1 && scan_line(t, l3) == 1 &&
+                                    l2.n > 0 && l2.p[0] == '+' && l1.n == l3.n;
+                    if (ok) {
+                        p = cand;
+                        break;
+                    }
+                    q = cand;
+                    scan_line(q, ln); /* not a header: move past this line */
+                }
+            }
+            pt.first = next_at_line(p);
+            size_t pos = p;
+            string err;
+            pt.rc = scan_records(pos, hi, pt.bases, ~0ull, pt.reads, 0xFFFFFFFFu, pt.recs, err);
+            pt.end = pos;
+        });
+    for (auto& t : th) t.join();
+    /* join in order while the pieces line up with the sequential scan */
+    for (int k = 0; k < T; k++) {
+        Part& pt = parts[k];
+        if (pt.rc == -1) continue; /* (empty piece: the next one must still line up with pos_) */
+        if (next_at_line(pos_) != pt.first || pt.recs.empty()) return;
+        for (const Rec& r : pt.recs) {
+            if (bases >= max_bases || reads >= max_reads) return;
+            recs.push_back(r);
+            g_parallel_records++;
+            bases += r.seq.n;
+            reads++;
+            pos_ = r.end;
+        }
+        if (pt.rc != 0) return; /* end of input or a malformed record: the sequential scan reports it */
+    }
+}
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double g_t_pull = 0, g_t_scan = 0, g_t_copy = 0;
+static const bool g_timing = getenv("FPLH_TIMING") != nullptr;
+struct TimingDump {
+    ~TimingDump() {
+        if (g_timing) fprintf(stderr, "reader phases: refill %.3f s, locate %.3f s, copy %.3f s\n", g_t_pull, g_t_scan, g_t_copy);
+    }
+} g_timing_dump;
+
 uint32_t FastqReader::fill(Batch& b, uint64_t max_bases, uint32_t max_reads) {
     if (b.off.empty()) {
         b.off.push_back(0);
         b.name_off.push_back(0);
     }
     uint32_t added = 0;
-    const Line none = {nullptr, 0};
     vector<Rec> recs;
     uint64_t bases = b.seq.size();
     uint32_t reads = b.n();
     bool end = false;
     while (!end && !malformed_ && bases < max_bases && reads < max_reads) {
-        /* locate the records of the current window (mapped file: of the next stretch of it) */
         recs.clear();
-        bool need_more = false;
-        while (bases < max_bases && reads < max_reads) {
-            /* one record = the next line that starts with '@' (src/fastqreader.cpp:316-319) and the three lines
-               after it; lines missing at the end of the input read as empty, as getLine() does */
-            Rec rc = {none, none, none, none};
-            size_t p = pos_;
-            int r;
-            for (;;) {
-                r = scan_line(p, rc.name);
-                if (r <= 0) break;
-                if (rc.name.n > 0 && rc.name.p[0] == '@') break;
-                pos_ = p; /* a skipped line is consumed for good */
+        if (fd_ >= 0 && max_bases < (1ull << 40) && !eof_) { /* have the stretch this batch needs in the window */
+            const uint64_t want = max_bases - bases;
+            const size_t stretch = (size_t)min<uint64_t>(file_size_ - (file_pos_ - (len_ - pos_)), want * 2 + want / 8 + (1u << 20));
+            if (len_ - pos_ < stretch) {
+                if (buf_.size() < stretch + (16u << 20)) { /* grow the window once (it is reused for every batch) */
+                    vector<char> nb(stretch + (16u << 20));
+                    memcpy(nb.data(), buf_.data() + pos_, len_ - pos_);
+                    len_ -= pos_;
+                    pos_ = 0;
+                    buf_.swap(nb);
+                    win_ = buf_.data();
+                }
+                const double t0 = now_s();
+                pull();
+                g_t_pull += now_s() - t0;
             }
-            if (r == 0) {
-                need_more = true;
-                break;
-            }
-            if (r < 0) {
-                end = true;
-                break;
-            }
-            Line* rest[3] = {&rc.seq, &rc.strand, &rc.qual};
-            for (int k = 0; k < 3 && !need_more; k++) {
-                r = scan_line(p, *rest[k]);
-                if (r == 0) need_more = true;
-                else if (r < 0) *rest[k] = none;
-            }
-            if (need_more) break; /* the record continues beyond the window: restart it after reading more */
-            if (rc.strand.n == 0 || rc.strand.p[0] != '+') {
-                cerr << string(rc.name.p, rc.name.n) << endl
-                     << "Expected '+', got " << string(rc.strand.p ? rc.strand.p : "", rc.strand.n) << endl
-                     << "Your FASTQ may be invalid, please check the tail of your FASTQ file" << endl;
-                malformed_ = true;
-                break;
-            }
-            if (rc.qual.n != rc.seq.n) {
-                cerr << "ERROR: sequence and quality have different length:" << endl << string(rc.name.p, rc.name.n) << endl
-                     << string(rc.seq.p ? rc.seq.p : "", rc.seq.n) << endl << string(rc.strand.p, rc.strand.n) << endl
-                     << string(rc.qual.p ? rc.qual.p : "", rc.qual.n) << endl
-                     << "Your FASTQ may be invalid, please check the tail of your FASTQ file" << endl;
-                malformed_ = true;
-                break;
-            }
-            pos_ = p;
-            recs.push_back(rc);
-            bases += rc.seq.n;
-            reads++;
         }
+        const double t1 = now_s();
+        /* (only when the batch is cut by bases: with a small read cap the stretch to scan cannot be sized) */
+        if (fd_ >= 0 && copy_threads_ > 1 && max_bases < (1ull << 40) && max_reads - reads >= (1u << 24))
+            scan_parallel(bases, max_bases, reads, max_reads, recs);
+        /* locate the (remaining) records of the current window sequentially */
+        string err;
+        const int rc = scan_records(pos_, len_, bases, max_bases, reads, max_reads, recs, err);
+        const double t2 = now_s();
         copy_records(b, recs); /* before the window moves */
+        g_t_scan += t2 - t1;
+        g_t_copy += now_s() - t2;
         added += (uint32_t)recs.size();
-        if (need_more && !pull()) end = true;
+        if (rc == 3) {
+            cerr << err;
+            malformed_ = true;
+        } else if (rc == 2) {
+            end = true;
+        } else if (rc == 1 && !pull()) {
+            end = true;
+        }
     }
     return added;
 }
@@ -417,6 +574,26 @@ void* fplh_batch_read(const char* path, uint64_t max_bases, uint32_t max_reads) 
     }
     return b;
 }
+/* test hook: the whole file through repeated fill() calls of the given caps, concatenated */
+void* fplh_batch_read_all(const char* path, uint64_t max_bases, uint32_t max_reads) {
+    fplh::FastqReader rd(path);
+    if (!rd.ok()) return nullptr;
+    fplh::Batch* all = new fplh::Batch();
+    all->off.push_back(0);
+    all->name_off.push_back(0);
+    for (;;) {
+        fplh::Batch t;
+        if (rd.fill(t, max_bases, max_reads) == 0) break;
+        const size_t o = all->seq.size();
+        all->seq.resize_uninit(o + t.seq.size());
+        all->qual.resize_uninit(o + t.seq.size());
+        memcpy(all->seq.data() + o, t.seq.data(), t.seq.size());
+        memcpy(all->qual.data() + o, t.qual.data(), t.seq.size());
+        for (uint32_t i = 0; i < t.n(); i++) all->off.push_back(o + t.off[i + 1]);
+    }
+    return all;
+}
+uint64_t fplh_parallel_records(void) { return fplh::g_parallel_records.exchange(0); }
 uint32_t fplh_batch_n(void* b) { return ((fplh::Batch*)b)->n(); }
 uint64_t fplh_batch_bytes(void* b) { return ((fplh::Batch*)b)->seq.size(); }
 const uint8_t* fplh_batch_seq(void* b) { return ((fplh::Batch*)b)->seq.data(); }

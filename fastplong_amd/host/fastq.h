@@ -82,22 +82,28 @@ class FastqReader {
     };
     struct Rec {
         Line name, seq, strand, qual;
+        size_t end; /* window position behind the record's last line terminator */
     };
-    /* The input is scanned in place (one SIMD pass for both terminators): a regular uncompressed file is mapped
-     * whole, anything else (gzip, pipes) streams through one large window that is refilled behind the
-     * unconsumed tail.  fill() first only LOCATES the records of a stretch of the window, then copies their
+    /* The input is scanned in place (one SIMD pass for both terminators) in one large window that is refilled
+     * behind the unconsumed tail: by gzread for gzip and pipes, by parallel pread for a regular uncompressed
+     * file (whose window grows to hold a whole batch, so that the scan can be split over threads too).  fill() first only LOCATES the records of a stretch of the window, then copies their
      * lines into the batch on copy_threads_ threads.  scan_line: 1 = a line, 0 = the window ends inside the
      * line and more input exists, -1 = end of input with nothing left. */
     int scan_line(size_t& pos, Line& ln) const;
+    int scan_records(size_t& pos, size_t start_limit, uint64_t& bases, uint64_t max_bases, uint32_t& reads,
+                     uint32_t max_reads, std::vector<Rec>& recs, std::string& err) const;
+    size_t next_at_line(size_t from) const;
+    void scan_parallel(uint64_t& bases, uint64_t max_bases, uint32_t& reads, uint32_t max_reads, std::vector<Rec>& recs);
     bool pull(); /* stream mode: keep [pos_, len_), read more behind it (growing the window when a record fills it) */
     void copy_records(Batch& b, const std::vector<Rec>& recs) const;
-    void* fp_ = nullptr;       /* gzFile (stream mode) or a non-null token (mapped mode) */
-    const char* win_ = nullptr; /* the window: buf_.data() or the mapping */
+    void* fp_ = nullptr;       /* gzFile (gzip, pipes) or a non-null token (regular file, fd_) */
+    const char* win_ = nullptr; /* the window: buf_.data() */
     std::vector<char> buf_;
-    void* map_ = nullptr;
-    size_t map_len_ = 0;
+    int fd_ = -1;              /* regular uncompressed file: refilled with parallel pread */
+    uint64_t file_size_ = 0, file_pos_ = 0;
     size_t pos_ = 0, len_ = 0;
     int copy_threads_ = 1;
+    size_t parse_min_ = 8u << 20; /* smallest piece worth a scanning thread (FPLH_PARSE_MIN: test hook) */
     bool eof_ = false, malformed_ = false;
 };
 
@@ -127,6 +133,8 @@ void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threa
 extern "C" {
 /* test hooks: parse a FASTQ file into CSR arrays; format a batch from result records */
 void* fplh_batch_read(const char* path, uint64_t max_bases, uint32_t max_reads);
+void* fplh_batch_read_all(const char* path, uint64_t max_bases, uint32_t max_reads);
+uint64_t fplh_parallel_records(void); /* records the multi-threaded scan contributed since the last call */
 uint32_t fplh_batch_n(void* b);
 uint64_t fplh_batch_bytes(void* b);
 const uint8_t* fplh_batch_seq(void* b);

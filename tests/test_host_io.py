@@ -90,6 +90,65 @@ def test_fastq_reader_refills_anywhere(hostlib, tmp_path, monkeypatch, window, e
     assert np.array_equal(o2, off) and np.array_equal(s2, seq) and np.array_equal(q2, qual)
 
 
+def _read_all(L, path, mb, mr):
+    L.fplh_batch_read_all.restype = C.c_void_p
+    L.fplh_batch_read_all.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32]
+    b = L.fplh_batch_read_all(str(path).encode(), mb, mr)
+    assert b
+    n, nb = L.fplh_batch_n(b), L.fplh_batch_bytes(b)
+    seq = np.ctypeslib.as_array(C.cast(L.fplh_batch_seq(b), C.POINTER(C.c_uint8)), (max(nb, 1),))[:nb].copy()
+    qual = np.ctypeslib.as_array(C.cast(L.fplh_batch_qual(b), C.POINTER(C.c_uint8)), (max(nb, 1),))[:nb].copy()
+    off = np.ctypeslib.as_array(C.cast(L.fplh_batch_off(b), C.POINTER(C.c_uint64)), (n + 1,)).copy()
+    L.fplh_batch_free(b)
+    return seq, qual, off
+
+
+@pytest.mark.parametrize("variant", ["clean", "crlf", "junk", "malformed", "at_quals"])
+@pytest.mark.parametrize("caps", [(10 ** 9, 2 ** 30), (30000, 2 ** 30), (5000, 2 ** 30)])
+def test_parallel_scan_equals_sequential(hostlib, tmp_path, monkeypatch, variant, caps):
+    """mapped files are scanned by several threads, each starting at a header it had to guess; the pieces are
+    only joined where they line up with the one-thread scan, so the result can never differ from it"""
+    rng = np.random.default_rng(21)
+    reads = []
+    for _ in range(300):
+        n = int(rng.integers(1, 700))
+        q = rng.integers(33, 75, n).astype(np.uint8)
+        if variant == "at_quals" or rng.random() < 0.3:
+            q[0] = ord("@")  # a quality line that starts like a header
+            if n > 1 and rng.random() < 0.5:
+                q[1] = ord("+")
+        reads.append((synth._ACGT[rng.integers(0, 4, n)].astype(np.uint8), q))
+    seq, qual, off = synth.pack(reads)
+    text, _, _ = hostio.make_fastq(seq, qual, off, crlf=(variant == "crlf"), strand_names=True)
+    if variant == "junk":
+        lines = text.split(b"\n")
+        for i in range(40, len(lines) - 8, 41 * 4):  # stray lines between records
+            lines[i:i] = [b"stray line", b"", b"+not a record"]
+        text = b"\n".join(lines)
+    if variant == "malformed":
+        lines = text.split(b"\n")
+        lines[4 * 150 + 2] = b"-"  # the '+' line of record 150
+        text = b"\n".join(lines)
+    p = tmp_path / "in.fq"
+    p.write_bytes(text)
+    monkeypatch.setenv("FPLH_PARSE_THREADS", "1")
+    want = _read_all(hostlib, p, *caps)
+    monkeypatch.setenv("FPLH_PARSE_MIN", "512")
+    for threads in ("2", "7"):
+        monkeypatch.setenv("FPLH_PARSE_THREADS", threads)
+        hostlib.fplh_parallel_records.restype = C.c_uint64
+        hostlib.fplh_parallel_records()
+        got = _read_all(hostlib, p, *caps)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        if variant in ("clean", "crlf"):  # nearly every record came from the threads, not from the sequential tail
+            assert hostlib.fplh_parallel_records() > 0.8 * (len(want[2]) - 1)
+    if variant == "malformed":
+        assert len(want[2]) - 1 == 150
+    elif variant != "junk":
+        assert np.array_equal(want[2], off)
+
+
 def test_format_batch_matches_python_composition(orc, hostlib, tmp_path):
     cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1, complexity_filter=1),
                      synth.START_ADAPTER, synth.END_ADAPTER)
