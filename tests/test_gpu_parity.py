@@ -177,10 +177,11 @@ def test_random_option_sets_bit_exact(orc, engine_mod, seed):
 
 
 def test_very_long_reads_bit_exact(orc, engine_mod):
-    """BASELINE configs[3] goes up to 200 kb per read: many cycle tiles, long histories in every kernel"""
+    """BASELINE configs[3] goes up to 200 kb per read, ultra-long ONT reads beyond a megabase: thousands of cycle
+    tiles, long histories in every kernel"""
     rng = np.random.default_rng(77)
     reads = []
-    for L in (262144, 200000, 131073, 65536, 65535, 9000, 50):
+    for L in (1200000, 262144, 200000, 131073, 65536, 65535, 9000, 50):  # (ultra-long ONT reads exceed a megabase)
         s, q, o = synth.ont_like(1, seed=int(L) % 1000, median_len=L, sigma_len=0.0, min_len=L, max_len=L, p_middle=1.0)
         reads.append((s[:int(o[1])], q[:int(o[1])]))
     for _ in range(40):
