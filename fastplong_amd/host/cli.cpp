@@ -10,7 +10,7 @@
  * counter buffers are summed with one RCCL all-reduce (the replacement of Stats::merge /
  * FilterResult::merge, src/seprocessor.cpp:108-121) and rank 0's copy feeds the reports.
  *
- * Not implemented (SURVEY.md section 8f "next" rows): --split*, the HTML report.
+ * Not implemented (SURVEY.md section 8f "next" rows): --split*.
  */
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -271,7 +271,13 @@ int main(int argc, char* argv[]) {
         error_exit("the window size of --mask / --break must be positive");
     const bool fragmentMode = o.mask_enabled || o.break_enabled;
     if (cmd.exist("split") || cmd.exist("split_by_lines")) error_exit("--split / --split_by_lines are not implemented in fastplong_amd");
-    const string jsonFile = cmd.str("json");
+    const string jsonFile = cmd.str("json"), htmlFile = cmd.str("html");
+    int workers = cmd.i("thread"); /* Options::validate, src/options.cpp:120-125: only the HTML report's point order sees it */
+    if (workers < 1) workers = 1;
+    else if (workers > 16) {
+        cerr << "WARNING: fastp uses up to 16 threads although you specified " << workers << endl;
+        workers = 16;
+    }
     const int nGpus = max(1, cmd.i("gpus"));
     const uint64_t batchBases = (uint64_t)max(1L, cmd.l("batch_mbases")) * 1000000ull;
     const uint32_t batchReads = cmd.l("batch_reads") > 0 ? (uint32_t)cmd.l("batch_reads") : 0x3FFFFFFFu;
@@ -478,6 +484,26 @@ int main(int argc, char* argv[]) {
             }
             doneq.push(nullptr);
         });
+    fplh::HtmlInputs page; /* per-read lengths and median qualities: what Stats keeps beyond the counters */
+    page.threads = workers;
+    page.title = cmd.str("report_title");
+    uint64_t readBase = 0;
+    auto note_reads = [&](const Work& w) {
+        const uint32_t n = w.batch.n();
+        for (uint32_t i = 0; i < n; i++) {
+            const uint8_t wk = fplh::ReadLists::worker_of(readBase + i, workers);
+            const fpl_read_result& r = w.res[i];
+            page.pre.add(wk, (int32_t)(w.batch.off[i + 1] - w.batch.off[i]), r.median_q_pre);
+            if (!fragmentMode)
+                for (int f = 0; f < r.n_frag; f++)
+                    if (r.code[f] == FPL_PASS_FILTER) page.post.add(wk, (int32_t)r.frag_len[f], r.median_q_post[f]);
+        }
+        if (fragmentMode)
+            for (const fpl_fragment& fr : w.frags.frags)
+                if (fr.code == FPL_PASS_FILTER)
+                    page.post.add(fplh::ReadLists::worker_of(readBase + fr.read, workers), (int32_t)fr.len, fr.median_q);
+        readBase += n;
+    };
     { /* writer: this thread, in input order */
         map<uint64_t, Work*> ready;
         uint64_t next = 0;
@@ -496,6 +522,7 @@ int main(int argc, char* argv[]) {
                 const double t0 = now();
                 if (fout) write_pieces(fout, r->outs);
                 if (ffail) write_pieces(ffail, r->faileds);
+                note_reads(*r);
                 tWrite += now() - t0;
                 next++;
                 freeq.push(r);
@@ -564,9 +591,11 @@ int main(int argc, char* argv[]) {
     ri.command = command;
     cerr << fplh::summary_text(ri);
     if (!fplh::write_json(jsonFile, ri)) error_exit("Failed to write: " + jsonFile);
+    if (!fplh::write_html(htmlFile, ri, page)) error_exit("Failed to write: " + htmlFile);
 
     time_t t2 = time(NULL);
     cerr << endl << "JSON report: " << jsonFile << endl;
+    cerr << "HTML report: " << htmlFile << endl;
     cerr << endl << command << endl;
     cerr << "fastplong v0.4.1 (fastplong_amd), time used: " << (t2) - t1 << " seconds" << endl;
     return 0;

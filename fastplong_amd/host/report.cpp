@@ -1,6 +1,7 @@
 /* report.cpp -- see report.h.  Formatting goes through std::ostream exactly like the reference
  * (default precision, `endl`, tabs), so the bytes match as long as the numbers do. */
 #include "report.h"
+#include "report_internal.h"
 
 #include <fstream>
 #include <iostream>
@@ -12,27 +13,9 @@ using namespace std;
 namespace fplh {
 
 namespace {
-
-/* per-cycle accessors on one Stats block, cls = base ASCII & 7 */
-struct StatsBlock {
-    const int64_t* st;
-    uint32_t C;
-    long cyc(uint32_t c, int kind, int cls) const { return st[FPL_ST_CYC(c, kind, cls)]; }
-    long total_base(uint32_t c) const {
-        long t = 0;
-        for (int b = 0; b < 8; b++) t += cyc(c, 0, b);
-        return t;
-    }
-    long total_qual(uint32_t c) const {
-        long t = 0;
-        for (int b = 0; b < 8; b++) t += cyc(c, 1, b);
-        return t;
-    }
-    long base_qual_hist(int q) const { return st[FPL_ST_BASE_QUAL_HIST(C) + q]; }
-    long kmer(int i) const { return st[FPL_ST_KMER(C) + i]; }
-    long reads() const { return st[FPL_ST_READS(C)]; }
-    long length_sum() const { return st[FPL_ST_LENGTH_SUM(C)]; }
-};
+using detail::StatsBlock;
+using detail::kmer2;
+using detail::kmer3;
 
 /* adapter strings ordered by (length, then lexicographic): struct classcomp, src/filterresult.h:14-23 */
 struct ByLenThenLex {
@@ -41,22 +24,6 @@ struct ByLenThenLex {
         return a < b;
     }
 };
-
-string kmer3(int val, bool is_rna) { /* Stats::kmer3 / kmer2, src/stats.cpp:826-845 */
-    const char bases[4] = {'A', is_rna ? 'U' : 'T', 'C', 'G'};
-    string ret(3, ' ');
-    ret[0] = bases[(val & 0x30) >> 4];
-    ret[1] = bases[(val & 0x0C) >> 2];
-    ret[2] = bases[(val & 0x03)];
-    return ret;
-}
-string kmer2(int val, bool is_rna) {
-    const char bases[4] = {'A', is_rna ? 'U' : 'T', 'C', 'G'};
-    string ret(2, ' ');
-    ret[0] = bases[(val & 0x0C) >> 2];
-    ret[1] = bases[(val & 0x03)];
-    return ret;
-}
 
 /* Stats::reportJson, src/stats.cpp:473-548 (curves from Stats::summarize, :204-244) */
 void stats_json(ofstream& ofs, const string& padding, const StatsBlock& s, const StatsSummary& sm, bool is_rna) {

@@ -23,6 +23,8 @@
  *   JSON block: J_BEGIN threads seqlen isrna adapter_enabled polyx complexity =start =end
  *               J_PRE =seq =qual | J_POST =seq =qual | J_FR code | J_AD =key | J_ART bases
  *               | J_PXT base len | J_END =path   -> Stats/FilterResult/JsonReporter::report
+ *               | J_ENDH lf maxlen =json =html =title words...  -> the same plus calcLengthHistogram and
+ *                 HtmlReporter::report (lf / maxlen = Options::lengthFilter.enabled / .maxLength)
  */
 #include <cstdio>
 #include <cstring>
@@ -35,6 +37,7 @@
 #include "editdistance.h"
 #include "filter.h"
 #include "filterresult.h"
+#include "htmlreporter.h"
 #include "jsonreporter.h"
 #include "options.h"
 #include "polyx.h"
@@ -224,15 +227,32 @@ int main() {
             job.fr[cur_thread]->addReadTrimmed(atoi(t[1].c_str()));
         } else if (op == "J_PXT") {
             job.fr[cur_thread]->addPolyXTrimmed(atoi(t[1].c_str()), atoi(t[2].c_str()));
-        } else if (op == "J_END") {
-            job.opt.jsonFile = str(t[1]);
+        } else if (op == "J_END" || op == "J_ENDH") {
+            const bool html = op == "J_ENDH";
+            job.opt.jsonFile = str(t[html ? 3 : 1]);
+            if (html) {
+                job.opt.lengthFilter.enabled = atoi(t[1].c_str());
+                job.opt.lengthFilter.maxLength = atoi(t[2].c_str());
+                job.opt.htmlFile = str(t[4]);
+                string title = str(t[5]);
+                for (size_t i = 6; i < t.size(); i++) title += " " + t[i];
+                job.opt.reportTitle = title;
+            }
             /* what SingleEndProcessor::process does after the join, src/seprocessor.cpp:108-142 */
             Stats* finalPre = Stats::merge(job.pre);
             Stats* finalPost = Stats::merge(job.post);
+            if (html) {
+                finalPre->calcLengthHistogram();
+                finalPost->calcLengthHistogram();
+            }
             FilterResult* finalFr = FilterResult::merge(job.fr);
             command = "";
             JsonReporter jr(&job.opt);
             jr.report(finalFr, finalPre, finalPost);
+            if (html) {
+                HtmlReporter hr(&job.opt);
+                hr.report(finalFr, finalPre, finalPost);
+            }
             delete finalPre;
             delete finalPost;
             delete finalFr;

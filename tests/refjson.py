@@ -1,14 +1,20 @@
 """Replay a run's per-read outcome into the REAL reference Stats / FilterResult / JsonReporter
 objects (oracle/_ref/ref_harness) and let the reference write fastplong.json."""
+import re
+
 import numpy as np
 
 from fastplong_amd import abi
 
 
-def reference_json(ref, path, cfg, seq, qual, off, res, counters, c, threads, is_rna=False, frags=None, regs=None):
+STAMP = re.compile(rb"\d{4}-\d\d-\d\d      \d\d:\d\d:\d\d")  # HtmlReporter::getCurrentSystemTime
+
+
+def reference_json(ref, path, cfg, seq, qual, off, res, counters, c, threads, is_rna=False, frags=None, regs=None,
+                   html=None, title="fastplong report"):
     """replay the oracle's per-read outcome into the reference's own Stats / FilterResult objects
     (pre reads, passing fragments, filter codes, adapter keys, polyX) and let the reference write
-    the JSON."""
+    the JSON (and, with `html`, the HTML report through the real HtmlReporter)."""
     s = ref.s
     v = abi.CountersView(counters, c, cfg.n_adapters)
     lines = ["J_BEGIN %d %d %d %d %d %d %s %s" % (threads, 0, int(is_rna), cfg.opt.adapter_enabled, cfg.opt.polyx,
@@ -52,7 +58,10 @@ def reference_json(ref, path, cfg, seq, qual, off, res, counters, c, threads, is
                 fa = int(r["frag_start"][f])
                 fb = fa + int(r["frag_len"][f])
                 lines.append("J_POST %s %s" % (s(rs[fa:fb]), s(rq[fa:fb])))
-    lines.append("J_END %s" % s(path))
+    if html is None:
+        lines.append("J_END %s" % s(path))
+    else:
+        lines.append("J_ENDH %d %d %s %s %s" % (cfg.opt.length_filter, cfg.opt.max_length, s(path), s(html), "=" + title))  # the title may hold spaces: last field
     out = ref.run(lines)
     assert out.strip().endswith("OK"), out[-200:]
 

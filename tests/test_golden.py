@@ -1,17 +1,19 @@
 """Committed golden fixtures (tests/golden/*, produced by tests/golden/make_golden.py from the
 oracle + the real reference report writer).  CPU: the oracle and the host formatter reproduce
 them.  GPU (-m gpu): the `fastplong_amd` CLI -- FASTQ in, HIP path through the C-ABI, FASTQ +
-fastplong.json out -- reproduces them byte for byte (JSON modulo the `command` line)."""
+fastplong.json + fastplong.html out -- reproduces them byte for byte (reports modulo the `command` line and the
+HTML time stamps)."""
 import gzip
 import json
 import os
+import re
 import subprocess
 
 import numpy as np
 import pytest
 
 from fastplong_amd import abi, build, synth
-from tests import hostio
+from tests import hostio, refjson
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
@@ -97,7 +99,7 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
     flags = [f if f != "ADAPTERS.fa" else os.path.join(GOLD, case, "ADAPTERS.fa") for f in meta["flags"]]
     cmd = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "--failed_out", str(tmp_path / "failed.fq"),
-           "-j", str(tmp_path / "out.json"), "--batch_reads", batch_reads] + flags
+           "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"), "--batch_reads", batch_reads] + flags
     if batch_reads != "0":
         cmd += ["--reads_to_process", str(meta["reads"])]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
@@ -107,7 +109,11 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     got = [l for l in (tmp_path / "out.json").read_bytes().split(b"\n") if not l.startswith(b'\t"command":')]
     want = gz(os.path.join(GOLD, case, "expected.json.gz")).split(b"\n")
     assert got == want
-    assert b"reads passed filter: " in p.stderr
+    # the HTML report against the real HtmlReporter's page (default -w 3; time stamps and the command line masked)
+    page = refjson.STAMP.sub(b"<time>", (tmp_path / "out.html").read_bytes())
+    page = re.sub(rb"<div id='footer'> <p>.*?</p>", b"<div id='footer'> <p></p>", page, flags=re.S)
+    assert page == gz(os.path.join(GOLD, case, "expected.html.gz"))
+    assert b"reads passed filter: " in p.stderr and b"HTML report: " in p.stderr
 
 
 @pytest.mark.gpu
@@ -117,7 +123,8 @@ def test_cli_gzip_outputs_on_gpu(tmp_path):
     build.build_all()
     meta = json.load(open(os.path.join(GOLD, case, "case.json")))
     cmd = [build.CLI, "-i", os.path.join(GOLD, case, "in.fq.gz"), "-o", str(tmp_path / "out.fq.gz"), "--failed_out",
-           str(tmp_path / "failed.fq.gz"), "-j", str(tmp_path / "out.json"), "-z", "6", "--batch_reads", "50"] + meta["flags"]
+           str(tmp_path / "failed.fq.gz"), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"), "-z", "6",
+           "--batch_reads", "50"] + meta["flags"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert gz(str(tmp_path / "out.fq.gz")) == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
@@ -143,7 +150,8 @@ def test_cli_detects_adapters_when_left_at_auto(tmp_path):
     text, _, _ = hostio.make_fastq(seq, qual, off)
     inp = tmp_path / "in.fq"
     inp.write_bytes(text)
-    p = subprocess.run([build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "-j", str(tmp_path / "out.json")],
+    p = subprocess.run([build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "-j", str(tmp_path / "out.json"), "-h",
+                        str(tmp_path / "out.html")],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     err = p.stderr.decode()

@@ -1,0 +1,165 @@
+"""fastplong.html: the host report writer (fastplong_amd/host/report_html.cpp, working from the flat counter
+buffer plus the per-read length / median-quality lists) against the REAL reference HtmlReporter + Stats +
+FilterResult objects in oracle/_ref, byte for byte (both sides leave `command` empty; the two time stamps are
+masked)."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+from fastplong_amd import abi, build, synth
+from tests.refjson import STAMP, reference_json
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    build.build_host()
+    L = C.CDLL(build.HOST_LIB)
+    L.fplh_write_html.restype = C.c_int
+    L.fplh_write_html.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_char_p,
+                                  C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+    return L
+
+
+def read_lists(off, res, frags=None):
+    """(read index, length, median quality char) of every input read and of every output read"""
+    n = len(off) - 1
+    lens = np.diff(off.astype(np.int64)).astype(np.int32)
+    pre = (np.arange(n, dtype=np.uint32), lens, res["median_q_pre"].astype(np.uint8))
+    r, l, m = [], [], []
+    if frags is None:
+        for i in range(n):
+            for f in range(int(res[i]["n_frag"])):
+                if res[i]["code"][f] == abi.FPL_PASS_FILTER:
+                    r.append(i), l.append(int(res[i]["frag_len"][f])), m.append(int(res[i]["median_q_post"][f]))
+    else:
+        for fr in frags:
+            if fr["code"] == abi.FPL_PASS_FILTER:
+                r.append(int(fr["read"])), l.append(int(fr["len"])), m.append(int(fr["median_q"]))
+    post = (np.array(r, dtype=np.uint32), np.array(l, dtype=np.int32), np.array(m, dtype=np.uint8))
+    return pre, post
+
+
+def write_html(L, path, counters, c, adapters, opt, pre, post, threads, is_rna=False, title="fastplong report", stamp=None):
+    n = len(adapters)
+    arr = (C.c_char_p * n)(*adapters)
+    lens = (C.c_int * n)(*[len(a) for a in adapters])
+    keep = [np.ascontiguousarray(x) for x in (*pre, *post)]
+    rc = L.fplh_write_html(path.encode(), counters.ctypes.data, c, n, arr, lens, opt.adapter_enabled, opt.polyx,
+                           opt.complexity_filter, int(is_rna), opt.length_filter, opt.max_length, b"", threads, title.encode(),
+                           stamp, len(keep[0]), keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data,
+                           len(keep[3]), keep[3].ctypes.data, keep[4].ctypes.data, keep[5].ctypes.data)
+    assert rc == 0
+
+
+DENSITY = re.compile(rb"var density=\{x:\[([^\]]*)\],y:\[([^\]]*)\]")
+
+
+def mask_density_tails(page, empties):
+    """The reference sizes the density plot's arrays by mReads but fills one slot per NON-EMPTY read
+    (src/stats.cpp:676-686): with E empty reads its last E x and y entries are uninitialised heap memory.
+    Blank those on both sides (block 0 = before filtering, 1 = after)."""
+    it = iter(empties)
+
+    def fix(m):
+        e = next(it)
+        cut = lambda t: b",".join(t.split(b",")[:-e] + [b"?"] * e) if e else t  # noqa: E731
+        return b"var density={x:[" + cut(m.group(1)) + b"],y:[" + cut(m.group(2)) + b"]"
+    return DENSITY.sub(fix, page)
+
+
+def assert_same_page(mine, theirs, empties=(0, 0)):
+    a, b = STAMP.sub(b"<t>", open(mine, "rb").read()), STAMP.sub(b"<t>", open(theirs, "rb").read())
+    a, b = mask_density_tails(a, empties), mask_density_tails(b, empties)
+    assert a.count(b"<t>") == 2 and b.count(b"<t>") == 2
+    assert len(a) > 20000
+    if a != b:
+        la, lb = a.split(b"\n"), b.split(b"\n")
+        for i, (x, y) in enumerate(zip(la, lb)):
+            if x != y:
+                k = next((j for j in range(min(len(x), len(y))) if x[j] != y[j]), min(len(x), len(y)))
+                raise AssertionError("line %d col %d:\n mine %r\n ref  %r" % (i, k, x[max(0, k - 80):k + 80], y[max(0, k - 80):k + 80]))
+        assert len(la) == len(lb)
+
+
+CASES = [
+    # name, options, worker threads, RNA, reads, title
+    ("full", dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1), 3, False, 300,
+     "fastplong report"),
+    ("one_worker", dict(), 1, False, 200, "my run, second try"),
+    ("sixteen_workers_max_length", dict(max_length=2500, adapter_enabled=0), 16, False, 700, "x"),
+    ("rna_no_length_filter", dict(polyx=1, length_filter=0), 2, True, 150, "fastplong report"),
+]
+
+
+@pytest.mark.parametrize("name,okw,threads,is_rna,n,title", CASES)
+def test_html_matches_reference_writer(orc, ref, hostlib, tmp_path, name, okw, threads, is_rna, n, title):
+    cfg = orc.Config(abi.FplOptions.default(**okw), synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = synth.adversarial(n, seed=len(name))
+    if is_rna:
+        seq = seq.copy()
+        seq[seq == ord("T")] = ord("U")
+    c = int(np.diff(off.astype(np.int64)).max())
+    res, counters = orc.process_batch(cfg, seq, qual, off, max_cycles=c + 5)
+    c += 5
+    mine, theirs = str(tmp_path / "mine.html"), str(tmp_path / "ref.html")
+    pre, post = read_lists(off, res)
+    write_html(hostlib, mine, counters, c, cfg.adapter_list(), cfg.opt, pre, post, threads, is_rna, title)
+    reference_json(ref, str(tmp_path / "ref.json"), cfg, seq, qual, off, res, counters, c, threads, is_rna, html=theirs, title=title)
+    assert_same_page(mine, theirs, (int((pre[1] == 0).sum()), int((post[1] == 0).sum())))
+
+
+def test_html_short_reads_and_break_mask(orc, ref, hostlib, tmp_path):
+    """<= 300 cycles takes the unsampled branch of the curve plots; --break / --mask output reads come from the
+    fragment list (their bases carry the N of maskRegionWithN, which the k-mer table must reflect)."""
+    rng = np.random.default_rng(11)
+    lens = rng.integers(30, 280, size=400)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(off[-1]))
+    qual = (33 + np.clip(rng.normal(16, 9, size=int(off[-1])), 2, 50)).astype(np.uint8)
+    cfg = orc.Config(abi.FplOptions.default(break_enabled=1, break_window=20, break_quality=12, mask_enabled=1, mask_window=10,
+                                            mask_quality=9, required_length=15), synth.START_ADAPTER, synth.END_ADAPTER)
+    res, counters, frags, regs = orc.process_batch_ex(cfg, seq, qual, off, max_cycles=300)
+    pre, post = read_lists(off, res, frags)
+    mine, theirs = str(tmp_path / "mine.html"), str(tmp_path / "ref.html")
+    write_html(hostlib, mine, counters, 300, cfg.adapter_list(), cfg.opt, pre, post, 3)
+    reference_json(ref, str(tmp_path / "ref.json"), cfg, seq, qual, off, res, counters, 300, 3, frags=frags, regs=regs, html=theirs)
+    assert_same_page(mine, theirs)
+
+
+def test_html_fixed_timestamp_and_command(orc, hostlib, tmp_path):
+    cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = synth.adversarial(40, seed=2)
+    c = int(np.diff(off.astype(np.int64)).max())
+    res, counters = orc.process_batch(cfg, seq, qual, off, max_cycles=c)
+    pre, post = read_lists(off, res)
+    p = str(tmp_path / "a.html")
+    write_html(hostlib, p, counters, c, cfg.adapter_list(), cfg.opt, pre, post, 3, stamp=b"2025-01-02      03:04:05")
+    page = open(p, "rb").read()
+    assert page.count(b"2025-01-02      03:04:05") == 2
+    assert page.startswith(b"<html><head><meta http-equiv=\"content-type\"") and page.endswith(b"</div></body></html>")
+
+
+def test_html_reproduces_golden_fixtures(orc, hostlib, tmp_path):
+    """tests/golden/*/expected.html.gz (the real HtmlReporter's pages, committed) from the counters alone: runs
+    where /root/reference does not exist"""
+    import os
+
+    from tests import test_golden as tg
+    for case in tg.CASES:
+        okw, start, end = tg.OPTS[case]
+        seq, qual, off, _, _ = tg.parse_fastq(tg.gz(os.path.join(tg.GOLD, case, "in.fq.gz")))
+        cfg = orc.Config(abi.FplOptions.default(**okw), start, end, tg.fasta_list(case))
+        c = int(np.diff(off.astype(np.int64)).max())
+        frags = None
+        if cfg.opt.break_enabled or cfg.opt.mask_enabled:
+            res, counters, frags, _ = orc.process_batch_ex(cfg, seq, qual, off, max_cycles=c)
+        else:
+            res, counters = orc.process_batch(cfg, seq, qual, off, max_cycles=c)
+        pre, post = read_lists(off, res, frags)
+        p = str(tmp_path / (case + ".html"))
+        write_html(hostlib, p, counters, c, cfg.adapter_list(), cfg.opt, pre, post, 3)
+        assert STAMP.sub(b"<time>", open(p, "rb").read()) == tg.gz(os.path.join(tg.GOLD, case, "expected.html.gz")), case
