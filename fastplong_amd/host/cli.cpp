@@ -10,7 +10,8 @@
  * counter buffers are summed with one RCCL all-reduce (the replacement of Stats::merge /
  * FilterResult::merge, src/seprocessor.cpp:108-121) and rank 0's copy feeds the reports.
  *
- * Not implemented (SURVEY.md section 8f "next" rows): --split*.
+ * --split / --split_by_lines replay what the reference's workers do with their private writers
+ * (src/threadconfig.cpp:72-120) in the one writer thread: see SplitOutput.
  */
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -209,6 +210,117 @@ class Channel {
     deque<T> q_;
 };
 
+/* one complete gzip member (any gzip reader takes a concatenation of members as one stream) */
+static string gzip_member(const string& in, int level) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) error_exit("deflateInit2 failed");
+    string o;
+    o.resize(deflateBound(&zs, (uLong)in.size()) + 64);
+    zs.next_in = (Bytef*)in.data();
+    zs.avail_in = (uInt)in.size();
+    zs.next_out = (Bytef*)&o[0];
+    zs.avail_out = (uInt)o.size();
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) error_exit("deflate failed");
+    o.resize(zs.total_out);
+    deflateEnd(&zs);
+    return o;
+}
+
+/* --split / --split_by_lines.  Each of the reference's workers owns a writer and walks through the file numbers
+ * t, t + T, t + 2T, ... as its current file fills up (ThreadConfig::initWriterForSplit / markProcessed /
+ * writeEmptyFilesForSplitting, src/threadconfig.cpp:72-120); packs of PACK_SIZE = 16 reads reach the workers
+ * round-robin (src/seprocessor.cpp:343-378), so which file a read lands in is a function of its input index.  The
+ * one writer thread of this host replays that, pack by pack.
+ * One deliberate difference: when --split's files are used up, the reference lets some workers stop and DROP the
+ * packs still queued for them (mCanBeStopped, a race against the reader thread: src/threadconfig.cpp:103-107,
+ * src/seprocessor.cpp:430-433); here such a worker keeps writing into its last file, so no read is lost and the
+ * result does not depend on timing. */
+class SplitOutput {
+   public:
+    SplitOutput(const string& out, int digits, int workers, bool by_lines, int number, long size, int gz_level)
+        : out_(out), digits_(digits), T_(workers), by_lines_(by_lines), number_(number), size_(size), level_(gz_level), w_(workers) {
+        for (int t = 0; t < T_; t++) {
+            w_[t].working = t; /* mWorkingSplit = threadId */
+            open(w_[t]);
+        }
+    }
+    void write(int t, const string& text) { /* config->getWriter1()->writeString(outstr), src/seprocessor.cpp:297-301 */
+        if (out_.empty()) return;
+        Worker& w = w_[t];
+        w.pending += text;
+        if (w.pending.size() >= (4u << 20)) flush(w);
+    }
+    void mark(int t, long reads) { /* ThreadConfig::markProcessed */
+        Worker& w = w_[t];
+        w.current += reads;
+        if (w.current >= size_ && (by_lines_ || w.working + T_ < number_)) {
+            w.working += T_;
+            open(w);
+            w.current = 0;
+        }
+    }
+    void close() { /* ThreadConfig::cleanup: files a short input never reached still have to exist */
+        for (Worker& w : w_) {
+            if (!by_lines_)
+                while (w.working + T_ < number_) {
+                    w.working += T_;
+                    open(w);
+                }
+            shut(w);
+        }
+    }
+    vector<string> names;
+
+   private:
+    struct Worker {
+        int working = 0;
+        long current = 0;
+        FILE* f = nullptr;
+        bool gz = false, wrote = false;
+        string pending;
+    };
+    void flush(Worker& w) {
+        if (w.pending.empty() || !w.f) return;
+        const string& bytes = w.gz ? gzip_member(w.pending, level_) : w.pending;
+        if (fwrite(bytes.data(), 1, bytes.size(), w.f) != bytes.size()) error_exit("write failed");
+        w.wrote = true;
+        w.pending.clear();
+    }
+    void shut(Worker& w) {
+        if (!w.f) return;
+        flush(w);
+        if (w.gz && !w.wrote) {
+            const string e = gzip_member(string(), level_);
+            fwrite(e.data(), 1, e.size(), w.f);
+        }
+        fclose(w.f);
+        w.f = nullptr;
+    }
+    void open(Worker& w) { /* ThreadConfig::initWriterForSplit: 1-based number, zero-padded, in front of the base name */
+        if (out_.empty()) return;
+        shut(w);
+        string num = to_string(w.working + 1);
+        while ((int)num.size() < digits_) num = "0" + num;
+        const size_t slash = out_.find_last_of('/');
+        const string dir = slash == string::npos ? "./" : out_.substr(0, slash + 1);
+        const string base = slash == string::npos ? out_ : out_.substr(slash + 1);
+        const string path = dir + num + "." + base;
+        w.f = fopen(path.c_str(), "wb");
+        if (!w.f) error_exit("Failed to write: " + path);
+        w.gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+        w.wrote = false;
+        names.push_back(path);
+    }
+    string out_;
+    int digits_, T_;
+    bool by_lines_;
+    int number_;
+    long size_;
+    int level_;
+    vector<Worker> w_;
+};
+
 int main(int argc, char* argv[]) {
     if (argc == 1) {
         cerr << "fastplong_amd: fastplong's per-read hot path on MI355X" << endl << "version 0.4.1-compatible" << endl;
@@ -270,9 +382,27 @@ int main(int argc, char* argv[]) {
     if ((o.mask_enabled && o.mask_window <= 0) || (o.break_enabled && o.break_window <= 0))
         error_exit("the window size of --mask / --break must be positive");
     const bool fragmentMode = o.mask_enabled || o.break_enabled;
-    if (cmd.exist("split") || cmd.exist("split_by_lines")) error_exit("--split / --split_by_lines are not implemented in fastplong_amd");
+    /* src/main.cpp:225-250 */
+    const bool splitEnabled = cmd.exist("split") || cmd.exist("split_by_lines");
+    const int splitDigits = cmd.i("split_prefix_digits");
+    int splitNumber = 0;
+    long splitSize = 0;
+    bool splitByNumber = false, splitByLines = false;
+    if (cmd.exist("split") && cmd.exist("split_by_lines"))
+        error_exit("You cannot set both splitting by file number (--split) and splitting by file lines (--split_by_lines), please choose either.");
+    if (cmd.exist("split")) {
+        splitNumber = cmd.i("split");
+        splitByNumber = true;
+    }
+    if (cmd.exist("split_by_lines")) {
+        const long lines = cmd.l("split_by_lines");
+        if (lines % 4 != 0) error_exit("Line number (--split_by_lines) should be a multiple of 4");
+        splitSize = lines / 4; /* 4 lines per record */
+        splitByLines = true;
+    }
+    if ((fromStdin || in == "/dev/stdin") && splitByNumber) error_exit("Splitting by file number is not supported in STDIN mode");
     const string jsonFile = cmd.str("json"), htmlFile = cmd.str("html");
-    int workers = cmd.i("thread"); /* Options::validate, src/options.cpp:120-125: only the HTML report's point order sees it */
+    int workers = cmd.i("thread"); /* Options::validate, src/options.cpp:120-125: the HTML report's point order and --split see it */
     if (workers < 1) workers = 1;
     else if (workers > 16) {
         cerr << "WARNING: fastp uses up to 16 threads although you specified " << workers << endl;
@@ -294,6 +424,18 @@ int main(int argc, char* argv[]) {
         out = "";
     }
     if (!failedOut.empty() && failedOut == out) error_exit("--failed_out and --out shouldn't have same file name");
+    if (toStdout && splitEnabled) error_exit("splitting mode cannot work with stdout mode");
+    if (splitEnabled) { /* src/options.cpp:151-168 */
+        if (splitDigits < 0 || splitDigits > 10)
+            error_exit("you have enabled splitting output to multiple files, the digits number of file name prefix (--split_prefix_digits) should be 0 ~ 10.");
+        if (splitByNumber) {
+            if (splitNumber < 2 || splitNumber >= 1000)
+                error_exit("you have enabled splitting output by file number, the number of files (--split) should be 2 ~ 999.");
+            if (workers > splitNumber) workers = splitNumber; /* thread number cannot be more than the number of file to split */
+        }
+        if (splitByLines && splitSize < 1000 / 4)
+            error_exit("you have enabled splitting output by file lines, the file lines (--split_by_lines) should be >= 1000.");
+    }
     if (readsToProcess < 0) error_exit("the number of reads to process (--reads_to_process) cannot be negative");
     if (o.trim_front < 0) error_exit("trim_front1 (--trim_front1) should be >0, suggest 0 ~ 100");
     if (o.trim_tail < 0) error_exit("trim_tail1 (--trim_tail1) should be >0, suggest 0 ~ 100");
@@ -343,11 +485,20 @@ int main(int argc, char* argv[]) {
         }
     }
     /* adapter auto-detection, src/main.cpp:270-277 (an undetected "auto" stays literal, as in the reference) */
+    long readNum = 0;
     if (o.adapter_enabled && (startAd == "auto" || endAd == "auto")) {
         if (fromStdin || in == "/dev/stdin") cerr << "Adapter auto-detection is disabled for STDIN mode" << endl;
         else {
-            fplh::detect_adapters(in, o.trim_tail, isRNA, startAd, endAd);
+            fplh::detect_adapters(in, o.trim_tail, isRNA, startAd, endAd, &readNum);
             cerr << endl;
+        }
+    }
+    if (splitByNumber) { /* src/main.cpp:282-293: the evaluator's guess of the read count decides the file size */
+        if (readNum == 0) readNum = fplh::evaluate_read_num(in);
+        splitSize = readNum / splitNumber;
+        if (splitSize <= 0) { /* one record per file at least */
+            splitSize = 1;
+            cerr << "WARNING: the input file has less reads than the number of files to split" << endl;
         }
     }
 
@@ -383,29 +534,17 @@ int main(int argc, char* argv[]) {
         if (!o.f) error_exit("Failed to write: " + path);
         return o;
     };
-    OutFile fout = open_out(out), ffail = open_out(failedOut);
+    /* with --split* the reference never calls initOutput (src/seprocessor.cpp:65-67): no single --out file and no
+       --failed_out either; the workers' private writers take the passing reads */
+    OutFile fout = open_out(splitEnabled ? string() : out), ffail = open_out(splitEnabled ? string() : failedOut);
     if (toStdout) fout.f = stdout, fout.gz = false;
     const int gzLevel = min(9, max(1, cmd.i("compression")));
-    auto gzip_member = [gzLevel](const string& in) -> string {
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, gzLevel, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) error_exit("deflateInit2 failed");
-        string o;
-        o.resize(deflateBound(&zs, (uLong)in.size()) + 64);
-        zs.next_in = (Bytef*)in.data();
-        zs.avail_in = (uInt)in.size();
-        zs.next_out = (Bytef*)&o[0];
-        zs.avail_out = (uInt)o.size();
-        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) error_exit("deflate failed");
-        o.resize(zs.total_out);
-        deflateEnd(&zs);
-        return o;
-    };
+    SplitOutput* split = splitEnabled ? new SplitOutput(out, splitDigits, workers, splitByLines, splitNumber, splitSize, gzLevel) : nullptr;
     auto gzip_pieces = [&](vector<string>& pieces) { /* in parallel; pieces stay below 4 GiB (one slice of a batch) */
         vector<thread> th;
         for (auto& piece : pieces)
-            th.emplace_back([&gzip_member, &piece]() {
-                if (!piece.empty()) piece = gzip_member(piece);
+            th.emplace_back([gzLevel, &piece]() {
+                if (!piece.empty()) piece = gzip_member(piece, gzLevel);
             });
         for (auto& t : th) t.join();
     };
@@ -472,7 +611,7 @@ int main(int argc, char* argv[]) {
                     }
                 }
                 if (w->rc != FPL_OK) w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
-                else {
+                else if (!split) { /* (--split* output is cut per pack of 16 reads by the writer) */
                     fplh::format_batch_parallel(w->batch, w->res.data(), fmtThreads, w->outs, ffail ? &w->faileds : nullptr,
                                                 fragmentMode ? &w->frags : nullptr);
                     if (fout && fout.gz) gzip_pieces(w->outs);
@@ -504,6 +643,35 @@ int main(int argc, char* argv[]) {
                     page.post.add(fplh::ReadLists::worker_of(readBase + fr.read, workers), (int32_t)fr.len, fr.median_q);
         readBase += n;
     };
+    long packReads = 0, packPassed = 0; /* the pack of 16 input reads under way (it may straddle two batches) */
+    string packText;
+    auto split_reads = [&](const Work& w) { /* before note_reads: readBase is the index of the batch's first read */
+        const uint32_t n = w.batch.n();
+        const fplh::FragmentList* fl = fragmentMode ? &w.frags : nullptr;
+        for (uint32_t i = 0; i < n;) {
+            const uint64_t g = readBase + i;
+            const uint32_t j = (uint32_t)min<uint64_t>(n, i + (16 - g % 16));
+            const int wk = (int)((g / 16) % (uint64_t)workers);
+            packText.clear();
+            fplh::format_range(w.batch, w.res.data(), i, j, packText, nullptr, fl);
+            split->write(wk, packText);
+            for (uint32_t k = i; k < j; k++) { /* `passed`, src/seprocessor.cpp:264-276: any output read of the read passes */
+                bool passed = false;
+                if (fl) {
+                    for (uint32_t x = fl->first[k]; x < fl->first[k + 1]; x++) passed |= fl->frags[x].code == FPL_PASS_FILTER;
+                } else {
+                    for (int f = 0; f < w.res[k].n_frag; f++) passed |= w.res[k].code[f] == FPL_PASS_FILTER;
+                }
+                packPassed += passed;
+            }
+            packReads += j - i;
+            if ((readBase + j) % 16 == 0) { /* the pack is complete: ThreadConfig::markProcessed */
+                split->mark(wk, splitByLines ? packPassed : packReads);
+                packReads = packPassed = 0;
+            }
+            i = j;
+        }
+    };
     { /* writer: this thread, in input order */
         map<uint64_t, Work*> ready;
         uint64_t next = 0;
@@ -522,12 +690,19 @@ int main(int argc, char* argv[]) {
                 const double t0 = now();
                 if (fout) write_pieces(fout, r->outs);
                 if (ffail) write_pieces(ffail, r->faileds);
+                if (split) split_reads(*r);
                 note_reads(*r);
                 tWrite += now() - t0;
                 next++;
                 freeq.push(r);
             }
         }
+    }
+    if (split) {
+        if (packReads > 0) /* the last, short pack */
+            split->mark((int)(((readBase - 1) / 16) % (uint64_t)workers), splitByLines ? packPassed : packReads);
+        split->close();
+        delete split;
     }
     readerThread.join();
     for (auto& t : devThreads) t.join();
@@ -541,7 +716,7 @@ int main(int argc, char* argv[]) {
     for (OutFile* o : {&fout, &ffail})
         if (*o) {
             if (o->gz && !o->wrote) { /* an empty .gz still has to be a gzip stream */
-                const string e = gzip_member(string());
+                const string e = gzip_member(string(), gzLevel);
                 fwrite(e.data(), 1, e.size(), o->f);
             }
             if (o->f == stdout) fflush(stdout);

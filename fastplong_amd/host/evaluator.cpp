@@ -1,9 +1,12 @@
 #include "evaluator.h"
 
+#include <stdio.h>
 #include <string.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <iostream>
+#include <utility>
 #include <vector>
 
 #include "fastq.h"
@@ -138,16 +141,113 @@ static string extend_key(int key, const unsigned int* counts, const unsigned lon
     return adapter;
 }
 
-/* Evaluator::evalAdapterAndReadNum, src/evaluator.cpp:105-266 (the read-number estimate it also produces only
- * feeds --split, which this host does not have) */
-void detect_adapters(const string& path, int trim_tail, bool is_rna, string& start, string& end) {
+namespace {
+
+const uint64_t REF_BUF = 1ull << 23; /* FQ_BUF_SIZE, src/fastqreader.cpp:30 */
+
+/* FastqReader::getBytes' bytesRead at the moment the reference's reader has handed out the record that ends in
+ * front of uncompressed offset u (u >= 1): it refills only when a line runs off the end of its buffer. */
+struct PulledBytes {
+    bool gz = false;
+    uint64_t size = 0;
+    vector<pair<uint64_t, uint64_t>> steps; /* gzip: (uncompressed bytes out, compressed bytes in) after each inflate call */
+    PulledBytes(const string& path, uint64_t upto) {
+        gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) return;
+        fseeko(f, 0, SEEK_END);
+        size = (uint64_t)ftello(f);
+        fseeko(f, 0, SEEK_SET);
+        if (gz) { /* replay the inflate calls: 8 MiB of output each, a call also ends with its gzip member */
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, 15 + 16) == Z_OK) {
+                vector<unsigned char> in(1u << 20), out(REF_BUF);
+                uint64_t tin = 0, tout = 0;
+                bool more = true;
+                while (more && tout < upto) {
+                    zs.next_out = out.data();
+                    zs.avail_out = (uInt)out.size();
+                    int rc = Z_OK;
+                    while (zs.avail_out > 0) {
+                        if (zs.avail_in == 0) {
+                            zs.next_in = in.data();
+                            zs.avail_in = (uInt)fread(in.data(), 1, in.size(), f);
+                            if (zs.avail_in == 0) {
+                                more = false;
+                                break;
+                            }
+                        }
+                        const uInt before = zs.avail_in;
+                        rc = inflate(&zs, Z_NO_FLUSH);
+                        tin += before - zs.avail_in;
+                        if (rc == Z_STREAM_END) {
+                            inflateReset(&zs);
+                            break;
+                        }
+                        if (rc != Z_OK) {
+                            more = false;
+                            break;
+                        }
+                    }
+                    const uint64_t got = out.size() - zs.avail_out;
+                    tout += got;
+                    if (got > 0) steps.emplace_back(tout, tin);
+                }
+                inflateEnd(&zs);
+            }
+        }
+        fclose(f);
+    }
+    uint64_t at(uint64_t u) const {
+        if (!gz) return min(size, ((u - 1) / REF_BUF + 1) * REF_BUF);
+        for (auto& st : steps)
+            if (st.first >= u) return st.second;
+        return steps.empty() ? 0 : steps.back().second;
+    }
+};
+
+/* the tail of evaluateReadNum / evalAdapterAndReadNum (src/evaluator.cpp:93-102, :141-150) */
+long read_num_from(const string& path, long records, bool reached_eof, uint64_t first_end, uint64_t last_end) {
+    if (reached_eof) return records;
+    if (records <= 0) return 0;
+    const PulledBytes pb(path, last_end);
+    const double bytesPerRead = (double)(pb.at(last_end) - pb.at(first_end)) / (double)records;
+    const double est = (double)pb.size * 1.01 / bytesPerRead;
+    /* everything inside one buffer: the reference converts +inf to long (LONG_MIN on x86-64) */
+    if (!(est < 9.2e18)) return (long)0x8000000000000000ull;
+    return (long)est;
+}
+
+/* the reference's loop `while(records < READ_LIMIT && bases < BASE_LIMIT) read()` with the position bookkeeping */
+long read_prefix(FastqReader& reader, Batch& b, long read_limit, long base_limit, const string& path) {
+    reader.fill(b, ~0ull, 1);
+    const uint64_t first_end = reader.consumed();
+    if (b.n() == 1) reader.fill(b, (uint64_t)base_limit, (uint32_t)read_limit);
+    const long records = b.n();
+    const bool reached_eof = records < read_limit && (long)b.seq.size() < base_limit;
+    return read_num_from(path, records, reached_eof, first_end, reader.consumed());
+}
+
+}  // namespace
+
+long evaluate_read_num(const string& path) {
+    FastqReader reader(path);
+    if (!reader.ok()) return 0;
+    Batch b;
+    return read_prefix(reader, b, 512 * 1024, 151L * 512 * 1024, path);
+}
+
+/* Evaluator::evalAdapterAndReadNum, src/evaluator.cpp:105-266 */
+void detect_adapters(const string& path, int trim_tail, bool is_rna, string& start, string& end, long* read_num) {
     if (start != "auto" && end != "auto") return;
     const long READ_LIMIT = 64 * 1024;
     const long BASE_LIMIT = 8192 * READ_LIMIT;
     FastqReader reader(path);
     if (!reader.ok()) return;
     Batch b;
-    reader.fill(b, (uint64_t)BASE_LIMIT, (uint32_t)READ_LIMIT);
+    const long rn = read_prefix(reader, b, READ_LIMIT, BASE_LIMIT, path);
+    if (read_num) *read_num = rn;
     const long records = b.n();
     if (records < 100) return; /* we need at least 100 valid records to evaluate */
     const int shift_tail = max(1, trim_tail);
@@ -219,6 +319,13 @@ int fplh_seq2int(const char* seq, int rlen, int pos, int keylen, int last_val) {
 void fplh_int2seq(unsigned int val, int seqlen, int is_rna, char* out) {
     const std::string s = fplh::int2seq(val, seqlen, is_rna != 0);
     memcpy(out, s.c_str(), s.size() + 1);
+}
+long fplh_evaluate_read_num(const char* path) { return fplh::evaluate_read_num(path); }
+long fplh_detect_read_num(const char* path) {
+    std::string s = "auto", e = "auto";
+    long n = 0;
+    fplh::detect_adapters(path, 0, false, s, e, &n);
+    return n;
 }
 void fplh_detect_adapters(const char* path, int trim_tail, int is_rna, char* out_start, char* out_end) {
     std::string s = "auto", e = "auto";

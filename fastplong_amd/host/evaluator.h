@@ -20,7 +20,16 @@ int seq2int(const char* seq, int rlen, int pos, int keylen, int last_val = -1);
 
 /* Replaces `start` / `end` when they are "auto" and a sequence is detected; prints the reference's progress
  * lines to stderr.  trim_tail = -t (the evaluation skips max(1, trim_tail) bases at the end of every read). */
-void detect_adapters(const std::string& path, int trim_tail, bool is_rna, std::string& start, std::string& end);
+void detect_adapters(const std::string& path, int trim_tail, bool is_rna, std::string& start, std::string& end,
+                     long* read_num = nullptr);
+
+/* Evaluator::evaluateReadNum, src/evaluator.cpp:62-103: how many reads the input holds -- exact when the first
+ * 512 Ki reads / 77 Mbases reach the end of the file, else file size x 1.01 / (bytes per read so far), where
+ * "bytes so far" is what the reference's reader had PULLED from the file (FastqReader::getBytes,
+ * src/fastqreader.cpp:190-200: 8 MiB buffers of a plain file, compressed bytes behind each 8 MiB inflate call of a
+ * gzip file).  detect_adapters produces the same estimate from its own 64 Ki reads / 512 Mbases when asked.
+ * Only --split reads the number (src/main.cpp:282-293). */
+long evaluate_read_num(const std::string& path);
 
 }  // namespace fplh
 
@@ -30,5 +39,7 @@ int fplh_seq2int(const char* seq, int rlen, int pos, int keylen, int last_val);
 void fplh_int2seq(unsigned int val, int seqlen, int is_rna, char* out);
 /* out_start / out_end: buffers of >= 128 bytes, NUL-terminated results ("auto" when nothing was detected) */
 void fplh_detect_adapters(const char* path, int trim_tail, int is_rna, char* out_start, char* out_end);
+long fplh_evaluate_read_num(const char* path);
+long fplh_detect_read_num(const char* path); /* the estimate detect_adapters gives */
 }
 #endif

@@ -147,6 +147,7 @@ bool FastqReader::pull() {
             return true;
         }
         len_ += want;
+        pulled_ += want;
         file_pos_ += want;
         if (file_pos_ >= file_size_) eof_ = true;
         return true;
@@ -159,6 +160,7 @@ bool FastqReader::pull() {
             break;
         }
         len_ += (size_t)n;
+        pulled_ += (uint64_t)n;
     }
     return true;
 }

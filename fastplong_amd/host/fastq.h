@@ -72,6 +72,8 @@ class FastqReader {
      * number of records appended (0 at end of input) */
     uint32_t fill(Batch& b, uint64_t max_bases, uint32_t max_reads);
     bool malformed() const { return malformed_; }
+    /* offset, in the (uncompressed) input, of the byte behind the last record handed out */
+    uint64_t consumed() const { return pulled_ - (len_ - pos_); }
 
     void set_copy_threads(int t) { copy_threads_ = t < 1 ? 1 : t; }
 
@@ -100,7 +102,7 @@ class FastqReader {
     const char* win_ = nullptr; /* the window: buf_.data() */
     std::vector<char> buf_;
     int fd_ = -1;              /* regular uncompressed file: refilled with parallel pread */
-    uint64_t file_size_ = 0, file_pos_ = 0;
+    uint64_t file_size_ = 0, file_pos_ = 0, pulled_ = 0;
     size_t pos_ = 0, len_ = 0;
     int copy_threads_ = 1;
     size_t parse_min_ = 8u << 20; /* smallest piece worth a scanning thread (FPLH_PARSE_MIN: test hook) */

@@ -73,3 +73,37 @@ def expected_outputs_fragments(seq, qual, off, names, strands, res, frags, regs,
                 failed += [names[i], b" ", abi.FAILED_TYPES[int(fr["code"])].encode(), b"\n", masked(ra, rl, fr, in_place), b"\n",
                            strands[i], b"\n", q[ra:ra + rl], b"\n"]
     return b"".join(out), b"".join(failed)
+
+
+def expected_split(texts, passed, out, workers, by_lines, number, size, digits=4):
+    """--split / --split_by_lines: {file name: bytes}.  texts[i] / passed[i] = what read i contributes to the output /
+    whether any of its output reads passed.  Packs of 16 reads go round-robin to `workers` workers
+    (src/seprocessor.cpp:343-378); each worker appends to its current file and moves on by `workers` file numbers
+    when the file has taken `size` reads (src/threadconfig.cpp:72-120).  A worker out of files keeps its last one
+    (the reference would stop it and drop its queued packs -- a race; see fastplong_amd/host/cli.cpp)."""
+    import os
+    d, base = os.path.split(out)
+
+    def name(k):
+        num = str(k + 1)
+        return os.path.join(d, num.rjust(digits, "0") + "." + base)
+    files = {}
+    working, current = list(range(workers)), [0] * workers
+    for t in range(workers):
+        files[name(t)] = b""
+    n = len(texts)
+    for p in range((n + 15) // 16):
+        t = p % workers
+        lo, hi = p * 16, min(n, p * 16 + 16)
+        files[name(working[t])] += b"".join(texts[lo:hi])
+        current[t] += sum(passed[lo:hi]) if by_lines else hi - lo
+        if current[t] >= size and (by_lines or working[t] + workers < number):
+            working[t] += workers
+            files[name(working[t])] = b""
+            current[t] = 0
+    if not by_lines:
+        for t in range(workers):
+            while working[t] + workers < number:
+                working[t] += workers
+                files[name(working[t])] = b""
+    return files

@@ -158,3 +158,60 @@ def test_cli_detects_adapters_when_left_at_auto(tmp_path):
     assert err.count("Detected: ") == 2, err
     js = json.loads((tmp_path / "out.json").read_text().replace("},\n}", "}\n}"))
     assert js["adapter_cutting"]["adapter_trimmed_reads"] > 200
+
+
+def _per_read_outputs(seq, qual, off, names, strands, res):
+    texts, passed = [], []
+    for i in range(len(off) - 1):
+        out, _ = hostio.expected_outputs(seq, qual, off[i:i + 2], names[i:i + 1], strands[i:i + 1], res[i:i + 1], with_failed=False)
+        texts.append(out)
+        passed.append(bool((res[i]["code"][:int(res[i]["n_frag"])] == abi.FPL_PASS_FILTER).any()))
+    return texts, passed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["number", "number_gz_one_batch", "lines"])
+def test_cli_split_outputs_on_gpu(orc, tmp_path, mode):
+    """--split N / --split_by_lines L: the numbered files hold what the reference's per-worker writers would put
+    there (which file a read lands in follows from its input index, -w and the evaluated read count)"""
+    build.build_all()
+    okw, start, end = OPTS["c3_full"]
+    seq, qual, off = synth.ont_like(1500, seed=21, median_len=700, max_len=2500, p_middle=0.1, p_polya=0.2)
+    text, names, strands = hostio.make_fastq(seq, qual, off)
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    cfg = orc.Config(abi.FplOptions.default(**okw), start, end)
+    res, _ = orc.process_batch(cfg, seq, qual, off)
+    texts, passed = _per_read_outputs(seq, qual, off, names, strands, res)
+    flags = json.load(open(os.path.join(GOLD, "c3_full", "case.json")))["flags"]
+    gzipped = mode == "number_gz_one_batch"
+    out = str(tmp_path / ("out.fq.gz" if gzipped else "out.fq"))
+    if mode == "lines":
+        extra, want = ["--split_by_lines", "1000", "-w", "3", "--split_prefix_digits", "0"], \
+            hostio.expected_split(texts, passed, out, 3, True, 0, 250, digits=0)
+    elif gzipped:  # 7 files, -w 16 is capped at the file count; 1500 reads are below the evaluator's limits: exact count
+        extra, want = ["--split", "7", "-w", "16"], hostio.expected_split(texts, passed, out, 7, False, 7, 1500 // 7)
+    else:  # two workers walk through files 1,3,5,7 and 2,4,6
+        extra, want = ["--split", "7", "-w", "2"], hostio.expected_split(texts, passed, out, 2, False, 7, 1500 // 7)
+    cmd = [build.CLI, "-i", str(inp), "-o", out, "--failed_out", str(tmp_path / "failed.fq"), "-j", str(tmp_path / "o.json"),
+           "-h", str(tmp_path / "o.html"), "--batch_reads", "0" if gzipped else "101"] + flags + extra
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = {str(f): (gz(str(f)) if gzipped else f.read_bytes()) for f in tmp_path.iterdir() if "out.fq" in f.name}
+    assert sorted(got) == sorted(want) and len(want) >= 6
+    for k in want:
+        assert got[k] == want[k], k
+    assert sum(len(v) > 0 for v in want.values()) >= 6
+    assert not (tmp_path / "failed.fq").exists()  # the reference opens --failed_out only without --split*
+
+
+@pytest.mark.gpu
+def test_cli_split_rejects_what_the_reference_rejects(tmp_path):
+    build.build_all()
+    inp = os.path.join(GOLD, "c3_full", "in.fq.gz")
+    for extra, msg in ([["--split", "1"], "should be 2 ~ 999"], [["--split_by_lines", "1001"], "multiple of 4"],
+                       [["--split_by_lines", "400"], "should be >= 1000"], [["--split", "3", "--split_by_lines", "2000"], "either"],
+                       [["--split", "3", "--split_prefix_digits", "11"], "should be 0 ~ 10"]):
+        p = subprocess.run([build.CLI, "-i", inp, "-o", str(tmp_path / "o.fq"), "-j", str(tmp_path / "o.json"), "-h",
+                            str(tmp_path / "o.html")] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode != 0 and msg in p.stderr.decode(), (extra, p.stderr.decode()[-300:])

@@ -70,3 +70,57 @@ def test_nothing_detected_in_random_reads_or_small_files(hostlib, tmp_path):
     reads = [(synth._ACGT[rng.integers(0, 4, 600)].astype(np.uint8), np.full(600, 33 + 20, np.uint8)) for _ in range(300)]
     assert _detect(hostlib, tmp_path, reads) == ("auto", "auto")
     assert _detect(hostlib, tmp_path, reads[:50]) == ("auto", "auto")  # fewer than 100 records: no evaluation
+
+
+def _write_reads(path, n, length, seed=0, gz=False):
+    import gzip
+    rng = np.random.default_rng(seed)
+    body = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (n, length))]
+    rec = np.empty((n, 17 + 2 * length), np.uint8)
+    names = np.array([list(b"@r%010d" % i) for i in range(n)], np.uint8)
+    rec[:, :12] = names
+    rec[:, 12] = 10
+    rec[:, 13:13 + length] = body
+    rec[:, 13 + length] = 10
+    rec[:, 14 + length] = ord("+")
+    rec[:, 15 + length] = 10
+    rec[:, 16 + length:16 + 2 * length] = 33 + 20
+    rec[:, 16 + 2 * length] = 10
+    data = rec.tobytes()
+    if gz:
+        with gzip.GzipFile(path, "wb", compresslevel=1, mtime=0) as f:
+            f.write(data)
+    else:
+        open(path, "wb").write(data)
+    return len(data), 17 + 2 * length
+
+
+def test_read_number_estimate(hostlib, tmp_path):
+    """Evaluator::evaluateReadNum / the estimate of evalAdapterAndReadNum (src/evaluator.cpp:62-103,141-150): exact when
+    the evaluated prefix reaches the end of the file, else size * 1.01 / (bytes per read), with `bytes` counted in the
+    8 MiB buffers the reference's reader had pulled (FastqReader::getBytes)."""
+    L = hostlib
+    L.fplh_evaluate_read_num.restype = C.c_long
+    L.fplh_evaluate_read_num.argtypes = [C.c_char_p]
+    L.fplh_detect_read_num.restype = C.c_long
+    L.fplh_detect_read_num.argtypes = [C.c_char_p]
+    p = str(tmp_path / "small.fq")
+    _write_reads(p, 3000, 150)
+    assert L.fplh_evaluate_read_num(p.encode()) == 3000 and L.fplh_detect_read_num(p.encode()) == 3000
+    # 80 000 reads of 200 bases: the adapter evaluation stops after 65 536 reads = 27.3 MB, inside the 4th buffer
+    p = str(tmp_path / "mid.fq")
+    size, rec = _write_reads(p, 80000, 200)
+    buf = 1 << 23
+    pulled = lambda u: min(size, ((u - 1) // buf + 1) * buf)  # noqa: E731
+    want = int(size * 1.01 / ((pulled(65536 * rec) - pulled(rec)) / 65536))
+    assert L.fplh_detect_read_num(p.encode()) == want and abs(want - 80000) < 20000
+    assert L.fplh_evaluate_read_num(p.encode()) == 80000  # 512 Ki reads / 77 Mbases are not reached: exact
+    # everything evaluated sits in the first buffer: bytes per read = 0, the reference's (long)(+inf)
+    p = str(tmp_path / "tiny_reads.fq")
+    _write_reads(p, 70000, 30)
+    assert L.fplh_detect_read_num(p.encode()) == -(1 << 63)
+    # gzip: compressed bytes behind each 8 MiB inflate call
+    p = str(tmp_path / "mid.fq.gz")
+    _write_reads(p, 80000, 200, gz=True)
+    got = L.fplh_detect_read_num(p.encode())
+    assert abs(got - 80000) < 25000, got
