@@ -765,8 +765,12 @@ int main(int argc, char* argv[]) {
     ri.is_rna = isRNA;
     ri.command = command;
     cerr << fplh::summary_text(ri);
+    const double tRep0 = now();
     if (!fplh::write_json(jsonFile, ri)) error_exit("Failed to write: " + jsonFile);
+    const double tRep1 = now();
     if (!fplh::write_html(htmlFile, ri, page)) error_exit("Failed to write: " + htmlFile);
+    if (cmd.exist("verbose"))
+        cerr << "reports: json " << tRep1 - tRep0 << " s, html " << now() - tRep1 << " s; since start " << now() - tStart << " s" << endl;
 
     time_t t2 = time(NULL);
     cerr << endl << "JSON report: " << jsonFile << endl;

@@ -7,6 +7,7 @@
 #include <iostream>
 #include <map>
 #include <sstream>
+#include <thread>
 
 using namespace std;
 
@@ -45,31 +46,37 @@ void stats_json(ofstream& ofs, const string& padding, const StatsBlock& s, const
     const char t_or_u = is_rna ? 'U' : 'T';
 
     string qualNames[5] = {"A", string(1, t_or_u), "C", "G", "mean"};
+    string contentNames[6] = {"A", string(1, t_or_u), "C", "G", "N", "GC"};
+    /* the eleven per-cycle lists are hundreds of thousands of numbers each for long reads: one thread per list,
+       every number still through a default-formatted ostream */
+    string curveText[11];
+    {
+        vector<thread> th;
+        for (int k = 0; k < 11; k++)
+            th.emplace_back([&, k]() {
+                ostringstream o;
+                for (int c = 0; c < cycles; c++) {
+                    if (k < 4) o << qual_curve(qualNames[k][0], c);
+                    else if (k == 4) o << mean[c];
+                    else if (k < 10) o << content_curve(contentNames[k - 5][0], c);
+                    else o << (double)(s.cyc(c, 0, 'G' & 0x07) + s.cyc(c, 0, 'C' & 0x07)) / (double)s.total_base(c);
+                    if (c != cycles - 1) o << ",";
+                }
+                curveText[k] = o.str();
+            });
+        for (auto& t : th) t.join();
+    }
     ofs << padding << "\t" << "\"quality_curves\": {" << endl;
     for (int i = 0; i < 5; i++) {
-        ofs << padding << "\t\t" << "\"" << qualNames[i] << "\":[";
-        for (int c = 0; c < cycles; c++) {
-            ofs << (i == 4 ? mean[c] : qual_curve(qualNames[i][0], c));
-            if (c != cycles - 1) ofs << ",";
-        }
-        ofs << "]";
+        ofs << padding << "\t\t" << "\"" << qualNames[i] << "\":[" << curveText[i] << "]";
         if (i != 5 - 1) ofs << ",";
         ofs << endl;
     }
     ofs << padding << "\t" << "}," << endl;
 
-    string contentNames[6] = {"A", string(1, t_or_u), "C", "G", "N", "GC"};
     ofs << padding << "\t" << "\"content_curves\": {" << endl;
     for (int i = 0; i < 6; i++) {
-        ofs << padding << "\t\t" << "\"" << contentNames[i] << "\":[";
-        for (int c = 0; c < cycles; c++) {
-            if (i == 5)
-                ofs << (double)(s.cyc(c, 0, 'G' & 0x07) + s.cyc(c, 0, 'C' & 0x07)) / (double)s.total_base(c);
-            else
-                ofs << content_curve(contentNames[i][0], c);
-            if (c != cycles - 1) ofs << ",";
-        }
-        ofs << "]";
+        ofs << padding << "\t\t" << "\"" << contentNames[i] << "\":[" << curveText[5 + i] << "]";
         if (i != 6 - 1) ofs << ",";
         ofs << endl;
     }

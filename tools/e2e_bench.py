@@ -46,4 +46,4 @@ for outp in ("/dev/null", "/tmp/e2e_out.fq"):
     r = subprocess.run(cmd + ["-V"], capture_output=True, text=True, env=dict(os.environ, FPLH_TIMING="1"))
     dt = time.perf_counter() - t0
     print("CLI -> %s: rc=%d %.2f s -> %.2f Gbases/s end to end" % (outp, r.returncode, dt, nb / dt / 1e9))
-    print("   " + "\n   ".join(l for l in r.stderr.splitlines() if "host pipeline" in l or "reader phases" in l or r.returncode))
+    print("   " + "\n   ".join(l for l in r.stderr.splitlines() if "host pipeline" in l or "reader phases" in l or "reports:" in l or r.returncode))
