@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -423,7 +424,16 @@ int main(int argc, char* argv[]) {
         cerr << "In STDOUT mode, ignore the output filename " << out << endl;
         out = "";
     }
-    if (!failedOut.empty() && failedOut == out) error_exit("--failed_out and --out shouldn't have same file name");
+    { /* --dont_overwrite, src/options.cpp:90-112 */
+        const bool keep = cmd.exist("dont_overwrite");
+        auto exists = [](const string& f) { return !f.empty() && access(f.c_str(), F_OK) == 0; };
+        const string why = " already exists and you have set to not rewrite output files by --dont_overwrite";
+        if (keep && exists(out)) error_exit(out + why);
+        if (keep && exists(failedOut)) error_exit(failedOut + why);
+        if (!failedOut.empty() && failedOut == out) error_exit("--failed_out and --out shouldn't have same file name");
+        if (keep && exists(cmd.str("json"))) error_exit(cmd.str("json") + why);
+        if (keep && exists(cmd.str("html"))) error_exit(cmd.str("html") + why);
+    }
     if (toStdout && splitEnabled) error_exit("splitting mode cannot work with stdout mode");
     if (splitEnabled) { /* src/options.cpp:151-168 */
         if (splitDigits < 0 || splitDigits > 10)

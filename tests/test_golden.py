@@ -211,7 +211,8 @@ def test_cli_split_rejects_what_the_reference_rejects(tmp_path):
     inp = os.path.join(GOLD, "c3_full", "in.fq.gz")
     for extra, msg in ([["--split", "1"], "should be 2 ~ 999"], [["--split_by_lines", "1001"], "multiple of 4"],
                        [["--split_by_lines", "400"], "should be >= 1000"], [["--split", "3", "--split_by_lines", "2000"], "either"],
-                       [["--split", "3", "--split_prefix_digits", "11"], "should be 0 ~ 10"]):
+                       [["--split", "3", "--split_prefix_digits", "11"], "should be 0 ~ 10"],
+                       [["--dont_overwrite", "-j", inp], "already exists and you have set to not rewrite"]):
         p = subprocess.run([build.CLI, "-i", inp, "-o", str(tmp_path / "o.fq"), "-j", str(tmp_path / "o.json"), "-h",
                             str(tmp_path / "o.html")] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert p.returncode != 0 and msg in p.stderr.decode(), (extra, p.stderr.decode()[-300:])
