@@ -299,6 +299,16 @@ __device__ __forceinline__ u32 lshl_or(u32 a, u32 b) {
     return r;
 #endif
 }
+/* a * b + c for a, b < 2^24 in one full-rate VALU op (v_mad_u32_u24) */
+__device__ __forceinline__ u32 mad_u24(u32 a, u32 b, u32 c) {
+#ifdef FPL_EMU
+    return a * b + c;
+#else
+    u32 r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+#endif
+}
 __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__popc(x); }
 
 /* 0x01 in every byte of x that is non-zero */

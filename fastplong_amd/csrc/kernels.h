@@ -948,23 +948,20 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
  * one slab of the scratch buffer (plain coalesced stores); k_stats_reduce sums the slabs per tile.
  * ======================================================================================= */
 constexpr int FS_T = 512;
-constexpr int FS_SMAX = 128;
+constexpr int FS_SMAX = 96;
 constexpr int FS_PT = FS_T + FS_SMAX;          /* post cycles per slab */
 constexpr int FS_SLAB = 8 * FS_T + 8 * FS_PT;  /* u64 per slab: pre table, then post table */
+/* In LDS the two tables are interleaved per base class -- [cls][FS_T pre cells | FS_PT post cells] -- so that one
+   multiply-add per byte gives the pre address and the post address is a wave-uniform offset away from it. */
+constexpr int FS_STRIDE = FS_T + FS_PT;
+__device__ __forceinline__ u32 fs_pre_cell(u32 i) { return (i / FS_T) * FS_STRIDE + (i % FS_T); }           /* i = cls * FS_T + x */
+__device__ __forceinline__ u32 fs_post_cell(u32 j) { return (j / FS_PT) * FS_STRIDE + FS_T + (j % FS_PT); } /* j = cls * FS_PT + y */
 constexpr u32 CS_MAX_ITEMS_PER_SLICE = 16383;
 #ifndef FPL_ABL
 #define FPL_ABL 0 /* profiling only (-DFPL_ABL=bits): 1 no pre-table, 2 no post-table, 4 no 5-mer updates in k_stats */
 #endif
 constexpr int CS_GROUP = 4; /* items whose loads are in flight together, per wave */
 constexpr u32 PLAN_TO_POST = 1u; /* ReadState::pad bit: r1 passes unsplit and s <= FS_SMAX */
-
-__device__ __forceinline__ int base2val_dev(u32 b, bool& valid) {
-    /* Stats::base2val, src/stats.cpp:411-425: A0 T/U1 C2 G3 else invalid */
-    const u32 d = b - 0x41u;
-    valid = d < 32u && ((0x00180045u >> d) & 1u);
-    const u32 c = (b >> 1) & 3u; /* A0 C1 T/U2 G3 */
-    return (int)(((c & 1u) << 1) | (c >> 1));
-}
 
 /* 2-bit base codes of the four bytes of d, one per byte (Stats::base2val: A0 T/U1 C2 G3; other letters give
    some code and are caught by the validity mask) */
@@ -973,6 +970,14 @@ __device__ __forceinline__ u32 kmer_codes(u32 d) { return (d & 0x02020202u) | ((
 __device__ __forceinline__ u32 kmer_pack(u32 v) {
     const u32 x = lshl_or<10>(v, v);
     return lshl_or<20>(x, x);
+}
+/* d = four bases, mapped = the letters their 2-bit codes stand for (A T C G): bit i of the result is set when base i is
+   not one of A, T, U, C, G.  A mapped T also admits U (0x54 ^ 0x55 = 1; T is the only mapped letter with bit 4). */
+__device__ __forceinline__ u32 invalid_nibble(u32 mapped, u32 d) {
+    const u32 x = (mapped ^ d) & ~((mapped >> 4) & 0x01010101u);
+    const u32 nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; /* bit 7 of every non-zero byte */
+    const u32 y = lshl_or<7>(nz, nz);                                      /* gather bits 7,15,23,31 into 28..31 */
+    return lshl_or<14>(y, y) >> 28;
 }
 /* bits [lo, hi) of a byte, lo/hi clamped to 0..8 */
 __device__ __forceinline__ u32 range_mask8(int lo, int hi) {
@@ -1007,13 +1012,13 @@ __device__ __forceinline__ void fs_unpack_add(u64 v, u64& qsum, u64& cnt, u64& q
    k_stats_reduce sums the slabs of a tile and unpacks them.  (Flushing with global atomics instead cost
    more than the counting itself.)  The 5-mer counts are few: atomics. */
 template <bool EXTRA>
-__device__ __forceinline__ void fs_hand_over(const u64* tpre, const u64* tpost, const u32* kpre, const u32* kpost,
+__device__ __forceinline__ void fs_hand_over(const u64* tbl, const u32* kpre, const u32* kpost,
                                              u64* __restrict__ scratch, u8* __restrict__ flags, size_t slab,
                                              long long* kg0, long long* kg1) {
     u64* dst = scratch + slab * FS_SLAB;
     if (!EXTRA)
-        for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) dst[i] = tpre[i];
-    for (u32 i = threadIdx.x; i < 8 * FS_PT; i += blockDim.x) dst[8 * FS_T + i] = tpost[i];
+        for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) dst[i] = tbl[fs_pre_cell(i)];
+    for (u32 i = threadIdx.x; i < 8 * FS_PT; i += blockDim.x) dst[8 * FS_T + i] = tbl[fs_post_cell(i)];
     if (threadIdx.x == 0) {
         flags[gridDim.y + slab] = 1;
         flags[blockIdx.y] = 1; /* this tile has at least one slab */
@@ -1036,10 +1041,14 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
        k_scan built (count in n_items_dev), cycle = position in the fragment. */
     /* one LDS array carved by hand: the 5-mer tables come first so that their (data-dependent) addresses
        take the table choice as an instruction offset */
-    __shared__ u64 lds_all[1024 + 8 * FS_T + 8 * FS_PT];
+    __shared__ u64 lds_all[1024 + 256 + 8 * FS_STRIDE];
+    static_assert(sizeof(u64) * (1024 + 256 + 8 * FS_STRIDE) <= 81920, "two blocks per CU");
     u32* const kmer = (u32*)lds_all; /* [0,1024): 5-mers counted pre-filter only; [1024,2048): pre- AND post-filter */
-    u64* const tpre = lds_all + 1024;
-    u64* const tpost = tpre + 8 * FS_T;
+    u64* const inc_of = lds_all + 1024; /* the packed increment of every quality byte: one LDS read instead of two compares,
+                                          two selects and two ORs per base */
+    u64* const tbl = inc_of + 256;      /* [8][FS_STRIDE] */
+    for (u32 q = threadIdx.x; q < 256; q += blockDim.x)
+        inc_of[q] = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);
     u32* const kpre = kmer;
     u32* const kpost = kmer + 1024;
     u32& any_work = kpost[0]; /* (2 x 81920 bytes of LDS per CU: no room for one more word) */
@@ -1085,7 +1094,7 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
         /* the packed fields could overflow: empty the tables with atomics (never seen outside tests) */
         __syncthreads();
         for (u32 i = threadIdx.x; i < 8 * FS_PT; i += blockDim.x) {
-            const u64 v = tpost[i];
+            const u64 v = tbl[fs_post_cell(i)];
             if (!v) continue;
             const u32 cls = i / FS_PT, slot = i % FS_PT;
             const u32 pl = (slot % (FS_PT / 8)) * 8 + slot / (FS_PT / 8);
@@ -1106,8 +1115,8 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
     }
     if (!ready) {
         if (!EXTRA)
-            for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) tpre[i] = 0;
-        for (u32 i = threadIdx.x; i < 8 * FS_PT; i += blockDim.x) tpost[i] = 0;
+            for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) tbl[fs_pre_cell(i)] = 0;
+        for (u32 i = threadIdx.x; i < 8 * FS_PT; i += blockDim.x) tbl[fs_post_cell(i)] = 0;
         for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) kpre[i] = kpost[i] = 0;
         __syncthreads();
         ready = true;
@@ -1189,28 +1198,19 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                    are recognised by mapping the codes back to letters; anything else takes the exact count */
                 u32 okmask;
                 {
-                    u32 bad = (perm_lo(0x47435441u, v0) ^ sw[0]) | (perm_lo(0x47435441u, v1) ^ sw[1]);
-                    if (have_halo) bad |= perm_lo(0x47435441u, vh) ^ halo;
+                    const u32 m0 = perm_lo(0x47435441u, v0), m1 = perm_lo(0x47435441u, v1), mh = perm_lo(0x47435441u, vh);
+                    u32 bad = (m0 ^ sw[0]) | (m1 ^ sw[1]);
+                    if (have_halo) bad |= mh ^ halo;
                     if (!wave_ballot(nvalid > 0 && bad != 0)) {
                         okmask = have_halo ? 0xFFu : 0xF0u;
                     } else {
-                        int run = 0;
-                        okmask = 0;
-                        if (have_halo) {
-#pragma unroll
-                            for (int h = 0; h < 4; h++) {
-                                bool v;
-                                (void)base2val_dev((halo >> (8 * h)) & 0xFF, v);
-                                run = v ? run + 1 : 0;
-                            }
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            bool v;
-                            (void)base2val_dev((sw[k >> 2] >> (8 * (k & 3))) & 0xFF, v);
-                            run = v ? run + 1 : 0;
-                            okmask |= (run >= 5 ? 1u : 0u) << k;
-                        }
+                        /* the exact rule (Stats::base2val: A, T, U, C, G are the valid bases) without a per-byte
+                           chain: bit j of inv = base j of [halo | this lane's eight] is invalid; a window is counted
+                           when none of its five bases is */
+                        const u32 ih = have_halo ? invalid_nibble(mh, halo) : 0xFu;
+                        const u32 inv = lshl_or<8>(invalid_nibble(m1, sw[1]), lshl_or<4>(invalid_nibble(m0, sw[0]), ih));
+                        const u32 r = inv | (inv >> 1) | (inv >> 2) | (inv >> 3) | (inv >> 4);
+                        okmask = ~r & 0xFFu;
                     }
                     okmask &= (1u << nvalid) - 1u;
                 }
@@ -1225,13 +1225,13 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
     if (FULL || (k) < nvalid) {                                                                                   \
         const u32 bb = (sw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                    \
         const u32 q = (qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                     \
-        const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);                \
-        const u32 cls = bb & 7u;                                                                                  \
-        if (DO_PRE && !(FPL_ABL & 1)) atomicAdd(&tpre[cls * FS_T + (k)*64 + lane], inc);                          \
+        const u64 inc = inc_of[q];                                                                                \
+        const u32 cell = mad_u24(bb & 7u, FS_STRIDE, lane);                                                       \
+        if (DO_PRE && !(FPL_ABL & 1)) atomicAdd(&tbl[cell + (k)*64], inc);                                        \
         if (DO_POST && !(FPL_ABL & 2)) {                                                                          \
             const int uu = u0 + (k); /* wave-uniform */                                                           \
             if (FULL || ((bodymask >> (k)) & 1u))                                                                 \
-                atomicAdd(&tpost[cls * FS_PT + (uu & 7) * (FS_PT / 8) + (uu >> 3) + lane], inc);                  \
+                atomicAdd(&tbl[cell + (FS_T + (uu & 7) * (FS_PT / 8) + (uu >> 3))], inc);                         \
         }                                                                                                         \
         /* ONE 5-mer update per byte: a window counted post-filter is also counted pre-filter, so kpost   \
            holds the windows inside r1 (both tables) and kpre the pre-only rest */                              \
@@ -1285,13 +1285,13 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
     }
     if (EXTRA) continue;
     __syncthreads();
-    fs_hand_over<EXTRA>(tpre, tpost, kpre, kpost, scratch, flags, (size_t)blockIdx.y * n_slices + slice, kg0, kg1);
+    fs_hand_over<EXTRA>(tbl, kpre, kpost, scratch, flags, (size_t)blockIdx.y * n_slices + slice, kg0, kg1);
     __syncthreads(); /* (the tables would be reused by a next slice) */
     ready = false;
     }
     if (EXTRA && ready) {
         __syncthreads();
-        fs_hand_over<EXTRA>(tpre, tpost, kpre, kpost, scratch, flags, (size_t)blockIdx.y * n_slices + blockIdx.x, kg0,
+        fs_hand_over<EXTRA>(tbl, kpre, kpost, scratch, flags, (size_t)blockIdx.y * n_slices + blockIdx.x, kg0,
                             kg1);
     }
 }
