@@ -2,7 +2,7 @@
 # profiling only: SQ instruction / activity counters per kernel for the default bench batch (two --pmc passes)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/sq
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT   # (gpurun merges scratch output of earlier calls back: start clean)
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --cpu-bases 0 --steps 2 --warmup 1"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $OUT/p1 -- $B > $OUT/p1.log 2>&1
