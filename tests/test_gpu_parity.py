@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP path through the C-ABI (libfastplong_amd.so) against the oracle
 on the same seeded inputs, bit for bit (integer / byte / index work => exact equality), plus
 size-independent properties at larger sizes.  Need a real MI355X: run with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -136,7 +138,7 @@ def test_break_and_mask_bit_exact(orc, engine_mod, be, me, bw, mw):
         assert (want_f["code"] == abi.FPL_PASS_FILTER).any()
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FPL_FUZZ_SEEDS", "32"))))  # (more seeds: a one-off soak)
 def test_random_option_sets_bit_exact(orc, engine_mod, seed):
     """seeded random corners of the option space (including --break / --mask) on adversarial + ONT-like reads"""
     rng = np.random.default_rng(1000 + seed)
