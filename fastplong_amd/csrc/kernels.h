@@ -87,12 +87,14 @@ __device__ __forceinline__ int lev_bp32(const u32* __restrict__ peq, int m, cons
     return score;
 }
 
-/* word w of (peq_full[c] >> shift) */
-__device__ __forceinline__ u64 peq_word(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int c, int shift, int w) {
+/* word w of (peq_full[c] >> shift); PW = words the table keeps per byte value (PEQ_WORDS, or 1 for the LDS copy of
+   an adapter of <= 64 bases) */
+template <int PW>
+__device__ __forceinline__ u64 peq_word(const uint64_t (*__restrict__ peq)[PW], int c, int shift, int w) {
     int i = (shift >> 6) + w, r = shift & 63;
-    u64 lo = i < PEQ_WORDS ? peq[c][i] : 0;
+    u64 lo = i < PW ? peq[c][i] : 0;
     if (r == 0) return lo;
-    u64 hi = (i + 1) < PEQ_WORDS ? peq[c][i + 1] : 0;
+    u64 hi = (i + 1) < PW ? peq[c][i + 1] : 0;
     return (lo >> r) | (hi << (64 - r));
 }
 
@@ -221,8 +223,8 @@ __device__ __forceinline__ bool lev_round64(const WaveVals64 (&pub)[PEQ_WORDS], 
  * words in parallel (64 columns per round), then every lane runs the identical recurrence on
  * v_readlane-broadcast words -- no serial chain of dependent memory loads, result wave-uniform.
  * BYTE(j) yields text byte j.  Exact when the distance is <= thr, otherwise some value > thr. */
-template <class ByteFn>
-__device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m, int n,
+template <int PW, class ByteFn>
+__device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[PW], int shift, int m, int n,
                                              int thr, ByteFn&& BYTE) {
     if (m == 0) return n;
     if (n == 0) return m;
@@ -556,8 +558,8 @@ __device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const PT
 }
 
 /* lev_wave with the text taken from a Win */
-template <bool LDSWIN>
-__device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
+template <bool LDSWIN, int PW>
+__device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[PW], int shift, int m,
                                             const Win<LDSWIN>& win, int p, int n, int thr) {
     return lev_wave_core(peq, shift, m, n, thr, [&](int j) { return win.byte(p + j); });
 }
@@ -567,10 +569,10 @@ __device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[P
  * updated; returns the reference's return value; keylen = cmplen handed to addAdapterTrimmed. */
 /* r = first base of r1 -- the global read or a copy of its first 200 bytes in LDS; peq16 / peqf = the
  * adapter's Myers tables, global or LDS copies. */
-template <bool LDSWIN, class PT>
+template <bool LDSWIN, class PT, int PW>
 __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                                const PT* __restrict__ peq16,
-                                               const uint64_t (*__restrict__ peqf)[PEQ_WORDS],
+                                               const uint64_t (*__restrict__ peqf)[PW],
                                                const DevConfig* __restrict__ cfg, int& keylen) {
     const int lane = lane_id();
     const int rlen = e - s;
@@ -659,10 +661,10 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
  * asLeftAsPossible mode, :84-107, inlined). */
 /* r = first base of r1 as an address: only its last 200 bytes are dereferenced, so r may point
  * 200 - rlen bytes in front of an LDS copy of that tail. */
-template <bool LDSWIN, class PT>
+template <bool LDSWIN, class PT, int PW>
 __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                              const PT* __restrict__ peq16,
-                                             const uint64_t (*__restrict__ peqf)[PEQ_WORDS],
+                                             const uint64_t (*__restrict__ peqf)[PW],
                                              const DevConfig* __restrict__ cfg, int& keylen) {
     const int lane = lane_id();
     const int rlen = e - s;
@@ -768,11 +770,14 @@ struct TrimBlockAcc {
 /* LDS copies for the two command-line adapters: their 16-column Peq tables, their full Peq tables,
  * and per wave the first / last 200 bases of the read being trimmed.  Everything the 2 x 184 Myers
  * runs and the window Hamming scans touch is then an LDS read instead of a dependent global load. */
+#ifndef FPL_TRIM_WAVES_PER_SIMD
+#define FPL_TRIM_WAVES_PER_SIMD 7 /* 13.6 KB of LDS and <= 72 VGPRs per 4-wave block */
+#endif
 constexpr int TRIM_WIN = 256; /* FPL_END_WINDOW rounded up, plus slack for the aligned dword reads */
 template <int WAVES>
 struct TrimLds {
     uint16_t peq16[2][256];        /* [0] = start adapter's peq16_start, [1] = end adapter's peq16_end (16 columns) */
-    uint64_t peqf[2][256][PEQ_WORDS];
+    uint64_t peqf[2][256][1];      /* word 0 of the full Peq tables: adapters of <= 64 bases (longer ones use the global tables) */
     u32 win[WAVES][2][TRIM_WIN / 4];
     uint16_t peq16w[WAVES][256];   /* per wave: the 16-column Peq table of the FASTA adapter being tried */
 };
@@ -787,7 +792,7 @@ __device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __
 }
 
 template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, 5)
+__global__ void __launch_bounds__(WAVES * 64, FPL_TRIM_WAVES_PER_SIMD)
 k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
             uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
             ReadState* __restrict__ state, long long* __restrict__ counters, u32 C) {
@@ -799,11 +804,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
         lds.peq16[0][i] = (uint16_t)ads[0].peq16_start[i];
         lds.peq16[1][i] = (uint16_t)ads[1].peq16_end[i];
-#pragma unroll
-        for (int w = 0; w < PEQ_WORDS; w++) {
-            lds.peqf[0][i][w] = ads[0].peq_full[i][w];
-            lds.peqf[1][i][w] = ads[1].peq_full[i][w];
-        }
+        lds.peqf[0][i][0] = ads[0].peq_full[i][0];
+        lds.peqf[1][i][0] = ads[1].peq_full[i][0];
     }
     __syncthreads();
     const u8* seq_end = seq + n_bytes;
@@ -835,7 +837,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
         PROF(2) /* polyX */
         if (alive && cfg->adapter_enabled) { /* src/seprocessor.cpp:205-216 */
             int trimmed = 0, kl;
-            if (cfg->has_start && ads[0].len <= FPL_END_WINDOW) {
+            if (cfg->has_start && ads[0].len <= 64) {
                 /* the start trim only looks at r1[0, 200) */
                 stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end);
                 const Win<true> wn = {nullptr, win_s, 0, e - s};
@@ -847,7 +849,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(3) /* start adapter */
-            if (cfg->has_end && ads[1].len <= FPL_END_WINDOW) {
+            if (cfg->has_end && ads[1].len <= 64) {
                 /* the end trim only looks at the last 200 bases of r1 */
                 const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
                 stage_window(win_e, sq + e - wl, wl, seq_end);

@@ -72,6 +72,17 @@ def test_adversarial_reads_bit_exact(orc, engine_mod, name):
     _run_both(orc, engine_mod, CASES[name], seq, qual, off)
 
 
+@pytest.mark.parametrize("la,lb", [(64, 65), (65, 64), (100, 150), (250, 33)])
+def test_long_command_line_adapters_bit_exact(orc, engine_mod, la, lb):
+    """-s / -e adapters beyond 64 bases leave the LDS tables of k_trim_ends (one 64-column Peq word per byte value) and
+    take the global-memory path; beyond 200 bases they are longer than the end window"""
+    rng = np.random.default_rng(la * 1000 + lb)
+    start = "".join("ACGT"[i] for i in rng.integers(0, 4, la))
+    end = "".join("ACGT"[i] for i in rng.integers(0, 4, lb))
+    seq, qual, off = synth.adversarial(1500, seed=la + lb, start_adapter=start, end_adapter=end)
+    _run_both(orc, engine_mod, dict(opt=dict(cut_front=1, polyx=1), start=start, end=end), seq, qual, off)
+
+
 @pytest.mark.parametrize("name", ["defaults_adapters", "full_pipeline"])
 def test_ont_like_reads_bit_exact(orc, engine_mod, name):
     # lengths up to tens of kb: several cycle tiles, several scan tiles per read
