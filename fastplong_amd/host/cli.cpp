@@ -527,7 +527,11 @@ int main(int argc, char* argv[]) {
 
     fplh::FastqReader reader(in);
     if (!reader.ok()) error_exit("Failed to open file: " + in);
-    reader.set_copy_threads(max(1, min(8, (int)thread::hardware_concurrency() / 2)));
+    { /* threads of the reader's refill / locate / copy phases (FPLH_PARSE_THREADS overrides) */
+        const char* e = getenv("FPLH_PARSE_THREADS");
+        const int hw = (int)thread::hardware_concurrency();
+        reader.set_copy_threads(e && atoi(e) > 0 ? atoi(e) : max(1, min(8, hw / 2)));
+    }
     /* Outputs are plain files; a name ending in .gz gets gzip members (-z level), one per formatted slice,
        deflated on the formatter threads and concatenated by the writer: any gzip reader takes that as one stream */
     struct OutFile {
@@ -551,12 +555,9 @@ int main(int argc, char* argv[]) {
     const int gzLevel = min(9, max(1, cmd.i("compression")));
     SplitOutput* split = splitEnabled ? new SplitOutput(out, splitDigits, workers, splitByLines, splitNumber, splitSize, gzLevel) : nullptr;
     auto gzip_pieces = [&](vector<string>& pieces) { /* in parallel; pieces stay below 4 GiB (one slice of a batch) */
-        vector<thread> th;
-        for (auto& piece : pieces)
-            th.emplace_back([gzLevel, &piece]() {
-                if (!piece.empty()) piece = gzip_member(piece, gzLevel);
-            });
-        for (auto& t : th) t.join();
+        fplh::parallel_run((int)pieces.size(), [&](int i) {
+            if (!pieces[i].empty()) pieces[i] = gzip_member(pieces[i], gzLevel);
+        });
     };
     auto write_pieces = [](OutFile& o, const vector<string>& pieces) {
         for (auto& piece : pieces)

@@ -12,12 +12,103 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <iostream>
+#include <mutex>
 #include <thread>
 
 using namespace std;
 
 namespace fplh {
+
+namespace {
+class Pool {
+   public:
+    Pool() {
+        const int hw = (int)std::thread::hardware_concurrency();
+        int n = min(64, max(1, hw - 2));
+        if (const char* e = getenv("FPLH_POOL_THREADS"))
+            if (atoi(e) >= 0) n = atoi(e);
+        for (int i = 0; i < n; i++) workers_.emplace_back([this]() { work(); });
+    }
+    ~Pool() {
+        {
+            lock_guard<mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void run(int tasks, const function<void(int)>& fn) {
+        if (tasks <= 0) return;
+        if (tasks == 1 || workers_.empty()) {
+            for (int i = 0; i < tasks; i++) fn(i);
+            return;
+        }
+        Job job{&fn, tasks, 0, {0}};
+        {
+            lock_guard<mutex> g(m_);
+            jobs_.push_back(&job);
+        }
+        cv_.notify_all();
+        for (;;) { /* the caller works too */
+            int i;
+            {
+                lock_guard<mutex> g(m_);
+                i = claim(&job);
+            }
+            if (i < 0) break;
+            fn(i);
+            job.done.fetch_add(1);
+        }
+        unique_lock<mutex> g(m_);
+        done_cv_.wait(g, [&]() { return job.done.load() == tasks; });
+    }
+
+   private:
+    struct Job {
+        const function<void(int)>* fn;
+        int n, next;
+        atomic<int> done;
+    };
+    /* next index of job j, or -1 when all are handed out (m_ held); a job leaves the queue with its last index, so
+       nobody looks at it once its caller may have returned */
+    int claim(Job* j) {
+        if (j->next >= j->n) return -1;
+        const int i = j->next++;
+        if (j->next == j->n) jobs_.erase(std::find(jobs_.begin(), jobs_.end(), j));
+        return i;
+    }
+    void work() {
+        unique_lock<mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [&]() { return stop_ || !jobs_.empty(); });
+            if (stop_) return;
+            Job* j = jobs_.front();
+            const int i = claim(j);
+            if (i < 0) continue;
+            const function<void(int)>* fn = j->fn;
+            const int n = j->n;
+            g.unlock();
+            (*fn)(i);
+            const bool last = j->done.fetch_add(1) + 1 == n; /* j may be gone right after this */
+            g.lock();
+            if (last) done_cv_.notify_all();
+        }
+    }
+    mutex m_;
+    condition_variable cv_, done_cv_;
+    deque<Job*> jobs_;
+    vector<std::thread> workers_;
+    bool stop_ = false;
+};
+}  // namespace
+
+void parallel_run(int tasks, const function<void(int)>& fn) {
+    static Pool pool;
+    pool.run(tasks, fn);
+}
 
 /* FAILED_TYPES, src/common.h:55-64 */
 static const char* failed_type(int code) {
@@ -127,21 +218,18 @@ bool FastqReader::pull() {
     if (fd_ >= 0) { /* regular file: every thread preads its slice of the free part of the window */
         const size_t want = (size_t)min<uint64_t>(buf_.size() - len_, file_size_ - file_pos_);
         const int T = (int)max<size_t>(1, min<size_t>((size_t)copy_threads_, want / (4u << 20)));
-        vector<std::thread> th;
         std::atomic<bool> ok{true};
-        for (int t = 0; t < T; t++)
-            th.emplace_back([&, t]() {
-                size_t a = want / T * t, e = t == T - 1 ? want : want / T * (t + 1);
-                while (a < e) {
-                    const ssize_t n = pread(fd_, buf_.data() + len_ + a, e - a, (off_t)(file_pos_ + a));
-                    if (n <= 0) {
-                        ok = false;
-                        return;
-                    }
-                    a += (size_t)n;
+        parallel_run(T, [&](int t) {
+            size_t a = want / T * t, e = t == T - 1 ? want : want / T * (t + 1);
+            while (a < e) {
+                const ssize_t n = pread(fd_, buf_.data() + len_ + a, e - a, (off_t)(file_pos_ + a));
+                if (n <= 0) {
+                    ok = false;
+                    return;
                 }
-            });
-        for (auto& x : th) x.join();
+                a += (size_t)n;
+            }
+        });
         if (!ok) {
             eof_ = true; /* (truncated underneath us: stop with what was read so far) */
             return true;
@@ -220,17 +308,15 @@ void FastqReader::copy_records(Batch& b, const vector<Rec>& recs) const {
         work(0, nr);
         return;
     }
-    vector<std::thread> th;
-    size_t first = 0;
-    for (int t = 0; t < T; t++) { /* slices of about equal numbers of bases */
+    vector<size_t> cut(T + 1, nr);
+    cut[0] = 0;
+    for (int t = 0; t < T - 1; t++) { /* slices of about equal numbers of bases */
         const uint64_t want = base0 + (bases - base0) / T * (t + 1);
-        size_t last = t == T - 1 ? nr : (size_t)(std::lower_bound(b.off.begin() + n0 + 1, b.off.begin() + n0 + 1 + nr, want) -
-                                                 (b.off.begin() + n0 + 1)) + 1;
-        last = min(max(last, first), nr);
-        th.emplace_back(work, first, last);
-        first = last;
+        const size_t last = (size_t)(std::lower_bound(b.off.begin() + n0 + 1, b.off.begin() + n0 + 1 + nr, want) -
+                                     (b.off.begin() + n0 + 1)) + 1;
+        cut[t + 1] = min(max(last, cut[t]), nr);
     }
-    for (auto& x : th) x.join();
+    parallel_run(T, [&](int t) { work(cut[t], cut[t + 1]); });
 }
 
 /* Locate records starting at `pos` (a line start) while they START before `start_limit` and the running totals
@@ -318,9 +404,8 @@ void FastqReader::scan_parallel(uint64_t& bases, uint64_t max_bases, uint32_t& r
         int rc = 0;
     };
     vector<Part> parts(T);
-    vector<std::thread> th;
-    for (int k = 0; k < T; k++)
-        th.emplace_back([&, k]() {
+    parallel_run(T, [&](int k) {
+        {
             Part& pt = parts[k];
             const size_t lo = pos_ + (size_t)k * piece, hi = k == T - 1 ? pos_ + stretch : lo + piece;
             size_t p = lo;
@@ -352,8 +437,8 @@ void FastqReader::scan_parallel(uint64_t& bases, uint64_t max_bases, uint32_t& r
             string err;
             pt.rc = scan_records(pos, hi, pt.bases, ~0ull, pt.reads, 0xFFFFFFFFu, pt.recs, err);
             pt.end = pos;
-        });
-    for (auto& t : th) t.join();
+        }
+    });
     /* join in order while the pieces line up with the sequential scan */
     for (int k = 0; k < T; k++) {
         Part& pt = parts[k];
@@ -458,13 +543,10 @@ void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threa
         const uint64_t want = total / threads * t;
         cut[t] = (uint32_t)(std::lower_bound(b.off.begin(), b.off.begin() + n, want) - b.off.begin());
     }
-    vector<std::thread> th;
-    for (int t = 0; t < threads; t++)
-        th.emplace_back([&, t]() {
-            outs[t].reserve((size_t)((b.off[cut[t + 1]] - b.off[cut[t]]) * 2 + (uint64_t)(cut[t + 1] - cut[t]) * 128 + 64));
-            format_range(b, res, cut[t], cut[t + 1], outs[t], faileds ? &(*faileds)[t] : nullptr, fl);
-        });
-    for (auto& x : th) x.join();
+    parallel_run(threads, [&](int t) {
+        outs[t].reserve((size_t)((b.off[cut[t + 1]] - b.off[cut[t]]) * 2 + (uint64_t)(cut[t + 1] - cut[t]) * 128 + 64));
+        format_range(b, res, cut[t], cut[t + 1], outs[t], faileds ? &(*faileds)[t] : nullptr, fl);
+    });
 }
 
 /* bases [start, start + len) of a read with the regions Read::maskRegionWithN overwrote (src/read.cpp:217-225) */

@@ -12,12 +12,19 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
 #include "fastplong_amd.h"
 
 namespace fplh {
+
+/* Persistent worker threads for the short parallel phases of the host pipeline (window refill, record location,
+ * line copies, output formatting, gzip members): a phase lasts a few milliseconds, so starting threads for it costs
+ * as much as the work.  run(n, fn) executes fn(0) .. fn(n-1) on the workers and the calling thread and returns when
+ * all are done; any number of threads may call it at the same time. */
+void parallel_run(int tasks, const std::function<void(int)>& fn);
 
 /* growable byte array without the zero fill of std::vector::resize (batches are hundreds of megabytes and
  * every byte is overwritten by the parser's copy threads) */
