@@ -1002,7 +1002,7 @@ __device__ __forceinline__ u32x2 load8_guard(const u8* p, const u8* end) {
     return v;
 }
 
-/* (two blocks of 12 waves per CU need <= 80 VGPRs: 6 waves per SIMD) */
+/* (two blocks of 16 waves per CU need <= 64 VGPRs: 8 waves per SIMD) */
 /* packed counter -> its four fields */
 __device__ __forceinline__ void fs_unpack_add(u64 v, u64& qsum, u64& cnt, u64& q20, u64& q30) {
     qsum += v & 0x3FFFFF;

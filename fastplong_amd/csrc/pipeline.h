@@ -27,7 +27,10 @@ constexpr int SWAVES = 2;
 typedef void* fpl_stream_t;
 #else
 constexpr int KWAVES = 4;
-constexpr int SWAVES = 12; /* k_stats: 12 waves share one 80 KiB LDS table set -> 24 waves per CU */
+#ifndef FPL_SWAVES
+#define FPL_SWAVES 16
+#endif
+constexpr int SWAVES = FPL_SWAVES; /* k_stats: 16 waves share one 80 KiB LDS table set -> 32 waves per CU (64 VGPRs each) */
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #define FPL_MEMSET(ptr, bytes, stream) (void)hipMemsetAsync(ptr, 0, bytes, stream)
 typedef hipStream_t fpl_stream_t;
@@ -80,7 +83,7 @@ inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
 
 /* Slices of the item list for k_stats.  A (slice, tile) block is heavy only while its tile lies below the
  * typical item length, so the number of HEAVY blocks is about slices x (mean length / tile).  Every block pays
- * for zeroing its tables, the 72 KiB hand-over and the 5-mer flush, so slices should be as large as the
+ * for zeroing its tables, the 70 KiB hand-over and the 5-mer flush, so slices should be as large as the
  * 14-bit counter fields allow; measured optimum: ~1.25 heavy blocks per block slot of the chip (2 per CU). */
 inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu) {
     if (n_items == 0) return 64;
