@@ -342,6 +342,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.frag_cyc = ctx->d_frag_cyc;
     a.bm = ctx->bm;
     a.defer = ctx->hcfg.defer != 0;
+    a.trim_short = ctx->hcfg.trim_short != 0;
     a.counters = ctx->d_counters;
     a.C = ctx->C;
     a.work_ctr = ctx->d_work_ctr;

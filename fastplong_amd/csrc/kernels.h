@@ -223,7 +223,7 @@ __device__ __forceinline__ bool lev_round64(const WaveVals64 (&pub)[PEQ_WORDS], 
  * words in parallel (64 columns per round), then every lane runs the identical recurrence on
  * v_readlane-broadcast words -- no serial chain of dependent memory loads, result wave-uniform.
  * BYTE(j) yields text byte j.  Exact when the distance is <= thr, otherwise some value > thr. */
-template <int PW, class ByteFn>
+template <bool SHORT, int PW, class ByteFn>
 __device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[PW], int shift, int m, int n,
                                              int thr, ByteFn&& BYTE) {
     if (m == 0) return n;
@@ -231,7 +231,7 @@ __device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[
     const int W = (m + 63) >> 6;
     const int lane = lane_id();
     int score = m;
-    if (m <= 32) {
+    if (SHORT || m <= 32) { /* SHORT: the caller guarantees m <= 32 and the multi-word code below is not even compiled */
         u32 Pv = ~0u, Mv = 0;
         const u32 top = 1u << (m - 1);
         for (int j0 = 0; j0 < n; j0 += 64) {
@@ -269,7 +269,7 @@ __device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[
 }
 __device__ __forceinline__ int lev_wave(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
                                         const u8* __restrict__ text, int n, int thr) {
-    return lev_wave_core(peq, shift, m, n, thr, [&](int j) { return (u32)text[j]; });
+    return lev_wave_core<false>(peq, shift, m, n, thr, [&](int j) { return (u32)text[j]; });
 }
 
 /* run f() on lane 0 only and hand its int result to every lane */
@@ -558,10 +558,10 @@ __device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const PT
 }
 
 /* lev_wave with the text taken from a Win */
-template <bool LDSWIN, int PW>
+template <bool SHORT, bool LDSWIN, int PW>
 __device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[PW], int shift, int m,
                                             const Win<LDSWIN>& win, int p, int n, int thr) {
-    return lev_wave_core(peq, shift, m, n, thr, [&](int j) { return win.byte(p + j); });
+    return lev_wave_core<SHORT>(peq, shift, m, n, thr, [&](int j) { return win.byte(p + j); });
 }
 
 /* AdapterTrimmer::trimBySequenceStart, src/adaptertrimmer.cpp:168-236 (searchAdapter in its
@@ -569,7 +569,7 @@ __device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[P
  * updated; returns the reference's return value; keylen = cmplen handed to addAdapterTrimmed. */
 /* r = first base of r1 -- the global read or a copy of its first 200 bytes in LDS; peq16 / peqf = the
  * adapter's Myers tables, global or LDS copies. */
-template <bool LDSWIN, class PT, int PW>
+template <bool SHORT, bool LDSWIN, class PT, int PW>
 __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                                const PT* __restrict__ peq16,
                                                const uint64_t (*__restrict__ peqf)[PW],
@@ -592,7 +592,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
         for (int p0 = 0; p0 < npos; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < npos && !FPL_DBG(cfg->dbg, 256)) mm = alen <= 32 ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
+            if (p < npos && !FPL_DBG(cfg->dbg, 256)) mm = (SHORT || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
             const u64 m = wave_ballot(p < npos && mm <= thrA);
             if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
             if (p < npos) {
@@ -605,7 +605,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(u32)best;
-                const int ed = FPL_DBG(cfg->dbg, 64) ? 999 : lev_wave_win(peqf, 0, alen, win, pos, alen, thrA);
+                const int ed = FPL_DBG(cfg->dbg, 64) ? 999 : lev_wave_win<SHORT>(peqf, 0, alen, win, pos, alen, thrA);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -644,7 +644,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
     if (best != ~0ull) { /* :218-233 */
         int pos = (int)(u32)best;
         const int cmplen = min(pos + plen, alen);
-        const int ed = lev_wave_win(peqf, alen - cmplen, cmplen, win, pos + plen - cmplen, cmplen, cfg->thr[cmplen]);
+        const int ed = lev_wave_win<SHORT>(peqf, alen - cmplen, cmplen, win, pos + plen - cmplen, cmplen, cfg->thr[cmplen]);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - alen);
             keylen = cmplen;
@@ -661,7 +661,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
  * asLeftAsPossible mode, :84-107, inlined). */
 /* r = first base of r1 as an address: only its last 200 bytes are dereferenced, so r may point
  * 200 - rlen bytes in front of an LDS copy of that tail. */
-template <bool LDSWIN, class PT, int PW>
+template <bool SHORT, bool LDSWIN, class PT, int PW>
 __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                              const PT* __restrict__ peq16,
                                              const uint64_t (*__restrict__ peqf)[PW],
@@ -684,7 +684,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
         for (int p0 = ss; p0 < pend; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < pend) mm = alen <= 32 ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
+            if (p < pend) mm = (SHORT || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
             const u64 m = wave_ballot(p < pend && mm <= thrA);
             if (m) {
                 hit = p0 + __ffsll(m) - 1; /* leftmost hit, returned at once (:98-101) */
@@ -700,7 +700,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(0xFFFFFFFFu - (u32)best);
-                const int ed = lev_wave_win(peqf, 0, alen, win, pos, alen, thrA);
+                const int ed = lev_wave_win<SHORT>(peqf, 0, alen, win, pos, alen, thrA);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -749,7 +749,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     }
     if (pos > 0) { /* :288 strict */
         const int cmplen = min(pos + plen, alen);
-        const int ed = lev_wave_win(peqf, 0, cmplen, win, rlen - plen - pos, cmplen, cfg->thr[cmplen]);
+        const int ed = lev_wave_win<SHORT>(peqf, 0, cmplen, win, rlen - plen - pos, cmplen, cfg->thr[cmplen]);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - plen);
             keylen = cmplen;
@@ -773,6 +773,9 @@ struct TrimBlockAcc {
 #ifndef FPL_TRIM_WAVES_PER_SIMD
 #define FPL_TRIM_WAVES_PER_SIMD 7 /* 13.6 KB of LDS and <= 72 VGPRs per 4-wave block */
 #endif
+#ifndef FPL_TRIM_WAVES_PER_SIMD_SHORT
+#define FPL_TRIM_WAVES_PER_SIMD_SHORT 8 /* the SHORT instantiation needs 55 VGPRs */
+#endif
 constexpr int TRIM_WIN = 256; /* FPL_END_WINDOW rounded up, plus slack for the aligned dword reads */
 template <int WAVES>
 struct TrimLds {
@@ -791,8 +794,11 @@ __device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __
     wave_sync();
 }
 
-template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, FPL_TRIM_WAVES_PER_SIMD)
+/* SHORT: the host saw no FASTA adapters and command-line adapters of <= 32 bases (DevConfig::trim_short): the
+   global-memory paths, the FASTA chain and the multi-word Levenshtein are left out of that instantiation -- a
+   quarter of the code, fewer scalar registers to spill */
+template <int WAVES, bool SHORT>
+__global__ void __launch_bounds__(WAVES * 64, SHORT ? FPL_TRIM_WAVES_PER_SIMD_SHORT : FPL_TRIM_WAVES_PER_SIMD)
 k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
             uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
             ReadState* __restrict__ state, long long* __restrict__ counters, u32 C) {
@@ -837,28 +843,28 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
         PROF(2) /* polyX */
         if (alive && cfg->adapter_enabled) { /* src/seprocessor.cpp:205-216 */
             int trimmed = 0, kl;
-            if (cfg->has_start && ads[0].len <= 64) {
+            if (cfg->has_start && (SHORT || ads[0].len <= 64)) {
                 /* the start trim only looks at r1[0, 200) */
                 stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end);
                 const Win<true> wn = {nullptr, win_s, 0, e - s};
-                trimmed += trim_start_wave(wn, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
+                trimmed += trim_start_wave<SHORT>(wn, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
-            } else if (cfg->has_start) {
+            } else if (!SHORT && cfg->has_start) {
                 const Win<false> wn = {sq + s, nullptr, 0, e - s};
-                trimmed += trim_start_wave(wn, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
+                trimmed += trim_start_wave<false>(wn, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(3) /* start adapter */
-            if (cfg->has_end && ads[1].len <= 64) {
+            if (cfg->has_end && (SHORT || ads[1].len <= 64)) {
                 /* the end trim only looks at the last 200 bases of r1 */
                 const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
                 stage_window(win_e, sq + e - wl, wl, seq_end);
                 const Win<true> wn = {nullptr, win_e, rlen - wl, rlen};
-                trimmed += trim_end_wave(wn, s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
+                trimmed += trim_end_wave<SHORT>(wn, s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
-            } else if (cfg->has_end) {
+            } else if (!SHORT && cfg->has_end) {
                 const Win<false> wn = {sq + s, nullptr, 0, e - s};
-                trimmed += trim_end_wave(wn, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
+                trimmed += trim_end_wave<false>(wn, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(4) /* end adapter */
@@ -867,14 +873,14 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                each adapter's 16-column Peq table is copied next to them (4 loads per lane) */
             bool stale_s = true, stale_e = true;
             uint16_t* const pq = lds.peq16w[wave_in_block()];
-            for (int a = 0; a < cfg->n_fasta; a++) {
+            for (int a = 0; !SHORT && a < cfg->n_fasta; a++) {
                 const DevAdapter* ad = &ads[2 + a];
                 if (ad->len > FPL_END_WINDOW) { /* longer than the window: work on the read in global memory */
                     const Win<false> ws = {sq + s, nullptr, 0, e - s};
-                    trimmed += trim_start_wave(ws, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
+                    trimmed += trim_start_wave<false>(ws, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
                     const Win<false> we = {sq + s, nullptr, 0, e - s};
-                    trimmed += trim_end_wave(we, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
+                    trimmed += trim_end_wave<false>(we, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
                     stale_s = stale_e = true;
                     continue;
@@ -887,7 +893,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_s, 0, e - s};
-                    trimmed += trim_start_wave(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
+                    trimmed += trim_start_wave<false>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
                     if (s != s0 || e != e0) stale_s = stale_e = true;
                 }
@@ -900,7 +906,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_e, rlen - wl, rlen};
-                    trimmed += trim_end_wave(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
+                    trimmed += trim_end_wave<false>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
                     if (s != s0 || e != e0) stale_s = stale_e = true;
                 }

@@ -70,6 +70,7 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.frag_cyc = frag_cyc.data();
     a.bm = BmLists{frags.data(), regs.data(), frag_cap, reg_cap, item_cap, bm_counts};
     a.defer = cfg.defer != 0;
+    a.trim_short = cfg.trim_short != 0;
     a.counters = (long long*)counters;
     a.C = C;
     a.work_ctr = work_ctr;
