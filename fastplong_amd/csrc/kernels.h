@@ -1948,7 +1948,9 @@ __device__ __forceinline__ void lev_pair32_run(const u32 (*__restrict__ peq4)[4]
     ed1 = readlane_i32(res, 1);
 }
 
-template <int WAVES>
+/* SHORT: adapter trimming is off, or both command-line adapters are ACGT-only and <= 32 bases (DevConfig::scan_short):
+   the byte-wise scan and the multi-word Levenshtein are left out of that instantiation */
+template <int WAVES, bool SHORT>
 __global__ void __launch_bounds__(WAVES * 64, SCAN_BLOCKS_PER_CU * WAVES / 4)
 k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
        uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
@@ -2049,16 +2051,16 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         RangeSums sm = {0, 0, 0, 0};
         u64 key0 = ~0ull, key1 = ~0ull;
         const bool ham = !dropped && cfg->adapter_enabled;
-        if (ham && cfg->ham_fast)
+        if (ham && (SHORT || cfg->ham_fast))
             range_scan_fast<true, true>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, &ads[0], &ads[1], key0, key1);
-        else if (ham) /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
+        else if (!SHORT && ham) /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
             range_scan_bytes<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
         else
             range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, nullptr, nullptr, key0, key1);
         /* candidates of the middle-adapter search that still need their edit distance: fetch the two text
            windows now, confirm after the histogram work (edit distance <= Hamming distance, so only an argmin
            worse than the threshold needs it) */
-        const bool pair32 = ham && cfg->ham_fast && ads[0].len <= 32 && ads[1].len <= 32;
+        const bool pair32 = ham && (SHORT || (cfg->ham_fast && ads[0].len <= 32 && ads[1].len <= 32));
         const int thr0 = ham ? cfg->thr[ads[0].len] : 0, thr1 = ham ? cfg->thr[ads[1].len] : 0;
         const bool need0 = ham && key0 != ~0ull && (int)(key0 >> 32) > thr0;
         const bool need1 = ham && key1 != ~0ull && (int)(key1 >> 32) > thr1;
@@ -2126,7 +2128,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 const int p0 = (int)(u32)key0, p1 = (int)(u32)key1;
                 int ed0 = 0, ed1 = 0;
                 PROF(10)
-                if (pair32) {
+                if (SHORT || pair32) {
                     if (need0 || need1) lev_pair32_run(peq4, ltxt, al0, thr0, need0, al1, thr1, need1, ed0, ed1);
                     PROF(11)
                 } else {

@@ -53,6 +53,7 @@ struct BatchArgs {
     BmLists bm = {nullptr, nullptr, 0, 0, 0, nullptr}; /* fragment / region lists of k_break_mask */
     bool defer = false;      /* DevConfig::defer on the host side */
     bool trim_short = false; /* DevConfig::trim_short on the host side */
+    bool scan_short = false; /* DevConfig::scan_short on the host side */
     long long* counters;
     u32 C;
     u32* work_ctr; /* two words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count */
@@ -158,8 +159,12 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         u32 chunk = n / (waves * 32u);
         if (chunk < 4) chunk = n >= 8 * waves ? 4 : (n >= 2 * waves ? 2 : 1);
         if (chunk > 64) chunk = 64;
-        FPL_LAUNCH((k_scan<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
-                   a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk, a.work_ctr + 1);
+        if (a.scan_short)
+            FPL_LAUNCH((k_scan<KWAVES, true>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
+                       a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk, a.work_ctr + 1);
+        else
+            FPL_LAUNCH((k_scan<KWAVES, false>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
+                       a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk, a.work_ctr + 1);
     }
     if (a.defer) {
         u32 blocks = cdiv(n, KWAVES);
