@@ -39,7 +39,7 @@ struct DevConfig {
     int32_t polyx, polyx_min_len;
     int32_t adapter_enabled, ext;
     int32_t has_start, has_end, n_fasta;
-    int32_t trim_short; /* host-side dispatch: no FASTA adapters and both command-line adapters <= 32 bases -> k_trim_ends<SHORT> */
+    int32_t trim_short; /* host-side dispatch: no FASTA adapters and command-line adapters of 16..32 bases (or none) -> k_trim_ends<SHORT> */
     int32_t qual_filter, qualified_qual, unqual_pct, n_base_limit, n_pct_limit, avg_qual_req;
     int32_t length_filter, required_length, max_length;
     int32_t complexity, complexity_pct;
@@ -100,7 +100,8 @@ inline void build_config(DevConfig* c, const fpl_options* o, int start_len, int 
     c->has_start = start_len > 0;
     c->has_end = end_len > 0;
     c->n_fasta = n_fasta;
-    c->trim_short = n_fasta == 0 && start_len <= 32 && end_len <= 32;
+    c->trim_short = n_fasta == 0 && (start_len == 0 || (start_len >= 16 && start_len <= 32)) &&
+                    (end_len == 0 || (end_len >= 16 && end_len <= 32));
     c->qual_filter = o->qual_filter != 0;
     c->qualified_qual = o->qualified_qual;
     c->unqual_pct = o->unqualified_percent_limit;

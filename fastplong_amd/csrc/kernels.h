@@ -626,7 +626,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
         int pp[3], ed[3];
 #pragma unroll
         for (int u = 0; u < 3; u++) pp[u] = p0 + 64 * u + lane;
-        if (plen == 16) {
+        if (SHORT || plen == 16) { /* (SHORT: adapters of 16..32 bases, so plen == 16) */
 #pragma unroll
             for (int u = 0; u < 3; u++) ed[u] = lev16_win<true>(win, min(pp[u], lim - 1), peq16, 16, 16);
         } else {
@@ -718,7 +718,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     int pos = -1, mined = -1;
     bool stop = false;
     int ed3[3];
-    if (plen == 16) {
+    if (SHORT || plen == 16) {
 #pragma unroll
         for (int u = 0; u < 3; u++) /* lim <= 184 = three rounds; independent chains, one straight-line block */
             ed3[u] = lim > 0 ? lev16_win<true>(win, rlen - 16 - min(64 * u + lane, lim - 1), peq16, 16, 16) : 0x7fffffff;
@@ -774,7 +774,7 @@ struct TrimBlockAcc {
 #define FPL_TRIM_WAVES_PER_SIMD 7 /* 13.6 KB of LDS and <= 72 VGPRs per 4-wave block */
 #endif
 #ifndef FPL_TRIM_WAVES_PER_SIMD_SHORT
-#define FPL_TRIM_WAVES_PER_SIMD_SHORT 8 /* the SHORT instantiation needs 55 VGPRs */
+#define FPL_TRIM_WAVES_PER_SIMD_SHORT 7 /* (8 would cap it at 64 VGPRs: spills) */
 #endif
 constexpr int TRIM_WIN = 256; /* FPL_END_WINDOW rounded up, plus slack for the aligned dword reads */
 template <int WAVES>
@@ -794,7 +794,7 @@ __device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __
     wave_sync();
 }
 
-/* SHORT: the host saw no FASTA adapters and command-line adapters of <= 32 bases (DevConfig::trim_short): the
+/* SHORT: the host saw no FASTA adapters and command-line adapters of 16..32 bases (DevConfig::trim_short): the
    global-memory paths, the FASTA chain and the multi-word Levenshtein are left out of that instantiation -- a
    quarter of the code, fewer scalar registers to spill */
 template <int WAVES, bool SHORT>
