@@ -2080,10 +2080,10 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             if (s > SC_END_PF || l - e > SC_END_PF) { /* wave-uniform */
                 RangeSums dummy;
                 u64 d0, d1;
-                if (s > SC_END_PF)
-                    range_scan_fast<false, false>(rb, qb, SC_END_PF, s, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
-                if (l - e > SC_END_PF)
-                    range_scan_fast<false, false>(rb, qb, e + SC_END_PF, l, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+                for (int part = 0; part < 2; part++) { /* (one inlined copy of the scan loop for both ends) */
+                    const int a = part == 0 ? SC_END_PF : e + SC_END_PF, b = part == 0 ? s : l;
+                    if (b > a) range_scan_fast<false, false>(rb, qb, a, b, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+                }
                 u32 x0, x1;
                 hist_totals(h, x0, x1);
                 ht0 += x0;
