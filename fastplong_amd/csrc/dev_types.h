@@ -48,7 +48,7 @@ struct DevConfig {
     int32_t brk, brk_w, brk_thr, msk, msk_w, msk_thr, defer;
     int32_t dbg;      /* FPL_DEBUG_FLAGS: ablation switches for profiling (wrong results when set) */
     int32_t ham_fast; /* both command-line adapters are ACGT-only and <= 64 long: bit-sliced scan */
-    int32_t scan_short; /* host-side dispatch: adapters off, or ham_fast with both adapters <= 32 bases -> k_scan<SHORT> */
+    int32_t scan_short; /* host-side dispatch: adapter trimming on, ham_fast and both adapters <= 32 bases -> k_scan<SHORT> */
     int32_t thr[FPL_MAX_ADAPTER_LEN + 1]; /* (int)round(ed_max * len), computed in double on the host */
 };
 

@@ -144,7 +144,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         build_adapter(&ads[1], end_adapter, end_len);
         for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
         cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
-        cfg.scan_short = !cfg.adapter_enabled || (cfg.ham_fast && ads[0].len <= 32 && ads[1].len <= 32);
+        cfg.scan_short = cfg.adapter_enabled && cfg.ham_fast && ads[0].len <= 32 && ads[1].len <= 32;
         if (const char* e = getenv("FPL_DEBUG_FLAGS")) cfg.dbg = atoi(e);
         ctx->dbg = cfg.dbg;
         if ((cfg.brk && cfg.brk_w <= 0) || (cfg.msk && cfg.msk_w <= 0)) {

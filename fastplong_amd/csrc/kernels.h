@@ -1718,7 +1718,9 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
                                                 const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
                                                 ScanWaveLds* __restrict__ w, int qualified_qual, RangeSums& sums,
                                                 const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
-                                                u64& key0, u64& key1) {
+                                                u64& key0, u64& key1, bool do_ham = true) {
+    /* do_ham (wave-uniform): false turns a HAM instance into a plain scan -- no window is tested, the keys come out
+       as ~0 -- so that one inlined copy of the loop can serve reads with and without an adapter search */
     const int lane = lane_id();
     const int blen = b - a;
     constexpr int ACTIVE = HAM ? SC_LANES_HAM : 64;
@@ -1726,7 +1728,7 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
     u32* const h = w->hist;
     u32 lowq = 0, nn = 0, totq = 0, diff = 0;
     int bm0 = -1, bp0 = 0, bm1 = -1, bp1 = 0; /* best match count / its position, per lane */
-    const int npos0 = HAM ? blen - ad0->len : 0, npos1 = HAM ? blen - ad1->len : 0;
+    const int npos0 = (HAM && do_ham) ? blen - ad0->len : 0, npos1 = (HAM && do_ham) ? blen - ad1->len : 0;
     const int dbg = qualified_qual >> 8; /* ablation switches ride in the high bits */
     qualified_qual &= 0xFF;
     const u32 qqrep = 0x01010101u * (u32)(qualified_qual & 0x7F);
@@ -1948,7 +1950,7 @@ __device__ __forceinline__ void lev_pair32_run(const u32 (*__restrict__ peq4)[4]
     ed1 = readlane_i32(res, 1);
 }
 
-/* SHORT: adapter trimming is off, or both command-line adapters are ACGT-only and <= 32 bases (DevConfig::scan_short):
+/* SHORT: adapter trimming is on and both command-line adapters are ACGT-only and <= 32 bases (DevConfig::scan_short):
    the byte-wise scan and the multi-word Levenshtein are left out of that instantiation */
 template <int WAVES, bool SHORT>
 __global__ void __launch_bounds__(WAVES * 64, SCAN_BLOCKS_PER_CU * WAVES / 4)
@@ -2051,9 +2053,9 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         RangeSums sm = {0, 0, 0, 0};
         u64 key0 = ~0ull, key1 = ~0ull;
         const bool ham = !dropped && cfg->adapter_enabled;
-        if (ham && (SHORT || cfg->ham_fast))
-            range_scan_fast<true, true>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, &ads[0], &ads[1], key0, key1);
-        else if (!SHORT && ham) /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
+        if (SHORT || (ham && cfg->ham_fast)) /* (SHORT: also the reads without an adapter search, through do_ham) */
+            range_scan_fast<true, true>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, &ads[0], &ads[1], key0, key1, ham);
+        else if (ham) /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
             range_scan_bytes<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
         else
             range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, nullptr, nullptr, key0, key1);

@@ -36,7 +36,7 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
     cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
     if (getenv("FPL_EMU_NO_HAM_FAST")) cfg.ham_fast = 0;
-    cfg.scan_short = !cfg.adapter_enabled || (cfg.ham_fast && ads[0].len <= 32 && ads[1].len <= 32);
+    cfg.scan_short = cfg.adapter_enabled && cfg.ham_fast && ads[0].len <= 32 && ads[1].len <= 32;
 
     uint64_t n_bytes = n_reads ? off[n_reads] : 0;
     uint32_t max_len = 0;
