@@ -102,7 +102,7 @@ inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu) {
 /* EXTRA pass (post-only fragments; count known only on the device): a fixed number of blocks per tile walk
  * slices of FS_EXTRA_PER items and hand over one slab each. */
 constexpr u32 FS_EXTRA_PER = 1024;
-constexpr u32 FS_EXTRA_BLOCKS = 64;
+constexpr u32 FS_EXTRA_BLOCKS = 32; /* (64: 0.07 ms more on the 1 M-read batch: every block zeroes and hands over 70 KiB) */
 inline u32 env_u32(const char* name, u32 dflt) { /* tuning / test hooks */
     const char* e = getenv(name);
     return (e && atoi(e) > 0) ? (u32)atoi(e) : dflt;
