@@ -1713,7 +1713,9 @@ __device__ __forceinline__ void hist32(u32* __restrict__ h, const u32 q[8], int 
  *     by the bit-sliced method above; keys (mismatches << 32 | p), ~0 when nothing was tested.
  *     Requires ACGT-only adapters of <= 64 bases (DevConfig::ham_fast).
  */
-template <bool SUMS, bool HAM>
+/* LEAN: the rare callers (long trimmed ends, the fragments of a split read) take the byte-masked variants for every
+ * tile, full or ragged: half the code of an inlined copy, and the kernel's instruction footprint is what they cost. */
+template <bool SUMS, bool HAM, bool LEAN = false>
 __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
                                                 const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
                                                 ScanWaveLds* __restrict__ w, int qualified_qual, RangeSums& sums,
@@ -1755,7 +1757,7 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
         if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
         /* the last tile of a range is ragged (some lane holds fewer than 32 bytes): the whole wave then takes
            the byte-masked variants, so that no lane falls back to a byte-by-byte loop */
-        if (!wave_ballot(nstat > 0 && nstat < SC_CHUNK)) {
+        if (!LEAN && !wave_ballot(nstat > 0 && nstat < SC_CHUNK)) {
             if (nstat == SC_CHUNK) {
                 if (!FPL_DBG(dbg, 1)) hist32<false>(h, q, SC_CHUNK);
                 if (SUMS && !FPL_DBG(dbg, 2)) sums32<false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
@@ -2084,7 +2086,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 u64 d0, d1;
                 for (int part = 0; part < 2; part++) { /* (one inlined copy of the scan loop for both ends) */
                     const int a = part == 0 ? SC_END_PF : e + SC_END_PF, b = part == 0 ? s : l;
-                    if (b > a) range_scan_fast<false, false>(rb, qb, a, b, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+                    if (b > a) range_scan_fast<false, false, true>(rb, qb, a, b, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
                 }
                 u32 x0, x1;
                 hist_totals(h, x0, x1);
@@ -2192,7 +2194,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 RangeSums fs = sm;
                 if (split) { /* rare: re-derive sums and histogram for this fragment */
                     u64 d0, d1;
-                    range_scan_fast<true, false>(rb, qb, fa[f], fb[f], seq_end, qual_end, wl, qq, fs, nullptr, nullptr, d0, d1);
+                    range_scan_fast<true, false, true>(rb, qb, fa[f], fb[f], seq_end, qual_end, wl, qq, fs, nullptr, nullptr, d0, d1);
                     hist_totals(h, t0, t1);
                 }
                 const int code = filter_code(cfg, flen, fs);
