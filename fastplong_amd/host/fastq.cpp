@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <iostream>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -110,6 +111,183 @@ void parallel_run(int tasks, const function<void(int)>& fn) {
     pool.run(tasks, fn);
 }
 
+/* ---- gzip input made of several members ---------------------------------------------------------------
+ * One deflate stream cannot be inflated in parallel, but a gzip FILE is often a concatenation of members: bgzip
+ * blocks, `cat` of the per-chunk files sequencers write, the 4 MiB flushes of fastp / fastplong, the slices of this
+ * host's own writer.  Members start with 1f 8b 08 and a flag byte whose top three bits are zero; that pattern
+ * also occurs inside compressed data, so a candidate only counts once a member that starts there has been inflated
+ * to its end with a good CRC (zlib checks it) AND the chain of members starting at offset 0 lands on it.  Batches
+ * of candidates are inflated speculatively on the worker pool; the chain walk then keeps what lines up and drops
+ * the rest.  A member that inflates to more than 1 GiB (a plain `gzip` of a whole run) is not buffered:
+ * from there on the file is streamed through zlib as before. */
+class GzMembers {
+   public:
+    static std::atomic<uint64_t> delivered; /* members handed to the parser since the last fplh_gz_members() (test hook) */
+    static GzMembers* open(const string& path, int threads) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return nullptr;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 64) {
+            close(fd);
+            return nullptr;
+        }
+        void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            close(fd);
+            return nullptr;
+        }
+        GzMembers* g = new GzMembers;
+        g->fd_ = fd;
+        g->base_ = (const unsigned char*)m;
+        g->size_ = (size_t)st.st_size;
+        g->threads_ = max(1, threads);
+        if (const char* e = getenv("FPLH_GZ_MEMBER_CAP")) /* test hook */
+            if (atol(e) > 0) g->cap_ = (size_t)atol(e);
+        g->find_candidates();
+        if (g->cands_.size() < 2 || g->cands_[0] != 0) { /* one member (or not gzip): nothing to gain */
+            delete g;
+            return nullptr;
+        }
+        return g;
+    }
+    ~GzMembers() {
+        if (stream_) gzclose(stream_);
+        if (base_) munmap((void*)base_, size_);
+        if (fd_ >= 0 && !stream_) close(fd_); /* (gzclose closes the descriptor it was given) */
+    }
+    /* next bytes of the inflated stream; 0 = end of input */
+    size_t read(char* dst, size_t n) {
+        size_t got = 0;
+        while (got < n) {
+            if (stream_) {
+                const int r = gzread(stream_, dst + got, (unsigned)min<size_t>(n - got, 1u << 30));
+                if (r <= 0) break;
+                got += (size_t)r;
+                continue;
+            }
+            if (cur_off_ < cur_.size()) {
+                const size_t k = min(n - got, cur_.size() - cur_off_);
+                memcpy(dst + got, cur_.data() + cur_off_, k);
+                cur_off_ += k;
+                got += k;
+                continue;
+            }
+            if (!next_member()) break;
+        }
+        return got;
+    }
+    uint64_t members_inflated_in_parallel() const { return n_parallel_; }
+
+   private:
+    struct Result {
+        vector<char> out;
+        size_t end = 0; /* file offset behind the member's trailer */
+        int state = 0;  /* 1 = a whole member, 2 = too large to buffer, -1 = not a member */
+    };
+    static bool looks_like_header(const unsigned char* p) { return p[0] == 0x1f && p[1] == 0x8b && p[2] == 8 && (p[3] & 0xE0) == 0; }
+    void find_candidates() {
+        const int T = (int)max<size_t>(1, min<size_t>((size_t)threads_, size_ / (4u << 20)));
+        vector<vector<size_t>> found(T);
+        parallel_run(T, [&](int t) {
+            const size_t lo = size_ / T * t, hi = t == T - 1 ? size_ : size_ / T * (t + 1);
+            const unsigned char* p = base_ + lo;
+            const unsigned char* e = base_ + min(hi, size_ - 18); /* header 10 + trailer 8 at least */
+            while (p < e) {
+                p = (const unsigned char*)memchr(p, 0x1f, (size_t)(e - p));
+                if (!p) break;
+                if (looks_like_header(p)) found[t].push_back((size_t)(p - base_));
+                p++;
+            }
+        });
+        for (auto& v : found) cands_.insert(cands_.end(), v.begin(), v.end());
+    }
+    void inflate_at(size_t off, Result& r) const {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        r.state = -1;
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) return;
+        zs.next_in = (Bytef*)(base_ + off);
+        size_t in_left = size_ - off;
+        r.out.resize(min<size_t>(4u << 20, cap_));
+        size_t produced = 0;
+        for (;;) {
+            if (zs.avail_in == 0 && in_left > 0) {
+                zs.avail_in = (uInt)min<size_t>(in_left, 1u << 30);
+                in_left -= zs.avail_in;
+            }
+            if (produced == r.out.size()) {
+                if (r.out.size() >= cap_) {
+                    r.state = 2;
+                    break;
+                }
+                r.out.resize(r.out.size() * 2);
+            }
+            zs.next_out = (Bytef*)r.out.data() + produced;
+            zs.avail_out = (uInt)min<size_t>(r.out.size() - produced, 1u << 30);
+            const uInt before = zs.avail_out;
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            produced += before - zs.avail_out;
+            if (rc == Z_STREAM_END) {
+                r.state = 1;
+                r.end = (size_t)((const unsigned char*)zs.next_in - base_);
+                break;
+            }
+            if (rc != Z_OK || (zs.avail_in == 0 && in_left == 0 && zs.avail_out != 0)) break; /* bad data / truncated */
+        }
+        inflateEnd(&zs);
+        if (r.state == 1) r.out.resize(produced);
+        else r.out = vector<char>();
+    }
+    /* make the member at pos_ current; false at the end of the input */
+    bool next_member() {
+        cur_.clear();
+        cur_off_ = 0;
+        for (;;) {
+            if (pos_ >= size_ || size_ - pos_ < 18 || !looks_like_header(base_ + pos_)) return false; /* end, or trailing bytes zlib ignores too */
+            auto it = done_.find(pos_);
+            if (it == done_.end()) { /* inflate the next candidates at and behind pos_ that are not there yet */
+                vector<size_t> todo;
+                for (auto c = std::lower_bound(cands_.begin(), cands_.end(), pos_); c != cands_.end() && (int)todo.size() < threads_; ++c)
+                    if (!done_.count(*c)) todo.push_back(*c);
+                if (todo.empty() || todo[0] != pos_) todo.insert(todo.begin(), pos_);
+                vector<Result> res(todo.size());
+                parallel_run((int)todo.size(), [&](int i) { inflate_at(todo[i], res[i]); });
+                for (size_t i = 0; i < todo.size(); i++) done_[todo[i]] = std::move(res[i]);
+                it = done_.find(pos_);
+            }
+            Result& r = it->second;
+            if (r.state == 2 || r.state == -1) {
+                /* too large to buffer (or damaged: let zlib report it the usual way): stream the rest */
+                done_.clear();
+                if (lseek(fd_, (off_t)pos_, SEEK_SET) < 0) return false;
+                stream_ = gzdopen(fd_, "rb");
+                if (stream_) gzbuffer(stream_, 1 << 20);
+                return stream_ != nullptr;
+            }
+            cur_.swap(r.out);
+            const size_t end = r.end;
+            for (auto d = done_.begin(); d != done_.end();) /* speculative results the chain has passed */
+                d = d->first < end ? done_.erase(d) : std::next(d);
+            pos_ = end;
+            n_parallel_++;
+            delivered++;
+            if (!cur_.empty()) return true; /* (an empty member: go on to the next) */
+        }
+    }
+    int fd_ = -1;
+    const unsigned char* base_ = nullptr;
+    size_t size_ = 0, pos_ = 0, cur_off_ = 0;
+    int threads_ = 1;
+    size_t cap_ = 1ull << 30; /* largest inflated member that is buffered */
+    vector<size_t> cands_;
+    std::map<size_t, Result> done_;
+    vector<char> cur_;
+    gzFile stream_ = nullptr;
+    uint64_t n_parallel_ = 0;
+};
+
+std::atomic<uint64_t> GzMembers::delivered{0};
+
 /* FAILED_TYPES, src/common.h:55-64 */
 static const char* failed_type(int code) {
     switch (code) {
@@ -191,7 +369,11 @@ FastqReader::FastqReader(const string& path) {
             }
         }
     }
-    if (fd_ < 0) {
+    if (fd_ < 0 && path != "/dev/stdin" && allow_map && !getenv("FPLH_NO_GZ_MEMBERS")) {
+        members_ = GzMembers::open(path, max(copy_threads_, 16)); /* inflate is compute-bound: more workers than the memory-bound phases use */
+        if (members_) fp_ = this;
+    }
+    if (fd_ < 0 && !members_) {
         /* gzopen reads plain files transparently */
         fp_ = path == "/dev/stdin" ? (void*)gzdopen(0, "rb") : (void*)gzopen(path.c_str(), "rb");
         if (fp_) gzbuffer((gzFile)fp_, 1 << 20);
@@ -202,6 +384,7 @@ FastqReader::FastqReader(const string& path) {
 
 FastqReader::~FastqReader() {
     if (fd_ >= 0) close(fd_);
+    else if (members_) delete members_;
     else if (fp_) gzclose((gzFile)fp_);
 }
 
@@ -238,6 +421,13 @@ bool FastqReader::pull() {
         pulled_ += want;
         file_pos_ += want;
         if (file_pos_ >= file_size_) eof_ = true;
+        return true;
+    }
+    if (members_) {
+        const size_t n = members_->read(buf_.data() + len_, buf_.size() - len_);
+        if (n == 0) eof_ = true;
+        len_ += n;
+        pulled_ += n;
         return true;
     }
     while (len_ < buf_.size()) { /* gzread returns short counts on pipes */
@@ -678,6 +868,7 @@ void* fplh_batch_read_all(const char* path, uint64_t max_bases, uint32_t max_rea
     return all;
 }
 uint64_t fplh_parallel_records(void) { return fplh::g_parallel_records.exchange(0); }
+uint64_t fplh_gz_members(void) { return fplh::GzMembers::delivered.exchange(0); }
 uint32_t fplh_batch_n(void* b) { return ((fplh::Batch*)b)->n(); }
 uint64_t fplh_batch_bytes(void* b) { return ((fplh::Batch*)b)->seq.size(); }
 const uint8_t* fplh_batch_seq(void* b) { return ((fplh::Batch*)b)->seq.data(); }

@@ -67,6 +67,10 @@ struct Batch {
     void clear();
 };
 
+/* A gzip file that is a concatenation of members (bgzip, `cat` of per-chunk files as sequencers write them, the
+ * outputs of fastp / fastplong / this host) inflated on several threads: see fastq.cpp. */
+class GzMembers;
+
 /* Plain or gzip FASTQ (zlib).  Line splitting follows FastqReader::getLine: a line ends at
  * '\r' or '\n', "\r\n" counts once; records whose header does not start with '@' are skipped
  * line by line; a malformed record ends the input (src/fastqreader.cpp:326-341). */
@@ -105,7 +109,8 @@ class FastqReader {
     void scan_parallel(uint64_t& bases, uint64_t max_bases, uint32_t& reads, uint32_t max_reads, std::vector<Rec>& recs);
     bool pull(); /* stream mode: keep [pos_, len_), read more behind it (growing the window when a record fills it) */
     void copy_records(Batch& b, const std::vector<Rec>& recs) const;
-    void* fp_ = nullptr;       /* gzFile (gzip, pipes) or a non-null token (regular file, fd_) */
+    void* fp_ = nullptr;       /* gzFile (gzip, pipes) or a non-null token (regular file, fd_ / members_) */
+    GzMembers* members_ = nullptr; /* multi-member gzip file: parallel inflate */
     const char* win_ = nullptr; /* the window: buf_.data() */
     std::vector<char> buf_;
     int fd_ = -1;              /* regular uncompressed file: refilled with parallel pread */
@@ -144,6 +149,7 @@ extern "C" {
 void* fplh_batch_read(const char* path, uint64_t max_bases, uint32_t max_reads);
 void* fplh_batch_read_all(const char* path, uint64_t max_bases, uint32_t max_reads);
 uint64_t fplh_parallel_records(void); /* records the multi-threaded scan contributed since the last call */
+uint64_t fplh_gz_members(void);       /* gzip members inflated on the worker pool since the last call */
 uint32_t fplh_batch_n(void* b);
 uint64_t fplh_batch_bytes(void* b);
 const uint8_t* fplh_batch_seq(void* b);

@@ -228,3 +228,57 @@ def test_record_formats_match_reference(ref):
         assert abi.FAILED_TYPES[code] == tag
         out = ref.run(["TAG %d =@r1 =ACGT =+ =IIII" % code])
         assert out.split("\n", 1)[1] == "@r1 %s\nACGT\n+\nIIII\n" % tag
+
+
+def _gz_member(data, level=6):
+    import gzip
+    import io
+    b = io.BytesIO()
+    with gzip.GzipFile(fileobj=b, mode="wb", compresslevel=level, mtime=0) as f:
+        f.write(data)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("variant", ["members", "false_header", "big_member", "trailing_zeros", "single"])
+def test_multi_member_gzip_input(hostlib, tmp_path, monkeypatch, variant):
+    """a gzip file that is a concatenation of members is inflated member by member on the worker pool; headers that only
+    LOOK like member starts (inside stored blocks), a member too large to buffer, empty members and trailing padding
+    all end up with exactly what the single zlib stream delivers"""
+    rng = np.random.default_rng(5)
+    reads = [(synth._ACGT[rng.integers(0, 4, n)].astype(np.uint8), rng.integers(35, 70, n).astype(np.uint8))
+             for n in rng.integers(50, 3000, 400)]
+    seq, qual, off = synth.pack(reads)
+    text, _, _ = hostio.make_fastq(seq, qual, off)
+    lines = text.split(b"\n")
+    if variant == "false_header":  # gzip magic inside a read name, kept verbatim by a stored (level 0) member
+        lines[4 * 37] = b"@read37 \x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03 looks like a member"
+        lines[4 * 201] = b"@read201 \x1f\x8b\x08\x08 again"
+        text = b"\n".join(lines)
+    cuts = sorted(set(int(x) for x in rng.integers(0, len(text), 9)) | {0, len(text)})
+    parts = [text[a:b] for a, b in zip(cuts[:-1], cuts[1:])]  # members cut anywhere, also inside records
+    if variant == "single":
+        blob = _gz_member(text)
+    else:
+        level = 0 if variant == "false_header" else 6
+        blob = b"".join(_gz_member(p_, level) for p_ in parts[:4]) + _gz_member(b"") + b"".join(_gz_member(p_, level) for p_ in parts[4:])
+    if variant == "trailing_zeros":
+        blob += b"\0" * 1000
+    if variant == "big_member":
+        monkeypatch.setenv("FPLH_GZ_MEMBER_CAP", str(64 << 10))  # most members exceed 64 KiB: stream from the first such
+    p = tmp_path / "in.fq.gz"
+    p.write_bytes(blob)
+    hostlib.fplh_gz_members.restype = C.c_uint64
+    monkeypatch.setenv("FPLH_NO_GZ_MEMBERS", "1")
+    want = _read_all(hostlib, p, 10 ** 9, 2 ** 30)
+    assert len(want[2]) - 1 == 400 and np.array_equal(want[0], seq)
+    monkeypatch.delenv("FPLH_NO_GZ_MEMBERS")
+    hostlib.fplh_gz_members()
+    for caps in ((10 ** 9, 2 ** 30), (20000, 2 ** 30)):
+        got = _read_all(hostlib, p, *caps)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    n = hostlib.fplh_gz_members()
+    if variant in ("members", "false_header", "trailing_zeros"):
+        assert n >= 2 * 9
+    elif variant == "single":
+        assert n == 0
