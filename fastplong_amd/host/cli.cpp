@@ -568,7 +568,10 @@ int main(int argc, char* argv[]) {
     };
 
     long readsLeft = readsToProcess > 0 ? readsToProcess : -1;
-    const int fmtThreads = max(1, min(16, (int)thread::hardware_concurrency() / max(1, nGpus) - 1));
+    /* slices a batch's output is formatted in (one worker each); gzip outputs are deflated per slice, which is compute-
+       bound, so they get more, smaller slices */
+    const bool anyGz = (fout && fout.gz) || (ffail && ffail.gz);
+    const int fmtThreads = max(1, min(anyGz ? 48 : 16, (int)thread::hardware_concurrency() / max(1, nGpus) - 1));
     const int nWork = 2 * nGpus + 1;
     vector<Work> pool(nWork);
     Channel<Work*> freeq, doneq;
