@@ -211,20 +211,28 @@ class Channel {
     deque<T> q_;
 };
 
-/* one complete gzip member (any gzip reader takes a concatenation of members as one stream) */
-static string gzip_member(const string& in, int level) {
+/* one complete gzip member (any gzip reader takes a concatenation of members as one stream).  The deflated bytes go
+   through a buffer the calling thread keeps (the pool's workers are persistent): dozens of threads allocating and
+   releasing multi-megabyte strings per slice spend their time in the kernel's address-space lock instead. */
+static void gzip_into(const string& in, int level, string& out) {
+    static thread_local vector<char> scratch;
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) error_exit("deflateInit2 failed");
-    string o;
-    o.resize(deflateBound(&zs, (uLong)in.size()) + 64);
+    const size_t bound = deflateBound(&zs, (uLong)in.size()) + 64;
+    if (scratch.size() < bound) scratch.resize(bound);
     zs.next_in = (Bytef*)in.data();
     zs.avail_in = (uInt)in.size();
-    zs.next_out = (Bytef*)&o[0];
-    zs.avail_out = (uInt)o.size();
+    zs.next_out = (Bytef*)scratch.data();
+    zs.avail_out = (uInt)bound;
     if (deflate(&zs, Z_FINISH) != Z_STREAM_END) error_exit("deflate failed");
-    o.resize(zs.total_out);
+    const size_t n = zs.total_out;
     deflateEnd(&zs);
+    out.assign(scratch.data(), n); /* (when out is the input itself: shrinks inside its own allocation) */
+}
+static string gzip_member(const string& in, int level) {
+    string o;
+    gzip_into(in, level, o);
     return o;
 }
 
@@ -556,7 +564,7 @@ int main(int argc, char* argv[]) {
     SplitOutput* split = splitEnabled ? new SplitOutput(out, splitDigits, workers, splitByLines, splitNumber, splitSize, gzLevel) : nullptr;
     auto gzip_pieces = [&](vector<string>& pieces) { /* in parallel; pieces stay below 4 GiB (one slice of a batch) */
         fplh::parallel_run((int)pieces.size(), [&](int i) {
-            if (!pieces[i].empty()) pieces[i] = gzip_member(pieces[i], gzLevel);
+            if (!pieces[i].empty()) gzip_into(pieces[i], gzLevel, pieces[i]);
         });
     };
     auto write_pieces = [](OutFile& o, const vector<string>& pieces) {
@@ -571,7 +579,7 @@ int main(int argc, char* argv[]) {
     /* slices a batch's output is formatted in (one worker each); gzip outputs are deflated per slice, which is compute-
        bound, so they get more, smaller slices */
     const bool anyGz = (fout && fout.gz) || (ffail && ffail.gz);
-    const int fmtThreads = max(1, min(anyGz ? 48 : 16, (int)thread::hardware_concurrency() / max(1, nGpus) - 1));
+    const int fmtThreads = max(1, min(anyGz ? 64 : 16, (int)thread::hardware_concurrency() / max(1, nGpus) - 1));
     const int nWork = 2 * nGpus + 1;
     vector<Work> pool(nWork);
     Channel<Work*> freeq, doneq;
