@@ -118,7 +118,7 @@ void parallel_run(int tasks, const function<void(int)>& fn) {
  * also occurs inside compressed data, so a candidate only counts once a member that starts there has been inflated
  * to its end with a good CRC (zlib checks it) AND the chain of members starting at offset 0 lands on it.  Batches
  * of candidates are inflated speculatively on the worker pool; the chain walk then keeps what lines up and drops
- * the rest.  A member that inflates to more than 1 GiB (a plain `gzip` of a whole run) is not buffered:
+ * the rest.  A member that inflates to more than 512 MiB (a plain `gzip` of a whole run) is not buffered:
  * from there on the file is streamed through zlib as before. */
 class GzMembers {
    public:
@@ -278,7 +278,7 @@ class GzMembers {
     const unsigned char* base_ = nullptr;
     size_t size_ = 0, pos_ = 0, cur_off_ = 0;
     int threads_ = 1;
-    size_t cap_ = 1ull << 30; /* largest inflated member that is buffered */
+    size_t cap_ = 512ull << 20; /* largest inflated member that is buffered */
     vector<size_t> cands_;
     std::map<size_t, Result> done_;
     vector<char> cur_;
