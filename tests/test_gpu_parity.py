@@ -309,3 +309,39 @@ def test_large_batch_properties(engine_mod):
     cnt3 = eng3.counters()
     eng3.close()
     assert np.array_equal(cnt, cnt3)
+
+
+def test_counters_tensor_all_reduce_over_rccl(orc, engine_mod):
+    """bench.py --gpus N and multi-GPU hosts sum the counter buffers with torch.distributed (backend nccl = RCCL) on a
+    zero-copy view of the device buffer: exercise exactly that call on a one-rank group"""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from fastplong_amd import dist as fdist
+    cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = synth.adversarial(300, seed=3)
+    C = int(np.diff(off.astype(np.int64)).max())
+    _, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    eng = engine_mod.Engine(cfg.opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=C)
+    eng.process_host(seq, qual, off)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert fdist.agree_capacity(C, device=torch.device("cuda", 0)) == C
+        t = eng.counters_tensor()
+        assert t.is_cuda and t.dtype == torch.int64 and t.numel() == len(want_cnt)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)  # one rank: the sum is the buffer itself
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy(), want_cnt)
+        t += 1  # a view, not a copy: the context sees the change
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.counters(), want_cnt + 1)
+    finally:
+        dist.destroy_process_group()
+        eng.close()
