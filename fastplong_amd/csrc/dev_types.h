@@ -39,7 +39,8 @@ struct DevConfig {
     int32_t polyx, polyx_min_len;
     int32_t adapter_enabled, ext;
     int32_t has_start, has_end, n_fasta;
-    int32_t trim_short; /* host-side dispatch: no FASTA adapters and command-line adapters of 16..32 bases (or none) -> k_trim_ends<SHORT> */
+    int32_t trim_mode; /* host-side dispatch of k_trim_ends<MODE>: 1 = no FASTA adapters, command-line adapters of 16..32 bases
+                          (or none); 2 = every adapter 16..64 bases; else 0 (set by trim_mode_of once the adapters are known) */
     int32_t qual_filter, qualified_qual, unqual_pct, n_base_limit, n_pct_limit, avg_qual_req;
     int32_t length_filter, required_length, max_length;
     int32_t complexity, complexity_pct;
@@ -83,6 +84,17 @@ inline void build_adapter(DevAdapter* a, const char* seq, int len) {
     }
 }
 
+/* DevConfig::trim_mode from the adapter lengths (slot order: start, end, FASTA...; a length of 0 = slot unused) */
+inline int trim_mode_of(const int* lens, int n_adapters) {
+    bool short_ok = n_adapters == 2, mid_ok = true;
+    for (int i = 0; i < n_adapters; i++) {
+        const int l = lens[i];
+        if (l == 0 && i < 2) continue; /* command-line adapter not given */
+        if (l < 16 || l > 32) short_ok = false;
+        if (l < 16 || l > 64) mid_ok = false;
+    }
+    return short_ok ? 1 : (mid_ok ? 2 : 0);
+}
 inline void build_config(DevConfig* c, const fpl_options* o, int start_len, int end_len, int n_fasta) {
     memset(c, 0, sizeof(*c));
     c->trim_front = o->trim_front;
@@ -100,8 +112,7 @@ inline void build_config(DevConfig* c, const fpl_options* o, int start_len, int 
     c->has_start = start_len > 0;
     c->has_end = end_len > 0;
     c->n_fasta = n_fasta;
-    c->trim_short = n_fasta == 0 && (start_len == 0 || (start_len >= 16 && start_len <= 32)) &&
-                    (end_len == 0 || (end_len >= 16 && end_len <= 32));
+    c->trim_mode = 0;
     c->qual_filter = o->qual_filter != 0;
     c->qualified_qual = o->qualified_qual;
     c->unqual_pct = o->unqualified_percent_limit;

@@ -144,6 +144,11 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         build_adapter(&ads[1], end_adapter, end_len);
         for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
         cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
+        {
+            std::vector<int> lens(2 + n_fasta);
+            for (int i = 0; i < 2 + n_fasta; i++) lens[i] = ads[i].len;
+            cfg.trim_mode = trim_mode_of(lens.data(), 2 + n_fasta);
+        }
         cfg.scan_short = cfg.adapter_enabled && cfg.ham_fast && ads[0].len <= 32 && ads[1].len <= 32;
         if (const char* e = getenv("FPL_DEBUG_FLAGS")) cfg.dbg = atoi(e);
         ctx->dbg = cfg.dbg;
@@ -343,7 +348,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.frag_cyc = ctx->d_frag_cyc;
     a.bm = ctx->bm;
     a.defer = ctx->hcfg.defer != 0;
-    a.trim_short = ctx->hcfg.trim_short != 0;
+    a.trim_mode = ctx->hcfg.trim_mode;
     a.scan_short = ctx->hcfg.scan_short != 0;
     a.counters = ctx->d_counters;
     a.C = ctx->C;

@@ -104,9 +104,10 @@ __device__ __forceinline__ int lev_bp64(const uint64_t (*__restrict__ peq)[PEQ_W
     if (m == 0) return n;
     if (n == 0) return m;
     const int W = (m + 63) >> 6;
-    u64 Pv[PEQ_WORDS], Mv[PEQ_WORDS];
+    constexpr int MW = PEQ_WORDS;
+    u64 Pv[MW], Mv[MW];
 #pragma unroll
-    for (int b = 0; b < PEQ_WORDS; b++) {
+    for (int b = 0; b < MW; b++) {
         Pv[b] = ~0ull;
         Mv[b] = 0;
     }
@@ -116,7 +117,7 @@ __device__ __forceinline__ int lev_bp64(const uint64_t (*__restrict__ peq)[PEQ_W
         const int c = text[j];
         int hin = 1; /* D[0][j] - D[0][j-1] */
 #pragma unroll
-        for (int b = 0; b < PEQ_WORDS; b++) {
+        for (int b = 0; b < MW; b++) {
             if (b < W) {
                 u64 Eq = peq_word(peq, c, shift, b);
                 const u64 pv = Pv[b], mv = Mv[b];
@@ -186,12 +187,13 @@ __device__ __forceinline__ bool lev_round32(const WaveVals64& pub, int cnt, int 
     }
     return false;
 }
-__device__ __forceinline__ bool lev_round64(const WaveVals64 (&pub)[PEQ_WORDS], int W, int cnt, int left_after,
-                                            u64 (&Pv)[PEQ_WORDS], u64 (&Mv)[PEQ_WORDS], int& score, u64 last_top, int thr) {
+template <int MW>
+__device__ __forceinline__ bool lev_round64(const WaveVals64 (&pub)[MW], int W, int cnt, int left_after,
+                                            u64 (&Pv)[MW], u64 (&Mv)[MW], int& score, u64 last_top, int thr) {
     for (int t = 0; t < cnt; t++) {
         int hin = 1; /* D[0][j] - D[0][j-1] */
 #pragma unroll
-        for (int b = 0; b < PEQ_WORDS; b++) {
+        for (int b = 0; b < MW; b++) {
             if (b < W) {
                 u64 Eq = pub[b].get(t);
                 const u64 pv = Pv[b], mv = Mv[b];
@@ -223,7 +225,8 @@ __device__ __forceinline__ bool lev_round64(const WaveVals64 (&pub)[PEQ_WORDS], 
  * words in parallel (64 columns per round), then every lane runs the identical recurrence on
  * v_readlane-broadcast words -- no serial chain of dependent memory loads, result wave-uniform.
  * BYTE(j) yields text byte j.  Exact when the distance is <= thr, otherwise some value > thr. */
-template <bool SHORT, int PW, class ByteFn>
+/* MODE (see k_trim_ends): 0 = any pattern, 1 = the caller guarantees m <= 32, 2 = m <= 64 */
+template <int MODE, int PW, class ByteFn>
 __device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[PW], int shift, int m, int n,
                                              int thr, ByteFn&& BYTE) {
     if (m == 0) return n;
@@ -231,7 +234,7 @@ __device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[
     const int W = (m + 63) >> 6;
     const int lane = lane_id();
     int score = m;
-    if (SHORT || m <= 32) { /* SHORT: the caller guarantees m <= 32 and the multi-word code below is not even compiled */
+    if (MODE == 1 || m <= 32) { /* MODE 1: the multi-word code below is not even compiled */
         u32 Pv = ~0u, Mv = 0;
         const u32 top = 1u << (m - 1);
         for (int j0 = 0; j0 < n; j0 += 64) {
@@ -243,24 +246,25 @@ __device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[
         }
         return score;
     }
-    u64 Pv[PEQ_WORDS], Mv[PEQ_WORDS];
+    constexpr int MW = MODE == 2 ? 1 : PEQ_WORDS; /* 64-column words the recurrence may need */
+    u64 Pv[MW], Mv[MW];
 #pragma unroll
-    for (int b = 0; b < PEQ_WORDS; b++) {
+    for (int b = 0; b < MW; b++) {
         Pv[b] = ~0ull;
         Mv[b] = 0;
     }
     const u64 last_top = 1ull << ((m - 1) & 63);
     for (int j0 = 0; j0 < n; j0 += 64) {
-        u64 eqw[PEQ_WORDS] = {0, 0, 0, 0};
+        u64 eqw[MW] = {};
         if (j0 + lane < n) {
             const int c = (int)BYTE(j0 + lane);
 #pragma unroll
-            for (int b = 0; b < PEQ_WORDS; b++)
+            for (int b = 0; b < MW; b++)
                 if (b < W) eqw[b] = peq_word(peq, c, shift, b);
         }
-        WaveVals64 pub[PEQ_WORDS];
+        WaveVals64 pub[MW];
 #pragma unroll
-        for (int b = 0; b < PEQ_WORDS; b++)
+        for (int b = 0; b < MW; b++)
             if (b < W) pub[b] = wave_publish(eqw[b]);
         const int cnt = min(64, n - j0);
         if (lev_round64(pub, W, cnt, n - j0 - cnt, Pv, Mv, score, last_top, thr)) return thr + 1;
@@ -269,7 +273,7 @@ __device__ __forceinline__ int lev_wave_core(const uint64_t (*__restrict__ peq)[
 }
 __device__ __forceinline__ int lev_wave(const uint64_t (*__restrict__ peq)[PEQ_WORDS], int shift, int m,
                                         const u8* __restrict__ text, int n, int thr) {
-    return lev_wave_core<false>(peq, shift, m, n, thr, [&](int j) { return (u32)text[j]; });
+    return lev_wave_core<0>(peq, shift, m, n, thr, [&](int j) { return (u32)text[j]; });
 }
 
 /* run f() on lane 0 only and hand its int result to every lane */
@@ -558,10 +562,10 @@ __device__ __forceinline__ int lev16_win(const Win<LDSWIN>& win, int p, const PT
 }
 
 /* lev_wave with the text taken from a Win */
-template <bool SHORT, bool LDSWIN, int PW>
+template <int MODE, bool LDSWIN, int PW>
 __device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[PW], int shift, int m,
                                             const Win<LDSWIN>& win, int p, int n, int thr) {
-    return lev_wave_core<SHORT>(peq, shift, m, n, thr, [&](int j) { return win.byte(p + j); });
+    return lev_wave_core<MODE>(peq, shift, m, n, thr, [&](int j) { return win.byte(p + j); });
 }
 
 /* AdapterTrimmer::trimBySequenceStart, src/adaptertrimmer.cpp:168-236 (searchAdapter in its
@@ -569,7 +573,7 @@ __device__ __forceinline__ int lev_wave_win(const uint64_t (*__restrict__ peq)[P
  * updated; returns the reference's return value; keylen = cmplen handed to addAdapterTrimmed. */
 /* r = first base of r1 -- the global read or a copy of its first 200 bytes in LDS; peq16 / peqf = the
  * adapter's Myers tables, global or LDS copies. */
-template <bool SHORT, bool LDSWIN, class PT, int PW>
+template <int MODE, bool LDSWIN, class PT, int PW>
 __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                                const PT* __restrict__ peq16,
                                                const uint64_t (*__restrict__ peqf)[PW],
@@ -592,7 +596,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
         for (int p0 = 0; p0 < npos; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < npos && !FPL_DBG(cfg->dbg, 256)) mm = (SHORT || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
+            if (p < npos && !FPL_DBG(cfg->dbg, 256)) mm = (MODE == 1 || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
             const u64 m = wave_ballot(p < npos && mm <= thrA);
             if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
             if (p < npos) {
@@ -605,7 +609,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(u32)best;
-                const int ed = FPL_DBG(cfg->dbg, 64) ? 999 : lev_wave_win<SHORT>(peqf, 0, alen, win, pos, alen, thrA);
+                const int ed = FPL_DBG(cfg->dbg, 64) ? 999 : lev_wave_win<MODE>(peqf, 0, alen, win, pos, alen, thrA);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -626,7 +630,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
         int pp[3], ed[3];
 #pragma unroll
         for (int u = 0; u < 3; u++) pp[u] = p0 + 64 * u + lane;
-        if (SHORT || plen == 16) { /* (SHORT: adapters of 16..32 bases, so plen == 16) */
+        if (MODE != 0 || plen == 16) { /* (MODE 1 / 2: adapters of >= 16 bases, so plen == 16) */
 #pragma unroll
             for (int u = 0; u < 3; u++) ed[u] = lev16_win<true>(win, min(pp[u], lim - 1), peq16, 16, 16);
         } else {
@@ -644,7 +648,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
     if (best != ~0ull) { /* :218-233 */
         int pos = (int)(u32)best;
         const int cmplen = min(pos + plen, alen);
-        const int ed = lev_wave_win<SHORT>(peqf, alen - cmplen, cmplen, win, pos + plen - cmplen, cmplen, cfg->thr[cmplen]);
+        const int ed = lev_wave_win<MODE>(peqf, alen - cmplen, cmplen, win, pos + plen - cmplen, cmplen, cfg->thr[cmplen]);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - alen);
             keylen = cmplen;
@@ -661,7 +665,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
  * asLeftAsPossible mode, :84-107, inlined). */
 /* r = first base of r1 as an address: only its last 200 bytes are dereferenced, so r may point
  * 200 - rlen bytes in front of an LDS copy of that tail. */
-template <bool SHORT, bool LDSWIN, class PT, int PW>
+template <int MODE, bool LDSWIN, class PT, int PW>
 __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                              const PT* __restrict__ peq16,
                                              const uint64_t (*__restrict__ peqf)[PW],
@@ -684,7 +688,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
         for (int p0 = ss; p0 < pend; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < pend) mm = (SHORT || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
+            if (p < pend) mm = (MODE == 1 || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
             const u64 m = wave_ballot(p < pend && mm <= thrA);
             if (m) {
                 hit = p0 + __ffsll(m) - 1; /* leftmost hit, returned at once (:98-101) */
@@ -700,7 +704,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
             best = wave_min_u64(best);
             if (best != ~0ull) {
                 const int pos = (int)(0xFFFFFFFFu - (u32)best);
-                const int ed = lev_wave_win<SHORT>(peqf, 0, alen, win, pos, alen, thrA);
+                const int ed = lev_wave_win<MODE>(peqf, 0, alen, win, pos, alen, thrA);
                 if (ed <= thrA) mpos = pos;
             }
         }
@@ -718,7 +722,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     int pos = -1, mined = -1;
     bool stop = false;
     int ed3[3];
-    if (SHORT || plen == 16) {
+    if (MODE != 0 || plen == 16) {
 #pragma unroll
         for (int u = 0; u < 3; u++) /* lim <= 184 = three rounds; independent chains, one straight-line block */
             ed3[u] = lim > 0 ? lev16_win<true>(win, rlen - 16 - min(64 * u + lane, lim - 1), peq16, 16, 16) : 0x7fffffff;
@@ -749,7 +753,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     }
     if (pos > 0) { /* :288 strict */
         const int cmplen = min(pos + plen, alen);
-        const int ed = lev_wave_win<SHORT>(peqf, 0, cmplen, win, rlen - plen - pos, cmplen, cfg->thr[cmplen]);
+        const int ed = lev_wave_win<MODE>(peqf, 0, cmplen, win, rlen - plen - pos, cmplen, cfg->thr[cmplen]);
         if (ed <= cfg->thr[cmplen]) {
             pos = min(pos + ext, rlen - plen);
             keylen = cmplen;
@@ -794,11 +798,12 @@ __device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __
     wave_sync();
 }
 
-/* SHORT: the host saw no FASTA adapters and command-line adapters of 16..32 bases (DevConfig::trim_short): the
-   global-memory paths, the FASTA chain and the multi-word Levenshtein are left out of that instantiation -- a
-   quarter of the code, fewer scalar registers to spill */
-template <int WAVES, bool SHORT>
-__global__ void __launch_bounds__(WAVES * 64, SHORT ? FPL_TRIM_WAVES_PER_SIMD_SHORT : FPL_TRIM_WAVES_PER_SIMD)
+/* MODE (DevConfig::trim_mode, chosen by the host): 0 = anything; 1 = no FASTA adapters and command-line adapters of
+   16..32 bases; 2 = every adapter (command-line and FASTA) has 16..64 bases.  Modes 1 and 2 leave the global-memory
+   paths, the short-pattern variants and the multi-word Levenshtein out (mode 1 also the FASTA chain): a fraction of
+   the code, fewer scalar registers to spill */
+template <int WAVES, int MODE>
+__global__ void __launch_bounds__(WAVES * 64, MODE == 1 ? FPL_TRIM_WAVES_PER_SIMD_SHORT : FPL_TRIM_WAVES_PER_SIMD)
 k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
             uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
             ReadState* __restrict__ state, long long* __restrict__ counters, u32 C) {
@@ -843,28 +848,28 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
         PROF(2) /* polyX */
         if (alive && cfg->adapter_enabled) { /* src/seprocessor.cpp:205-216 */
             int trimmed = 0, kl;
-            if (cfg->has_start && (SHORT || ads[0].len <= 64)) {
+            if (cfg->has_start && (MODE != 0 || ads[0].len <= 64)) {
                 /* the start trim only looks at r1[0, 200) */
                 stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end);
                 const Win<true> wn = {nullptr, win_s, 0, e - s};
-                trimmed += trim_start_wave<SHORT>(wn, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
+                trimmed += trim_start_wave<MODE>(wn, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
-            } else if (!SHORT && cfg->has_start) {
+            } else if (MODE == 0 && cfg->has_start) {
                 const Win<false> wn = {sq + s, nullptr, 0, e - s};
-                trimmed += trim_start_wave<false>(wn, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
+                trimmed += trim_start_wave<0>(wn, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(3) /* start adapter */
-            if (cfg->has_end && (SHORT || ads[1].len <= 64)) {
+            if (cfg->has_end && (MODE != 0 || ads[1].len <= 64)) {
                 /* the end trim only looks at the last 200 bases of r1 */
                 const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
                 stage_window(win_e, sq + e - wl, wl, seq_end);
                 const Win<true> wn = {nullptr, win_e, rlen - wl, rlen};
-                trimmed += trim_end_wave<SHORT>(wn, s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
+                trimmed += trim_end_wave<MODE>(wn, s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
-            } else if (!SHORT && cfg->has_end) {
+            } else if (MODE == 0 && cfg->has_end) {
                 const Win<false> wn = {sq + s, nullptr, 0, e - s};
-                trimmed += trim_end_wave<false>(wn, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
+                trimmed += trim_end_wave<0>(wn, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(4) /* end adapter */
@@ -873,14 +878,14 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                each adapter's 16-column Peq table is copied next to them (4 loads per lane) */
             bool stale_s = true, stale_e = true;
             uint16_t* const pq = lds.peq16w[wave_in_block()];
-            for (int a = 0; !SHORT && a < cfg->n_fasta; a++) {
+            for (int a = 0; MODE != 1 && a < cfg->n_fasta; a++) {
                 const DevAdapter* ad = &ads[2 + a];
-                if (ad->len > FPL_END_WINDOW) { /* longer than the window: work on the read in global memory */
+                if (MODE == 0 && ad->len > FPL_END_WINDOW) { /* longer than the window: work on the read in global memory */
                     const Win<false> ws = {sq + s, nullptr, 0, e - s};
-                    trimmed += trim_start_wave<false>(ws, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
+                    trimmed += trim_start_wave<0>(ws, s, e, ad, ad->peq16_start, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
                     const Win<false> we = {sq + s, nullptr, 0, e - s};
-                    trimmed += trim_end_wave<false>(we, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
+                    trimmed += trim_end_wave<0>(we, s, e, ad, ad->peq16_end, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
                     stale_s = stale_e = true;
                     continue;
@@ -893,7 +898,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_s, 0, e - s};
-                    trimmed += trim_start_wave<false>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
+                    trimmed += trim_start_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
                     if (s != s0 || e != e0) stale_s = stale_e = true;
                 }
@@ -906,7 +911,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_e, rlen - wl, rlen};
-                    trimmed += trim_end_wave<false>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
+                    trimmed += trim_end_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
                     if (s != s0 || e != e0) stale_s = stale_e = true;
                 }

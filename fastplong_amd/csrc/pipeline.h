@@ -52,7 +52,7 @@ struct BatchArgs {
     u32* frag_cyc = nullptr; /* with --break / --mask: first cycle of the item | masked << 31 */
     BmLists bm = {nullptr, nullptr, 0, 0, 0, nullptr}; /* fragment / region lists of k_break_mask */
     bool defer = false;      /* DevConfig::defer on the host side */
-    bool trim_short = false; /* DevConfig::trim_short on the host side */
+    int trim_mode = 0;       /* DevConfig::trim_mode on the host side */
     bool scan_short = false; /* DevConfig::scan_short on the host side */
     long long* counters;
     u32 C;
@@ -140,12 +140,15 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         u32 blocks = cdiv(n, KWAVES);
         const u32 cap = 16 * a.n_cu;
         if (blocks > cap) blocks = cap;
-        /* the common case -- no FASTA list, adapters of <= 32 bases -- has its own, much smaller instantiation */
-        if (a.trim_short)
-            FPL_LAUNCH((k_trim_ends<KWAVES, true>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+        /* the usual adapter sets have their own, much smaller instantiations (DevConfig::trim_mode) */
+        if (a.trim_mode == 1)
+            FPL_LAUNCH((k_trim_ends<KWAVES, 1>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+                       a.ads, a.state, a.counters, a.C);
+        else if (a.trim_mode == 2)
+            FPL_LAUNCH((k_trim_ends<KWAVES, 2>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                        a.ads, a.state, a.counters, a.C);
         else
-            FPL_LAUNCH((k_trim_ends<KWAVES, false>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+            FPL_LAUNCH((k_trim_ends<KWAVES, 0>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                        a.ads, a.state, a.counters, a.C);
     }
     mark(1);

@@ -35,6 +35,11 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     build_adapter(&ads[1], end, end_len);
     for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
     cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
+    {
+        std::vector<int> lens(2 + n_fasta);
+        for (int i = 0; i < 2 + n_fasta; i++) lens[i] = ads[i].len;
+        cfg.trim_mode = trim_mode_of(lens.data(), 2 + n_fasta);
+    }
     if (getenv("FPL_EMU_NO_HAM_FAST")) cfg.ham_fast = 0;
     cfg.scan_short = cfg.adapter_enabled && cfg.ham_fast && ads[0].len <= 32 && ads[1].len <= 32;
 
@@ -71,7 +76,7 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.frag_cyc = frag_cyc.data();
     a.bm = BmLists{frags.data(), regs.data(), frag_cap, reg_cap, item_cap, bm_counts};
     a.defer = cfg.defer != 0;
-    a.trim_short = cfg.trim_short != 0;
+    a.trim_mode = cfg.trim_mode;
     a.scan_short = cfg.scan_short != 0;
     a.counters = (long long*)counters;
     a.C = C;
