@@ -1184,7 +1184,9 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                         svG[g] = load8_guard(seq + start + c0, seq_end);
                         qvG[g] = load8_guard(qual + start + c0, qual_end);
                     }
-                    if (lane == 0 && tile_start >= 4 && (!EXTRA || tile_start >= SG[g] + 4))
+                    /* (EXTRA: the four bases in front of the tile matter as soon as ONE of them belongs to the body --
+                       a body that starts 1..3 bases before a tile boundary still has windows reaching across it) */
+                    if (lane == 0 && tile_start >= 4 && (!EXTRA || tile_start > SG[g]))
                         haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
                 }
             }

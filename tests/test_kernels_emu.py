@@ -172,3 +172,18 @@ def test_emulated_break_mask(orc, be, me):
     assert (want_f["code"] == abi.FPL_PASS_FILTER).any() and (want_f["kind"] > 0).any()
     if me:  # a masked read that passes: its unmasked / all-N pieces feed the post-filter tables at their own cycles
         assert ((want_f["region_count"] > 0) & (want_f["code"] == abi.FPL_PASS_FILTER)).any()
+
+
+def test_emulated_mask_piece_starting_just_before_a_tile_boundary(orc):
+    """--mask: the unmasked piece behind a masked stretch is counted post-filter from the cycle it starts at; when that
+    cycle lies 1..3 bases in front of a 512-cycle tile boundary, the first 5-mer windows of the next tile reach back
+    across it (read 175 of fuzz case 13107: body starts at cycle 1021)"""
+    from tests.test_gpu_parity import random_case
+    okw, start, end, seq, qual, off = random_case(13107)
+    a, b = int(off[175]), int(off[176])
+    seq, qual, off1 = seq[a:b], qual[a:b], np.array([0, b - a], np.uint64)
+    cfg = orc.Config(abi.FplOptions.default(**okw), start, end)
+    want_res, want_cnt, want_f, want_r = orc.process_batch_ex(cfg, seq, qual, off1, max_cycles=b - a)
+    assert len(want_r) == 1 and (int(want_r[0]["start"]) + int(want_r[0]["len"]) - int(want_f[0]["start"])) % 512 in (509, 510, 511)
+    got = emu.process_batch(cfg, seq, qual, off1, b - a, with_fragments=True)
+    parity.assert_counters_equal(got[1], want_cnt, b - a, cfg.n_adapters)
