@@ -168,7 +168,7 @@ def random_case(seed):
     start = pick(synth.START_ADAPTER, synth.START_ADAPTER, "", "ACGTNACGTAGGCATCGATCGGCTA")
     end = pick(synth.END_ADAPTER, synth.END_ADAPTER, "", synth.revcomp(synth.START_ADAPTER)[:18])
     a = synth.adversarial(120, seed=seed, start_adapter=start or synth.START_ADAPTER, end_adapter=end or synth.END_ADAPTER)
-    b = _lowq_ont_like(60, seed=seed, median_len=1500)
+    b = _lowq_ont_like(60, seed=seed, median_len=int(os.environ.get("FPL_FUZZ_MEDIAN", "1500")))  # (soaks: longer reads)
     reads = []
     for (s_, q_, o_) in (a, b):
         reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
