@@ -1,6 +1,8 @@
 """The product kernels (fastplong_amd/csrc/kernels.h), compiled for the host on the test-only
 lock-step emulator, against the oracle on seeded batches.  This is host-logic coverage for the
 `-m "not gpu"` run; the real parity tests (-m gpu) run the same comparisons on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -187,3 +189,36 @@ def test_emulated_mask_piece_starting_just_before_a_tile_boundary(orc):
     assert len(want_r) == 1 and (int(want_r[0]["start"]) + int(want_r[0]["len"]) - int(want_f[0]["start"])) % 512 in (509, 510, 511)
     got = emu.process_batch(cfg, seq, qual, off1, b - a, with_fragments=True)
     parity.assert_counters_equal(got[1], want_cnt, b - a, cfg.n_adapters)
+
+
+def _random_fasta_case(seed):
+    from tests.test_gpu_parity import random_case
+    okw, start, end, _, _, _ = random_case(seed)
+    rng = np.random.default_rng(77000 + seed)
+    lens = [6, 7, 12, 15, 16, 17, 24, 31, 32, 33, 45, 63, 64, 65, 100, 199, 200, 201, 250]
+    fasta = ["".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.choice(lens)))) for _ in range(int(rng.integers(0, 5)))]
+    if rng.random() < 0.3:
+        start = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.choice(lens))))
+    if rng.random() < 0.3:
+        end = "".join("ACGTN"[i] for i in rng.integers(0, 5, int(rng.choice(lens))))
+    seq, qual, off = synth.adversarial(int(os.environ.get("FPL_EMU_FUZZ_READS", "36")), seed=seed,
+                                       start_adapter=start or synth.START_ADAPTER, end_adapter=end or synth.END_ADAPTER, fasta=fasta)
+    return okw, start, end, fasta, seq, qual, off
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FPL_EMU_FUZZ", "3"))))
+def test_emulated_random_fasta_cases(orc, seed):
+    """random options x random command-line / FASTA adapter sets (every length class, so all instantiations of
+    k_trim_ends / k_scan) on the emulator; FPL_EMU_FUZZ=<n> widens it for a soak on CPU"""
+    okw, start, end, fasta, seq, qual, off = _random_fasta_case(seed)
+    cfg = orc.Config(abi.FplOptions.default(**okw), start, end, fasta)
+    C = max(1, int(np.diff(off.astype(np.int64)).max()))
+    if okw["break_enabled"] or okw["mask_enabled"]:
+        want_res, want_cnt, want_f, want_r = orc.process_batch_ex(cfg, seq, qual, off, max_cycles=C)
+        got = emu.process_batch(cfg, seq, qual, off, C, with_fragments=True)
+        parity.assert_fragments_equal(got[2], got[3], want_f, want_r)
+    else:
+        want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+        got = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got[0], want_res, seq, off)
+    parity.assert_counters_equal(got[1], want_cnt, C, cfg.n_adapters)
