@@ -733,7 +733,10 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     }
     for (int p0 = 0; p0 < lim && !stop; p0 += 64) {
         const int p = p0 + lane;
-        const int edr = p0 == 0 ? ed3[0] : (p0 == 64 ? ed3[1] : ed3[2]);
+        /* (an adapter of fewer than 8 bases has up to 194 positions: the ones behind the three precomputed rounds
+           are evaluated here; the reduced instantiations only see partial patterns of 16 columns, 184 positions) */
+        int edr = p0 == 0 ? ed3[0] : (p0 == 64 ? ed3[1] : ed3[2]);
+        if (MODE == 0 && p0 >= 192) edr = lev16_win<false>(win, rlen - plen - min(p0 + lane, lim - 1), peq16, plen, plen);
         const int ed = p < lim ? edr : 0x7fffffff;
         u64 q = wave_ballot(p < lim && ed <= thrP);
         while (q && !stop) {
