@@ -207,7 +207,8 @@ def _random_fasta_case(seed):
 
 
 # 408: a 7-base FASTA adapter whose partial match sits at the last of its 193 end positions (beyond three rounds of 64)
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_EMU_FUZZ", "3")))) + [408])
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_EMU_FUZZ_FROM", "0")),
+                                            int(os.environ.get("FPL_EMU_FUZZ_FROM", "0")) + int(os.environ.get("FPL_EMU_FUZZ", "3")))) + [408])
 def test_emulated_random_fasta_cases(orc, seed):
     """random options x random command-line / FASTA adapter sets (every length class, so all instantiations of
     k_trim_ends / k_scan) on the emulator; FPL_EMU_FUZZ=<n> widens it for a soak on CPU"""
