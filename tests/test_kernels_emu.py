@@ -201,8 +201,17 @@ def _random_fasta_case(seed):
         start = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.choice(lens))))
     if rng.random() < 0.3:
         end = "".join("ACGTN"[i] for i in rng.integers(0, 5, int(rng.choice(lens))))
-    seq, qual, off = synth.adversarial(int(os.environ.get("FPL_EMU_FUZZ_READS", "36")), seed=seed,
-                                       start_adapter=start or synth.START_ADAPTER, end_adapter=end or synth.END_ADAPTER, fasta=fasta)
+    a = synth.adversarial(int(os.environ.get("FPL_EMU_FUZZ_READS", "36")), seed=seed,
+                          start_adapter=start or synth.START_ADAPTER, end_adapter=end or synth.END_ADAPTER, fasta=fasta)
+    # FPL_EMU_FUZZ_LONG (soaks; 5 x slower): a few longer reads (several cycle tiles / scan tiles, middle adapters) with the
+    # command-line pair or one FASTA adapter at the ends
+    ends = (fasta[0], synth.revcomp(fasta[0])) if (fasta and rng.random() < 0.5) else (start or synth.START_ADAPTER, end or synth.END_ADAPTER)
+    b = synth.ont_like(4 if os.environ.get("FPL_EMU_FUZZ_LONG") else 0, seed=seed, median_len=int(rng.choice([600, 1500, 4000])), start_adapter=ends[0][:120],
+                       end_adapter=ends[1].replace("N", "A")[:120], p_middle=0.4, p_polya=0.2)
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
     return okw, start, end, fasta, seq, qual, off
 
 
