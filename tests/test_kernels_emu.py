@@ -217,7 +217,7 @@ def _random_fasta_case(seed):
 
 # 408: a 7-base FASTA adapter whose partial match sits at the last of its 193 end positions (beyond three rounds of 64)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_EMU_FUZZ_FROM", "0")),
-                                            int(os.environ.get("FPL_EMU_FUZZ_FROM", "0")) + int(os.environ.get("FPL_EMU_FUZZ", "3")))) + [408])
+                                            int(os.environ.get("FPL_EMU_FUZZ_FROM", "0")) + int(os.environ.get("FPL_EMU_FUZZ", "1")))) + [408])
 def test_emulated_random_fasta_cases(orc, seed):
     """random options x random command-line / FASTA adapter sets (every length class, so all instantiations of
     k_trim_ends / k_scan) on the emulator; FPL_EMU_FUZZ=<n> widens it for a soak on CPU"""
@@ -233,3 +233,19 @@ def test_emulated_random_fasta_cases(orc, seed):
         got = emu.process_batch(cfg, seq, qual, off, C)
     parity.assert_results_equal(got[0], want_res, seq, off)
     parity.assert_counters_equal(got[1], want_cnt, C, cfg.n_adapters)
+
+
+def test_emulated_rna_batch(orc):
+    """direct-RNA data: U for T in reads and adapters (U adapters are not ACGT-only: the byte-wise scan; U counts as a
+    valid base for the 5-mers, Stats::base2val)"""
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, polyx=1, complexity_filter=1), synth.START_ADAPTER.replace("T", "U"),
+                     synth.END_ADAPTER.replace("T", "U"))
+    seq, qual, off = synth.ont_like(14, seed=4, median_len=900, p_middle=0.3, p_polya=0.2)
+    seq = seq.copy()
+    seq[seq == ord("T")] = ord("U")
+    C = int(np.diff(off.astype(np.int64)).max())
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    assert int(abi.CountersView(want_cnt, C, 2).post.kmer.sum()) > 5000
