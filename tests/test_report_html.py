@@ -163,3 +163,25 @@ def test_html_reproduces_golden_fixtures(orc, hostlib, tmp_path):
         p = str(tmp_path / (case + ".html"))
         write_html(hostlib, p, counters, c, cfg.adapter_list(), cfg.opt, pre, post, 3)
         assert STAMP.sub(b"<time>", open(p, "rb").read()) == tg.gz(os.path.join(tg.GOLD, case, "expected.html.gz")), case
+
+
+@pytest.mark.parametrize("name", ["empty", "all_fail"])
+def test_reports_on_degenerate_runs(orc, ref, hostlib, tmp_path, name):
+    """no reads at all / no read passing: divisions by zero come out as the reference prints them (nan, inf, 0.0)"""
+    import ctypes
+
+    from tests import test_report_json as tj
+    reads = [] if name == "empty" else [(np.frombuffer(b"ACGTACGTAC", np.uint8), np.full(10, 35, np.uint8))] * 3
+    seq, qual, off = synth.pack(reads) if reads else (np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER)
+    res, counters = orc.process_batch(cfg, seq, qual, off, max_cycles=16)
+    hostlib.fplh_write_json.restype = ctypes.c_int
+    hostlib.fplh_write_json.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                        ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    mj, mh, rj, rh = (str(tmp_path / f) for f in ("m.json", "m.html", "r.json", "r.html"))
+    tj.write_json(hostlib, mj, counters, 16, cfg.adapter_list(), cfg.opt)
+    pre, post = read_lists(off, res)
+    write_html(hostlib, mh, counters, 16, cfg.adapter_list(), cfg.opt, pre, post, 3)
+    reference_json(ref, rj, cfg, seq, qual, off, res, counters, 16, 3, html=rh)
+    assert open(mj, "rb").read() == open(rj, "rb").read()
+    assert STAMP.sub(b"<t>", open(mh, "rb").read()) == STAMP.sub(b"<t>", open(rh, "rb").read())
