@@ -69,7 +69,7 @@ CASES = {
 def test_emulated_kernels_match_oracle_adversarial(orc, name):
     case = CASES[name]
     cfg = orc.Config(abi.FplOptions.default(**case["opt"]), case["start"], case["end"])
-    seq, qual, off = synth.adversarial(160, seed=hash(name) % 1000, start_adapter=synth.START_ADAPTER,
+    seq, qual, off = synth.adversarial(110, seed=sum(map(ord, name)) % 1000, start_adapter=synth.START_ADAPTER,
                                        end_adapter=synth.END_ADAPTER)
     C = int(np.diff(off.astype(np.int64)).max()) + 3
     want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
@@ -93,7 +93,7 @@ def test_emulated_kernels_match_oracle_ont_like(orc):
 def test_emulated_kernels_multi_adapter(orc):
     fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA", "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG"]
     cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER, fasta)
-    seq, qual, off = synth.adversarial(100, seed=21, fasta=fasta)
+    seq, qual, off = synth.adversarial(70, seed=21, fasta=fasta)
     C = int(np.diff(off.astype(np.int64)).max()) + 1
     want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
     got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
