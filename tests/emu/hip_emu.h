@@ -140,32 +140,39 @@ inline T atomicMax(T* p, T v) {
     return old;
 }
 
+/* The work-item threads are created once per launch and walk through the blocks together (a thread start per
+ * work-item and BLOCK made the kernel's clone / stack mmap traffic the bulk of the test time). */
 template <class K, class... A>
 inline void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
-    int nthreads = (int)block.x;
+    const int nthreads = (int)block.x;
     if (nthreads % 64 != 0) throw "emu: blockDim.x must be a multiple of 64";
-    for (unsigned by = 0; by < grid.y; by++)
-        for (unsigned bx = 0; bx < grid.x; bx++) {
-            emu::Block blk(nthreads);
-            std::vector<std::thread> th;
-            th.reserve(nthreads);
-            for (int t = 0; t < nthreads; t++) {
-                th.emplace_back([&, t]() {
-                    threadIdx = dim3(t);
-                    blockIdx = dim3(bx, by);
-                    blockDim = block;
-                    gridDim = grid;
-                    emu::t_block = &blk;
-                    emu::t_wave = blk.waves[t / 64].get();
-                    emu::t_lane = t % 64;
-                    kernel(args...);
-                    emu::t_wave->active[emu::t_lane] = false;
-                    emu::t_wave->bar.arrive_and_drop();
-                    blk.bar.arrive_and_drop();
-                });
+    const unsigned nblocks = grid.x * grid.y;
+    if (nblocks == 0) return;
+    std::unique_ptr<emu::Block> blk;
+    std::barrier<> turn(nthreads); /* all work-items, between blocks */
+    std::vector<std::thread> th;
+    th.reserve(nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        th.emplace_back([&, t]() {
+            for (unsigned b = 0; b < nblocks; b++) {
+                if (t == 0) blk.reset(new emu::Block(nthreads));
+                turn.arrive_and_wait(); /* the block object is ready */
+                threadIdx = dim3(t);
+                blockIdx = dim3(b % grid.x, b / grid.x);
+                blockDim = block;
+                gridDim = grid;
+                emu::t_block = blk.get();
+                emu::t_wave = blk->waves[t / 64].get();
+                emu::t_lane = t % 64;
+                kernel(args...);
+                emu::t_wave->active[emu::t_lane] = false;
+                emu::t_wave->bar.arrive_and_drop();
+                blk->bar.arrive_and_drop();
+                turn.arrive_and_wait(); /* everyone has left the block before it is replaced */
             }
-            for (auto& x : th) x.join();
-        }
+        });
+    }
+    for (auto& x : th) x.join();
 }
 
 #endif
