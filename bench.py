@@ -28,13 +28,44 @@ WORKLOADS = {
     # BASELINE.json configs[2]: the metric's "trim+cut+filter" pipeline on the configs[1] reads
     "c3_full_pipeline": dict(opt=dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
                                       complexity_filter=1),
-                             flags="-s/-e fixed, --cut_front --cut_tail -W 5, -x, -y"),
+                             flags="-s/-e fixed, --cut_front --cut_tail -W 5, -x, -y", config=2, reads=1_000_000,
+                             gen=dict(kind="ont", median_len=8000, sigma_len=0.5),
+                             reads_desc="lognormal lengths (median 8000, sigma 0.5, N50 ~10 kb), Q~N(18,8)"),
     # BASELINE.json configs[1]: adapter trim only
-    "c2_adapter_only": dict(opt=dict(), flags="-s/-e fixed"),
+    "c2_adapter_only": dict(opt=dict(), flags="-s/-e fixed", config=1, reads=1_000_000,
+                            gen=dict(kind="ont", median_len=8000, sigma_len=0.5),
+                            reads_desc="lognormal lengths (median 8000, sigma 0.5, N50 ~10 kb), Q~N(18,8)"),
+    # BASELINE.json configs[3]: the mixed-length shard of one GPU (20 M reads over 8 GPUs = 2.5 M per GPU), full pipeline.
+    # lognormal sigma 0.9 clipped to [300, 200 000] (the generator needs 300 bases for its decorations; the
+    # configuration says 200), median 6673 = 15 kb * exp(-0.81): N50 ~15 kb
+    "c4_mixed": dict(opt=dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
+                              complexity_filter=1),
+                     flags="-s/-e fixed, --cut_front --cut_tail -W 5, -x, -y", config=3, reads=2_500_000,
+                     gen=dict(kind="ont", median_len=6673, sigma_len=0.9, min_len=200, max_len=200_000, seed0=4),
+                     reads_desc="lognormal lengths (sigma 0.9, clipped to [300, 200000], N50 ~15 kb), Q~N(18,8)"),
+    # BASELINE.json configs[4]: HiFi-like reads, --adapter_fasta of 64 adapters visited in header order
+    # (src/adaptertrimmer.cpp:42-57), no command-line adapters
+    "c5_hifi64": dict(opt=dict(), flags="--adapter_fasta (64 random 30-45-mers), defaults otherwise", config=4, reads=500_000,
+                      gen=dict(kind="hifi", mean_len=20000, sd_len=2000, n_adapters=64, seed0=5),
+                      reads_desc="N(20 kb, 2 kb) lengths, Q~N(35,6), 30 % of the reads with one FASTA adapter at an end, 1 % in the middle"),
 }
 
 
-def cpu_baseline(opt, seq_t, qual_t, off_t, target_bases, max_threads=16):
+def make_batch(wl, n_reads, rank, dev):
+    """-> (seq_t, qual_t, off_t, max_len, start_adapter, end_adapter, fasta list)"""
+    from fastplong_amd import synth
+
+    g = dict(wl["gen"])
+    kind = g.pop("kind")
+    seed = g.pop("seed0", 1) + rank
+    if kind == "hifi":
+        seq_t, qual_t, off_t, max_len, ads = synth.device_batch_hifi(n_reads, seed=seed, device=dev, **g)
+        return seq_t, qual_t, off_t, max_len, "", "", ads
+    seq_t, qual_t, off_t, max_len = synth.device_batch(n_reads, seed=seed, device=dev, **g)
+    return seq_t, qual_t, off_t, max_len, synth.START_ADAPTER, synth.END_ADAPTER, []
+
+
+def cpu_baseline(opt, adapters, seq_t, qual_t, off_t, target_bases, max_threads=16):
     """Time the oracle (C restatement of the reference path, kind="port") on the host cores over
     the first reads of the same batch.  Outside the timed region; the oracle is only the thing
     measured here, never part of the GPU path."""
@@ -50,7 +81,7 @@ def cpu_baseline(opt, seq_t, qual_t, off_t, target_bases, max_threads=16):
     seq = seq_t[:nb].cpu().numpy()
     qual = qual_t[:nb].cpu().numpy()
     threads = max(1, min(os.cpu_count() or 1, max_threads))
-    cfg = oracle.Config(opt, synth.START_ADAPTER, synth.END_ADAPTER)
+    cfg = oracle.Config(opt, adapters[0], adapters[1], adapters[2])
     oracle.lib()
     C = int(np.diff(off[:n + 1]).max())
     # contiguous shards, one per thread (the reference round-robins packs of 16 reads over <= 16 workers)
@@ -72,13 +103,132 @@ def cpu_baseline(opt, seq_t, qual_t, off_t, target_bases, max_threads=16):
                 n, nb, threads, dt)}
 
 
+CLI_FLAGS = {
+    "c3_full_pipeline": ["--cut_front", "--cut_tail", "-W", "5", "-x", "-y"],
+    "c4_mixed": ["--cut_front", "--cut_tail", "-W", "5", "-x", "-y"],
+    "c2_adapter_only": [],
+}
+
+
+def end_to_end(workload, opt, ad_start, ad_end, seq_t, qual_t, off_t, n_reads):
+    """End to end around the hot path, on the first n_reads reads of the resident batch -- reported NEXT to `value`,
+    never as `value`:
+      (1) the command line bin/fastplong_amd: FASTQ text in the page cache (tmpfs) -> chunk-parallel parse into
+          page-locked CSR batches -> H2D / kernels / D2H two batches deep -> trimmed FASTQ + fastplong.json / .html;
+          wall time of the whole process (HIP start-up, reports and exit included) and of its host pipeline alone;
+      (2) the PCIe-inclusive C-ABI call: fpl_process_batch_async / fpl_wait from page-locked arrays, two deep."""
+    import shutil
+    import subprocess
+
+    import ctypes as C
+    import numpy as np
+    import torch
+
+    from fastplong_amd import abi, build, engine
+
+    off = off_t[:n_reads + 1].cpu().numpy().astype(np.uint64)
+    nb = int(off[-1])
+    seq = seq_t[:nb].cpu().numpy()
+    qual = qual_t[:nb].cpu().numpy()
+    res = {"reads": n_reads, "bases": nb, "unit": "Gbases/s"}
+
+    # (2) first: it needs the arrays page-locked, the file writer below does not care
+    eng = engine.Engine(opt, ad_start, ad_end, device=torch.cuda.current_device(), max_cycles=int(np.diff(off.astype(np.int64)).max()))
+    n_parts = 16
+    n_pcie = min(n_reads, 400_000)  # (page-locking tens of gigabytes takes longer than the measurement)
+    nb_pcie = int(off[n_pcie])
+    cuts = [int(i * n_pcie / n_parts) for i in range(n_parts + 1)]
+    parts = []
+    for i in range(n_parts):
+        a, b = cuts[i], cuts[i + 1]
+        lo, hi = int(off[a]), int(off[b])
+        ps, pq, po = eng.pinned_array(hi - lo), eng.pinned_array(hi - lo), eng.pinned_array(b - a + 1, np.uint64)
+        ps[:], pq[:], po[:] = seq[lo:hi], qual[lo:hi], off[a:b + 1] - off[a]
+        parts.append((ps, pq, po, np.zeros(b - a, dtype=abi.RESULT_DTYPE)))
+    for rep in range(2):  # the first round allocates the staging slots
+        t0 = time.perf_counter()
+        for ps, pq, po, rr in parts:
+            if eng.in_flight() == abi.FPL_MAX_IN_FLIGHT:
+                eng.wait()
+            eng.submit_host(ps, pq, po, rr)
+        while eng.in_flight():
+            eng.wait()
+        dt = time.perf_counter() - t0
+    res["pcie_call"] = {"value": nb_pcie / dt / 1e9, "seconds": dt, "reads": n_pcie, "bases": nb_pcie,
+                        "what": "fpl_process_batch_async/fpl_wait, %d batches from page-locked arrays, two in flight "
+                                "(H2D 2 B/base + kernels + D2H of the records)" % n_parts}
+    eng.close()
+    del parts
+
+    # (1)
+    build.build_host()
+    host = C.CDLL(build.HOST_LIB)
+    host.fplh_write_fastq.restype = C.c_int
+    host.fplh_write_fastq.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_int]
+    need = 2.3 * (2 * nb + 16 * n_reads)
+    tmp = None
+    for d in ("/dev/shm", "/tmp"):
+        try:
+            if shutil.disk_usage(d).free > need:
+                tmp = d
+                break
+        except OSError:
+            pass
+    if tmp is None:
+        res["cli"] = None
+        res["note"] = "no scratch directory with %.0f GB free" % (need / 1e9)
+        return res
+    fq = os.path.join(tmp, "fpl_e2e_%d.fq" % os.getpid())
+    outp = os.path.join(tmp, "fpl_e2e_%d.out.fq" % os.getpid())
+    js, html = fq + ".json", fq + ".html"
+    try:
+        t0 = time.perf_counter()
+        rc = host.fplh_write_fastq(fq.encode(), seq.ctypes.data, qual.ctypes.data, off.ctypes.data, n_reads, b"r", 16)
+        assert rc == 0, "writing %s failed" % fq
+        res["input"] = "%s, %.2f GB of FASTQ text (written in %.1f s, in the page cache)" % (fq, os.path.getsize(fq) / 1e9,
+                                                                                            time.perf_counter() - t0)
+        cmd = [build.CLI, "-i", fq, "-s", ad_start, "-e", ad_end, "-j", js, "-h", html, "-V"] + CLI_FLAGS[workload]
+        runs = {}
+        for name, target in (("to_dev_null", "/dev/null"), ("to_file", outp)):
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd + ["-o", target], capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            pipe = None
+            for line in p.stderr.splitlines():
+                if line.startswith("host pipeline:"):
+                    pipe = float(line.split("wall ")[1].split(" s")[0])
+            runs[name] = {"rc": p.returncode, "process_seconds": dt, "value": nb / dt / 1e9,
+                          "pipeline_seconds": pipe, "pipeline_value": (nb / pipe / 1e9) if pipe else None,
+                          "stages": next((l for l in p.stderr.splitlines() if l.startswith("host pipeline:")), None)}
+            if p.returncode != 0:
+                runs[name]["stderr_tail"] = p.stderr[-500:]
+        res["cli"] = runs
+        if runs["to_dev_null"]["rc"] == 0:
+            res["value"] = runs["to_dev_null"]["value"]
+            res["what"] = ("bin/fastplong_amd -i <FASTQ in tmpfs> -o /dev/null + JSON + HTML: input bases / wall time of the "
+                           "whole process; cli.to_file = the same with the trimmed FASTQ written to tmpfs; "
+                           "pipeline_value = without process start-up (HIP context) and the report writers")
+            jr = json.load(open(js))
+            res["json_check"] = {"reads_in": jr["summary"]["before_filtering"]["total_reads"],
+                                 "reads_out": jr["summary"]["after_filtering"]["total_reads"]}
+    finally:
+        for f in (fq, outp, js, html):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (1 M x ~10 kb N50)")
-    ap.add_argument("--median-len", type=int, default=8000)
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's own: 1 M for c2/c3, 2.5 M for c4, 0.5 M for c5)")
+    ap.add_argument("--median-len", type=int, default=0, help="ablation only: median read length of the ONT-like workloads")
+    ap.add_argument("--e2e-reads", type=int, default=1_000_000,
+                    help="N = 1 only: reads of the batch written as FASTQ and run through bin/fastplong_amd (0 = skip)")
     ap.add_argument("--workload", default="c3_full_pipeline", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-bases", type=float, default=6e9, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--set", default="", help="ablation only: comma separated fpl_options overrides, e.g. adapter_enabled=0")
@@ -112,14 +262,16 @@ def main():
         k, val = kv.split("=")
         okw[k] = float(val) if k == "ed_max" else int(val)
     opt = abi.FplOptions.default(**okw)
-    # synthetic shard of this rank (weak scaling: every rank gets --reads reads of its own)
-    seq_t, qual_t, off_t, max_len = synth.device_batch(args.reads, seed=1 + rank, median_len=args.median_len,
-                                                       device=dev)
+    # synthetic shard of this rank (weak scaling: every rank gets its own reads)
+    if args.median_len:
+        wl = dict(wl, gen=dict(wl["gen"], median_len=args.median_len))
+    n_want = args.reads if args.reads > 0 else wl["reads"]
+    seq_t, qual_t, off_t, max_len, ad_start, ad_end, ad_fasta = make_batch(wl, n_want, rank, dev)
     n = off_t.numel() - 1
     n_bases = int(off_t[-1].item())
     # all ranks agree on the per-cycle capacity so that the counter buffers line up for the all-reduce
     C = fdist.agree_capacity(max_len, device=dev)
-    eng = engine.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=local_rank, max_cycles=C)
+    eng = engine.Engine(opt, ad_start, ad_end, ad_fasta, device=local_rank, max_cycles=C)
     res_t = torch.empty(n * 36, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
 
@@ -156,7 +308,7 @@ def main():
 
     if rank == 0:
         counters = eng.counters()
-        v = abi.CountersView(counters, C, 2)
+        v = abi.CountersView(counters, C, eng.n_adapters)
         dom = max(ktimes, key=ktimes.get)
         dom_ms = ktimes[dom] / max(1, nbatches)
         achieved = ALGO_BYTES_PER_BASE * n_bases / (dom_ms * 1e-3) / 1e9
@@ -185,11 +337,9 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": "%s%s: BASELINE.json configs[%d] -- %d synthetic ONT-like reads per GPU, lognormal lengths "
-                            "(median %d, sigma 0.5, N50 ~10 kb), Q~N(18,8), %s; inputs resident in HBM" % (
-                                args.workload, (" [ABLATION " + args.set + "]") if args.set else "",
-                                2 if args.workload.startswith("c3") else 1, n, args.median_len,
-                                wl["flags"]),
+                "workload": "%s%s: BASELINE.json configs[%d] -- %d synthetic reads per GPU, %s, %s; inputs resident in HBM" % (
+                    args.workload, (" [ABLATION " + " ".join(filter(None, [args.set, args.median_len and "median-len=%d" % args.median_len])) + "]")
+                    if (args.set or args.median_len) else "", wl["config"], n, wl["reads_desc"], wl["flags"]),
                 "reads_per_gpu": n, "bases_per_gpu": n_bases, "max_read_len": max_len,
                 "parallelism": "shard%d (independent read shards, one RCCL all-reduce of the counters)" % world,
             },
@@ -203,12 +353,15 @@ def main():
                                "fragments_out": int(v.post.reads), "bases_out": int(v.post.length_sum)},
         }
         if args.cpu_bases > 0 and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in the barrier meanwhile)
-            out["cpu_baseline"] = cpu_baseline(opt, seq_t, qual_t, off_t, args.cpu_bases)
+            out["cpu_baseline"] = cpu_baseline(opt, (ad_start, ad_end, ad_fasta), seq_t, qual_t, off_t, args.cpu_bases)
+        if args.e2e_reads > 0 and world == 1 and not ad_fasta and not args.set:
+            eng.close()
+            out["e2e"] = end_to_end(args.workload, opt, ad_start, ad_end, seq_t, qual_t, off_t, min(n, args.e2e_reads))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    eng.close()  # (idempotent)
 
 
 if __name__ == "__main__":

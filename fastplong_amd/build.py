@@ -70,10 +70,10 @@ def build_host(force=False, verbose=False):
         build_hip(force, verbose)
         os.makedirs(os.path.dirname(CLI), exist_ok=True)
         rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
-               "-I" + os.path.join(rocm, "include"), "-o", CLI, cli_src, "-L" + HERE, "-lfastplong_host",
-               "-lfastplong_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl",
-               "-Wl,-rpath,$ORIGIN/../fastplong_amd", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-ldl", "-lz"]
+        # the CLI only knows the C-ABI: HIP and RCCL stay behind libfastplong_amd.so (RCCL is dlopen'ed on first use)
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", CLI, cli_src, "-L" + HERE, "-lfastplong_host",
+               "-lfastplong_amd", "-Wl,-rpath,$ORIGIN/../fastplong_amd", "-Wl,-rpath," + os.path.join(rocm, "lib"),
+               "-Wl,-rpath-link," + os.path.join(rocm, "lib"), "-ldl", "-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

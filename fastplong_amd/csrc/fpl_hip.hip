@@ -3,6 +3,8 @@
  * Built by hipcc only (--offload-arch=gfx950); there is no CPU path in this library.
  */
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> /* types only: the library is loaded with dlopen in fpl_allreduce_counters */
+#include <dlfcn.h>
 
 #include <new>
 #include <stdio.h>
@@ -35,19 +37,30 @@ struct fpl_ctx {
     DevConfig hcfg;
     u32* d_frag_cyc = nullptr;
     BmLists bm = {nullptr, nullptr, 0, 0, 0, nullptr};
-    uint64_t bm_bytes = 0; /* n_bytes the lists are sized for */
-    u32 bm_reads = 0;
     size_t scratch_slabs = 0;
     u64* d_stats_scratch = nullptr;
     u8* d_stats_flags = nullptr;
-    /* staging for the host-pointer entry point */
-    uint64_t st_bytes = 0;
-    u32 st_reads = 0;
-    u8* d_seq = nullptr;
-    u8* d_qual = nullptr;
-    uint64_t* d_off = nullptr;
-    fpl_read_result* d_results = nullptr;
-    hipStream_t stream = nullptr; /* owned; used by fpl_process_batch() */
+    /* staging for the host-pointer entry points: FPL_MAX_IN_FLIGHT slots, so that the copies of one batch
+       overlap the kernels of the previous one */
+    struct Slot {
+        uint64_t st_bytes = 0;
+        u32 st_reads = 0;
+        u8* d_seq = nullptr;
+        u8* d_qual = nullptr;
+        uint64_t* d_off = nullptr;
+        fpl_read_result* d_results = nullptr;
+        fpl_read_result* h_results = nullptr; /* pinned: the D2H copy never waits for a pageable destination */
+        u32 h_reads = 0;
+        hipEvent_t ev_h2d = nullptr, ev_kern = nullptr, ev_done = nullptr;
+        fpl_read_result* user_results = nullptr;
+        u32 n_reads = 0;
+        int rc = FPL_OK; /* error met while enqueueing, reported by fpl_wait */
+    };
+    Slot slot[FPL_MAX_IN_FLIGHT];
+    u32 submitted = 0, waited = 0; /* batches handed to / collected from the asynchronous path */
+    hipStream_t stream = nullptr;  /* owned: the compute stream of the host-pointer entry points */
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr; /* owned: copy streams */
+    StatsTune tune; /* FPL_STATS_* tuning hooks, read once in fpl_create */
     /* timing */
     int timing = 0;
     static constexpr int EV_RING = 128;
@@ -137,6 +150,13 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         FPL_HIP(hipGetDeviceProperties(&prop, device));
         ctx->n_cu = prop.multiProcessorCount > 0 ? (u32)prop.multiProcessorCount : 256;
         FPL_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        FPL_HIP(hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
+        FPL_HIP(hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+        for (auto& sl : ctx->slot) {
+            FPL_HIP(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+            FPL_HIP(hipEventCreateWithFlags(&sl.ev_kern, hipEventDisableTiming));
+            FPL_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        }
         DevConfig cfg;
         build_config(&cfg, opt, start_len, end_len, n_fasta);
         std::vector<DevAdapter> ads(ctx->n_adapters);
@@ -150,7 +170,8 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
             cfg.trim_mode = trim_mode_of(lens.data(), 2 + n_fasta);
         }
         cfg.scan_short = cfg.adapter_enabled && cfg.ham_fast && ads[0].len <= 32 && ads[1].len <= 32;
-        if (const char* e = getenv("FPL_DEBUG_FLAGS")) cfg.dbg = atoi(e);
+        if (const char* e = getenv("FPL_DEBUG_FLAGS")) cfg.dbg = atoi(e); /* the environment is read here and nowhere else */
+        ctx->tune = stats_tune_from_env();
         ctx->dbg = cfg.dbg;
         if ((cfg.brk && cfg.brk_w <= 0) || (cfg.msk && cfg.msk_w <= 0)) {
             ctx->err = "break / mask window size must be positive";
@@ -183,10 +204,21 @@ void fpl_destroy(fpl_ctx* ctx) {
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->d_cfg, ctx->d_ads, ctx->d_counters, ctx->d_state, ctx->d_frag_off, ctx->d_frag_len,
-                    ctx->d_work_ctr, ctx->d_seq, ctx->d_qual, ctx->d_off, ctx->d_results, ctx->d_stats_scratch,
+                    ctx->d_work_ctr, ctx->d_stats_scratch,
                     ctx->d_stats_flags, ctx->d_frag_cyc, ctx->bm.frags, ctx->bm.regs, ctx->bm.counts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto& sl : ctx->slot) {
+        void* sp[] = {sl.d_seq, sl.d_qual, sl.d_off, sl.d_results};
+        for (void* p : sp)
+            if (p) (void)hipFree(p);
+        if (sl.h_results) (void)hipHostFree(sl.h_results);
+        if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
+        if (sl.ev_kern) (void)hipEventDestroy(sl.ev_kern);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
+    if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
     for (int r = 0; r < fpl_ctx::EV_RING; r++)
         for (int i = 0; i <= N_STAGES; i++)
             if (ctx->ev[r][i]) (void)hipEventDestroy(ctx->ev[r][i]);
@@ -239,6 +271,101 @@ int fpl_get_counters(fpl_ctx* ctx, int64_t* host_buf, size_t n) {
     return FPL_OK;
 }
 
+/* RCCL, loaded on first use: a host that never merges across devices does not need the library at all */
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            err = std::string("dlopen(librccl): ") + dlerror();
+            return false;
+        }
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !AllReduce) {
+            err = "librccl lacks an expected symbol";
+            lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+}  // namespace
+
+int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
+    if (!ctxs || n < 1) return FPL_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || ctxs[i]->n_adapters != ctxs[0]->n_adapters) return FPL_ERR_ARG;
+        for (int j = 0; j < i; j++)
+            if (ctxs[j]->device == ctxs[i]->device) return FPL_ERR_ARG; /* one context per device */
+    }
+    fpl_ctx* ctx = ctxs[0]; /* (FPL_HIP reports through this one) */
+    u32 C = 0;
+    for (int i = 0; i < n; i++) {
+        if (ctxs[i]->submitted != ctxs[i]->waited) return FPL_ERR_STATE;
+        C = std::max(C, ctxs[i]->C);
+    }
+    for (int i = 0; i < n; i++) {
+        const int r = fpl_reserve_cycles(ctxs[i], C);
+        if (r != FPL_OK) return r;
+        FPL_HIP(hipSetDevice(ctxs[i]->device));
+        FPL_HIP(hipDeviceSynchronize());
+    }
+    if (n == 1) return FPL_OK;
+    if (!g_rccl.load(ctx->err)) return FPL_ERR_STATE;
+#define FPL_NCCL(call)                                                                                   \
+    do {                                                                                                 \
+        const ncclResult_t r__ = (call);                                                                 \
+        if (r__ != ncclSuccess) {                                                                        \
+            ctx->err = std::string(#call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r__) : "rccl error"); \
+            rc = FPL_ERR_HIP;                                                                            \
+        }                                                                                                \
+    } while (0)
+    int rc = FPL_OK;
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
+    FPL_NCCL(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+    if (rc != FPL_OK) return rc;
+    const size_t len = FPL_COUNTERS_LEN(C, ctx->n_adapters);
+    FPL_NCCL(g_rccl.GroupStart());
+    for (int i = 0; i < n && rc == FPL_OK; i++) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) {
+            ctx->err = "hipSetDevice failed inside the all-reduce group";
+            rc = FPL_ERR_HIP;
+            break;
+        }
+        FPL_NCCL(g_rccl.AllReduce(ctxs[i]->d_counters, ctxs[i]->d_counters, len, ncclInt64, ncclSum, comms[i], ctxs[i]->stream));
+    }
+    FPL_NCCL(g_rccl.GroupEnd());
+    for (int i = 0; i < n; i++) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
+            if (rc == FPL_OK) ctx->err = "synchronizing the all-reduce failed";
+            rc = FPL_ERR_HIP;
+        }
+    }
+    for (int i = 0; i < n; i++)
+        if (comms[i]) FPL_NCCL(g_rccl.CommDestroy(comms[i]));
+#undef FPL_NCCL
+    return rc;
+}
+
 int fpl_reset_counters(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
     FPL_HIP(hipSetDevice(ctx->device));
@@ -248,7 +375,7 @@ int fpl_reset_counters(fpl_ctx* ctx) {
 }
 
 static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_read_len) {
-    const size_t slabs = stats_scratch_slabs(n_reads, n_bytes, max_read_len, ctx->n_cu);
+    const size_t slabs = stats_scratch_slabs(n_reads, n_bytes, max_read_len, ctx->n_cu, ctx->tune);
     if (slabs <= ctx->scratch_slabs) return FPL_OK;
     FPL_HIP(hipDeviceSynchronize());
     if (ctx->d_stats_scratch) (void)hipFree(ctx->d_stats_scratch);
@@ -263,11 +390,14 @@ static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_r
     return FPL_OK;
 }
 
-/* the fragment / region / piece lists of k_break_mask for a batch of this size */
+/* the fragment / region / piece lists of k_break_mask: capacities grow (25 % headroom) and never shrink, so that a
+   run whose batches differ a little in size does not reallocate -- and wait for the device -- on every batch */
 static int ensure_break_mask(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes) {
     if (!ctx->hcfg.defer) return FPL_OK;
     if (!ctx->bm.counts) FPL_HIP(hipMalloc((void**)&ctx->bm.counts, 4 * sizeof(u32)));
-    if (n_reads <= ctx->bm_reads && n_bytes <= ctx->bm_bytes && ctx->bm.frags) return FPL_OK;
+    u32 need_f = 0, need_r = 0, need_i = 0;
+    break_mask_caps(n_reads, n_bytes, ctx->hcfg.brk, ctx->hcfg.brk_w, ctx->hcfg.msk, ctx->hcfg.msk_w, need_f, need_r, need_i);
+    if (ctx->bm.frags && need_f <= ctx->bm.frag_cap && need_r <= ctx->bm.reg_cap && need_i <= ctx->bm.item_cap) return FPL_OK;
     FPL_HIP(hipDeviceSynchronize());
     if (ctx->bm.frags) (void)hipFree(ctx->bm.frags);
     if (ctx->bm.regs) (void)hipFree(ctx->bm.regs);
@@ -279,15 +409,19 @@ static int ensure_break_mask(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes) {
     ctx->d_frag_cyc = nullptr;
     ctx->d_frag_off = nullptr;
     ctx->d_frag_len = nullptr;
-    break_mask_caps(n_reads, n_bytes, ctx->hcfg.brk, ctx->hcfg.brk_w, ctx->hcfg.msk, ctx->hcfg.msk_w, ctx->bm.frag_cap,
-                    ctx->bm.reg_cap, ctx->bm.item_cap);
+    auto grow = [](u32 have, u32 need) -> u32 {
+        const uint64_t want = (uint64_t)need + need / 4 + 64;
+        const uint64_t cap = want < 0x7FFFFFF0ull ? want : 0x7FFFFFF0ull;
+        return have > cap ? have : (u32)cap;
+    };
+    ctx->bm.frag_cap = grow(ctx->bm.frag_cap, need_f);
+    ctx->bm.reg_cap = grow(ctx->bm.reg_cap, need_r);
+    ctx->bm.item_cap = grow(ctx->bm.item_cap, need_i);
     FPL_HIP(hipMalloc((void**)&ctx->bm.frags, sizeof(fpl_fragment) * (size_t)ctx->bm.frag_cap));
     FPL_HIP(hipMalloc((void**)&ctx->bm.regs, sizeof(fpl_region) * (size_t)ctx->bm.reg_cap));
     FPL_HIP(hipMalloc((void**)&ctx->d_frag_off, sizeof(uint64_t) * (size_t)ctx->bm.item_cap));
     FPL_HIP(hipMalloc((void**)&ctx->d_frag_len, sizeof(u32) * (size_t)ctx->bm.item_cap));
     FPL_HIP(hipMalloc((void**)&ctx->d_frag_cyc, sizeof(u32) * (size_t)ctx->bm.item_cap));
-    ctx->bm_reads = n_reads;
-    ctx->bm_bytes = n_bytes;
     return FPL_OK;
 }
 
@@ -357,6 +491,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.stats_flags = ctx->d_stats_flags;
     a.n_cu = ctx->n_cu;
     a.dbg = ctx->dbg;
+    a.tune = ctx->tune;
     const bool timing = ctx->timing != 0;
     const int slot = ctx->ev_calls % fpl_ctx::EV_RING;
     hipError_t ev_err = hipSuccess;
@@ -372,12 +507,68 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     return FPL_OK;
 }
 
-int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n_reads,
-                      fpl_read_result* results) {
+/* device staging of one slot for a batch of this size (grown with 25 % headroom; a grow waits for the device) */
+static int ensure_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, u32 n_reads, uint64_t n_bytes) {
+    if (n_bytes > sl.st_bytes || !sl.d_seq) {
+        FPL_HIP(hipDeviceSynchronize());
+        if (sl.d_seq) (void)hipFree(sl.d_seq);
+        if (sl.d_qual) (void)hipFree(sl.d_qual);
+        sl.d_seq = sl.d_qual = nullptr;
+        sl.st_bytes = 0;
+        const uint64_t cap = n_bytes + n_bytes / 4 + 64;
+        FPL_HIP(hipMalloc((void**)&sl.d_seq, cap));
+        FPL_HIP(hipMalloc((void**)&sl.d_qual, cap));
+        sl.st_bytes = cap;
+    }
+    if (n_reads > sl.st_reads) {
+        FPL_HIP(hipDeviceSynchronize());
+        if (sl.d_off) (void)hipFree(sl.d_off);
+        if (sl.d_results) (void)hipFree(sl.d_results);
+        if (sl.h_results) (void)hipHostFree(sl.h_results);
+        sl.d_off = nullptr;
+        sl.d_results = nullptr;
+        sl.h_results = nullptr;
+        sl.st_reads = 0;
+        const u32 cap = n_reads + n_reads / 4 + 16;
+        FPL_HIP(hipMalloc((void**)&sl.d_off, sizeof(uint64_t) * ((size_t)cap + 1)));
+        FPL_HIP(hipMalloc((void**)&sl.d_results, sizeof(fpl_read_result) * (size_t)cap));
+        FPL_HIP(hipHostMalloc((void**)&sl.h_results, sizeof(fpl_read_result) * (size_t)cap, hipHostMallocDefault));
+        sl.st_reads = cap;
+    }
+    return FPL_OK;
+}
+
+int fpl_in_flight(const fpl_ctx* ctx) { return ctx ? (int)(ctx->submitted - ctx->waited) : 0; }
+
+int fpl_wait(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
-    if (n_reads == 0) return FPL_OK;
-    if (!seq || !qual || !off || !results) return FPL_ERR_ARG;
+    if (ctx->submitted == ctx->waited) return FPL_ERR_STATE;
+    fpl_ctx::Slot& sl = ctx->slot[ctx->waited % FPL_MAX_IN_FLIGHT];
+    ctx->waited++;
+    if (sl.rc != FPL_OK) return sl.rc; /* nothing was enqueued behind the failure */
+    if (sl.n_reads == 0) return FPL_OK;
     FPL_HIP(hipSetDevice(ctx->device));
+    FPL_HIP(hipEventSynchronize(sl.ev_done));
+    memcpy(sl.user_results, sl.h_results, sizeof(fpl_read_result) * (size_t)sl.n_reads);
+    return FPL_OK;
+}
+
+int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint64_t* off,
+                            uint32_t n_reads, fpl_read_result* results) {
+    if (!ctx) return FPL_ERR_ARG;
+    if (n_reads && (!seq || !qual || !off || !results)) return FPL_ERR_ARG;
+    if (ctx->submitted - ctx->waited >= FPL_MAX_IN_FLIGHT) return FPL_ERR_STATE;
+    FPL_HIP(hipSetDevice(ctx->device));
+    /* --break / --mask: the fragment lists of the batch in flight live in buffers this batch's kernels reuse */
+    if (ctx->hcfg.defer && ctx->submitted != ctx->waited) return FPL_ERR_STATE;
+    fpl_ctx::Slot& sl = ctx->slot[ctx->submitted % FPL_MAX_IN_FLIGHT];
+    sl.n_reads = n_reads;
+    sl.user_results = results;
+    sl.rc = FPL_OK;
+    if (n_reads == 0) {
+        ctx->submitted++;
+        return FPL_OK;
+    }
     const uint64_t n_bytes = off[n_reads];
     u32 max_len = 0;
     for (u32 i = 0; i < n_reads; i++) {
@@ -385,41 +576,45 @@ int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, con
         const u32 l = (u32)(off[i + 1] - off[i]);
         if (l > max_len) max_len = l;
     }
-    if (n_bytes > ctx->st_bytes || !ctx->d_seq) {
-        FPL_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->d_seq) (void)hipFree(ctx->d_seq);
-        if (ctx->d_qual) (void)hipFree(ctx->d_qual);
-        ctx->d_seq = ctx->d_qual = nullptr;
-        ctx->st_bytes = 0;
-        const uint64_t cap = n_bytes + n_bytes / 4 + 64;
-        FPL_HIP(hipMalloc((void**)&ctx->d_seq, cap));
-        FPL_HIP(hipMalloc((void**)&ctx->d_qual, cap));
-        ctx->st_bytes = cap;
-    }
-    if (n_reads > ctx->st_reads) {
-        FPL_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->d_off) (void)hipFree(ctx->d_off);
-        if (ctx->d_results) (void)hipFree(ctx->d_results);
-        ctx->d_off = nullptr;
-        ctx->d_results = nullptr;
-        ctx->st_reads = 0;
-        const u32 cap = n_reads + n_reads / 4 + 16;
-        FPL_HIP(hipMalloc((void**)&ctx->d_off, sizeof(uint64_t) * ((size_t)cap + 1)));
-        FPL_HIP(hipMalloc((void**)&ctx->d_results, sizeof(fpl_read_result) * (size_t)cap));
-        ctx->st_reads = cap;
-    }
-    if (n_bytes) {
-        FPL_HIP(hipMemcpyAsync(ctx->d_seq, seq, n_bytes, hipMemcpyHostToDevice, ctx->stream));
-        FPL_HIP(hipMemcpyAsync(ctx->d_qual, qual, n_bytes, hipMemcpyHostToDevice, ctx->stream));
-    }
-    FPL_HIP(hipMemcpyAsync(ctx->d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
-    int r = fpl_process_batch_device(ctx, ctx->d_seq, ctx->d_qual, ctx->d_off, n_reads, n_bytes, max_len, ctx->d_results,
-                                     ctx->stream);
+    int r = ensure_slot(ctx, sl, n_reads, n_bytes);
     if (r != FPL_OK) return r;
-    FPL_HIP(hipMemcpyAsync(results, ctx->d_results, sizeof(fpl_read_result) * (size_t)n_reads, hipMemcpyDeviceToHost,
-                           ctx->stream));
-    FPL_HIP(hipStreamSynchronize(ctx->stream));
+    /* (the slot's previous batch has been waited for -- FPL_MAX_IN_FLIGHT slots, FIFO -- so its buffers are free) */
+    if (n_bytes) {
+        FPL_HIP(hipMemcpyAsync(sl.d_seq, seq, n_bytes, hipMemcpyHostToDevice, ctx->s_h2d));
+        FPL_HIP(hipMemcpyAsync(sl.d_qual, qual, n_bytes, hipMemcpyHostToDevice, ctx->s_h2d));
+    }
+    FPL_HIP(hipMemcpyAsync(sl.d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, ctx->s_h2d));
+    FPL_HIP(hipEventRecord(sl.ev_h2d, ctx->s_h2d));
+    FPL_HIP(hipStreamWaitEvent(ctx->stream, sl.ev_h2d, 0));
+    r = fpl_process_batch_device(ctx, sl.d_seq, sl.d_qual, sl.d_off, n_reads, n_bytes, max_len, sl.d_results, ctx->stream);
+    if (r != FPL_OK) return r;
+    /* the records leave on their own stream, so that they do not queue behind the next batch's input copies */
+    FPL_HIP(hipEventRecord(sl.ev_kern, ctx->stream));
+    FPL_HIP(hipStreamWaitEvent(ctx->s_d2h, sl.ev_kern, 0));
+    FPL_HIP(hipMemcpyAsync(sl.h_results, sl.d_results, sizeof(fpl_read_result) * (size_t)n_reads, hipMemcpyDeviceToHost,
+                           ctx->s_d2h));
+    FPL_HIP(hipEventRecord(sl.ev_done, ctx->s_d2h));
+    ctx->submitted++;
     return FPL_OK;
+}
+
+int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n_reads,
+                      fpl_read_result* results) {
+    if (!ctx) return FPL_ERR_ARG;
+    if (ctx->submitted != ctx->waited) return FPL_ERR_STATE; /* (collect the asynchronous batches first) */
+    if (n_reads == 0) return FPL_OK;
+    const int r = fpl_process_batch_async(ctx, seq, qual, off, n_reads, results);
+    if (r != FPL_OK) return r;
+    return fpl_wait(ctx);
+}
+
+void* fpl_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void fpl_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int fpl_enable_timing(fpl_ctx* ctx, int enable) {

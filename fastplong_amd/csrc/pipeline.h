@@ -36,6 +36,25 @@ constexpr int SWAVES = FPL_SWAVES; /* k_stats: 16 waves share one 80 KiB LDS tab
 typedef hipStream_t fpl_stream_t;
 #endif
 
+/* Tuning / test hooks of the statistics passes (FPL_STATS_PER, FPL_STATS_EXTRA_PER, FPL_STATS_EXTRA_BLOCKS,
+ * FPL_STATS_EXTRA_ACC in the environment; 0 = built-in choice).  The library reads them ONCE, in fpl_create(); the
+ * per-batch path only sees this struct. */
+struct StatsTune {
+    u32 per = 0, extra_per = 0, extra_blocks = 0, extra_acc = 0;
+};
+inline StatsTune stats_tune_from_env() {
+    auto get = [](const char* name) -> u32 {
+        const char* e = getenv(name);
+        return (e && atoi(e) > 0) ? (u32)atoi(e) : 0u;
+    };
+    StatsTune t;
+    t.per = get("FPL_STATS_PER");
+    t.extra_per = get("FPL_STATS_EXTRA_PER");
+    t.extra_blocks = get("FPL_STATS_EXTRA_BLOCKS");
+    t.extra_acc = get("FPL_STATS_EXTRA_ACC");
+    return t;
+}
+
 struct BatchArgs {
     const u8* seq;
     const u8* qual;
@@ -61,6 +80,7 @@ struct BatchArgs {
     u8* stats_flags;      /* n_tiles tile flags + one byte per slab, zeroed before each statistics pass */
     u32 n_cu;      /* compute units of the device (grid sizing) */
     int dbg = 0;   /* FPL_DEBUG_FLAGS ablation switches (profiling only) */
+    StatsTune tune; /* tuning / test hooks, read from the environment once by whoever builds the arguments */
 };
 
 constexpr int N_STAGES = 4;
@@ -87,10 +107,9 @@ inline u32 cdiv(u32 a, u32 b) { return (a + b - 1) / b; }
  * typical item length, so the number of HEAVY blocks is about slices x (mean length / tile).  Every block pays
  * for zeroing its tables, the 70 KiB hand-over and the 5-mer flush, so slices should be as large as the
  * 14-bit counter fields allow; measured optimum: ~1.25 heavy blocks per block slot of the chip (2 per CU). */
-inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu) {
+inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu, const StatsTune& tune) {
     if (n_items == 0) return 64;
-    const char* e = getenv("FPL_STATS_PER"); /* tuning hook */
-    if (e && atoi(e) > 0) return (u32)atoi(e);
+    if (tune.per) return tune.per;
     const u32 heavy_tiles = mean_len / FS_T + 1;
     const u32 slices = cdiv(5 * n_cu / 2, heavy_tiles);
     u32 per = cdiv(n_items, slices);
@@ -103,23 +122,19 @@ inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu) {
  * slices of FS_EXTRA_PER items and hand over one slab each. */
 constexpr u32 FS_EXTRA_PER = 1024;
 constexpr u32 FS_EXTRA_BLOCKS = 32; /* (64: 0.07 ms more on the 1 M-read batch: every block zeroes and hands over 70 KiB) */
-inline u32 env_u32(const char* name, u32 dflt) { /* tuning / test hooks */
-    const char* e = getenv(name);
-    return (e && atoi(e) > 0) ? (u32)atoi(e) : dflt;
-}
-inline u32 stats_extra_per() { return env_u32("FPL_STATS_EXTRA_PER", FS_EXTRA_PER); }
-inline u32 stats_extra_blocks(u32 n_reads) {
-    const u32 b = cdiv(2 * (n_reads ? n_reads : 1), stats_extra_per());
-    const u32 cap = env_u32("FPL_STATS_EXTRA_BLOCKS", FS_EXTRA_BLOCKS);
+inline u32 stats_extra_per(const StatsTune& tune) { return tune.extra_per ? tune.extra_per : FS_EXTRA_PER; }
+inline u32 stats_extra_blocks(u32 n_reads, const StatsTune& tune) {
+    const u32 b = cdiv(2 * (n_reads ? n_reads : 1), stats_extra_per(tune));
+    const u32 cap = tune.extra_blocks ? tune.extra_blocks : FS_EXTRA_BLOCKS;
     return b < cap ? b : (cap < FS_EXTRA_BLOCKS ? cap : FS_EXTRA_BLOCKS);
 }
 /* items a block may accumulate before it must empty its tables (test hook: force that path) */
-inline u32 stats_extra_max_acc() { return env_u32("FPL_STATS_EXTRA_ACC", CS_MAX_ITEMS_PER_SLICE); }
+inline u32 stats_extra_max_acc(const StatsTune& tune) { return tune.extra_acc ? tune.extra_acc : CS_MAX_ITEMS_PER_SLICE; }
 /* slabs (tiles x slices) the scratch buffer must hold for a batch */
-inline size_t stats_scratch_slabs(u32 n_reads, uint64_t n_bytes, u32 max_read_len, u32 n_cu) {
+inline size_t stats_scratch_slabs(u32 n_reads, uint64_t n_bytes, u32 max_read_len, u32 n_cu, const StatsTune& tune) {
     const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, FS_T);
     const u32 mean_len = n_reads ? (u32)(n_bytes / n_reads) : 0;
-    const u32 per = stats_items_per_slice(n_reads, mean_len, n_cu);
+    const u32 per = stats_items_per_slice(n_reads, mean_len, n_cu, tune);
     u32 slices = cdiv(n_reads ? n_reads : 1, per);
     if (slices < FS_EXTRA_BLOCKS) slices = FS_EXTRA_BLOCKS;
     return (size_t)slices * n_tiles;
@@ -180,7 +195,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     mark(2);
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
     {
-        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu);
+        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
         const u32 n_slices = cdiv(n, per);
         FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles + n_tiles, stream);
         FPL_LAUNCH((k_stats<SWAVES, false>), dim3(n_slices, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
@@ -193,11 +208,11 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     mark(3);
     {
         const u32 n_items = a.defer ? a.bm.item_cap : 2 * n; /* upper bound; the kernel reads the real count */
-        const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n); /* slabs per tile */
+        const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n, a.tune); /* slabs per tile */
         FPL_MEMSET(a.stats_flags, (size_t)gx * n_tiles + n_tiles, stream);
         FPL_LAUNCH((k_stats<SWAVES, true>), dim3(gx, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
                    (const uint64_t*)a.frag_off, (const u32*)a.frag_len, (const u32*)a.frag_cyc, (const ReadState*)nullptr, n_items,
-                   (const u32*)(a.work_ctr + 1), stats_extra_per(), gx, stats_extra_max_acc(), a.counters, a.stats_scratch,
+                   (const u32*)(a.work_ctr + 1), stats_extra_per(a.tune), gx, stats_extra_max_acc(a.tune), a.counters, a.stats_scratch,
                    a.stats_flags, a.C);
         FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, gx, n_tiles, a.counters, a.C, 0);

@@ -17,6 +17,7 @@ EXPORTS = [
     "fpl_process_batch_device", "fpl_process_batch", "fpl_max_cycles", "fpl_n_adapters", "fpl_counters_len",
     "fpl_reserve_cycles", "fpl_counters_device_ptr", "fpl_get_counters", "fpl_reset_counters", "fpl_synchronize",
     "fpl_enable_timing", "fpl_get_kernel_times", "fpl_fragment_counts", "fpl_get_fragments",
+    "fpl_process_batch_async", "fpl_wait", "fpl_in_flight", "fpl_host_alloc", "fpl_host_free", "fpl_allreduce_counters",
 ]
 
 
@@ -85,6 +86,18 @@ def load_library():
     L.fpl_fragment_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fpl_get_fragments.restype = C.c_int
     L.fpl_get_fragments.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.fpl_process_batch_async.restype = C.c_int
+    L.fpl_process_batch_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.fpl_wait.restype = C.c_int
+    L.fpl_wait.argtypes = [C.c_void_p]
+    L.fpl_in_flight.restype = C.c_int
+    L.fpl_in_flight.argtypes = [C.c_void_p]
+    L.fpl_host_alloc.restype = C.c_void_p
+    L.fpl_host_alloc.argtypes = [C.c_size_t]
+    L.fpl_host_free.restype = None
+    L.fpl_host_free.argtypes = [C.c_void_p]
+    L.fpl_allreduce_counters.restype = C.c_int
+    L.fpl_allreduce_counters.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
     if L.fpl_abi_version() != abi.FPL_ABI_VERSION:
         raise FplError("ABI version mismatch")
     _lib = L
@@ -154,6 +167,37 @@ class Engine:
         self._check(self.L.fpl_process_batch(self.h, seq.ctypes.data, qual.ctypes.data, off.ctypes.data, n,
                                              res.ctypes.data), "fpl_process_batch")
         return res[:n]
+
+    def submit_host(self, seq, qual, off, res):
+        """fpl_process_batch_async: the arrays (uint8, uint8, uint64 offsets; ideally views of pinned_array()) and
+        the result array must stay alive until wait() has returned for this batch"""
+        n = len(off) - 1
+        self._check(self.L.fpl_process_batch_async(self.h, seq.ctypes.data, qual.ctypes.data, off.ctypes.data, n,
+                                                   res.ctypes.data), "fpl_process_batch_async")
+
+    def wait(self):
+        self._check(self.L.fpl_wait(self.h), "fpl_wait")
+
+    def in_flight(self):
+        return int(self.L.fpl_in_flight(self.h))
+
+    def pinned_array(self, n, dtype=np.uint8):
+        """numpy view of n items of page-locked host memory (fpl_host_alloc); freed when the array is collected"""
+        nbytes = max(1, int(n) * np.dtype(dtype).itemsize)
+        ptr = self.L.fpl_host_alloc(nbytes)
+        if not ptr:
+            raise FplError("fpl_host_alloc(%d) failed" % nbytes)
+        L = self.L
+
+        class _Owner:
+            def __del__(self_inner):
+                L.fpl_host_free(ptr)
+
+        buf = (C.c_uint8 * nbytes).from_address(ptr)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(n))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append((_Owner(), buf))
+        return arr
 
     def fragments(self):
         """--break / --mask outcome of the LAST batch: (fpl_fragment records sorted by (read, seq_no), fpl_region list)"""

@@ -13,14 +13,15 @@
  * --split / --split_by_lines replay what the reference's workers do with their private writers
  * (src/threadconfig.cpp:72-120) in the one writer thread: see SplitOutput.
  */
-#include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <atomic>
 
 #include <algorithm>
 #include <iostream>
@@ -73,6 +74,7 @@ static const Flag FLAGS[] = {
     {"report_title", 'R', true, "fastplong report"}, {"thread", 'w', true, "3"}, {"split", 0, true, "0"},
     {"split_by_lines", 0, true, "0"}, {"split_prefix_digits", 0, true, "4"},
     {"gpus", 0, true, "1"}, {"batch_mbases", 0, true, "256"}, {"batch_reads", 0, true, "0"},
+    {"reader_threads", 0, true, "0"}, {"chunk_mb", 0, true, "32"},
 };
 
 struct Args {
@@ -138,41 +140,6 @@ static string reverse_complement(const string& s) {
     return r;
 }
 
-/* FastaReader + Options::loadFastaAdapters (src/fastareader.cpp:45-101, src/options.cpp:39-66): records keyed
- * by the full header line (=> visited in header-sorted order), sequences upper-cased and stripped to
- * letters / '-' / '*', entries shorter than 6 skipped. */
-static vector<string> load_fasta_adapters(const string& path) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) error_exit("There is a problem with the provided fasta file: could NOT read " + path);
-    string data;
-    char buf[65536];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) data.append(buf, n);
-    fclose(f);
-    map<string, string> contigs;
-    size_t p = data.find('>');
-    while (p != string::npos) {
-        size_t eol = data.find('\n', p);
-        if (eol == string::npos) eol = data.size();
-        string header = data.substr(p + 1, eol - p - 1);
-        size_t next = data.find('>', eol);
-        string body = data.substr(min(eol + 1, data.size()), (next == string::npos ? data.size() : next) - min(eol + 1, data.size()));
-        string seq;
-        for (char c : body) {
-            if (c >= 'a' && c <= 'z') c -= ('a' - 'A');
-            if (isalpha((unsigned char)c) || c == '-' || c == '*') seq += c;
-        }
-        contigs[header] = seq;
-        p = next;
-    }
-    vector<string> out;
-    for (auto& kv : contigs) {
-        if (kv.second.length() >= 6) out.push_back(kv.second);
-        else cerr << "skip too short adapter sequence in " << path << " (6bp required): " << kv.second << endl;
-    }
-    return out;
-}
-
 struct Device {
     fpl_ctx* ctx = nullptr;
 };
@@ -205,130 +172,23 @@ class Channel {
         q_.pop_front();
         return v;
     }
+    bool try_pop(T& v) {
+        lock_guard<mutex> g(m_);
+        if (q_.empty()) return false;
+        v = q_.front();
+        q_.pop_front();
+        return true;
+    }
    private:
     mutex m_;
     condition_variable cv_;
     deque<T> q_;
 };
 
-/* one complete gzip member (any gzip reader takes a concatenation of members as one stream).  The deflated bytes go
-   through a buffer the calling thread keeps (the pool's workers are persistent): dozens of threads allocating and
-   releasing multi-megabyte strings per slice spend their time in the kernel's address-space lock instead. */
-static void gzip_into(const string& in, int level, string& out) {
-    static thread_local vector<char> scratch;
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) error_exit("deflateInit2 failed");
-    const size_t bound = deflateBound(&zs, (uLong)in.size()) + 64;
-    if (scratch.size() < bound) scratch.resize(bound);
-    zs.next_in = (Bytef*)in.data();
-    zs.avail_in = (uInt)in.size();
-    zs.next_out = (Bytef*)scratch.data();
-    zs.avail_out = (uInt)bound;
-    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) error_exit("deflate failed");
-    const size_t n = zs.total_out;
-    deflateEnd(&zs);
-    out.assign(scratch.data(), n); /* (when out is the input itself: shrinks inside its own allocation) */
-}
-static string gzip_member(const string& in, int level) {
-    string o;
-    gzip_into(in, level, o);
-    return o;
-}
-
-/* --split / --split_by_lines.  Each of the reference's workers owns a writer and walks through the file numbers
- * t, t + T, t + 2T, ... as its current file fills up (ThreadConfig::initWriterForSplit / markProcessed /
- * writeEmptyFilesForSplitting, src/threadconfig.cpp:72-120); packs of PACK_SIZE = 16 reads reach the workers
- * round-robin (src/seprocessor.cpp:343-378), so which file a read lands in is a function of its input index.  The
- * one writer thread of this host replays that, pack by pack.
- * One deliberate difference: when --split's files are used up, the reference lets some workers stop and DROP the
- * packs still queued for them (mCanBeStopped, a race against the reader thread: src/threadconfig.cpp:103-107,
- * src/seprocessor.cpp:430-433); here such a worker keeps writing into its last file, so no read is lost and the
- * result does not depend on timing. */
-class SplitOutput {
-   public:
-    SplitOutput(const string& out, int digits, int workers, bool by_lines, int number, long size, int gz_level)
-        : out_(out), digits_(digits), T_(workers), by_lines_(by_lines), number_(number), size_(size), level_(gz_level), w_(workers) {
-        for (int t = 0; t < T_; t++) {
-            w_[t].working = t; /* mWorkingSplit = threadId */
-            open(w_[t]);
-        }
-    }
-    void write(int t, const string& text) { /* config->getWriter1()->writeString(outstr), src/seprocessor.cpp:297-301 */
-        if (out_.empty()) return;
-        Worker& w = w_[t];
-        w.pending += text;
-        if (w.pending.size() >= (4u << 20)) flush(w);
-    }
-    void mark(int t, long reads) { /* ThreadConfig::markProcessed */
-        Worker& w = w_[t];
-        w.current += reads;
-        if (w.current >= size_ && (by_lines_ || w.working + T_ < number_)) {
-            w.working += T_;
-            open(w);
-            w.current = 0;
-        }
-    }
-    void close() { /* ThreadConfig::cleanup: files a short input never reached still have to exist */
-        for (Worker& w : w_) {
-            if (!by_lines_)
-                while (w.working + T_ < number_) {
-                    w.working += T_;
-                    open(w);
-                }
-            shut(w);
-        }
-    }
-    vector<string> names;
-
-   private:
-    struct Worker {
-        int working = 0;
-        long current = 0;
-        FILE* f = nullptr;
-        bool gz = false, wrote = false;
-        string pending;
-    };
-    void flush(Worker& w) {
-        if (w.pending.empty() || !w.f) return;
-        const string& bytes = w.gz ? gzip_member(w.pending, level_) : w.pending;
-        if (fwrite(bytes.data(), 1, bytes.size(), w.f) != bytes.size()) error_exit("write failed");
-        w.wrote = true;
-        w.pending.clear();
-    }
-    void shut(Worker& w) {
-        if (!w.f) return;
-        flush(w);
-        if (w.gz && !w.wrote) {
-            const string e = gzip_member(string(), level_);
-            fwrite(e.data(), 1, e.size(), w.f);
-        }
-        fclose(w.f);
-        w.f = nullptr;
-    }
-    void open(Worker& w) { /* ThreadConfig::initWriterForSplit: 1-based number, zero-padded, in front of the base name */
-        if (out_.empty()) return;
-        shut(w);
-        string num = to_string(w.working + 1);
-        while ((int)num.size() < digits_) num = "0" + num;
-        const size_t slash = out_.find_last_of('/');
-        const string dir = slash == string::npos ? "./" : out_.substr(0, slash + 1);
-        const string base = slash == string::npos ? out_ : out_.substr(slash + 1);
-        const string path = dir + num + "." + base;
-        w.f = fopen(path.c_str(), "wb");
-        if (!w.f) error_exit("Failed to write: " + path);
-        w.gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
-        w.wrote = false;
-        names.push_back(path);
-    }
-    string out_;
-    int digits_, T_;
-    bool by_lines_;
-    int number_;
-    long size_;
-    int level_;
-    vector<Worker> w_;
-};
+#include "split.h"
+using fplh::gzip_into;
+using fplh::gzip_member;
+using fplh::SplitOutput;
 
 int main(int argc, char* argv[]) {
     if (argc == 1) {
@@ -354,7 +214,10 @@ int main(int argc, char* argv[]) {
     o.trimming_extension = cmd.i("trimming_extension");
     if (startAd != "auto" && endAd == "auto") endAd = reverse_complement(startAd); /* src/main.cpp:138-140 */
     vector<string> fasta;
-    if (!cmd.str("adapter_fasta").empty()) fasta = load_fasta_adapters(cmd.str("adapter_fasta"));
+    if (!cmd.str("adapter_fasta").empty()) {
+        string err;
+        if (!fplh::load_fasta_adapters(cmd.str("adapter_fasta"), fasta, &cerr, err)) error_exit(err);
+    }
     o.trim_front = cmd.i("trim_front");
     o.trim_tail = cmd.i("trim_tail");
     o.polyx = cmd.exist("trim_poly_x");
@@ -484,6 +347,13 @@ int main(int argc, char* argv[]) {
     if (o.ed_max < 0 || o.ed_max > 1.0) error_exit("the adapter <distance_threshold> should be 0.0 ~ 1.0, suggest 0.1 ~ 0.3");
     if (o.trimming_extension < 0 || o.trimming_extension > 100) error_exit("the adapter <trimming_extension> should be 0 ~ 100, suggest 5 ~ 30");
 
+    auto clk = []() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tMain = clk();
+    auto since_launch = [&]() -> double { /* measurement hook: FPLH_T0 = the launcher's time.time() */
+        const char* e = getenv("FPLH_T0");
+        return e ? chrono::duration<double>(chrono::system_clock::now().time_since_epoch()).count() - atof(e) : -1.0;
+    };
+    const double launchToMain = since_launch();
     /* Evaluator::evaluateSeqLenAndCheckRNA, src/evaluator.cpp:16-61: U vs T in the first 100 reads */
     bool isRNA = false;
     if (!fromStdin && in != "/dev/stdin") {
@@ -521,24 +391,62 @@ int main(int argc, char* argv[]) {
     }
 
     /* one context + one host thread per device */
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < nGpus)
-        error_exit("fastplong_amd needs " + to_string(nGpus) + " HIP device(s); there is no CPU path");
+    const double tEval = clk();
     vector<fpl_adapter> fa(fasta.size());
     for (size_t i = 0; i < fasta.size(); i++) fa[i] = fpl_adapter{fasta[i].data(), (int32_t)fasta[i].size()};
     vector<Device> dev(nGpus);
     for (int d = 0; d < nGpus; d++) {
         int rc = fpl_create(&dev[d].ctx, &o, startAd.data(), (int32_t)startAd.size(), endAd.data(), (int32_t)endAd.size(),
                             fa.data(), (int32_t)fa.size(), d, 65536);
+        if (rc == FPL_ERR_NO_DEVICE)
+            error_exit("fastplong_amd needs " + to_string(nGpus) + " HIP device(s); there is no CPU path");
         if (rc != FPL_OK) error_exit(string("fpl_create: ") + fpl_strerror(rc));
     }
 
-    fplh::FastqReader reader(in);
-    if (!reader.ok()) error_exit("Failed to open file: " + in);
-    { /* threads of the reader's refill / locate / copy phases (FPLH_PARSE_THREADS overrides) */
+    const double tCreate = clk();
+    if (cmd.exist("verbose"))
+        cerr << "start-up: input evaluation " << tEval - tMain << " s, device contexts " << tCreate - tEval << " s" << endl;
+    /* the CSR arrays of every batch are page-locked (fpl_host_alloc), so the DMA engines read them in place */
+    if (!getenv("FPLH_NO_PIN")) /* (measurement hook: pageable batches, the runtime stages the copies) */
+        fplh::ByteBuf::set_allocator(fpl_host_alloc, fpl_host_free);
+    const int hw = max(1, (int)thread::hardware_concurrency());
+    /* How the input is read.  A regular uncompressed file is cut into chunks of --chunk_mb that --reader_threads
+       workers parse at the same time (FastqReader::parse_chunk: each worker reads its chunk from the page cache,
+       locates the records and copies their lines into a page-locked batch); the sequencer below puts the chunks
+       back in order and checks every chunk's guessed start against its predecessor.  Everything else -- gzip,
+       pipes, --reads_to_process -- goes through the one sequential reader. */
+    int chunkFd = -1;
+    uint64_t chunkFileSize = 0;
+    if (!fromStdin && in != "/dev/stdin" && readsToProcess == 0 && !getenv("FPLH_NO_CHUNKS")) {
+        const int fd = open(in.c_str(), O_RDONLY);
+        struct stat st;
+        unsigned char magic[2] = {0, 0};
+        if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 &&
+            !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            chunkFd = fd;
+            chunkFileSize = (uint64_t)st.st_size;
+        } else if (fd >= 0) {
+            close(fd);
+        }
+    }
+    uint64_t chunkBytes = (uint64_t)max(1L, cmd.l("chunk_mb")) << 20;
+    if (const char* e = getenv("FPLH_CHUNK_BYTES")) /* test hook: tiny chunks put every cut inside some record */
+        if (atol(e) > 0) chunkBytes = (uint64_t)atol(e);
+    int readerThreads = cmd.i("reader_threads");
+    if (readerThreads <= 0) readerThreads = max(2, min(16, hw / 8));
+    const bool chunked = chunkFd >= 0 && chunkFileSize > chunkBytes;
+    fplh::FastqReader* reader = nullptr;
+    /* Work objects bound what is in flight: one per parser, FPL_MAX_IN_FLIGHT per device in the copy / kernel stage,
+       one per device being formatted, two waiting for the writer */
+    const int nWork = (chunked ? readerThreads : 1) + (FPL_MAX_IN_FLIGHT + 1) * nGpus + 2;
+    if (chunked) /* a chunk holds about half its bytes in bases: one block each for the bases and the qualities of a batch */
+        fplh::ByteBuf::set_arena((size_t)(chunkBytes / 2 + chunkBytes / 16 + (2u << 20)), 2 * (size_t)nWork);
+    if (!chunked) {
+        reader = new fplh::FastqReader(in);
+        if (!reader->ok()) error_exit("Failed to open file: " + in);
+        /* threads of the reader's refill / locate / copy phases (FPLH_PARSE_THREADS overrides) */
         const char* e = getenv("FPLH_PARSE_THREADS");
-        const int hw = (int)thread::hardware_concurrency();
-        reader.set_copy_threads(e && atoi(e) > 0 ? atoi(e) : max(1, min(8, hw / 2)));
+        reader->set_copy_threads(e && atoi(e) > 0 ? atoi(e) : max(1, min(8, hw / 2)));
     }
     /* Outputs are plain files; a name ending in .gz gets gzip members (-z level), one per formatted slice,
        deflated on the formatter threads and concatenated by the writer: any gzip reader takes that as one stream */
@@ -579,49 +487,78 @@ int main(int argc, char* argv[]) {
     /* slices a batch's output is formatted in (one worker each); gzip outputs are deflated per slice, which is compute-
        bound, so they get more, smaller slices */
     const bool anyGz = (fout && fout.gz) || (ffail && ffail.gz);
-    const int fmtThreads = max(1, min(anyGz ? 64 : 16, (int)thread::hardware_concurrency() / max(1, nGpus) - 1));
-    const int nWork = 2 * nGpus + 1;
+    const int fmtThreads = max(1, min(anyGz ? 64 : 16, hw / max(1, nGpus) - 1));
     vector<Work> pool(nWork);
-    Channel<Work*> freeq, doneq;
+    Channel<Work*> freeq, fmtq, doneq;
     vector<Channel<Work*>> devq(nGpus);
     for (auto& w : pool) freeq.push(&w);
     uint64_t nBatches = 0;
     /* --verbose: where the wall time of the host pipeline goes (busy seconds per stage) */
     auto now = []() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tStart = now();
-    double tParse = 0, tWrite = 0;
+    double tParse = 0, tWrite = 0, tRedo = 0;
+    uint64_t nRedo = 0;
     vector<double> tGpu(nGpus, 0), tFormat(nGpus, 0);
+    string inputError; /* a malformed record: reported the way the sequential reader does, the input ends there */
+    string ioError;    /* the input could not be read / decompressed to its end: the run fails (src/fastqreader.cpp:92-137) */
+
+    /* ---- stage 1: batches in input order -> devq (round-robin over the devices) */
     thread readerThread([&]() {
-        for (;;) {
-            uint32_t maxReads = batchReads;
-            if (readsLeft >= 0) maxReads = (uint32_t)min<long>(readsLeft, maxReads);
-            if (maxReads == 0) break;
-            Work* w = freeq.pop();
-            w->batch.clear();
-            const double t0 = now();
-            const uint32_t got = reader.fill(w->batch, batchBases, maxReads);
-            tParse += now() - t0;
-            if (got == 0) {
-                freeq.push(w);
-                break;
+        if (!chunked) {
+            for (;;) {
+                uint32_t maxReads = batchReads;
+                if (readsLeft >= 0) maxReads = (uint32_t)min<long>(readsLeft, maxReads);
+                if (maxReads == 0) break;
+                Work* w = freeq.pop();
+                w->batch.clear();
+                const double t0 = now();
+                const uint32_t got = reader->fill(w->batch, batchBases, maxReads);
+                tParse += now() - t0;
+                if (got == 0) {
+                    freeq.push(w);
+                    break;
+                }
+                if (readsLeft >= 0) readsLeft -= w->batch.n();
+                w->seq_no = nBatches++;
+                devq[w->seq_no % nGpus].push(w); /* batches are dealt round-robin in input order */
             }
-            if (readsLeft >= 0) readsLeft -= w->batch.n();
-            w->seq_no = nBatches++;
-            devq[w->seq_no % nGpus].push(w); /* batches are dealt round-robin in input order */
+            if (reader->input_error()) ioError = reader->input_error_text();
+        } else {
+            /* the parsers take their batches from the Work pool; next() puts the chunks back in input order */
+            auto acquire = [&]() {
+                fplh::ChunkedReader::Item it;
+                Work* w = freeq.pop();
+                it.batch = &w->batch;
+                it.token = w;
+                return it;
+            };
+            auto release = [&](fplh::ChunkedReader::Item it) { freeq.push((Work*)it.token); };
+            fplh::ChunkedReader cr(chunkFd, chunkFileSize, chunkBytes, readerThreads, acquire, release);
+            fplh::ChunkedReader::Item it;
+            while (cr.next(it)) {
+                Work* w = (Work*)it.token;
+                w->seq_no = nBatches++;
+                devq[w->seq_no % nGpus].push(w);
+            }
+            inputError = cr.malformed_text();
+            ioError = cr.io_error_text();
+            nRedo = cr.chunks_parsed_again();
+            tRedo = cr.redo_seconds();
+            tParse = cr.busiest_parser_seconds();
         }
         for (int d = 0; d < nGpus; d++) devq[d].push(nullptr);
     });
+    /* ---- stage 2, one thread per device: copies and kernels, FPL_MAX_IN_FLIGHT batches deep */
     vector<thread> devThreads;
     for (int d = 0; d < nGpus; d++)
         devThreads.emplace_back([&, d]() {
-            for (;;) {
-                Work* w = devq[d].pop();
-                if (!w) break;
-                w->res.resize(w->batch.n());
+            deque<Work*> inflight;
+            bool open = true;
+            auto collect = [&]() {
+                Work* w = inflight.front();
+                inflight.pop_front();
                 const double t0 = now();
-                w->rc = fpl_process_batch(dev[d].ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(),
-                                          w->batch.n(), w->res.data());
-                const double t1 = now();
+                if (w->rc == FPL_OK) w->rc = fpl_wait(dev[d].ctx);
                 if (w->rc == FPL_OK && fragmentMode) { /* any number of output reads per read: fetch the list */
                     uint32_t nf = 0, nr = 0;
                     w->rc = fpl_fragment_counts(dev[d].ctx, &nf, &nr);
@@ -633,14 +570,65 @@ int main(int argc, char* argv[]) {
                     }
                 }
                 if (w->rc != FPL_OK) w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
-                else if (!split) { /* (--split* output is cut per pack of 16 reads by the writer) */
+                tGpu[d] += now() - t0;
+                fmtq.push(w);
+            };
+            const size_t depth = fragmentMode ? 1 : FPL_MAX_IN_FLIGHT;
+            while (open || !inflight.empty()) {
+                Work* w = nullptr;
+                bool got = false;
+                if (open && inflight.size() < depth) {
+                    if (inflight.empty()) {
+                        w = devq[d].pop();
+                        got = true;
+                    } else {
+                        got = devq[d].try_pop(w); /* nothing parsed yet: collect the oldest batch meanwhile */
+                    }
+                }
+                if (got && !w) open = false;
+                if (got && w) {
+                    w->res.resize(w->batch.n());
+                    const double t0 = now();
+                    w->rc = fpl_process_batch_async(dev[d].ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(),
+                                                    w->batch.n(), w->res.data());
+                    tGpu[d] += now() - t0;
+                    if (w->rc != FPL_OK) { /* nothing was enqueued: hand the error on in order */
+                        w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
+                        while (!inflight.empty()) collect();
+                        fmtq.push(w);
+                        continue;
+                    }
+                    inflight.push_back(w);
+                    if (inflight.size() < depth) continue; /* room for another submission before waiting */
+                }
+                if (!inflight.empty()) collect();
+            }
+            fmtq.push(nullptr);
+        });
+    /* ---- stage 3: the output text of a batch, on helper threads (the writer below only writes) */
+    vector<thread> fmtStage;
+    std::atomic<int> devEnded{0};
+    for (int f = 0; f < nGpus; f++)
+        fmtStage.emplace_back([&, f]() {
+            for (;;) {
+                Work* w = fmtq.pop();
+                if (!w) {
+                    /* one end marker per device thread; the formatter that sees the last one wakes the others */
+                    if (devEnded.load() >= nGpus) break;
+                    if (++devEnded == nGpus) {
+                        for (int i = 0; i + 1 < nGpus; i++) fmtq.push(nullptr);
+                        break;
+                    }
+                    continue;
+                }
+                const double t1 = now();
+                if (w->rc == FPL_OK && !split) { /* (--split* output is cut per pack of 16 reads by the writer) */
                     fplh::format_batch_parallel(w->batch, w->res.data(), fmtThreads, w->outs, ffail ? &w->faileds : nullptr,
                                                 fragmentMode ? &w->frags : nullptr);
                     if (fout && fout.gz) gzip_pieces(w->outs);
                     if (ffail && ffail.gz) gzip_pieces(w->faileds);
                 }
-                tGpu[d] += t1 - t0;
-                tFormat[d] += now() - t1;
+                tFormat[f] += now() - t1;
                 doneq.push(w);
             }
             doneq.push(nullptr);
@@ -728,50 +716,40 @@ int main(int argc, char* argv[]) {
     }
     readerThread.join();
     for (auto& t : devThreads) t.join();
+    for (auto& t : fmtStage) t.join();
+    if (!inputError.empty()) cerr << inputError; /* (the sequential reader printed it when it met the record) */
+    if (!ioError.empty()) error_exit(ioError);
     if (cmd.exist("verbose")) {
         double g = 0, f = 0;
         for (int d = 0; d < nGpus; d++) g = max(g, tGpu[d]), f = max(f, tFormat[d]);
         cerr << "host pipeline: " << nBatches << " batches, wall " << now() - tStart << " s; busy: parse " << tParse
-             << " s, fpl_process_batch " << g << " s, format (" << fmtThreads << " threads) " << f << " s, write " << tWrite
+             << " s" << (chunked ? " (busiest of " + to_string(readerThreads) + " chunk parsers; " + to_string(nRedo) + " chunks parsed again, " + to_string(tRedo) + " s)" : string())
+             << ", copies + kernels (waits) " << g << " s, format (" << fmtThreads << " threads) " << f << " s, write " << tWrite
              << " s" << endl;
     }
     for (OutFile* o : {&fout, &ffail})
         if (*o) {
             if (o->gz && !o->wrote) { /* an empty .gz still has to be a gzip stream */
                 const string e = gzip_member(string(), gzLevel);
-                fwrite(e.data(), 1, e.size(), o->f);
+                if (fwrite(e.data(), 1, e.size(), o->f) != e.size()) error_exit("write failed");
             }
-            if (o->f == stdout) fflush(stdout);
-            else fclose(o->f);
+            /* the buffered tail goes out here: a full disk shows up as a failing flush / close */
+            if (o->f == stdout ? (fflush(stdout) != 0 || ferror(stdout)) : (fclose(o->f) != 0)) error_exit("write failed");
         }
 
-    /* merge: agree on the per-cycle capacity, then ONE all-reduce (sum, int64) over RCCL */
-    uint32_t C = 0;
-    for (auto& D : dev) C = max(C, fpl_max_cycles(D.ctx));
-    for (auto& D : dev)
-        if (fpl_reserve_cycles(D.ctx, C) != FPL_OK) error_exit("fpl_reserve_cycles failed");
-    const size_t ncnt = fpl_counters_len(dev[0].ctx);
-    if (nGpus > 1) {
-        vector<ncclComm_t> comms(nGpus);
-        vector<int> ids(nGpus);
-        for (int d = 0; d < nGpus; d++) ids[d] = d;
-        if (ncclCommInitAll(comms.data(), nGpus, ids.data()) != ncclSuccess) error_exit("ncclCommInitAll failed");
-        ncclGroupStart();
-        for (int d = 0; d < nGpus; d++) {
-            (void)hipSetDevice(d);
-            void* p = fpl_counters_device_ptr(dev[d].ctx);
-            ncclAllReduce(p, p, ncnt, ncclInt64, ncclSum, comms[d], 0);
-        }
-        ncclGroupEnd();
-        for (int d = 0; d < nGpus; d++) {
-            (void)hipSetDevice(d);
-            (void)hipDeviceSynchronize();
-            ncclCommDestroy(comms[d]);
-        }
+    /* merge: agree on the per-cycle capacity, then ONE all-reduce (sum, int64) over RCCL -- behind the C-ABI */
+    {
+        vector<fpl_ctx*> ctxs;
+        for (auto& D : dev) ctxs.push_back(D.ctx);
+        const int rc = fpl_allreduce_counters(ctxs.data(), (int32_t)ctxs.size());
+        if (rc != FPL_OK) error_exit(string("fpl_allreduce_counters: ") + fpl_strerror(rc) + " " + fpl_last_error(ctxs[0]));
     }
+    const uint32_t C = fpl_max_cycles(dev[0].ctx);
+    const size_t ncnt = fpl_counters_len(dev[0].ctx);
     vector<int64_t> counters(ncnt);
     if (fpl_get_counters(dev[0].ctx, counters.data(), ncnt) != FPL_OK) error_exit("fpl_get_counters failed");
-    for (auto& D : dev) fpl_destroy(D.ctx);
+    /* (the contexts, the page-locked arena and the HIP runtime are not torn down piece by piece: the process is about
+       to end -- see the _exit at the bottom -- and unpinning a gigabyte of staging costs tenths of a second) */
 
     fplh::ReportInputs ri;
     ri.counters = counters.data();
@@ -788,16 +766,30 @@ int main(int argc, char* argv[]) {
     ri.command = command;
     cerr << fplh::summary_text(ri);
     const double tRep0 = now();
-    if (!fplh::write_json(jsonFile, ri)) error_exit("Failed to write: " + jsonFile);
-    const double tRep1 = now();
-    if (!fplh::write_html(htmlFile, ri, page)) error_exit("Failed to write: " + htmlFile);
-    if (cmd.exist("verbose"))
-        cerr << "reports: json " << tRep1 - tRep0 << " s, html " << now() - tRep1 << " s; since start " << now() - tStart << " s" << endl;
+    { /* the two report writers only read the counters: side by side */
+        bool jsonOk = true;
+        double tJson = 0;
+        thread jt([&]() {
+            jsonOk = fplh::write_json(jsonFile, ri);
+            tJson = now() - tRep0;
+        });
+        const bool htmlOk = fplh::write_html(htmlFile, ri, page);
+        const double tHtml = now() - tRep0;
+        jt.join();
+        if (!jsonOk) error_exit("Failed to write: " + jsonFile);
+        if (!htmlOk) error_exit("Failed to write: " + htmlFile);
+        if (cmd.exist("verbose"))
+            cerr << "reports: json " << tJson << " s beside html " << tHtml << " s; since start " << now() - tStart << " s" << endl;
+    }
 
     time_t t2 = time(NULL);
     cerr << endl << "JSON report: " << jsonFile << endl;
     cerr << "HTML report: " << htmlFile << endl;
     cerr << endl << command << endl;
     cerr << "fastplong v0.4.1 (fastplong_amd), time used: " << (t2) - t1 << " seconds" << endl;
-    return 0;
+    if (cmd.exist("verbose") && launchToMain >= 0)
+        cerr << "since launch: main() entered at " << launchToMain << " s, returning at " << since_launch() << " s" << endl;
+    /* every output has been written, flushed and closed above; skip the static destructors (worker pool, HIP runtime) */
+    fflush(NULL);
+    _exit(0);
 }

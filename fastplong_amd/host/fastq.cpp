@@ -23,6 +23,10 @@ using namespace std;
 
 namespace fplh {
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static const bool g_timing = getenv("FPLH_TIMING") != nullptr;
+static std::atomic<uint64_t> g_chunk_us[3]; /* FPLH_TIMING: microseconds the chunk parsers spent reading / locating / copying */
+
 namespace {
 class Pool {
    public:
@@ -161,7 +165,12 @@ class GzMembers {
         while (got < n) {
             if (stream_) {
                 const int r = gzread(stream_, dst + got, (unsigned)min<size_t>(n - got, 1u << 30));
-                if (r <= 0) break;
+                if (r <= 0) {
+                    int errnum = Z_OK;
+                    gzerror(stream_, &errnum);
+                    if (r < 0 || (errnum != Z_OK && errnum != Z_STREAM_END)) err_ = errnum == Z_OK ? Z_ERRNO : errnum;
+                    break;
+                }
                 got += (size_t)r;
                 continue;
             }
@@ -177,6 +186,7 @@ class GzMembers {
         return got;
     }
     uint64_t members_inflated_in_parallel() const { return n_parallel_; }
+    int error() const { return err_; } /* zlib's code when the stream turned out damaged or truncated, else 0 */
 
    private:
     struct Result {
@@ -262,6 +272,7 @@ class GzMembers {
                 if (lseek(fd_, (off_t)pos_, SEEK_SET) < 0) return false;
                 stream_ = gzdopen(fd_, "rb");
                 if (stream_) gzbuffer(stream_, 1 << 20);
+                else err_ = Z_ERRNO;
                 return stream_ != nullptr;
             }
             cur_.swap(r.out);
@@ -284,6 +295,7 @@ class GzMembers {
     vector<char> cur_;
     gzFile stream_ = nullptr;
     uint64_t n_parallel_ = 0;
+    int err_ = 0;
 };
 
 std::atomic<uint64_t> GzMembers::delivered{0};
@@ -301,6 +313,85 @@ static const char* failed_type(int code) {
         case 24: return "failed_low_complexity";
         default: return "";
     }
+}
+
+static std::atomic<uint64_t> g_alloc_seconds_x1000{0}, g_alloc_bytes{0}; /* microseconds / bytes spent in the page-locked allocator */
+static ByteBuf::AllocFn g_alloc = nullptr;
+static ByteBuf::FreeFn g_free = nullptr;
+void ByteBuf::set_allocator(AllocFn a, FreeFn f) {
+    g_alloc = a;
+    g_free = f;
+}
+namespace {
+struct Arena {
+    uint8_t* base = nullptr;
+    size_t block = 0, n = 0;
+    vector<uint8_t*> free_blocks;
+    mutex mu;
+    bool owns(const uint8_t* p) const { return base && p >= base && p < base + block * n; }
+} g_arena;
+}  // namespace
+void ByteBuf::set_arena(size_t block_bytes, size_t n_blocks) {
+    if (!g_alloc || g_arena.base || block_bytes == 0 || n_blocks == 0) return;
+    block_bytes = (block_bytes + 4095) & ~(size_t)4095;
+    const double t0 = now_s();
+    g_arena.base = (uint8_t*)g_alloc(block_bytes * n_blocks);
+    g_alloc_seconds_x1000.fetch_add((uint64_t)((now_s() - t0) * 1e6));
+    if (!g_arena.base) return; /* (buffers then come from the allocator one by one) */
+    g_alloc_bytes.fetch_add(block_bytes * n_blocks);
+    g_arena.block = block_bytes;
+    g_arena.n = n_blocks;
+    for (size_t i = n_blocks; i-- > 0;) g_arena.free_blocks.push_back(g_arena.base + i * block_bytes);
+}
+static void buf_release(uint8_t* p) {
+    if (g_arena.owns(p)) {
+        lock_guard<mutex> g(g_arena.mu);
+        g_arena.free_blocks.push_back(p);
+    } else if (g_free) {
+        g_free(p);
+    } else {
+        free(p);
+    }
+}
+ByteBuf::~ByteBuf() {
+    if (p_) buf_release(p_);
+}
+void ByteBuf::reserve(size_t c) {
+    if (c <= cap_) return;
+    uint8_t* np = nullptr;
+    size_t nc = 0;
+    if (g_arena.base && c <= g_arena.block) {
+        lock_guard<mutex> g(g_arena.mu);
+        if (!g_arena.free_blocks.empty()) {
+            np = g_arena.free_blocks.back();
+            g_arena.free_blocks.pop_back();
+            nc = g_arena.block;
+        }
+    }
+    if (!np) {
+        nc = cap_ ? cap_ : 4096;
+        while (nc < c) nc += nc / 2 + 4096; /* (page-locked memory is not cheap: grow by halves, not by doubling) */
+        if (g_alloc) {
+            const double t0 = now_s();
+            np = (uint8_t*)g_alloc(nc);
+            g_alloc_seconds_x1000.fetch_add((uint64_t)((now_s() - t0) * 1e6));
+            g_alloc_bytes.fetch_add(nc);
+            if (!np) {
+                cerr << "ERROR: cannot allocate " << nc << " bytes of page-locked host memory" << endl;
+                exit(-1);
+            }
+        } else {
+            np = (uint8_t*)malloc(nc);
+            if (!np) {
+                cerr << "ERROR: out of memory" << endl;
+                exit(-1);
+            }
+        }
+    }
+    if (n_) memcpy(np, p_, n_);
+    if (p_) buf_release(p_);
+    p_ = np;
+    cap_ = nc;
 }
 
 void Batch::clear() {
@@ -342,7 +433,13 @@ static size_t find_eol(const char* p, size_t n) {
     return avx2 ? find_eol_avx2(p, n) : find_eol_sse2(p, n);
 }
 
+/* the reference's words for a gzip stream that ends early / does not decode (src/fastqreader.cpp:92-137) */
+static string gz_error_text(int zerr, const string& path) {
+    return zerr == Z_BUF_ERROR ? string("igzip: unexpected eof") : "igzip: encountered while decompressing file: " + path;
+}
+
 FastqReader::FastqReader(const string& path) {
+    path_ = path;
     size_t cap = 32u << 20;
     bool allow_map = true;
     if (const char* e = getenv("FPLH_READ_WINDOW")) /* test hook: tiny windows exercise the refill paths */
@@ -382,14 +479,24 @@ FastqReader::FastqReader(const string& path) {
     win_ = buf_.data();
 }
 
+FastqReader::FastqReader(const char* data, size_t len, bool at_eof) {
+    mem_ = true;
+    fp_ = this;
+    win_ = data;
+    len_ = len;
+    pulled_ = len;
+    eof_ = at_eof;
+}
+
 FastqReader::~FastqReader() {
+    if (mem_) return;
     if (fd_ >= 0) close(fd_);
     else if (members_) delete members_;
     else if (fp_) gzclose((gzFile)fp_);
 }
 
 bool FastqReader::pull() {
-    if (eof_ || !fp_) return false;
+    if (eof_ || !fp_ || mem_) return false;
     if (pos_ > 0) {
         memmove(buf_.data(), buf_.data() + pos_, len_ - pos_);
         len_ -= pos_;
@@ -414,7 +521,8 @@ bool FastqReader::pull() {
             }
         });
         if (!ok) {
-            eof_ = true; /* (truncated underneath us: stop with what was read so far) */
+            eof_ = true; /* (truncated underneath us: stop with what was read so far, and say so) */
+            io_error_ = "reading " + path_ + " failed (file truncated while it was being read?)";
             return true;
         }
         len_ += want;
@@ -426,6 +534,10 @@ bool FastqReader::pull() {
     if (members_) {
         const size_t n = members_->read(buf_.data() + len_, buf_.size() - len_);
         if (n == 0) eof_ = true;
+        if (members_->error()) {
+            eof_ = true;
+            io_error_ = gz_error_text(members_->error(), path_);
+        }
         len_ += n;
         pulled_ += n;
         return true;
@@ -435,6 +547,9 @@ bool FastqReader::pull() {
         const int n = gzread((gzFile)fp_, buf_.data() + len_, (unsigned)want);
         if (n <= 0) {
             eof_ = true;
+            int errnum = Z_OK;
+            gzerror((gzFile)fp_, &errnum);
+            if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END)) io_error_ = gz_error_text(errnum == Z_OK ? Z_ERRNO : errnum, path_);
             break;
         }
         len_ += (size_t)n;
@@ -646,12 +761,103 @@ void FastqReader::scan_parallel(uint64_t& bases, uint64_t max_bases, uint32_t& r
     }
 }
 
-static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool FastqReader::parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b, bool exact, vector<char>& window,
+                              Batch& out, ChunkInfo& info, int threads) {
+    info = ChunkInfo();
+    if (out.off.empty()) {
+        out.off.push_back(0);
+        out.name_off.push_back(0);
+    }
+    if (a >= file_size) {
+        info.status = 2;
+        return true;
+    }
+    if (b > file_size) b = file_size;
+    const uint64_t w0 = (exact || a == 0) ? a : a - 1; /* (a guessing chunk looks at the byte in front of the cut) */
+    if (threads < 1) threads = 1;
+    for (uint64_t slack = 4u << 20;; slack *= 4) { /* the last record may run past b: read on, more if it has to be */
+        const double t_begin = now_s();
+        const uint64_t w1 = min<uint64_t>(file_size, b + slack);
+        const size_t n = (size_t)(w1 - w0);
+        if (window.size() < n) window.resize(n);
+        {
+            const int T = (int)max<size_t>(1, min<size_t>((size_t)threads, n / (8u << 20)));
+            std::atomic<bool> ok{true};
+            parallel_run(T, [&](int t) {
+                size_t x = n / T * t, e = t == T - 1 ? n : n / T * (t + 1);
+                while (x < e) {
+                    const ssize_t r = pread(fd, window.data() + x, e - x, (off_t)(w0 + x));
+                    if (r <= 0) {
+                        ok = false;
+                        return;
+                    }
+                    x += (size_t)r;
+                }
+            });
+            if (!ok) {
+                info.status = 4;
+                info.err = "reading the input failed (file truncated while it was being read?)";
+                return false;
+            }
+        }
+        const double t_read = now_s();
+        FastqReader m(window.data(), n, w1 >= file_size);
+        m.copy_threads_ = threads;
+        size_t pos = (size_t)(a - w0);
+        if (!exact && a > 0) { /* the first header at or behind the cut that validates (see scan_parallel) */
+            Line ln;
+            if (window[pos - 1] != '\n' && window[pos - 1] != '\r') m.scan_line(pos, ln); /* finish the line we fell into */
+            for (;;) {
+                const size_t cand = m.next_at_line(pos);
+                if (cand >= n) {
+                    pos = n;
+                    break;
+                }
+                size_t t = cand;
+                Line l0, l1, l2, l3;
+                const bool good = m.scan_line(t, l0) == 1 && m.scan_line(t, l1) == 1 && m.scan_line(t, l2) == 1 &&
+                                  m.scan_line(t, l3) == 1 && l2.n > 0 && l2.p[0] == '+' && l1.n == l3.n;
+                if (good || cand >= (size_t)(b - w0)) { /* (beyond the chunk nothing is taken anyway) */
+                    pos = cand;
+                    break;
+                }
+                pos = cand;
+                m.scan_line(pos, ln); /* not a header: move past this line */
+            }
+        }
+        vector<Rec> recs;
+        uint64_t bases = 0;
+        uint32_t reads = 0;
+        string err;
+        const int rc = m.scan_records(pos, (size_t)(b - w0), bases, ~0ull, reads, 0xFFFFFFFFu, recs, err);
+        if (rc == 1) continue; /* the window ends inside a record although the file goes on */
+        if (!recs.empty()) info.first = w0 + (uint64_t)(recs[0].name.p - window.data());
+        const double t_scan = now_s();
+        m.copy_records(out, recs);
+        if (g_timing) {
+            const double t_copy = now_s();
+            g_chunk_us[0].fetch_add((uint64_t)((t_read - t_begin) * 1e6));
+            g_chunk_us[1].fetch_add((uint64_t)((t_scan - t_read) * 1e6));
+            g_chunk_us[2].fetch_add((uint64_t)((t_copy - t_scan) * 1e6));
+        }
+        if (rc == 0) info.next = w0 + pos;
+        else if (rc == 2) info.status = 2;
+        else {
+            info.status = 3;
+            info.err = err;
+        }
+        return true;
+    }
+}
+
 static double g_t_pull = 0, g_t_scan = 0, g_t_copy = 0;
-static const bool g_timing = getenv("FPLH_TIMING") != nullptr;
 struct TimingDump {
     ~TimingDump() {
-        if (g_timing) fprintf(stderr, "reader phases: refill %.3f s, locate %.3f s, copy %.3f s\n", g_t_pull, g_t_scan, g_t_copy);
+        if (!g_timing) return;
+        fprintf(stderr, "reader phases: refill %.3f s, locate %.3f s, copy %.3f s\n", g_t_pull, g_t_scan, g_t_copy);
+        fprintf(stderr, "chunk parsers (summed over threads): read %.3f s, locate %.3f s, copy %.3f s; page-locked allocations %.3f s for %.2f GB\n",
+                g_chunk_us[0].load() * 1e-6, g_chunk_us[1].load() * 1e-6, g_chunk_us[2].load() * 1e-6,
+                g_alloc_seconds_x1000.load() * 1e-6, g_alloc_bytes.load() * 1e-9);
     }
 } g_timing_dump;
 
@@ -708,6 +914,138 @@ uint32_t FastqReader::fill(Batch& b, uint64_t max_bases, uint32_t max_reads) {
     return added;
 }
 
+struct ChunkedReader::Impl {
+    int fd;
+    uint64_t file_size, chunk_bytes, n_chunks;
+    std::function<Item()> acquire;
+    std::function<void(Item)> release;
+    struct Parsed {
+        Item item;
+        FastqReader::ChunkInfo info;
+    };
+    mutex take_mu, parsed_mu;
+    condition_variable parsed_cv;
+    map<uint64_t, Parsed> parsed;
+    uint64_t next_chunk = 0, seq_chunk = 0, expected = 0;
+    bool stop = false, done = false;
+    vector<std::thread> threads;
+    vector<double> busy;
+    vector<char> window; /* of the calling thread, for chunks that are parsed again */
+};
+
+ChunkedReader::ChunkedReader(int fd, uint64_t file_size, uint64_t chunk_bytes, int threads, std::function<Item()> acquire,
+                             std::function<void(Item)> release) {
+    d_ = new Impl;
+    d_->fd = fd;
+    d_->file_size = file_size;
+    d_->chunk_bytes = chunk_bytes ? chunk_bytes : 1;
+    d_->n_chunks = (file_size + d_->chunk_bytes - 1) / d_->chunk_bytes;
+    d_->acquire = acquire;
+    d_->release = release;
+    if (threads < 1) threads = 1;
+    d_->busy.assign(threads, 0.0);
+    for (int t = 0; t < threads; t++)
+        d_->threads.emplace_back([this, t]() {
+            Impl& D = *d_;
+            vector<char> window;
+            for (;;) {
+                /* a batch first, then the chunk number: chunk numbers are only ever handed to threads that already
+                   hold a batch, so the lowest chunk not yet parsed never waits behind later chunks for one (the
+                   batches of the chunks in front of it are on their way through the caller's pipeline and come back) */
+                Impl::Parsed ps;
+                uint64_t k;
+                {
+                    lock_guard<mutex> g(D.take_mu);
+                    if (D.stop || D.next_chunk >= D.n_chunks) break;
+                }
+                ps.item = D.acquire(); /* may block; not under the lock */
+                if (!ps.item.batch) break;
+                {
+                    lock_guard<mutex> g(D.take_mu);
+                    if (D.stop || D.next_chunk >= D.n_chunks) {
+                        D.release(ps.item);
+                        break;
+                    }
+                    k = D.next_chunk++;
+                }
+                ps.item.batch->clear();
+                const auto t0 = std::chrono::steady_clock::now();
+                FastqReader::parse_chunk(D.fd, D.file_size, k * D.chunk_bytes, (k + 1) * D.chunk_bytes, false, window,
+                                         *ps.item.batch, ps.info, 1);
+                D.busy[t] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                {
+                    lock_guard<mutex> g(D.parsed_mu);
+                    D.parsed[k] = std::move(ps);
+                }
+                D.parsed_cv.notify_all();
+            }
+        });
+}
+
+ChunkedReader::~ChunkedReader() {
+    {
+        lock_guard<mutex> g(d_->take_mu);
+        d_->stop = true;
+    }
+    for (auto& t : d_->threads) t.join();
+    for (auto& kv : d_->parsed) d_->release(kv.second.item);
+    delete d_;
+}
+
+double ChunkedReader::busiest_parser_seconds() const {
+    double m = 0;
+    for (double x : d_->busy) m = max(m, x);
+    return m;
+}
+
+bool ChunkedReader::next(Item& out) {
+    Impl& D = *d_;
+    while (!D.done && D.seq_chunk < D.n_chunks) {
+        const uint64_t k = D.seq_chunk++;
+        Impl::Parsed ps;
+        {
+            unique_lock<mutex> g(D.parsed_mu);
+            D.parsed_cv.wait(g, [&] { return D.parsed.count(k) > 0; });
+            ps = std::move(D.parsed[k]);
+            D.parsed.erase(k);
+        }
+        const uint64_t a = k * D.chunk_bytes, b = (k + 1) * D.chunk_bytes;
+        const bool has = ps.info.first != FastqReader::ChunkInfo::NONE;
+        /* the chunk's first record must be the one its predecessor announced */
+        const bool ok = k == 0 || (has ? ps.info.first == D.expected : (ps.info.status == 0 && ps.info.next == D.expected));
+        if (!ok) { /* the guess was wrong (or there was nothing to find): parse again from the known start */
+            const double t0 = now_s();
+            ps.item.batch->clear();
+            if (D.expected >= b) { /* the record in front runs across this whole chunk */
+                ps.info = FastqReader::ChunkInfo();
+                ps.info.next = D.expected;
+                ps.item.batch->off.push_back(0);
+                ps.item.batch->name_off.push_back(0);
+            } else {
+                const int hw = (int)std::thread::hardware_concurrency();
+                FastqReader::parse_chunk(D.fd, D.file_size, max(a, D.expected), b, true, D.window, *ps.item.batch, ps.info,
+                                         max(1, min(8, hw / 2)));
+            }
+            t_redo_ += now_s() - t0;
+            n_redo_++;
+        }
+        D.expected = ps.info.next;
+        if (ps.info.status == 3) malformed_ = ps.info.err;
+        if (ps.info.status == 4) io_error_ = ps.info.err;
+        if (ps.info.status != 0) { /* end of input, or a malformed record / a read error ends it */
+            D.done = true;
+            lock_guard<mutex> g(D.take_mu);
+            D.stop = true;
+        }
+        if (ps.item.batch->n() > 0) {
+            out = ps.item;
+            return true;
+        }
+        D.release(ps.item);
+    }
+    return false;
+}
+
 void format_batch(const Batch& b, const fpl_read_result* res, string& out, string* failed) {
     format_range(b, res, 0, b.n(), out, failed);
 }
@@ -723,8 +1061,14 @@ void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threa
                            vector<string>* faileds, const FragmentList* fl) {
     const uint32_t n = b.n();
     if (threads < 1) threads = 1;
-    outs.assign(threads, string());
-    if (faileds) faileds->assign(threads, string());
+    /* the pieces keep their capacity from batch to batch (the Work objects are recycled): fresh multi-megabyte strings
+       would be mapped, faulted in page by page and unmapped again for every batch */
+    outs.resize(threads);
+    for (auto& o : outs) o.clear();
+    if (faileds) {
+        faileds->resize(threads);
+        for (auto& o : *faileds) o.clear();
+    }
     /* slices of about equal numbers of bases */
     vector<uint32_t> cut(threads + 1, n);
     cut[0] = 0;
@@ -734,7 +1078,8 @@ void format_batch_parallel(const Batch& b, const fpl_read_result* res, int threa
         cut[t] = (uint32_t)(std::lower_bound(b.off.begin(), b.off.begin() + n, want) - b.off.begin());
     }
     parallel_run(threads, [&](int t) {
-        outs[t].reserve((size_t)((b.off[cut[t + 1]] - b.off[cut[t]]) * 2 + (uint64_t)(cut[t + 1] - cut[t]) * 128 + 64));
+        const size_t want = (size_t)((b.off[cut[t + 1]] - b.off[cut[t]]) * 2 + (uint64_t)(cut[t + 1] - cut[t]) * 128 + 64);
+        if (outs[t].capacity() < want) outs[t].reserve(want + want / 4);
         format_range(b, res, cut[t], cut[t + 1], outs[t], faileds ? &(*faileds)[t] : nullptr, fl);
     });
 }
@@ -866,6 +1211,112 @@ void* fplh_batch_read_all(const char* path, uint64_t max_bases, uint32_t max_rea
         for (uint32_t i = 0; i < t.n(); i++) all->off.push_back(o + t.off[i + 1]);
     }
     return all;
+}
+void* fplh_batch_read_chunked(const char* path, uint64_t chunk_bytes, int threads, uint64_t* chunks_parsed_again) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        return nullptr;
+    }
+    fplh::Batch* all = new fplh::Batch();
+    all->off.push_back(0);
+    all->name_off.push_back(0);
+    {
+        /* a small pool of batches, as the CLI's Work objects are */
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<fplh::Batch*> pool;
+        for (int i = 0; i < threads + 2; i++) pool.push_back(new fplh::Batch());
+        std::vector<fplh::Batch*> owned = pool;
+        auto acquire = [&]() {
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return !pool.empty(); });
+            fplh::ChunkedReader::Item it;
+            it.batch = pool.back();
+            pool.pop_back();
+            return it;
+        };
+        auto release = [&](fplh::ChunkedReader::Item it) {
+            {
+                std::lock_guard<std::mutex> g(mu);
+                pool.push_back(it.batch);
+            }
+            cv.notify_all();
+        };
+        {
+            fplh::ChunkedReader cr(fd, (uint64_t)st.st_size, chunk_bytes, threads, acquire, release);
+            fplh::ChunkedReader::Item it;
+            while (cr.next(it)) {
+                const fplh::Batch& t = *it.batch;
+                const size_t o = all->seq.size();
+                all->seq.resize_uninit(o + t.seq.size());
+                all->qual.resize_uninit(o + t.seq.size());
+                memcpy(all->seq.data() + o, t.seq.data(), t.seq.size());
+                memcpy(all->qual.data() + o, t.qual.data(), t.seq.size());
+                const size_t to = all->text.size();
+                all->text.insert(all->text.end(), t.text.begin(), t.text.end());
+                for (uint32_t i = 0; i < t.n(); i++) {
+                    all->off.push_back(o + t.off[i + 1]);
+                    all->name_off.push_back(to + t.name_off[i + 1]);
+                    all->name_len.push_back(t.name_len[i]);
+                    all->strand_len.push_back(t.strand_len[i]);
+                }
+                release(it);
+            }
+            if (chunks_parsed_again) *chunks_parsed_again = cr.chunks_parsed_again();
+        }
+        for (fplh::Batch* b : owned) delete b;
+    }
+    close(fd);
+    return all;
+}
+/* bench / test helper: a CSR batch as a FASTQ file ("@<prefix><i>" names, "+" strand lines); the text is composed on
+   `threads` threads, slice by slice, and written in order.  0 on success. */
+int fplh_write_fastq(const char* path, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n,
+                     const char* prefix, int threads) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    if (threads < 1) threads = 1;
+    const std::string pre = prefix ? prefix : "r";
+    const uint32_t per_round = 65536u * (uint32_t)threads; /* bounds the text held in memory */
+    int rc = 0;
+    for (uint32_t r0 = 0; r0 < n && rc == 0; r0 += per_round) {
+        const uint32_t r1 = (uint32_t)std::min<uint64_t>(n, (uint64_t)r0 + per_round);
+        std::vector<std::string> parts((size_t)threads);
+        fplh::parallel_run(threads, [&](int t) {
+            const uint32_t a = r0 + (uint32_t)((uint64_t)(r1 - r0) * t / threads), b = r0 + (uint32_t)((uint64_t)(r1 - r0) * (t + 1) / threads);
+            std::string& s = parts[t];
+            s.reserve((size_t)(2 * (off[b] - off[a]) + (uint64_t)(b - a) * (pre.size() + 20)));
+            for (uint32_t i = a; i < b; i++) {
+                s += '@';
+                s += pre;
+                s += std::to_string(i);
+                s += '\n';
+                s.append((const char*)seq + off[i], (size_t)(off[i + 1] - off[i]));
+                s += "\n+\n";
+                s.append((const char*)qual + off[i], (size_t)(off[i + 1] - off[i]));
+                s += '\n';
+            }
+        });
+        for (auto& s : parts)
+            if (!s.empty() && fwrite(s.data(), 1, s.size(), f) != s.size()) rc = -2;
+    }
+    if (fclose(f) != 0) rc = -2;
+    return rc;
+}
+/* test hook: read the whole file; 1 (and the message) when the input could not be read / decompressed to its end */
+int fplh_read_error(const char* path, char* msg, int msg_len) {
+    fplh::FastqReader rd(path);
+    if (!rd.ok()) return -1;
+    for (;;) {
+        fplh::Batch t;
+        if (rd.fill(t, 64u << 20, 0x3FFFFFFFu) == 0) break;
+    }
+    if (!rd.input_error()) return 0;
+    if (msg && msg_len > 0) snprintf(msg, (size_t)msg_len, "%s", rd.input_error_text().c_str());
+    return 1;
 }
 uint64_t fplh_parallel_records(void) { return fplh::g_parallel_records.exchange(0); }
 uint64_t fplh_gz_members(void) { return fplh::GzMembers::delivered.exchange(0); }

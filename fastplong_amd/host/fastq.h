@@ -27,13 +27,22 @@ namespace fplh {
 void parallel_run(int tasks, const std::function<void(int)>& fn);
 
 /* growable byte array without the zero fill of std::vector::resize (batches are hundreds of megabytes and
- * every byte is overwritten by the parser's copy threads) */
+ * every byte is overwritten by the parser's copy threads).  The memory comes from a process-wide allocator pair the
+ * host may replace ONCE, before the first batch exists: the CLI installs fpl_host_alloc / fpl_host_free, so that the
+ * CSR arrays are page-locked and the GPU's DMA engines read them in place (no staging copy). */
 class ByteBuf {
    public:
+    typedef void* (*AllocFn)(size_t);
+    typedef void (*FreeFn)(void*);
+    static void set_allocator(AllocFn a, FreeFn f);
+    /* ... and carve the usual buffers out of ONE allocation of n_blocks x block_bytes made right away (page-locking
+       memory is slow and does not scale over threads: 24 parser threads allocating their first batches spent 13 s in
+       it for 5 GB); a buffer that needs more than a block, or finds none free, falls back to the allocator */
+    static void set_arena(size_t block_bytes, size_t n_blocks);
     ByteBuf() = default;
     ByteBuf(const ByteBuf&) = delete;
     ByteBuf& operator=(const ByteBuf&) = delete;
-    ~ByteBuf() { free(p_); }
+    ~ByteBuf();
     uint8_t* data() { return p_; }
     const uint8_t* data() const { return p_; }
     size_t size() const { return n_; }
@@ -41,13 +50,7 @@ class ByteBuf {
     void clear() { n_ = 0; }
     const uint8_t* begin() const { return p_; }
     const uint8_t* end() const { return p_ + n_; }
-    void reserve(size_t c) {
-        if (c <= cap_) return;
-        size_t nc = cap_ ? cap_ : 4096;
-        while (nc < c) nc *= 2;
-        p_ = (uint8_t*)realloc(p_, nc);
-        cap_ = nc;
-    }
+    void reserve(size_t c);
     void resize_uninit(size_t n) {
         reserve(n);
         n_ = n;
@@ -77,12 +80,37 @@ class GzMembers;
 class FastqReader {
    public:
     explicit FastqReader(const std::string& path);
+    /* the same reader over bytes already in memory (parse_chunk): no refill; at_eof = the bytes end the input */
+    FastqReader(const char* data, size_t len, bool at_eof);
     ~FastqReader();
+
+    /* Chunk-parallel reading of a regular, uncompressed file: the file is cut at fixed byte offsets and a record
+     * belongs to the chunk its '@' falls into, so any number of threads can parse different chunks at the same
+     * time.  A chunk that does not start the file has to GUESS where its first record begins (the first '@' line at
+     * or behind the cut whose third line starts with '+' and whose second and fourth lines are equally long); the
+     * caller checks every guess against what the chunk in front of it reports as the next record (ChunkInfo::next)
+     * and parses the chunk again with exact = true when they differ, so the records are always those the
+     * sequential reader finds.  Reads [a, b) of the file behind fd (plus the tail of the last record) into
+     * `window`, appends the records to `out`. */
+    struct ChunkInfo {
+        static constexpr uint64_t NONE = ~0ull;
+        uint64_t first = NONE; /* file offset of the first record taken, NONE when the chunk holds none */
+        uint64_t next = NONE;  /* file offset at which the next record starts: the first '@' line behind the last
+                                  record taken that lies at or behind b (NONE after the end of input / a bad record) */
+        int status = 0;        /* 0 = more input follows, 2 = end of input reached, 3 = malformed record, 4 = read error (message in err) */
+        std::string err;
+    };
+    static bool parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b, bool exact, std::vector<char>& window,
+                            Batch& out, ChunkInfo& info, int threads);
     bool ok() const { return fp_ != nullptr; }
     /* append records until the batch holds >= max_bases bases or max_reads reads; returns the
      * number of records appended (0 at end of input) */
     uint32_t fill(Batch& b, uint64_t max_bases, uint32_t max_reads);
     bool malformed() const { return malformed_; }
+    /* decompression / read errors end the input like the end of the file does, but are remembered: the reference
+       aborts there (error_exit in src/fastqreader.cpp:92-137), so the caller must not report success */
+    bool input_error() const { return !io_error_.empty(); }
+    const std::string& input_error_text() const { return io_error_; }
     /* offset, in the (uncompressed) input, of the byte behind the last record handed out */
     uint64_t consumed() const { return pulled_ - (len_ - pos_); }
 
@@ -119,6 +147,39 @@ class FastqReader {
     int copy_threads_ = 1;
     size_t parse_min_ = 8u << 20; /* smallest piece worth a scanning thread (FPLH_PARSE_MIN: test hook) */
     bool eof_ = false, malformed_ = false;
+    bool mem_ = false; /* memory mode: the window is the caller's */
+    std::string io_error_, path_;
+};
+
+/* The chunk-parallel reader built on FastqReader::parse_chunk: `threads` parser threads take chunks of
+ * `chunk_bytes` in file order, each into a Batch it obtains from `acquire` (blocking; the caller's pool bounds how far
+ * the parsers run ahead); next() hands the non-empty batches back in input order after checking every chunk's guessed
+ * start against its predecessor (a chunk whose guess was wrong is parsed again from the known offset, on the calling
+ * thread), and returns the batches it does not pass on through `release`.  The records are exactly those the
+ * sequential FastqReader finds (tests/test_host_io.py::test_chunked_reader_equals_sequential). */
+class ChunkedReader {
+   public:
+    struct Item {
+        Batch* batch = nullptr;
+        void* token = nullptr; /* the caller's handle for the batch (e.g. the Work object it lives in) */
+    };
+    ChunkedReader(int fd, uint64_t file_size, uint64_t chunk_bytes, int threads, std::function<Item()> acquire,
+                  std::function<void(Item)> release);
+    ~ChunkedReader();
+    /* the next batch in input order; false at the end of the input (or behind a malformed record / read error) */
+    bool next(Item& out);
+    const std::string& malformed_text() const { return malformed_; } /* "" or the reference's message for a bad record */
+    const std::string& io_error_text() const { return io_error_; }
+    uint64_t chunks_parsed_again() const { return n_redo_; }
+    double redo_seconds() const { return t_redo_; }
+    double busiest_parser_seconds() const;
+
+   private:
+    struct Impl;
+    Impl* d_;
+    std::string malformed_, io_error_;
+    uint64_t n_redo_ = 0;
+    double t_redo_ = 0;
 };
 
 /* --break / --mask: the outcome list of a batch (fpl_get_fragments: sorted by read, then seq_no) and where
@@ -148,6 +209,11 @@ extern "C" {
 /* test hooks: parse a FASTQ file into CSR arrays; format a batch from result records */
 void* fplh_batch_read(const char* path, uint64_t max_bases, uint32_t max_reads);
 void* fplh_batch_read_all(const char* path, uint64_t max_bases, uint32_t max_reads);
+/* test hook: the whole (regular, uncompressed) file through the chunk-parallel reader, concatenated */
+void* fplh_batch_read_chunked(const char* path, uint64_t chunk_bytes, int threads, uint64_t* chunks_parsed_again);
+int fplh_read_error(const char* path, char* msg, int msg_len);
+int fplh_write_fastq(const char* path, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n,
+                     const char* prefix, int threads);
 uint64_t fplh_parallel_records(void); /* records the multi-threaded scan contributed since the last call */
 uint64_t fplh_gz_members(void);       /* gzip members inflated on the worker pool since the last call */
 uint32_t fplh_batch_n(void* b);

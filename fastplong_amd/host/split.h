@@ -1,0 +1,81 @@
+/*
+ * split.h -- gzip members for the output files and the --split / --split_by_lines writer
+ * (reference src/threadconfig.cpp:72-120, src/seprocessor.cpp:297-316), shared by the CLI and the host tests.
+ */
+#ifndef FPLH_SPLIT_H
+#define FPLH_SPLIT_H
+
+#include <stdio.h>
+
+#include <map>
+#include <ostream>
+#include <string>
+#include <vector>
+
+namespace fplh {
+
+/* one complete gzip member holding `in` (any gzip reader takes a concatenation of members as one stream) */
+void gzip_into(const std::string& in, int level, std::string& out);
+std::string gzip_member(const std::string& in, int level);
+
+/* --split / --split_by_lines.  Each of the reference's workers owns a writer and walks through the file numbers
+ * t, t + T, t + 2T, ... as its current file fills up (ThreadConfig::initWriterForSplit / markProcessed /
+ * writeEmptyFilesForSplitting, src/threadconfig.cpp:72-120); packs of PACK_SIZE = 16 reads reach the workers
+ * round-robin (src/seprocessor.cpp:343-378), so which file a read lands in is a function of its input index.  The
+ * one writer thread of this host replays that, pack by pack: write(t, text) is the worker's
+ * getWriter1()->writeString(outstr), mark(t, n) its markProcessed(n), close() the ThreadConfig destructors.
+ * Pinned against the real ThreadConfig / Writer objects of the reference (tests/test_host_split.py).
+ *
+ * What the pin leaves open is timing, not logic: with --split, a worker whose files are used up while
+ * number % threads != 0 and id >= number % threads gets mCanBeStopped (src/threadconfig.cpp:103-107) and leaves
+ * its loop the next time it finds its input queue EMPTY (src/seprocessor.cpp:432-441) -- packs that reach it later are
+ * never processed, so how many reads the reference loses there depends on how far its reader thread is ahead.  This
+ * writer reproduces the reference run in which the reader stays ahead (the worker never sees an empty queue before
+ * the input ends): nothing is lost and the worker's last file takes the rest, exactly what the real objects do when
+ * every pack is handed to them (the S_* commands of the test harness). */
+class SplitOutput {
+   public:
+    SplitOutput(const std::string& out, int digits, int workers, bool by_lines, int number, long size, int gz_level);
+    void write(int t, const std::string& text);
+    void mark(int t, long reads);
+    void close();
+    std::vector<std::string> names;
+
+   private:
+    struct Worker {
+        int working = 0;
+        long current = 0;
+        FILE* f = nullptr;
+        bool gz = false, wrote = false;
+        std::string pending;
+    };
+    void flush(Worker& w);
+    void shut(Worker& w);
+    void open(Worker& w);
+    std::string out_;
+    int digits_, T_;
+    bool by_lines_;
+    int number_;
+    long size_;
+    int level_;
+    std::vector<Worker> w_;
+};
+
+/* --adapter_fasta: FastaReader + Options::loadFastaAdapters (src/fastareader.cpp:5-101, src/options.cpp:39-66).
+ * load_fasta_contigs restates the reader byte for byte (pinned against the real FastaReader, tests/test_host_split.py);
+ * load_fasta_adapters keeps the sequences of >= 6 characters in header order -- the order trimByMultiSequences visits
+ * them in -- and reports the skipped ones on `log` like the reference.  false + err when the file cannot be read. */
+bool load_fasta_contigs(const std::string& path, std::map<std::string, std::string>& contigs, std::string& err);
+bool load_fasta_adapters(const std::string& path, std::vector<std::string>& adapters, std::ostream* log, std::string& err);
+
+}  // namespace fplh
+
+extern "C" {
+/* test hook: "header\tsequence\n" for every contig in map order; malloc'ed, free with fplh_free */
+int fplh_load_fasta(const char* path, char** out, unsigned long long* out_len);
+/* test hook: replay n_packs packs (worker, reads, passing reads, text) through a SplitOutput; returns the number of
+   files it opened */
+int fplh_split_replay(const char* out, int digits, int workers, int by_lines, int number, long size, int gz_level,
+                      unsigned n_packs, const int* worker, const long* reads, const long* passed, const char* const* texts);
+}
+#endif

@@ -277,3 +277,67 @@ def device_batch(n_reads, seed=1, median_len=8000, sigma_len=0.5, min_len=50, ma
             scatter(ri, pos, mat, vlen, var)
     off_t = torch.from_numpy(off).to(device)
     return seq, qual, off_t, int(lens.max())
+
+
+def device_batch_hifi(n_reads, seed=5, mean_len=20000, sd_len=2000, n_adapters=64, mu=35.0, sigma=6.0, device="cuda",
+                      chunk=1 << 27, n_variants=256, err=0.10):
+    """Config 5 style batch built in HBM: N(20 kb, 2 kb) lengths, iid ACGT (+0.1 % N), quality
+    clamp(round(N(35, 6)), 2, 50) + 33, and a FASTA of `n_adapters` random 30-45-mers (names ad00..): 30 % of the
+    reads carry one adapter (10 % errors) at an end, 1 % in the middle (decorations overwrite bases).
+    Returns (seq, qual, off int64, max_len, adapters) -- adapters in the order trimByMultiSequences visits them
+    (sorted by FASTA header = index order)."""
+    import torch
+
+    rng = np.random.default_rng(seed)
+    ads = ["".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(30, 46)))) for _ in range(n_adapters)]
+    lens = np.maximum(300, np.rint(rng.normal(mean_len, sd_len, n_reads))).astype(np.int64)
+    off = np.zeros(n_reads + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    total = int(off[-1])
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    seq = torch.empty(total, dtype=torch.uint8, device=device)
+    qual = torch.empty(total, dtype=torch.uint8, device=device)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    for a in range(0, total, chunk):
+        b = min(total, a + chunk)
+        idx = torch.randint(0, 4, (b - a,), generator=g, device=device, dtype=torch.int64)
+        s_ = lut[idx]
+        del idx
+        s_[torch.rand(b - a, generator=g, device=device) < 0.001] = ord("N")
+        seq[a:b] = s_
+        del s_
+        q = torch.randn(b - a, generator=g, device=device) * sigma + mu
+        qual[a:b] = (q.round_().clamp_(2, 50) + 33).to(torch.uint8)
+        del q
+    # one pool of noisy copies per adapter, flattened: variant id = adapter * n_variants + copy
+    per = max(1, n_variants // max(1, n_adapters // 8))
+    mats, vlens = [], []
+    for a in ads:
+        m, vl = _variant_pool(rng, np.frombuffer(a.encode(), np.uint8), err, per)
+        mats.append(m)
+        vlens.append(vl)
+    width = max(m.shape[1] for m in mats)
+    mat = np.zeros((n_adapters * per, width), np.uint8)
+    for i, m in enumerate(mats):
+        mat[i * per:(i + 1) * per, :m.shape[1]] = m
+    vlen = np.concatenate(vlens)
+    u = rng.random(n_reads)
+    which = rng.integers(0, n_adapters, n_reads) * per + rng.integers(0, per, n_reads)
+    side = rng.random(n_reads) < 0.5
+    pos = np.zeros(n_reads, np.int64)
+    at_end = (u < 0.30) & ~side
+    pos[at_end] = lens[at_end] - vlen[which[at_end]]
+    mid = (u >= 0.30) & (u < 0.31)
+    pos[mid] = 100 + (rng.random(int(mid.sum())) * (lens[mid] - 250)).astype(np.int64)
+    ri = np.nonzero(u < 0.31)[0]
+    if len(ri):
+        base = torch.from_numpy(off[ri] + pos[ri]).to(device)
+        var = torch.from_numpy(which[ri]).to(device)
+        m = torch.from_numpy(mat).to(device)
+        vl = torch.from_numpy(vlen).to(device)
+        j = torch.arange(m.shape[1], device=device)
+        flat = base[:, None] + j[None, :]
+        mask = j[None, :] < vl[var][:, None]
+        seq[flat[mask]] = m[var][mask]
+    return seq, qual, torch.from_numpy(off).to(device), int(lens.max()), ads

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 2
+#define FPL_ABI_VERSION 3
 
 /* limits */
 #define FPL_MAX_ADAPTER_LEN 255 /* longest adapter the device path accepts            */
@@ -273,6 +273,32 @@ int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, con
                       uint32_t n_reads, fpl_read_result* results);
 
 /*
+ * The same without the wait: the pipelined form a host thread uses to keep the PCIe link and the
+ * kernels busy together (what the reference gets from its producer/consumer queues,
+ * src/seprocessor.cpp:331-485).  fpl_process_batch_async() enqueues H2D copies on a copy stream,
+ * the kernels on the context's compute stream behind them, the D2H of the records on a third
+ * stream, and returns; fpl_wait() blocks until the OLDEST batch in flight is complete and its
+ * records are in the `results` array given at submission.  Up to FPL_MAX_IN_FLIGHT batches may be
+ * in flight per context (the device staging is double-buffered): the copies of batch k+1 overlap
+ * the kernels of batch k.  seq / qual / off must stay valid until the batch has been waited for;
+ * they should come from fpl_host_alloc() (pinned) -- pageable memory works but the runtime then
+ * stages the copy on the calling thread.  With break_enabled / mask_enabled, a submission first
+ * drains the batch in flight (its fragment list lives in buffers the next batch reuses), and
+ * fpl_get_fragments() refers to the batch most recently waited for.
+ * Errors of the asynchronous part are reported by fpl_wait().
+ */
+#define FPL_MAX_IN_FLIGHT 2
+int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint64_t* off,
+                            uint32_t n_reads, fpl_read_result* results);
+int fpl_wait(fpl_ctx* ctx);
+int fpl_in_flight(const fpl_ctx* ctx);
+
+/* Page-locked host memory for the arrays handed to fpl_process_batch[_async] (hipHostMalloc): the
+ * DMA engines read it directly.  NULL when the allocation fails. */
+void* fpl_host_alloc(size_t bytes);
+void fpl_host_free(void* p);
+
+/*
  * Fragment list of the LAST batch (contexts created with break_enabled or mask_enabled; otherwise the counts
  * are zero).  fpl_get_fragments synchronizes, copies the records to the host and sorts them by (read, seq_no).
  */
@@ -290,6 +316,16 @@ int fpl_reserve_cycles(fpl_ctx* ctx, uint32_t max_cycles);
    multi-GPU host all-reduces (sum) this buffer in place over RCCL. */
 void* fpl_counters_device_ptr(fpl_ctx* ctx);
 int fpl_get_counters(fpl_ctx* ctx, int64_t* host_buf, size_t n);
+/*
+ * The merge that follows the join in the reference (Stats::merge src/stats.cpp:1013-1082,
+ * FilterResult::merge src/filterresult.cpp:28-61), for the contexts of ONE process (one per device):
+ * agrees on the per-cycle capacity (max over the contexts, fpl_reserve_cycles), then sums the counter
+ * buffers in place with one grouped RCCL all-reduce (int64, sum) over xGMI, so that afterwards every
+ * context holds the totals.  n == 1 only reserves.  librccl is loaded on first use (dlopen), so hosts
+ * that never call this do not need it.  Hosts that run one PROCESS per device all-reduce
+ * fpl_counters_device_ptr() themselves (bench.py does, through torch.distributed) after agreeing on C.
+ */
+int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n);
 int fpl_reset_counters(fpl_ctx* ctx);
 int fpl_synchronize(fpl_ctx* ctx);
 

@@ -5,7 +5,7 @@
  * /root/reference/src by oracle/Makefile into oracle/_ref/).  It contains no algorithm of its
  * own: every answer it prints comes out of reference code.  Linked reference files:
  * editdistance, filter, polyx, stats, filterresult, read, options, fastareader, jsonreporter,
- * htmlreporter.  NOT linked (they include Google Highway / ISA-L headers the image lacks):
+ * htmlreporter, writer, threadconfig (+ the system's libdeflate.so.0, which Writer calls for .gz names).  NOT linked (they include Google Highway / ISA-L headers the image lacks):
  * adaptertrimmer, sequence, fastqreader, seprocessor, evaluator, main.
  *
  * Protocol (stdin, one command per line, fields separated by one space, strings carry a
@@ -25,16 +25,27 @@
  *               | J_PXT base len | J_END =path   -> Stats/FilterResult/JsonReporter::report
  *               | J_ENDH lf maxlen =json =html =title words...  -> the same plus calcLengthHistogram and
  *                 HtmlReporter::report (lf / maxlen = Options::lengthFilter.enabled / .maxLength)
+ *   FA =path                                    -> FastaReader::readAll: the contig count, then "=hex(header) =hex(sequence)"
+ *                                                  per contig in map order
+ *   --split / --split_by_lines block (real ThreadConfig + Writer objects, one per worker, as
+ *   SingleEndProcessor::initConfig / processSingleEnd / ~ThreadConfig drive them, src/seprocessor.cpp:54-63,297-316):
+ *               S_BEGIN threads bylines number size digits compression =out -> ThreadConfig(opt, t) x threads,
+ *                       initWriterForSplit() each
+ *               S_PACK worker n =text -> getWriter1()->writeString(text) (when --out is set), markProcessed(n);
+ *                       prints canBeStopped() afterwards
+ *               S_END   -> the ThreadConfig destructors (writeEmptyFilesForSplitting, writers flushed and closed)
  */
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
 
 #include "editdistance.h"
+#include "fastareader.h"
 #include "filter.h"
 #include "filterresult.h"
 #include "htmlreporter.h"
@@ -43,6 +54,7 @@
 #include "polyx.h"
 #include "read.h"
 #include "stats.h"
+#include "threadconfig.h"
 
 using namespace std;
 
@@ -60,6 +72,15 @@ static vector<string> split(const string& s) {
         i = j + 1;
     }
     return out;
+}
+static string hex_of(const string& s) { /* (headers and sequences may hold any byte) */
+    static const char* d = "0123456789abcdef";
+    string o;
+    for (unsigned char c : s) {
+        o += d[c >> 4];
+        o += d[c & 15];
+    }
+    return o;
 }
 static string str(const string& tok) { return tok.empty() ? string() : tok.substr(1); }
 
@@ -85,6 +106,8 @@ int main() {
     string line;
     JsonJob job;
     long cur_thread = 0;
+    Options split_opt;
+    vector<ThreadConfig*> split_cfg;
     while (getline(cin, line)) {
         if (line.empty()) continue;
         vector<string> t = split(line);
@@ -192,6 +215,42 @@ int main() {
             string s;
             r.appendToStringWithTag(&s, FAILED_TYPES[atoi(t[1].c_str())]);
             cout << s.size() << "\n" << s;
+        } else if (op == "FA") { /* FastaReader::readAll, src/fastareader.cpp:91-101 */
+            FastaReader reader(str(t[1]));
+            reader.readAll();
+            map<string, string> contigs = reader.contigs();
+            cout << contigs.size() << "\n";
+            for (auto& kv : contigs) cout << "=" << hex_of(kv.first) << " =" << hex_of(kv.second) << "\n";
+        } else if (op == "S_BEGIN") {
+            for (auto c : split_cfg) delete c;
+            split_cfg.clear();
+            split_opt = Options();
+            split_opt.seqLen = 1000; /* (Options() leaves it unset; main.cpp evaluates it before any Stats exists) */
+            split_opt.thread = atoi(t[1].c_str());
+            split_opt.split.enabled = true;
+            split_opt.split.byFileLines = atoi(t[2].c_str()) != 0;
+            split_opt.split.byFileNumber = !split_opt.split.byFileLines;
+            split_opt.split.number = atoi(t[3].c_str());
+            split_opt.split.size = atol(t[4].c_str());
+            split_opt.split.digits = atoi(t[5].c_str());
+            split_opt.compression = atoi(t[6].c_str());
+            split_opt.out = str(t[7]);
+            for (int w = 0; w < split_opt.thread; w++) { /* SingleEndProcessor::initConfig, src/seprocessor.cpp:54-63 */
+                ThreadConfig* c = new ThreadConfig(&split_opt, w, false);
+                c->initWriterForSplit();
+                split_cfg.push_back(c);
+            }
+            cout << "ok\n";
+        } else if (op == "S_PACK") {
+            ThreadConfig* c = split_cfg.at(atoi(t[1].c_str()));
+            const string text = str(t[3]);
+            if (!split_opt.out.empty()) c->getWriter1()->writeString(text); /* src/seprocessor.cpp:297-301 */
+            c->markProcessed(atol(t[2].c_str()));                           /* :313-316 */
+            cout << (c->canBeStopped() ? 1 : 0) << "\n";
+        } else if (op == "S_END") {
+            for (auto c : split_cfg) delete c;
+            split_cfg.clear();
+            cout << "ok\n";
         } else if (op == "J_BEGIN") {
             job.clear();
             job.threads = atoi(t[1].c_str());

@@ -82,7 +82,8 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.C = C;
     a.work_ctr = work_ctr;
     a.n_cu = n_cu ? n_cu : 2;
-    const size_t slabs = stats_scratch_slabs(n_reads, n_bytes, max_len, a.n_cu);
+    a.tune = stats_tune_from_env(); /* (the tests set the hooks per case) */
+    const size_t slabs = stats_scratch_slabs(n_reads, n_bytes, max_len, a.n_cu, a.tune);
     std::vector<u64> scratch(slabs * (size_t)FS_SLAB + 1);
     std::vector<u8> sflags(slabs + slabs / 8 + 4096);
     a.stats_scratch = scratch.data();

@@ -91,7 +91,9 @@ def test_oracle_reproduces_golden(orc, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("batch_reads", ["0", "37"])  # 37 reads per batch: several batches, counters accumulate
+# 37 reads per batch: several batches, counters accumulate (sequential reader); "chunks": the chunk-parallel reader with
+# chunks of 30 kB -- every cut falls inside some record -- and batches two deep in the copy / kernel stage
+@pytest.mark.parametrize("batch_reads", ["0", "37", "chunks"])
 def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     build.build_all()
     meta = json.load(open(os.path.join(GOLD, case, "case.json")))
@@ -99,10 +101,16 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
     flags = [f if f != "ADAPTERS.fa" else os.path.join(GOLD, case, "ADAPTERS.fa") for f in meta["flags"]]
     cmd = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "--failed_out", str(tmp_path / "failed.fq"),
-           "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"), "--batch_reads", batch_reads] + flags
-    if batch_reads != "0":
-        cmd += ["--reads_to_process", str(meta["reads"])]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+           "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html")] + flags
+    env = dict(os.environ)
+    if batch_reads == "chunks":
+        cmd += ["--reader_threads", "3", "-V"]
+        env["FPLH_CHUNK_BYTES"] = "30000"
+    else:
+        cmd += ["--batch_reads", batch_reads]
+        if batch_reads != "0":
+            cmd += ["--reads_to_process", str(meta["reads"])]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert (tmp_path / "out.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
     assert (tmp_path / "failed.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
@@ -114,6 +122,8 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     page = re.sub(rb"<div id='footer'> <p>.*?</p>", b"<div id='footer'> <p></p>", page, flags=re.S)
     assert page == gz(os.path.join(GOLD, case, "expected.html.gz"))
     assert b"reads passed filter: " in p.stderr and b"HTML report: " in p.stderr
+    if batch_reads == "chunks":
+        assert b"chunk parsers" in p.stderr  # (the chunk-parallel reader really ran)
 
 
 @pytest.mark.gpu

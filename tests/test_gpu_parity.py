@@ -352,3 +352,118 @@ def test_counters_tensor_all_reduce_over_rccl(orc, engine_mod):
     finally:
         dist.destroy_process_group()
         eng.close()
+
+
+def test_async_pipeline_two_deep_bit_exact(orc, engine_mod):
+    """fpl_process_batch_async / fpl_wait: batches of different sizes (the staging slots grow at different moments)
+    from page-locked arrays, FPL_MAX_IN_FLIGHT deep; every batch's records and the accumulated counters equal the
+    oracle's, and the misuse cases report FPL_ERR_STATE instead of queueing silently"""
+    cfgd = CASES["full_pipeline"]
+    cfg = orc.Config(abi.FplOptions.default(**cfgd["opt"]), cfgd["start"], cfgd["end"])
+    sizes = [40, 300, 7, 120, 500, 64]
+    batches = [synth.ont_like(n, seed=100 + i, median_len=1500, p_middle=0.05) if i % 2 == 0 else
+               synth.adversarial(n, seed=200 + i) for i, n in enumerate(sizes)]
+    C = max(int(np.diff(o.astype(np.int64)).max()) for _, _, o in batches)
+    want, want_cnt = [], None
+    for s, q, o in batches:
+        r, c = orc.process_batch(cfg, s, q, o, max_cycles=C)
+        want.append(r)
+        want_cnt = c if want_cnt is None else want_cnt + c
+    eng = engine_mod.Engine(cfg.opt, cfgd["start"], cfgd["end"], device=0, max_cycles=C)
+    with pytest.raises(engine_mod.FplError, match="invalid state"):
+        eng.wait()  # nothing in flight
+    pinned = []
+    for s, q, o in batches:  # page-locked copies, alive until the end of the test
+        ps, pq, po = eng.pinned_array(len(s)), eng.pinned_array(len(q)), eng.pinned_array(len(o), np.uint64)
+        ps[:], pq[:], po[:] = s, q, o
+        pinned.append((ps, pq, po, np.zeros(max(len(o) - 1, 1), dtype=abi.RESULT_DTYPE)))
+    done = 0
+    for i, (ps, pq, po, res) in enumerate(pinned):
+        if eng.in_flight() == abi.FPL_MAX_IN_FLIGHT:
+            with pytest.raises(engine_mod.FplError, match="invalid state"):
+                eng.submit_host(ps, pq, po, res)  # a third batch needs a wait first
+            eng.wait()
+            done += 1
+        eng.submit_host(ps, pq, po, res)
+    with pytest.raises(engine_mod.FplError, match="invalid state"):
+        eng.process_host(*batches[0])  # the synchronous call does not jump the queue
+    while eng.in_flight():
+        eng.wait()
+        done += 1
+    assert done == len(batches)
+    for (s, q, o), w, (_, _, _, res) in zip(batches, want, pinned):
+        parity.assert_results_equal(res[:len(o) - 1], w, s, o)
+    parity.assert_counters_equal(eng.counters(), want_cnt, C, 2)
+    # the in-process merge entry point with one context: agrees on C (a no-op here) and leaves the totals alone
+    import ctypes as Ct
+    arr = (Ct.c_void_p * 1)(eng.h)
+    assert eng.L.fpl_allreduce_counters(arr, 1) == 0
+    parity.assert_counters_equal(eng.counters(), want_cnt, C, 2)
+    assert eng.L.fpl_allreduce_counters(arr, 0) == abi.FPL_ERR_ARG
+    eng.close()
+
+
+def test_offsets_beyond_4_gib_bit_exact(orc, engine_mod):
+    """A batch whose byte offsets pass 2^32 (the bench batch is 9 GB per array): the records of the LAST reads --
+    the ones whose addresses need more than 32 bits in every kernel -- equal the oracle's on the same reads taken
+    alone (results are per read), the counters conserve reads and bases, and they do not depend on how the batch is
+    cut (partition invariance at full size)."""
+    import torch
+
+    n_reads, median = 560_000, 8000
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ~25 GiB of free HBM")
+    dev = torch.device("cuda", 0)
+    seq_t, qual_t, off_t, max_len = synth.device_batch(n_reads, seed=77, median_len=median, device=dev)
+    n_bytes = int(off_t[-1].item())
+    assert n_bytes > 2 ** 32 + 2 ** 28, n_bytes
+    cfgd = CASES["full_pipeline"]
+    opt = abi.FplOptions.default(**cfgd["opt"])
+    C = max_len
+    eng = engine_mod.Engine(opt, cfgd["start"], cfgd["end"], device=0, max_cycles=C)
+    rt = eng.process_device(seq_t, qual_t, off_t, max_len)
+    torch.cuda.synchronize()
+    res = eng.results_to_numpy(rt, n_reads)
+    cnt = eng.counters()
+    eng.close()
+    off = off_t.cpu().numpy().astype(np.int64)
+    # (1) the tail of the batch, beyond 4 GiB, against the oracle
+    tail = 1500
+    first = n_reads - tail
+    assert off[first] > 2 ** 32
+    a = int(off[first])
+    s_tail = seq_t[a:].cpu().numpy()
+    q_tail = qual_t[a:].cpu().numpy()
+    o_tail = (off[first:] - a).astype(np.uint64)
+    cfg = orc.Config(opt, cfgd["start"], cfgd["end"])
+    want_res, _ = orc.process_batch(cfg, s_tail, q_tail, o_tail, max_cycles=C)
+    parity.assert_results_equal(res[first:], want_res, s_tail, o_tail)
+    # ... and a window that straddles the 4 GiB line
+    k = int(np.searchsorted(off, 2 ** 32)) - 200
+    a, b = int(off[k]), int(off[k + 400])
+    want_mid, _ = orc.process_batch(cfg, seq_t[a:b].cpu().numpy(), qual_t[a:b].cpu().numpy(),
+                                    (off[k:k + 401] - a).astype(np.uint64), max_cycles=C)
+    parity.assert_results_equal(res[k:k + 400], want_mid)
+    # (2) conservation
+    v = abi.CountersView(cnt, C, 2)
+    assert int(v.pre.reads) == n_reads and int(v.pre.length_sum) == n_bytes
+    assert int(np.asarray(v.pre.base_qual_hist).sum()) == n_bytes
+    assert int(np.asarray(v.pre.cyc)[:, 0, :].sum()) == n_bytes  # kind 0 (base contents) over all cycles and classes
+    passing = 0
+    for f in range(2):
+        m = (res["n_frag"] > f) & (res["code"][:, f] == abi.FPL_PASS_FILTER) & (res["dropped"] == 0)
+        passing += int(res["frag_len"][m, f].astype(np.int64).sum())
+    assert int(v.post.length_sum) == passing == int(np.asarray(v.post.cyc)[:, 0, :].sum())
+    # (3) partition invariance at this size: two halves, the second one entirely beyond 2^31 bytes
+    h = n_reads // 2
+    cut = int(off[h])
+    eng2 = engine_mod.Engine(opt, cfgd["start"], cfgd["end"], device=0, max_cycles=C)
+    r1 = eng2.process_device(seq_t[:cut], qual_t[:cut], off_t[:h + 1].contiguous(), max_len)
+    r2 = eng2.process_device(seq_t[cut:], qual_t[cut:], (off_t[h:] - cut).contiguous(), max_len)
+    torch.cuda.synchronize()
+    cnt2 = eng2.counters()
+    res2 = np.concatenate([eng2.results_to_numpy(r1, h), eng2.results_to_numpy(r2, n_reads - h)])
+    eng2.close()
+    assert np.array_equal(cnt, cnt2)
+    parity.assert_results_equal(res2, res)

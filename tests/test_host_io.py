@@ -282,3 +282,86 @@ def test_multi_member_gzip_input(hostlib, tmp_path, monkeypatch, variant):
         assert n >= 2 * 9
     elif variant == "single":
         assert n == 0
+
+
+@pytest.mark.parametrize("variant", ["clean", "crlf", "junk", "at_quals", "malformed", "long_record", "noeol"])
+def test_chunked_reader_equals_sequential(hostlib, tmp_path, variant):
+    """the chunk-parallel reader of the CLI (FastqReader::parse_chunk + ChunkedReader): parser threads guess where
+    the first record of their chunk starts, the sequencer checks every guess against the chunk in front and parses
+    again where they differ -- whatever the chunk size, the records are those of the sequential reader"""
+    rng = np.random.default_rng(33)
+    reads = []
+    for i in range(300):
+        n = int(rng.integers(1, 700))
+        if variant == "long_record" and i % 60 == 7:
+            n = 9000  # a record that runs across several (tiny) chunks
+        q = rng.integers(33, 75, n).astype(np.uint8)
+        if variant == "at_quals" or rng.random() < 0.3:
+            q[0] = ord("@")  # a quality line that starts like a header
+            if n > 1 and rng.random() < 0.5:
+                q[1] = ord("+")
+        reads.append((synth._ACGT[rng.integers(0, 4, n)].astype(np.uint8), q))
+    seq, qual, off = synth.pack(reads)
+    text, _, _ = hostio.make_fastq(seq, qual, off, crlf=(variant == "crlf"), strand_names=True)
+    if variant == "junk":
+        lines = text.split(b"\n")
+        for i in range(40, len(lines) - 8, 41 * 4):  # stray lines between records
+            lines[i:i] = [b"stray line", b"", b"+not a record"]
+        text = b"\n".join(lines)
+    if variant == "malformed":
+        lines = text.split(b"\n")
+        lines[4 * 150 + 2] = b"-"  # the '+' line of record 150
+        text = b"\n".join(lines)
+    if variant == "noeol":
+        text = text[:-1]
+    p = tmp_path / "in.fq"
+    p.write_bytes(text)
+    want = _read_all(hostlib, p, 2 ** 62, 2 ** 30)
+    hostlib.fplh_batch_read_chunked.restype = C.c_void_p
+    hostlib.fplh_batch_read_chunked.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    redo_total = 0
+    for chunk, threads in ((997, 3), (4096, 5), (50_000, 2), (10 ** 9, 4)):
+        redo = C.c_uint64(0)
+        b = hostlib.fplh_batch_read_chunked(str(p).encode(), chunk, threads, C.byref(redo))
+        assert b
+        n, nb = hostlib.fplh_batch_n(b), hostlib.fplh_batch_bytes(b)
+        s2 = np.ctypeslib.as_array(C.cast(hostlib.fplh_batch_seq(b), C.POINTER(C.c_uint8)), (max(nb, 1),))[:nb].copy()
+        q2 = np.ctypeslib.as_array(C.cast(hostlib.fplh_batch_qual(b), C.POINTER(C.c_uint8)), (max(nb, 1),))[:nb].copy()
+        o2 = np.ctypeslib.as_array(C.cast(hostlib.fplh_batch_off(b), C.POINTER(C.c_uint64)), (n + 1,)).copy()
+        hostlib.fplh_batch_free(b)
+        assert np.array_equal(o2, want[2]) and np.array_equal(s2, want[0]) and np.array_equal(q2, want[1]), (variant, chunk)
+        redo_total += redo.value
+    if variant == "malformed":
+        assert len(want[2]) - 1 == 150
+    elif variant not in ("junk",):
+        assert np.array_equal(want[2], off)
+    if variant == "clean":
+        assert redo_total < 40  # guesses are right for well-formed input (a cut inside a header line aside)
+
+
+def test_truncated_gzip_is_an_error(hostlib, tmp_path):
+    """a .fq.gz cut short (an incomplete transfer) must not pass for a complete input: the reference aborts with
+    "igzip: unexpected eof" (src/fastqreader.cpp:133-137); the reader here ends the input and reports the error"""
+    hostlib.fplh_read_error.restype = C.c_int
+    hostlib.fplh_read_error.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    seq, qual, off = synth.ont_like(60, seed=5, median_len=2000)
+    text, _, _ = hostio.make_fastq(seq, qual, off)
+    whole = gzip.compress(text)
+    msg = C.create_string_buffer(512)
+    good = tmp_path / "good.fq.gz"
+    good.write_bytes(whole)
+    assert hostlib.fplh_read_error(str(good).encode(), msg, 512) == 0
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(whole[:len(whole) * 2 // 3])
+    assert hostlib.fplh_read_error(str(cut).encode(), msg, 512) == 1
+    assert b"igzip" in msg.value
+    # the same for a file of several members whose last member is cut (the member-parallel path)
+    members = b"".join(gzip.compress(text[i:i + len(text) // 5 + 1]) for i in range(0, len(text), len(text) // 5 + 1))
+    multi = tmp_path / "multi.fq.gz"
+    multi.write_bytes(members[:-40])
+    assert hostlib.fplh_read_error(str(multi).encode(), msg, 512) == 1
+    bad = bytearray(whole)
+    bad[len(bad) // 2] ^= 0xFF  # damaged in the middle
+    dmg = tmp_path / "dmg.fq.gz"
+    dmg.write_bytes(bytes(bad))
+    assert hostlib.fplh_read_error(str(dmg).encode(), msg, 512) == 1
