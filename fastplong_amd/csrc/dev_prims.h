@@ -310,6 +310,27 @@ __device__ __forceinline__ u32 mad_u24(u32 a, u32 b, u32 c) {
 #endif
 }
 __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__popc(x); }
+/* popcount(x) + acc in one VALU op (v_bcnt_u32_b32 takes an addend; left to itself the compiler counts against zero
+   and sums the counts with v_add3_u32: three instructions for two counts instead of two) */
+__device__ __forceinline__ u32 popc_acc(u32 x, u32 acc) {
+#ifdef FPL_EMU
+    return (u32)__popc(x) + acc;
+#else
+    u32 r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+#endif
+}
+/* (a & b) | c in one VALU op (v_and_or_b32; b wave-uniform) */
+__device__ __forceinline__ u32 and_or(u32 a, u32 b, u32 c) {
+#ifdef FPL_EMU
+    return (a & b) | c;
+#else
+    u32 r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+#endif
+}
 
 /* 0x01 in every byte of x that is non-zero */
 __device__ __forceinline__ u32 nonzero_bytes01(u32 x) {

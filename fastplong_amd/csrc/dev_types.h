@@ -28,6 +28,9 @@ struct DevAdapter {
        plane byte offset = 4 * (code(seq[i]) * 64 + (i >> 5)), shift = i & 31, code A0 C1 T2 G3 */
     uint32_t term[64];
     int32_t acgt_only; /* every byte is one of A C G T and len <= 64 */
+    /* one-hot nibbles of the first 64 bases (A 1, C 2, G 4, T 8; base i in bits 4i..4i+3 of word i / 8), zero behind the
+       adapter: the window Hamming scans of k_trim_ends count matches as popcount(text nibbles & these) */
+    uint32_t onehot[8];
 };
 
 /* Options as the kernels consume them: integers only. */
@@ -78,20 +81,26 @@ inline void build_adapter(DevAdapter* a, const char* seq, int len) {
         const uint32_t code = (c >> 1) & 3u; /* A0 C1 T2 G3 */
         a->term[i] = ((4u * (code * 64u + (uint32_t)(i >> 5))) << 8) | (uint32_t)(i & 31);
     }
+    for (int i = 0; i < len && i < 64; i++) {
+        const uint8_t c = (uint8_t)seq[i];
+        const uint32_t nib = c == 'A' ? 1u : (c == 'C' ? 2u : (c == 'G' ? 4u : (c == 'T' ? 8u : 0u)));
+        a->onehot[i >> 3] |= nib << (4 * (i & 7));
+    }
     for (int j = 0; j < a->plen; j++) {
         a->peq16_start[(uint8_t)seq[len - a->plen + j]] |= 1u << j;
         a->peq16_end[(uint8_t)seq[j]] |= 1u << j;
     }
 }
 
-/* DevConfig::trim_mode from the adapter lengths (slot order: start, end, FASTA...; a length of 0 = slot unused) */
-inline int trim_mode_of(const int* lens, int n_adapters) {
+/* DevConfig::trim_mode from the adapters (slot order: start, end, FASTA...; a length of 0 = slot unused): the reduced
+   instantiations take adapters of A / C / G / T only (their window scans work on one-hot nibbles) */
+inline int trim_mode_of(const int* lens, const int* acgt_only, int n_adapters) {
     bool short_ok = n_adapters == 2, mid_ok = true;
     for (int i = 0; i < n_adapters; i++) {
         const int l = lens[i];
         if (l == 0 && i < 2) continue; /* command-line adapter not given */
-        if (l < 16 || l > 32) short_ok = false;
-        if (l < 16 || l > 64) mid_ok = false;
+        if (l < 16 || l > 32 || !acgt_only[i]) short_ok = false;
+        if (l < 16 || l > 64 || !acgt_only[i]) mid_ok = false;
     }
     return short_ok ? 1 : (mid_ok ? 2 : 0);
 }

@@ -165,9 +165,9 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         for (int i = 0; i < n_fasta; i++) build_adapter(&ads[2 + i], fasta[i].seq, fasta[i].len);
         cfg.ham_fast = ads[0].acgt_only && ads[1].acgt_only;
         {
-            std::vector<int> lens(2 + n_fasta);
-            for (int i = 0; i < 2 + n_fasta; i++) lens[i] = ads[i].len;
-            cfg.trim_mode = trim_mode_of(lens.data(), 2 + n_fasta);
+            std::vector<int> lens(2 + n_fasta), acgt(2 + n_fasta);
+            for (int i = 0; i < 2 + n_fasta; i++) lens[i] = ads[i].len, acgt[i] = ads[i].acgt_only;
+            cfg.trim_mode = trim_mode_of(lens.data(), acgt.data(), 2 + n_fasta);
         }
         cfg.scan_short = cfg.adapter_enabled && cfg.ham_fast && ads[0].len <= 32 && ads[1].len <= 32;
         if (const char* e = getenv("FPL_DEBUG_FLAGS")) cfg.dbg = atoi(e); /* the environment is read here and nowhere else */

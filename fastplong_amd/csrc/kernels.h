@@ -45,6 +45,25 @@ __device__ unsigned long long g_fpl_prof[64];
 #endif
 
 
+/* compile-time A/B switches of individual optimisations (tools/ab_bench.py builds the variants; the defaults ship) */
+#ifndef FPL_OPT_HIST
+#define FPL_OPT_HIST 0 /* histogram counter address by v_and_or_b32 on a 4 KiB-aligned slice (hist_bump): 32 VALU fewer per
+                          tile and 2.5 % SLOWER side by side (profiles/r02_ab): the asm pins the counter updates in place */
+#endif
+#ifndef FPL_OPT_PREFETCH
+#define FPL_OPT_PREFETCH 0 /* k_scan touches the lines of a read's next tile one tile ahead (range_scan_fast): 2 % slower side by side --
+                              the other waves of the SIMD already cover the trip to HBM */
+#endif
+#ifndef FPL_OPT_BCNT
+#define FPL_OPT_BCNT 1 /* v_bcnt_u32_b32 with its addend in the passFilter sums (sums32) */
+#endif
+#ifndef FPL_OPT_NB6
+#define FPL_OPT_NB6 1 /* six count planes instead of seven when both adapters have <= 32 bases */
+#endif
+#ifndef FPL_OPT_ONEHOT
+#define FPL_OPT_ONEHOT 1 /* window Hamming scans of k_trim_ends on one-hot nibbles */
+#endif
+
 /* profiling-only ablation switches (FPL_DEBUG_FLAGS); compiled out unless -DFPL_ABLATE */
 #ifdef FPL_ABLATE
 #define FPL_DBG(x, bit) ((x) & (bit))
@@ -283,11 +302,27 @@ __device__ __forceinline__ int lev_wave(const uint64_t (*__restrict__ peq)[PEQ_W
  * k_trim_ends
  * ======================================================================================= */
 
+/* One array of a read (bases or qualities) whose first and last TRIM_WIN bytes sit in LDS (stage_ends): the sequential
+ * scans of trimAndCut / polyX almost always end inside those windows, so a read costs ONE trip to memory instead of one
+ * per scan round.  A round takes the LDS copy when its whole index range [lo, hi] lies in a window (a wave-uniform
+ * test), the global array otherwise. */
+constexpr int TRIM_WIN = 256; /* FPL_END_WINDOW rounded up, plus room for the few bases trimAndCut / polyX usually take */
+struct EndsView {
+    const u8* g;    /* the read in global memory */
+    const u8* head; /* LDS: bytes [0, TRIM_WIN) */
+    const u8* tail; /* LDS: bytes [tail0, tail0 + TRIM_WIN), tail0 = max(0, l - TRIM_WIN) */
+    int tail0;
+    __device__ __forceinline__ bool in_head(int lo, int hi) const { return lo >= 0 && hi < TRIM_WIN; }
+    __device__ __forceinline__ bool in_tail(int lo, int hi) const { return lo >= tail0 && hi < tail0 + TRIM_WIN; }
+};
+
 /* Filter::trimAndCut, src/filter.cpp:130-232.  Returns false when the reference returns NULL.
  * [s,e) is the surviving window in coordinates of the original read (length l). */
-__device__ inline bool trim_and_cut_wave(const u8* __restrict__ sq, const u8* __restrict__ ql, int l,
+__device__ inline bool trim_and_cut_wave(const EndsView& vs, const EndsView& vq, int l,
                                          const DevConfig* __restrict__ cfg, int& s_out, int& e_out) {
     const int lane = lane_id();
+    const u8* __restrict__ sq = vs.g;
+    const u8* __restrict__ ql = vq.g;
     int front = cfg->trim_front, tail = cfg->trim_tail;
     s_out = 0;
     e_out = l;
@@ -307,8 +342,12 @@ __device__ inline bool trim_and_cut_wave(const u8* __restrict__ sq, const u8* __
         for (int s0 = front; s0 < lim; s0 += 64) {
             const int sc = s0 + lane;
             int tot = 0;
-            if (sc < lim)
+            if (vq.in_head(s0, min(s0 + 63, lim - 1) + w - 1)) {
+                if (sc < lim)
+                    for (int i = 0; i < w; i++) tot += vq.head[sc + i];
+            } else if (sc < lim) {
                 for (int i = 0; i < w; i++) tot += ql[sc + i];
+            }
             const u64 m = wave_ballot(sc < lim && tot >= thr);
             if (m) {
                 s = s0 + __ffsll(m) - 1;
@@ -318,7 +357,10 @@ __device__ inline bool trim_and_cut_wave(const u8* __restrict__ sq, const u8* __
         if (s > 0) s = s + w - 1;
         for (;;) { /* while (s < l && seq[s] == 'N') s++ */
             const int p = s + lane;
-            const u64 stop = wave_ballot(!(p < l && sq[p] == 'N'));
+            bool isn = false;
+            if (vs.in_head(s, min(s + 63, l - 1))) isn = p < l && vs.head[p] == 'N';
+            else if (p < l) isn = sq[p] == 'N';
+            const u64 stop = wave_ballot(!isn);
             if (stop) {
                 s += __ffsll(stop) - 1;
                 break;
@@ -336,8 +378,12 @@ __device__ inline bool trim_and_cut_wave(const u8* __restrict__ sq, const u8* __
         for (int t0 = tstart; t0 >= tlow; t0 -= 64) {
             const int tc = t0 - lane;
             int tot = 0;
-            if (tc >= tlow)
+            if (vq.in_tail(max(t0 - 63, tlow) - (w - 1), t0)) {
+                if (tc >= tlow)
+                    for (int i = 0; i < w; i++) tot += vq.tail[tc - i - vq.tail0];
+            } else if (tc >= tlow) {
                 for (int i = 0; i < w; i++) tot += ql[tc - i];
+            }
             const u64 m = wave_ballot(tc >= tlow && tot >= thr);
             if (m) {
                 t = t0 - (__ffsll(m) - 1);
@@ -347,7 +393,10 @@ __device__ inline bool trim_and_cut_wave(const u8* __restrict__ sq, const u8* __
         if (t < l - 1) t = t - w + 1;
         for (;;) { /* while (t >= 0 && seq[t] == 'N') t-- */
             const int p = t - lane;
-            const u64 stop = wave_ballot(!(p >= 0 && sq[p] == 'N'));
+            bool isn = false;
+            if (vs.in_tail(max(t - 63, 0), t)) isn = p >= 0 && vs.tail[p - vs.tail0] == 'N';
+            else if (p >= 0) isn = sq[p] == 'N';
+            const u64 stop = wave_ballot(!isn);
             if (stop) {
                 t -= __ffsll(stop) - 1;
                 break;
@@ -362,10 +411,11 @@ __device__ inline bool trim_and_cut_wave(const u8* __restrict__ sq, const u8* __
     return true;
 }
 
-/* PolyX::trimPolyX, src/polyx.cpp:11-78, on the window r[0, rlen).  Returns the new length
+/* PolyX::trimPolyX, src/polyx.cpp:11-78, on the window [s0, s0 + rlen) of the read.  Returns the new length
  * and, when a polyX was cut, poly (0..3 = A,T,C,G) and the number of bases trimmed. */
-__device__ inline int trim_polyx_wave(const u8* __restrict__ r, int rlen, int compareReq, int& poly_out, int& trimmed_out) {
+__device__ inline int trim_polyx_wave(const EndsView& vs, int s0, int rlen, int compareReq, int& poly_out, int& trimmed_out) {
     const int lane = lane_id();
+    const u8* __restrict__ r = vs.g + s0;
     poly_out = -1;
     trimmed_out = 0;
     int carry[4] = {0, 0, 0, 0};
@@ -376,13 +426,22 @@ __device__ inline int trim_polyx_wave(const u8* __restrict__ r, int rlen, int co
         const int pos = p0 + lane;
         const bool valid = pos < rlen;
         u32 oh = 0; /* one-hot, one byte per base: A | T<<8 | C<<16 | G<<24 */
-        if (valid) {
-            const u8 c = r[rlen - pos - 1];
-            if (c == 'A') oh = 0x00000001u;
-            else if (c == 'T') oh = 0x00000100u;
-            else if (c == 'C') oh = 0x00010000u;
-            else if (c == 'G') oh = 0x01000000u;
-            else if (c == 'N') oh = 0x01010101u;
+        {
+            /* this round looks at read bytes s0 + rlen - 1 - (p0 + 63) .. s0 + rlen - 1 - p0 */
+            const int hi = s0 + rlen - 1 - p0;
+            u8 c = 0;
+            if (vs.in_tail(max(hi - 63, s0), hi)) {
+                if (valid) c = vs.tail[hi - lane - vs.tail0];
+            } else if (valid) {
+                c = r[rlen - pos - 1];
+            }
+            if (valid) {
+                if (c == 'A') oh = 0x00000001u;
+                else if (c == 'T') oh = 0x00000100u;
+                else if (c == 'C') oh = 0x00010000u;
+                else if (c == 'G') oh = 0x01000000u;
+                else if (c == 'N') oh = 0x01010101u;
+            }
         }
         const u32 sc = wave_scan_incl_u32(oh); /* per-byte counts <= 64 */
         const int nA = carry[0] + (int)(sc & 0xFF), nT = carry[1] + (int)((sc >> 8) & 0xFF);
@@ -425,7 +484,10 @@ __device__ inline int trim_polyx_wave(const u8* __restrict__ r, int rlen, int co
     int found = -1;
     for (int i0 = idx0; i0 < rlen; i0 += 64) {
         const int i = i0 + lane;
-        const u64 m = wave_ballot(i < rlen && r[i] == polyBase);
+        bool hit = false;
+        if (vs.in_tail(s0 + i0, s0 + min(i0 + 63, rlen - 1))) hit = i < rlen && vs.tail[s0 + i - vs.tail0] == polyBase;
+        else if (i < rlen) hit = r[i] == polyBase;
+        const u64 m = wave_ballot(hit);
         if (m) {
             found = i0 + __ffsll(m) - 1;
             break;
@@ -453,6 +515,7 @@ struct Win {
     const u32* w; /* LDS window */
     int bias;
     int rlen;
+    const u32* w4 = nullptr; /* LDS: the same window as one-hot nibbles, 8 bases per dword (stage_window) */
     __device__ __forceinline__ u32 byte(int j) const {
         if (LDSWIN) {
             const int b = j - bias;
@@ -528,6 +591,23 @@ __device__ __forceinline__ int hamming_win32(const Win<LDSWIN>& win, int p, cons
     return mm;
 }
 
+/* The same on one-hot nibbles (adapters of A / C / G / T only, DevAdapter::onehot): matches = popcount(window & adapter),
+ * eight bases per dword.  NW = dwords that hold the adapter (4: <= 32 bases, 8: <= 64); the bits behind the adapter are
+ * zero, so no tail mask is needed.  Anything that is not exactly A, C, G or T in the read has a zero nibble: a mismatch,
+ * as in the byte comparison (the adapter has no such byte). */
+template <int NW>
+__device__ __forceinline__ int hamming_onehot(const u32* __restrict__ w4, int b, const u32 (&ad1h)[NW], int alen) {
+    const u32* q = w4 + (b >> 3);
+    const u32 sh = ((u32)b & 7u) * 4u;
+    u32 x[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; k++) x[k] = q[k];
+    u32 matches = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) matches += popc32(alignbit(x[k + 1], x[k], sh) & ad1h[k]);
+    return alen - (int)matches;
+}
+
 /* 16-column Myers run on r1[p, p + n), n <= 16 */
 /* FULL: m == n == 16 (every adapter of >= 16 bases), known at compile time: no per-column tests, one
  * straight-line block that the scheduler can interleave with the other chains of the lane */
@@ -584,9 +664,14 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
     if (rlen < FPL_PATTERN_LEN) return 0;
     const int alen = ad->len, plen = ad->plen, ext = cfg->ext;
     const int thrA = cfg->thr[alen];
-    u32 adw[8]; /* the adapter's first 32 bytes (zero padded), in scalar registers */
+    /* the adapter in scalar registers: one-hot nibbles for the reduced instantiations (A / C / G / T only), else its
+       first 32 bytes (zero padded) */
+    constexpr int NW1H = MODE == 1 ? 4 : 8;
+    u32 adw[8], ad1h[NW1H];
 #pragma unroll
-    for (int k = 0; k < 8; k++) adw[k] = uniform_u32(((const u32*)ad->seq)[k]);
+    for (int k = 0; k < 8; k++) adw[k] = (MODE == 0 || !FPL_OPT_ONEHOT) ? uniform_u32(((const u32*)ad->seq)[k]) : 0u;
+#pragma unroll
+    for (int k = 0; k < NW1H; k++) ad1h[k] = (MODE != 0 && FPL_OPT_ONEHOT) ? uniform_u32(ad->onehot[k]) : 0u;
     int mpos = -1;
     const int searchEnd = min(rlen, FPL_END_WINDOW);
     if (alen <= rlen && searchEnd > alen) {
@@ -596,7 +681,10 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
         for (int p0 = 0; p0 < npos; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < npos && !FPL_DBG(cfg->dbg, 256)) mm = (MODE == 1 || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
+            if (p < npos && !FPL_DBG(cfg->dbg, 256)) {
+                if (MODE != 0 && FPL_OPT_ONEHOT) mm = hamming_onehot<NW1H>(win.w4, p - win.bias, ad1h, alen);
+                else mm = (MODE == 1 || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
+            }
             const u64 m = wave_ballot(p < npos && mm <= thrA);
             if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
             if (p < npos) {
@@ -676,9 +764,12 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     if (rlen < FPL_PATTERN_LEN) return 0;
     const int alen = ad->len, plen = ad->plen, ext = cfg->ext;
     const int thrA = cfg->thr[alen];
-    u32 adw[8]; /* the adapter's first 32 bytes (zero padded), in scalar registers */
+    constexpr int NW1H = MODE == 1 ? 4 : 8; /* (see trim_start_wave) */
+    u32 adw[8], ad1h[NW1H];
 #pragma unroll
-    for (int k = 0; k < 8; k++) adw[k] = uniform_u32(((const u32*)ad->seq)[k]);
+    for (int k = 0; k < 8; k++) adw[k] = (MODE == 0 || !FPL_OPT_ONEHOT) ? uniform_u32(((const u32*)ad->seq)[k]) : 0u;
+#pragma unroll
+    for (int k = 0; k < NW1H; k++) ad1h[k] = (MODE != 0 && FPL_OPT_ONEHOT) ? uniform_u32(ad->onehot[k]) : 0u;
     const int ss = max(0, rlen - FPL_END_WINDOW);
     int mpos = -1;
     if (ss + alen <= rlen) {
@@ -688,7 +779,10 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
         for (int p0 = ss; p0 < pend; p0 += 64) {
             const int p = p0 + lane;
             int mm = 0x7fffffff;
-            if (p < pend) mm = (MODE == 1 || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
+            if (p < pend) {
+                if (MODE != 0 && FPL_OPT_ONEHOT) mm = hamming_onehot<NW1H>(win.w4, p - win.bias, ad1h, alen);
+                else mm = (MODE == 1 || alen <= 32) ? hamming_win32(win, p, adw, alen) : hamming_win(win, p, ad);
+            }
             const u64 m = wave_ballot(p < pend && mm <= thrA);
             if (m) {
                 hit = p0 + __ffsll(m) - 1; /* leftmost hit, returned at once (:98-101) */
@@ -783,21 +877,81 @@ struct TrimBlockAcc {
 #ifndef FPL_TRIM_WAVES_PER_SIMD_SHORT
 #define FPL_TRIM_WAVES_PER_SIMD_SHORT 7 /* (8 would cap it at 64 VGPRs: spills) */
 #endif
-constexpr int TRIM_WIN = 256; /* FPL_END_WINDOW rounded up, plus slack for the aligned dword reads */
 template <int WAVES>
 struct TrimLds {
     uint16_t peq16[2][256];        /* [0] = start adapter's peq16_start, [1] = end adapter's peq16_end (16 columns) */
     uint64_t peqf[2][256][1];      /* word 0 of the full Peq tables: adapters of <= 64 bases (longer ones use the global tables) */
-    u32 win[WAVES][2][TRIM_WIN / 4];
+    /* per wave: the first / last TRIM_WIN bytes of the read being trimmed (stage_ends), [0] bases at the head, [1] bases
+       at the tail, [2] / [3] the qualities; + 8 zero dwords the dword-aligned reads of the last positions run into */
+    u32 win[WAVES][4][TRIM_WIN / 4 + 8];
+    u32 win4[WAVES][2][TRIM_WIN / 8 + 8]; /* the two base windows as one-hot nibbles (+ what a shifted read runs into) */
     uint16_t peq16w[WAVES][256];   /* per wave: the 16-column Peq table of the FASTA adapter being tried */
 };
 
 /* copy bytes [from, from + n) of a read (n <= TRIM_WIN) into this wave's window, 4 bytes per lane */
+/* ... and, when dst4 is given, the same bytes as one-hot nibbles (A 1, C 2, G 4, T 8, anything else 0), 16 bits per lane */
 __device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __restrict__ src, int n,
-                                             const u8* __restrict__ seq_end) {
+                                             const u8* __restrict__ seq_end, u32* __restrict__ dst4 = nullptr) {
     const int lane = lane_id();
     wave_sync();
-    if (lane < TRIM_WIN / 4) dst[lane] = (4 * lane < n) ? load4_guard(src + 4 * lane, seq_end) : 0u;
+    if (lane < TRIM_WIN / 4) {
+        u32 w = (4 * lane < n) ? load4_guard(src + 4 * lane, seq_end) : 0u;
+        if (4 * lane + 4 > n && 4 * lane < n) w &= (1u << (8 * (n - 4 * lane))) - 1u; /* bytes behind the window read as 0 */
+        dst[lane] = w;
+        if (dst4) {
+            const u32 code = (w >> 1) & 0x03030303u;            /* A0 C1 T2 G3 */
+            const u32 t = perm_lo(0x47544341u, code) ^ w;       /* zero byte <=> exactly that letter */
+            const u32 ok = (~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) >> 7) & 0x01010101u;
+            const u32 nib = perm_lo(0x04080201u, code) & (ok * 15u);
+            const u32 h = (nib | (nib >> 4)) & 0x00FF00FFu;
+            ((uint16_t*)dst4)[lane] = (uint16_t)((h | (h >> 8)) & 0xFFFFu);
+        }
+    }
+    if (dst4 && lane < 16) dst4[TRIM_WIN / 8 + (lane & 7)] = 0u; /* (what a shifted read of the last positions touches) */
+    wave_sync();
+}
+
+/* The one trip to memory of a read in k_trim_ends: lane i fetches dword i of the first and of the last TRIM_WIN bytes of
+ * the bases and of the qualities (bytes behind the read are zeroed in the base windows), the base windows also go out
+ * as one-hot nibbles when the adapter scans want them.  tail0 = max(0, l - TRIM_WIN). */
+template <bool ONEHOT>
+__device__ __forceinline__ void stage_ends(u32* __restrict__ hs, u32* __restrict__ ts, u32* __restrict__ hq, u32* __restrict__ tq,
+                                           u32* __restrict__ h4, u32* __restrict__ t4, const u8* __restrict__ sq,
+                                           const u8* __restrict__ ql, int l, int tail0, const u8* __restrict__ seq_end,
+                                           const u8* __restrict__ qual_end) {
+    const int lane = lane_id();
+    auto keep = [](u32 w, int n) -> u32 { return n >= 4 ? w : (n <= 0 ? 0u : (w & ((1u << (8 * n)) - 1u))); };
+    const int hn = l - 4 * lane, tn = l - (tail0 + 4 * lane); /* bytes of the read at / behind this lane's dword */
+    u32 a = 0, b = 0, c = 0, d = 0;
+    if (hn > 0) {
+        a = load4_guard(sq + 4 * lane, seq_end);
+        c = load4_guard(ql + 4 * lane, qual_end);
+    }
+    if (tn > 0) {
+        b = load4_guard(sq + tail0 + 4 * lane, seq_end);
+        d = load4_guard(ql + tail0 + 4 * lane, qual_end);
+    }
+    a = keep(a, hn);
+    b = keep(b, tn);
+    auto onehot16 = [](u32 w) -> u32 {
+        const u32 code = (w >> 1) & 0x03030303u;            /* A0 C1 T2 G3 */
+        const u32 t = perm_lo(0x47544341u, code) ^ w;       /* zero byte <=> exactly that letter */
+        const u32 ok = (~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) >> 7) & 0x01010101u;
+        const u32 nib = perm_lo(0x04080201u, code) & (ok * 15u);
+        const u32 h = (nib | (nib >> 4)) & 0x00FF00FFu;
+        return (h | (h >> 8)) & 0xFFFFu;
+    };
+    wave_sync();
+    hs[lane] = a;
+    ts[lane] = b;
+    hq[lane] = c;
+    tq[lane] = d;
+    if (lane < 8) hs[TRIM_WIN / 4 + lane] = ts[TRIM_WIN / 4 + lane] = 0u;
+    if (ONEHOT) {
+        ((uint16_t*)h4)[lane] = (uint16_t)onehot16(a);
+        ((uint16_t*)t4)[lane] = (uint16_t)onehot16(b);
+        if (lane < 8) h4[TRIM_WIN / 8 + lane] = t4[TRIM_WIN / 8 + lane] = 0u;
+    }
     wave_sync();
 }
 
@@ -823,8 +977,13 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     }
     __syncthreads();
     const u8* seq_end = seq + n_bytes;
-    u32* const win_s = lds.win[wave_in_block()][0];
-    u32* const win_e = lds.win[wave_in_block()][1];
+    const u8* qual_end = qual + n_bytes;
+    u32* const win_s = lds.win[wave_in_block()][0];  /* head of the read, bases (later: the start trim's window) */
+    u32* const win_e = lds.win[wave_in_block()][1];  /* tail of the read, bases (later: the end trim's window) */
+    u32* const win_hq = lds.win[wave_in_block()][2]; /* head / tail, qualities */
+    u32* const win_tq = lds.win[wave_in_block()][3];
+    u32* const win4_s = MODE != 0 ? lds.win4[wave_in_block()][0] : nullptr; /* (only the reduced instantiations scan nibbles) */
+    u32* const win4_e = MODE != 0 ? lds.win4[wave_in_block()][1] : nullptr;
 
     const u32 wave_global = blockIdx.x * WAVES + wave_in_block();
     const u32 n_waves = gridDim.x * WAVES;
@@ -837,11 +996,16 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
         const u8* ql = qual + o0;
         int s, e;
         PROF(0)
-        bool alive = trim_and_cut_wave(sq, ql, l, cfg, s, e);
+        /* the read's one trip to memory: its first and last TRIM_WIN bytes, bases and qualities, into LDS */
+        const int tail0 = max(0, l - TRIM_WIN);
+        stage_ends<MODE != 0>(win_s, win_e, win_hq, win_tq, win4_s, win4_e, sq, ql, l, tail0, seq_end, qual_end);
+        const EndsView vs = {sq, (const u8*)win_s, (const u8*)win_e, tail0};
+        const EndsView vq = {ql, (const u8*)win_hq, (const u8*)win_tq, tail0};
+        bool alive = trim_and_cut_wave(vs, vq, l, cfg, s, e);
         PROF(1)
         if (alive && cfg->polyx) { /* src/seprocessor.cpp:198-201 */
             int poly, tl;
-            const int nl = trim_polyx_wave(sq + s, e - s, cfg->polyx_min_len, poly, tl);
+            const int nl = trim_polyx_wave(vs, s, e - s, cfg->polyx_min_len, poly, tl);
             e = s + nl;
             if (poly >= 0 && lane == 0) {
                 atomicAdd(&acc.fr[FPL_FR_POLYX_READS + poly], (u64)1);
@@ -852,9 +1016,15 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
         if (alive && cfg->adapter_enabled) { /* src/seprocessor.cpp:205-216 */
             int trimmed = 0, kl;
             if (cfg->has_start && (MODE != 0 || ads[0].len <= 64)) {
-                /* the start trim only looks at r1[0, 200) */
-                stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end);
-                const Win<true> wn = {nullptr, win_s, 0, e - s};
+                /* the start trim only looks at r1[0, 200): still inside the staged head of the read unless trimAndCut
+                   took more than TRIM_WIN - 200 bases (then the window is fetched again) */
+                const int wl = min(e - s, FPL_END_WINDOW);
+                int bias = -s; /* r1 byte j lives at window byte j - bias */
+                if (s + wl > TRIM_WIN) {
+                    stage_window(win_s, sq + s, wl, seq_end, win4_s);
+                    bias = 0;
+                }
+                const Win<true> wn = {nullptr, win_s, bias, e - s, win4_s};
                 trimmed += trim_start_wave<MODE>(wn, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             } else if (MODE == 0 && cfg->has_start) {
@@ -866,8 +1036,12 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
             if (cfg->has_end && (MODE != 0 || ads[1].len <= 64)) {
                 /* the end trim only looks at the last 200 bases of r1 */
                 const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
-                stage_window(win_e, sq + e - wl, wl, seq_end);
-                const Win<true> wn = {nullptr, win_e, rlen - wl, rlen};
+                int bias = tail0 - s; /* (the staged tail of the read starts at byte tail0) */
+                if (e - wl < tail0) {
+                    stage_window(win_e, sq + e - wl, wl, seq_end, win4_e);
+                    bias = rlen - wl;
+                }
+                const Win<true> wn = {nullptr, win_e, bias, rlen, win4_e};
                 trimmed += trim_end_wave<MODE>(wn, s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             } else if (MODE == 0 && cfg->has_end) {
@@ -894,26 +1068,26 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     continue;
                 }
                 {
-                    if (stale_s) stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end);
+                    if (stale_s) stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end, win4_s);
                     stale_s = false;
                     wave_sync();
                     for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_start[i];
                     wave_sync();
                     const int s0 = s, e0 = e;
-                    const Win<true> wn = {nullptr, win_s, 0, e - s};
+                    const Win<true> wn = {nullptr, win_s, 0, e - s, win4_s};
                     trimmed += trim_start_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
                     if (s != s0 || e != e0) stale_s = stale_e = true;
                 }
                 {
                     const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
-                    if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end);
+                    if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end, win4_e);
                     stale_e = false;
                     wave_sync();
                     for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_end[i];
                     wave_sync();
                     const int s0 = s, e0 = e;
-                    const Win<true> wn = {nullptr, win_e, rlen - wl, rlen};
+                    const Win<true> wn = {nullptr, win_e, rlen - wl, rlen, win4_e};
                     trimmed += trim_end_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
                     if (s != s0 || e != e0) stale_s = stale_e = true;
@@ -1382,10 +1556,12 @@ constexpr int SC_FBUF = 32;     /* fragments a wave gathers per reservation in t
 constexpr int SC_LANES_HAM = 62; /* lanes 62/63 only provide the plane words the last windows reach into */
 
 /* per-wave LDS of k_scan */
+/* The quality histogram of the range being scanned (128 bins x HIST_COPIES lane-copies, all zero between uses) lives
+ * in its own array, one 4 KiB-aligned slice per wave (k_scan: hist_all): with the bin index in address bits 5..11 and
+ * the lane's copy in bits 2..4, the address of a byte's counter is (shifted byte & 0xfe0) | lane base -- one
+ * v_and_or_b32 after the shift instead of an and and an add. */
 struct alignas(16) ScanWaveLds {
     u32 planes[5][64];            /* letter bit-planes of the current tile: [A,C,T,G][chunk]; row 4 stays zero */
-    u32 hist[129 * HIST_COPIES];  /* quality histogram of the range being scanned; all zero between uses
-                                     (bin 128 swallows the bytes past the end of a ragged tile; never read) */
     u32 ehist[128];               /* quality histogram of the trimmed-off ends of the read; all zero between uses */
     uint64_t fbuf_off[SC_FBUF];   /* passing fragments waiting for a slot in the global list */
     u32 fbuf_len[SC_FBUF];
@@ -1593,14 +1769,15 @@ __device__ __forceinline__ void build_planes(const u32 s[8], u32& PA, u32& PC, u
  * (count <= 64).  plane_lane = &planes[0][lane] in LDS; term i fetches the plane of adapter letter
  * i shifted by i positions (two neighbouring words + v_alignbit); Harley-Seal carry-save adders
  * (v_bitop3 majority / parity) sum eight 1-bit planes with seven CSAs. */
-__device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane, const DevAdapter* __restrict__ ad, u32 B[7]) {
+template <int NB>
+__device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane, const DevAdapter* __restrict__ ad, u32 (&B)[NB]) {
     const int alen = ad->len;
 #ifndef FPL_EMU
     /* LDS byte address of lane 0's plane word, minus what the instruction adds for this lane */
     const u32 planes_m0 = uniform_u32((u32)(size_t)plane_lane - 4u * (u32)lane_id());
 #endif
 #pragma unroll
-    for (int b = 0; b < 7; b++) B[b] = 0;
+    for (int b = 0; b < NB; b++) B[b] = 0;
     for (int i0 = 0; i0 < alen; i0 += 8) {
         u32 m[8], tw[8];
 #pragma unroll
@@ -1645,7 +1822,7 @@ __device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane,
         csa(e, B[2], B[2], f1, f2);
         u32 c = e; /* ripple the eights carry upwards */
 #pragma unroll
-        for (int b = 3; b < 7; b++) {
+        for (int b = 3; b < NB; b++) {
             const u32 t = B[b] & c;
             B[b] ^= c;
             c = t;
@@ -1654,10 +1831,11 @@ __device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane,
 }
 
 /* largest count among the positions in `cand` (non-zero) and the first position holding it */
-__device__ __forceinline__ void sliced_max(const u32 B[7], u32 cand, int& val, int& first) {
+template <int NB>
+__device__ __forceinline__ void sliced_max(const u32 (&B)[NB], u32 cand, int& val, int& first) {
     val = 0;
 #pragma unroll
-    for (int b = 6; b >= 0; b--) { /* branch-free: selects, no exec-mask juggling */
+    for (int b = NB - 1; b >= 0; b--) { /* branch-free: selects, no exec-mask juggling */
         const u32 t = cand & B[b];
         const bool nz = t != 0;
         cand = nz ? t : cand;
@@ -1683,40 +1861,67 @@ __device__ __forceinline__ void sums32(const u32 s[8], const u32 q[8], int nvali
             fm &= bm;
         }
         const u32 t = (q[d] | 0x80808080u) - qqrep; /* per byte, no borrow: bit 7 survives iff q >= qq */
-        lowq += popc32(~t & fm);
+        lowq = FPL_OPT_BCNT ? popc_acc(~t & fm, lowq) : lowq + popc32(~t & fm);
         totq = sum_bytes(q[d] & bm, totq);
         const u32 x = s[d] ^ 0x4E4E4E4Eu;
         const u32 zx = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
-        nn += popc32(~zx & fm);
+        nn = FPL_OPT_BCNT ? popc_acc(~zx & fm, nn) : nn + popc32(~zx & fm);
         const u32 y = s[d] ^ alignbyte(s[d], pd, 3);
         const u32 zy = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
-        diff += popc32(zy & fm);
+        diff = FPL_OPT_BCNT ? popc_acc(zy & fm, diff) : diff + popc32(zy & fm);
         pd = s[d];
     }
 }
-/* the 32 quality bytes of a lane into the wave's histogram; MASKED: bytes past nvalid go to the dump bin */
+/* This lane's way into its wave's histogram slice: a typed pointer to its copy of bin 0 and the same as an LDS byte
+   address (see ScanWaveLds) */
+struct HistLane {
+    u32* p;   /* &hist[lane & (HIST_COPIES - 1)] */
+    u32 addr; /* the LDS byte address of p: bits 5..11 zero (HIST_COPIES == 8) */
+};
+__device__ __forceinline__ HistLane hist_lane(u32* __restrict__ h) {
+    HistLane hl;
+    hl.p = h + (lane_id() & (HIST_COPIES - 1));
+    hl.addr = (u32)(size_t)hl.p;
+    return hl;
+}
+/* count byte K of the dword qd (a quality < 128) */
+template <int K>
+__device__ __forceinline__ void hist_bump(const HistLane& hl, u32 qd) {
+#if defined(FPL_EMU) || FPL_HIST_COPIES != 8 || !defined(__HIP_DEVICE_COMPILE__) || !FPL_OPT_HIST
+    atomicAdd(&hl.p[((qd >> (8 * K)) & 0x7Fu) * HIST_COPIES], 1u);
+#else
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    const u32 sh = K == 0 ? (qd << 5) : (qd >> (8 * K - 5));
+    const u32 a = and_or(sh, 0xfe0u, hl.addr);
+    __hip_atomic_fetch_add((lds_u32*)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+/* the 32 quality bytes of a lane into the wave's histogram.  MASKED: the bytes past nvalid are counted in bin 0 --
+   the caller takes them out of that bin's total again (hist_dumped): a quality byte of 0 does not occur in FASTQ,
+   and if it does, it still counts exactly */
 template <bool MASKED>
-__device__ __forceinline__ void hist32(u32* __restrict__ h, const u32 q[8], int nvalid) {
-    const int lane = lane_id();
+__device__ __forceinline__ void hist32(const HistLane& hl, const u32 q[8], int nvalid) {
 #pragma unroll
     for (int d = 0; d < 8; d++) {
         u32 qd = q[d];
         if (MASKED) {
             const int c = nvalid - 4 * d;
             const u32 bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
-            qd = (qd & bm & 0x7F7F7F7Fu) | (~bm & 0x80808080u);
+            qd &= bm;
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u32 qq = (qd >> (8 * k)) & (MASKED ? 0xFFu : 0x7Fu);
-            atomicAdd(&h[qq * HIST_COPIES + (lane & (HIST_COPIES - 1))], 1u);
-        }
+        hist_bump<0>(hl, qd);
+        hist_bump<1>(hl, qd);
+        hist_bump<2>(hl, qd);
+        hist_bump<3>(hl, qd);
     }
 }
+/* bytes a masked scan of a range of blen bytes parks in bin 0: only the lane that holds the end of the range has a
+   partly filled chunk */
+__device__ __forceinline__ u32 hist_dumped(int blen) { return blen > 0 ? (u32)((SC_CHUNK - (blen % SC_CHUNK)) % SC_CHUNK) : 0u; }
 
 /*
  * One pass over bytes [a, b) of a read, 32 bases per lane and tile:
- *   - quality histogram into w->hist,
+ *   - quality histogram into h (this wave's slice, see ScanWaveLds),
  *   - the passFilter sums (src/filter.cpp:27-39, 67-81) when SUMS,
  *   - when HAM, the Hamming argmin of both middle-adapter scans (searchAdapter default mode,
  *     src/adaptertrimmer.cpp:133-151: positions p in [0, (b-a) - alen), first global minimum)
@@ -1725,19 +1930,22 @@ __device__ __forceinline__ void hist32(u32* __restrict__ h, const u32 q[8], int 
  */
 /* LEAN: the rare callers (long trimmed ends, the fragments of a split read) take the byte-masked variants for every
  * tile, full or ragged: half the code of an inlined copy, and the kernel's instruction footprint is what they cost. */
-template <bool SUMS, bool HAM, bool LEAN = false>
-__device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
-                                                const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
-                                                ScanWaveLds* __restrict__ w, int qualified_qual, RangeSums& sums,
-                                                const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
-                                                u64& key0, u64& key1, bool do_ham = true) {
+/* NB: bit-planes the match counts need (6 when both adapters have <= 32 bases, else 7).  h = this wave's histogram
+ * slice.  Returns the number of bytes the masked tiles parked in bin 0 of the histogram (hist_dumped): the caller takes
+ * them out of that bin's total. */
+template <bool SUMS, bool HAM, bool LEAN = false, int NB = 7>
+__device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
+                                               const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
+                                               ScanWaveLds* __restrict__ w, u32* __restrict__ h, int qualified_qual, RangeSums& sums,
+                                               const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
+                                               u64& key0, u64& key1, bool do_ham = true) {
     /* do_ham (wave-uniform): false turns a HAM instance into a plain scan -- no window is tested, the keys come out
        as ~0 -- so that one inlined copy of the loop can serve reads with and without an adapter search */
     const int lane = lane_id();
     const int blen = b - a;
     constexpr int ACTIVE = HAM ? SC_LANES_HAM : 64;
     constexpr int ADV = ACTIVE * SC_CHUNK;
-    u32* const h = w->hist;
+    const HistLane hl = hist_lane(h);
     u32 lowq = 0, nn = 0, totq = 0, diff = 0;
     int bm0 = -1, bp0 = 0, bm1 = -1, bp1 = 0; /* best match count / its position, per lane */
     const int npos0 = (HAM && do_ham) ? blen - ad0->len : 0, npos1 = (HAM && do_ham) ? blen - ad1->len : 0;
@@ -1746,6 +1954,14 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
     const u32 qqrep = 0x01010101u * (u32)(qualified_qual & 0x7F);
     u32 prev_tile_last = 0;
     for (int t0 = 0; t0 < blen; t0 += ADV) {
+        /* A wave consumes its tile as soon as the loads are back, so it sits out one trip to HBM per tile.  One byte
+           of every 128-byte line of the NEXT tile (lanes 0..31 the bases, 32..63 the qualities), requested before this
+           tile's own loads, brings that tile into the XCD's L2 meanwhile. */
+        u32 pf = 0;
+        if (FPL_OPT_PREFETCH && !LEAN) {
+            const int line = 128 * (lane & 31), nx = t0 + ADV + line;
+            if (line < ADV + 128 && nx < blen) pf = (u32)(lane < 32 ? rb : qb)[a + nx];
+        }
         const int j0 = t0 + SC_CHUNK * lane;
         const int navail = blen > j0 ? min(SC_CHUNK, blen - j0) : 0; /* bytes of the range in this chunk */
         const int nstat = lane < ACTIVE ? navail : 0;                 /* bytes this lane accounts for */
@@ -1769,12 +1985,12 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
            the byte-masked variants, so that no lane falls back to a byte-by-byte loop */
         if (!LEAN && !wave_ballot(nstat > 0 && nstat < SC_CHUNK)) {
             if (nstat == SC_CHUNK) {
-                if (!FPL_DBG(dbg, 1)) hist32<false>(h, q, SC_CHUNK);
+                if (!FPL_DBG(dbg, 1)) hist32<false>(hl, q, SC_CHUNK);
                 if (SUMS && !FPL_DBG(dbg, 2)) sums32<false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
                 if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
             }
         } else if (nstat > 0) {
-            hist32<true>(h, q, nstat);
+            hist32<true>(hl, q, nstat);
             if (SUMS) sums32<true>(s, q, nstat, prevd, qqrep, lowq, nn, totq, diff);
         }
         if (HAM) {
@@ -1789,7 +2005,7 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
                 wave_sync();
                 /* lanes 62/63 hold halo words only; their (clamped) plane reads are never used */
                 const u32* plane_lane = &w->planes[0][lane < ACTIVE ? lane : 0];
-                u32 B[7];
+                u32 B[NB];
                 if (npos0 > t0 && !FPL_DBG(dbg, 8)) {
                     match_counts(plane_lane, ad0, B);
                     const int nv = npos0 - j0;
@@ -1818,6 +2034,11 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
                 }
             }
         }
+#if !defined(FPL_EMU)
+        if (FPL_OPT_PREFETCH && !LEAN) asm volatile("" ::"v"(pf)); /* (keeps the touch load alive; it has long returned) */
+#else
+        (void)pf;
+#endif
     }
     if (SUMS) {
         sums.lowq = wave_sum_u32(lowq);
@@ -1829,6 +2050,7 @@ __device__ __forceinline__ void range_scan_fast(const u8* __restrict__ rb, const
         key0 = wave_min_u64(bm0 < 0 ? ~0ull : (((u64)(u32)(ad0->len - bm0) << 32) | (u32)bp0));
         key1 = wave_min_u64(bm1 < 0 ? ~0ull : (((u64)(u32)(ad1->len - bm1) << 32) | (u32)bp1));
     }
+    return hist_dumped(blen);
 }
 
 /* Filter::passFilter + passLowComplexityFilter from the sums, src/filter.cpp:12-81.  The
@@ -1971,12 +2193,14 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
        ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
        uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, long long* __restrict__ counters, u32 C,
        u32* __restrict__ work_ctr, u32 chunk, u32* __restrict__ frag_count) {
+    __shared__ alignas(4096) u32 hist_all[WAVES][128 * HIST_COPIES]; /* 4 KiB per wave when HIST_COPIES == 8: hist_bump */
     __shared__ ScanWaveLds wlds[WAVES];
     __shared__ ScanBlockAcc acc;
     __shared__ u32 peq4[2][4]; /* Peq words of A, C, T, G for the two command-line adapters (lev_pair32) */
     const int lane = lane_id();
     ScanWaveLds* const wl = &wlds[wave_in_block()];
-    u32* h = wl->hist;
+    u32* const h = hist_all[wave_in_block()];
+    constexpr int NB = (SHORT && FPL_OPT_NB6) ? 6 : 7; /* count planes: both adapters <= 32 bases / <= 64 */
     wl->planes[4][lane] = 0;
     hist_zero(h); /* from here on every user of the histograms leaves them zeroed */
     wl->ehist[lane] = 0;
@@ -2065,12 +2289,13 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         RangeSums sm = {0, 0, 0, 0};
         u64 key0 = ~0ull, key1 = ~0ull;
         const bool ham = !dropped && cfg->adapter_enabled;
+        u32 dumped = 0; /* bytes the masked tiles of the body scan parked in bin 0 (hist_dumped) */
         if (SHORT || (ham && cfg->ham_fast)) /* (SHORT: also the reads without an adapter search, through do_ham) */
-            range_scan_fast<true, true>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, &ads[0], &ads[1], key0, key1, ham);
+            dumped = range_scan_fast<true, true, false, NB>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, &ads[0], &ads[1], key0, key1, ham);
         else if (ham) /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
             range_scan_bytes<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
         else
-            range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, qq, sm, nullptr, nullptr, key0, key1);
+            dumped = range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, nullptr, nullptr, key0, key1);
         /* candidates of the middle-adapter search that still need their edit distance: fetch the two text
            windows now, confirm after the histogram work (edit distance <= Hamming distance, so only an argmin
            worse than the threshold needs it) */
@@ -2084,6 +2309,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         PROF(2) /* body scan */
         u32 hb0, hb1;
         hist_totals(h, hb0, hb1);
+        if (lane == 0) hb0 -= dumped;
         PROF(3)
         /* ---- the ends: their first SC_END_PF bytes from the prefetched registers into the small histogram,
            any rest (rare) by a scan; pre-filter totals = body + ends */
@@ -2094,12 +2320,14 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             if (s > SC_END_PF || l - e > SC_END_PF) { /* wave-uniform */
                 RangeSums dummy;
                 u64 d0, d1;
+                u32 dmp = 0;
                 for (int part = 0; part < 2; part++) { /* (one inlined copy of the scan loop for both ends) */
                     const int a = part == 0 ? SC_END_PF : e + SC_END_PF, b = part == 0 ? s : l;
-                    if (b > a) range_scan_fast<false, false, true>(rb, qb, a, b, seq_end, qual_end, wl, qq, dummy, nullptr, nullptr, d0, d1);
+                    if (b > a) dmp += range_scan_fast<false, false, true>(rb, qb, a, b, seq_end, qual_end, wl, h, qq, dummy, nullptr, nullptr, d0, d1);
                 }
                 u32 x0, x1;
                 hist_totals(h, x0, x1);
+                if (lane == 0) x0 -= dmp;
                 ht0 += x0;
                 ht1 += x1;
             }
@@ -2204,8 +2432,9 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 RangeSums fs = sm;
                 if (split) { /* rare: re-derive sums and histogram for this fragment */
                     u64 d0, d1;
-                    range_scan_fast<true, false, true>(rb, qb, fa[f], fb[f], seq_end, qual_end, wl, qq, fs, nullptr, nullptr, d0, d1);
+                    const u32 dmp = range_scan_fast<true, false, true>(rb, qb, fa[f], fb[f], seq_end, qual_end, wl, h, qq, fs, nullptr, nullptr, d0, d1);
                     hist_totals(h, t0, t1);
+                    if (lane == 0) t0 -= dmp;
                 }
                 const int code = filter_code(cfg, flen, fs);
                 int med = 0;

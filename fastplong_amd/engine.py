@@ -28,10 +28,11 @@ class FplError(RuntimeError):
 _lib = None
 
 
-def load_library():
-    """dlopen the in-tree HIP library and declare its prototypes; raises if it is missing."""
+def load_library(path=None):
+    """dlopen the in-tree HIP library and declare its prototypes; raises if it is missing.
+    path: another build of the same library (tools/ab_bench.py compares kernel variants side by side); not cached."""
     global _lib
-    if _lib is not None:
+    if _lib is not None and path is None:
         return _lib
     # torch first: PyTorch-ROCm carries its own libamdhip64; loading ours afterwards makes the
     # dynamic loader resolve to that same runtime, so device pointers and streams are shared.
@@ -40,10 +41,11 @@ def load_library():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    lib_path = path or LIB_PATH
+    if not os.path.exists(lib_path):
         raise FplError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % lib_path)
+    L = C.CDLL(lib_path)
     L.fpl_abi_version.restype = C.c_int
     L.fpl_strerror.restype = C.c_char_p
     L.fpl_strerror.argtypes = [C.c_int]
@@ -100,7 +102,8 @@ def load_library():
     L.fpl_allreduce_counters.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
     if L.fpl_abi_version() != abi.FPL_ABI_VERSION:
         raise FplError("ABI version mismatch")
-    _lib = L
+    if path is None:
+        _lib = L
     return L
 
 
@@ -111,8 +114,8 @@ def _b(s):
 class Engine:
     """One fpl_ctx on one device."""
 
-    def __init__(self, opt=None, start_adapter="", end_adapter="", fasta=(), device=0, max_cycles=1024):
-        self.L = load_library()
+    def __init__(self, opt=None, start_adapter="", end_adapter="", fasta=(), device=0, max_cycles=1024, lib=None):
+        self.L = lib if lib is not None else load_library()
         self.opt = opt if opt is not None else abi.FplOptions.default()
         self.start, self.end = _b(start_adapter), _b(end_adapter)
         self.fasta = [_b(a) for a in fasta]

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --cpu-bases 0 $*"
+BENCH="python $ROOT/bench.py --cpu-bases 0 --e2e-reads 0 $*"
 $BENCH --steps 10 --warmup 2 > "$OUT/bench_1M.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 5 --warmup 1 > "$OUT/stats.log" 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do

@@ -1,0 +1,57 @@
+"""usage: PYTHONPATH=. python tools/ab_bench.py [--reads N] [--workload W] lib1.so lib2.so ...
+Measurement aid: per-kernel times of several builds of libfastplong_amd.so (tools/ab_build.sh) on the SAME resident
+batch, same box, interleaved rounds -- boxes of the pool differ by a few per cent, so kernel variants are only comparable
+side by side."""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from fastplong_amd import abi, engine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=1_000_000)
+ap.add_argument("--workload", default="c3_full_pipeline")
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("libs", nargs="+")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+wl = bench.WORKLOADS[a.workload]
+opt = abi.FplOptions.default(**wl["opt"])
+seq_t, qual_t, off_t, max_len, s_ad, e_ad, fasta = bench.make_batch(wl, a.reads, 0, dev)
+n = off_t.numel() - 1
+nb = int(off_t[-1].item())
+res_t = torch.empty(n * 36, dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+engs = []
+for spec in a.libs:  # lib.so or lib.so@FLAGS (FPL_DEBUG_FLAGS for a build with -DFPL_ABLATE: wrong results, timing only)
+    p, _, flags = spec.partition("@")
+    L = engine.load_library(os.path.abspath(p))
+    os.environ["FPL_DEBUG_FLAGS"] = flags or "0"
+    engs.append((spec, engine.Engine(opt, s_ad, e_ad, fasta, device=0, max_cycles=max_len, lib=L)))
+os.environ.pop("FPL_DEBUG_FLAGS", None)
+ref_cnt = None
+tot = {p: {} for p, _ in engs}
+for r in range(a.rounds + 1):
+    for p, e in engs:
+        e.reset_counters()
+        e.enable_timing(True)
+        for _ in range(a.steps if r else 2):
+            e.process_device(seq_t, qual_t, off_t, max_len, res_t, st)
+        torch.cuda.synchronize()
+        kt, nbat = e.kernel_times()
+        e.enable_timing(False)
+        if r == 0:  # warm-up round: also check that every build computes the same counters
+            c = e.counters()
+            if ref_cnt is None:
+                ref_cnt = c
+            elif "@" not in p and not (c == ref_cnt).all():
+                print("!! %s: counters differ from %s" % (p, engs[0][0]))
+            continue
+        for k, v in kt.items():
+            tot[p].setdefault(k, []).append(v / nbat)
+print("%d reads, %.2f Gbases, %s; ms per batch (mean of %d rounds x %d steps)" % (n, nb / 1e9, a.workload, a.rounds, a.steps))
+for p, _ in engs:
+    m = {k: sum(v) / len(v) for k, v in tot[p].items()}
+    s = sum(m.values())
+    print("%-34s total %7.3f  %s  -> %.1f Gbases/s" % (os.path.basename(p), s, "  ".join("%s %.3f" % (k, v) for k, v in m.items()), nb / s / 1e6))

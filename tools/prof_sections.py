@@ -12,7 +12,10 @@ seq_t, qual_t, off_t, max_len = synth.device_batch(n, seed=1, median_len=med, de
 opt = abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1)
 eng = engine.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=max_len + 1)
 res_t = torch.empty(n * 36, dtype=torch.uint8, device=dev)
-lib = engine.load_library()
+import os
+lib = engine.load_library(os.environ.get("FPL_PROF_LIB"))
+eng.close()
+eng = engine.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=max_len + 1, lib=lib)
 lib.fpl_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
 out = (ctypes.c_ulonglong * 64)()
 for it in range(2):

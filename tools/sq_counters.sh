@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/sq
 rm -rf $OUT; mkdir -p $OUT   # (gpurun merges scratch output of earlier calls back: start clean)
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --cpu-bases 0 --steps 2 --warmup 1"
+B="python $ROOT/bench.py --cpu-bases 0 --e2e-reads 0 --steps 2 --warmup 1"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $OUT/p1 -- $B > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/p2 -- $B > $OUT/p2.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/p3 -- $B > $OUT/p3.log 2>&1
