@@ -226,7 +226,41 @@ def end_to_end(workload, opt, ad_start, ad_end, seq_t, qual_t, off_t, n_reads):
     return res
 
 
-def main():
+class Rig:
+    """What the rank code of main() stands on: the device, the collective backend, where the batch and the engine come
+    from.  bench.py always runs the default -- a GPU, RCCL, the HIP library; tests/test_distributed_gloo.py swaps in CPU
+    tensors, gloo and a stand-in engine to run THIS rank code (sharding by seed, capacity agreement, timed region,
+    counter all-reduce, MAX / SUM reductions of the line) with world_size 2 on a box without GPUs."""
+    backend = "nccl"
+
+    def device(self, local_rank):
+        import torch
+
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank)
+
+    def synchronize(self, dev):
+        import torch
+
+        torch.cuda.synchronize(dev)
+
+    def stream(self, dev):
+        import torch
+
+        return torch.cuda.current_stream(dev).cuda_stream
+
+    def make_batch(self, wl, n_reads, rank, dev):
+        return make_batch(wl, n_reads, rank, dev)
+
+    def engine(self, opt, ad_start, ad_end, ad_fasta, local_rank, C):
+        from fastplong_amd import engine
+
+        return engine.Engine(opt, ad_start, ad_end, ad_fasta, device=local_rank, max_cycles=C)
+
+
+def main(argv=None, rig=None):
+    rig = rig or Rig()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -240,13 +274,13 @@ def main():
     ap.add_argument("--set", default="", help="ablation only: comma separated fpl_options overrides, e.g. adapter_enabled=0")
     ap.add_argument("--hbm-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from fastplong_amd import abi, dist as fdist, engine, synth
+    from fastplong_amd import abi, dist as fdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -255,12 +289,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (
                 args.gpus, args.gpus))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = rig.device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dev.type == "cuda":
+            dist.init_process_group(rig.backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(rig.backend, rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     okw = dict(wl["opt"])
@@ -272,33 +307,33 @@ def main():
     if args.median_len:
         wl = dict(wl, gen=dict(wl["gen"], median_len=args.median_len))
     n_want = args.reads if args.reads > 0 else wl["reads"]
-    seq_t, qual_t, off_t, max_len, ad_start, ad_end, ad_fasta = make_batch(wl, n_want, rank, dev)
+    seq_t, qual_t, off_t, max_len, ad_start, ad_end, ad_fasta = rig.make_batch(wl, n_want, rank, dev)
     n = off_t.numel() - 1
     n_bases = int(off_t[-1].item())
     # all ranks agree on the per-cycle capacity so that the counter buffers line up for the all-reduce
     C = fdist.agree_capacity(max_len, device=dev)
-    eng = engine.Engine(opt, ad_start, ad_end, ad_fasta, device=local_rank, max_cycles=C)
+    eng = rig.engine(opt, ad_start, ad_end, ad_fasta, local_rank, C)
     res_t = torch.empty(n * 36, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    stream = rig.stream(dev)
 
     def step():
-        eng.process_device(seq_t, qual_t, off_t, max_len, res_t, stream.cuda_stream)
+        eng.process_device(seq_t, qual_t, off_t, max_len, res_t, stream)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
+    rig.synchronize(dev)
     eng.reset_counters()
     eng.enable_timing(True)  # HIP events around every kernel, on the launch stream, inside the timed region
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    rig.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     if world > 1:
         # the only collective of the path: sum the Stats / FilterResult counters over RCCL
         fdist.allreduce_counters(eng.counters_tensor())
-    torch.cuda.synchronize(dev)
+    rig.synchronize(dev)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0

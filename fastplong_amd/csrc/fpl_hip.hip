@@ -182,7 +182,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         FPL_HIP(hipMemcpy(ctx->d_cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
         FPL_HIP(hipMalloc((void**)&ctx->d_ads, sizeof(DevAdapter) * ads.size()));
         FPL_HIP(hipMemcpy(ctx->d_ads, ads.data(), sizeof(DevAdapter) * ads.size(), hipMemcpyHostToDevice));
-        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, 2 * sizeof(u32)));
+        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, 4 * sizeof(u32)));
         ctx->C = max_cycles ? max_cycles : 1;
         int r = alloc_counters(ctx, ctx->C, &ctx->d_counters);
         if (r != FPL_OK) return r;
@@ -463,7 +463,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         if (r != FPL_OK) return r;
         r = ensure_break_mask(ctx, n_reads, n_bytes);
         if (r != FPL_OK) return r;
-        FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, 2 * sizeof(u32), stream));
+        FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, 4 * sizeof(u32), stream));
     }
     if (ctx->hcfg.defer && ctx->bm.counts) FPL_HIP(hipMemsetAsync(ctx->bm.counts, 0, 4 * sizeof(u32), stream));
     BatchArgs a;

@@ -60,6 +60,10 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_OPT_NB6
 #define FPL_OPT_NB6 1 /* six count planes instead of seven when both adapters have <= 32 bases */
 #endif
+#ifndef FPL_OPT_SGFILTER
+#define FPL_OPT_SGFILTER 1 /* k_trim_ends_batched: a lane-parallel Myers search pass decides which reads need the
+                              partial-pattern search at all (partial16_possible) */
+#endif
 #ifndef FPL_OPT_ONEHOT
 #define FPL_OPT_ONEHOT 1 /* window Hamming scans of k_trim_ends on one-hot nibbles */
 #endif
@@ -174,36 +178,33 @@ __device__ __forceinline__ bool lev_round32(const WaveVals64& pub, int cnt, int 
        share: keep it short -- the score moves by a bit-field of Ph / Mh, and the exit bound is tested once per
        two columns (it only grows: the bound at column t implies the one at t + 1 or an exact result) */
     const u32 tsh = (u32)__builtin_ctz(top);
+    /* one column of the recurrence (everything in scalar registers) */
+#define FPL_LEV_COL(tt)                                               \
+    {                                                                 \
+        const u32 Eq = (u32)pub.get(tt);                              \
+        const u32 Xv = Eq | Mv;                                       \
+        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;                  \
+        u32 Ph = Mv | ~(Xh | Pv);                                     \
+        u32 Mh = Pv & Xh;                                             \
+        score += (int)((Ph >> tsh) & 1u) - (int)((Mh >> tsh) & 1u);   \
+        Ph = (Ph << 1) | 1u;                                          \
+        Mh <<= 1;                                                     \
+        Pv = Mh | ~(Xv | Ph);                                         \
+        Mv = Ph & Xv;                                                 \
+    }
     int t = 0;
-    for (; t + 2 <= cnt; t += 2) {
+#ifndef FPL_LEV_UNROLL
+#define FPL_LEV_UNROLL 4 /* columns between two tests of the exit bound: the test and the loop bookkeeping cost as much
+                            as a column on the scalar unit, which is what bounds k_trim_ends */
+#endif
+    for (; t + FPL_LEV_UNROLL <= cnt; t += FPL_LEV_UNROLL) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const u32 Eq = (u32)pub.get(t + u);
-            const u32 Xv = Eq | Mv;
-            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-            u32 Ph = Mv | ~(Xh | Pv);
-            u32 Mh = Pv & Xh;
-            score += (int)((Ph >> tsh) & 1u) - (int)((Mh >> tsh) & 1u);
-            Ph = (Ph << 1) | 1u;
-            Mh <<= 1;
-            Pv = Mh | ~(Xv | Ph);
-            Mv = Ph & Xv;
-        }
-        if (score - (left_after + cnt - 2 - t) > thr) return true; /* wave-uniform */
+        for (int u = 0; u < FPL_LEV_UNROLL; u++) FPL_LEV_COL(t + u)
+        if (score - (left_after + cnt - FPL_LEV_UNROLL - t) > thr) return true; /* wave-uniform */
     }
-    if (t < cnt) {
-        const u32 Eq = (u32)pub.get(t);
-        const u32 Xv = Eq | Mv;
-        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-        u32 Ph = Mv | ~(Xh | Pv);
-        u32 Mh = Pv & Xh;
-        score += (int)((Ph >> tsh) & 1u) - (int)((Mh >> tsh) & 1u);
-        Ph = (Ph << 1) | 1u;
-        Mh <<= 1;
-        Pv = Mh | ~(Xv | Ph);
-        Mv = Ph & Xv;
-        if (score - left_after > thr) return true;
-    }
+    for (; t < cnt; t++) FPL_LEV_COL(t)
+    if (score - left_after > thr) return true;
+#undef FPL_LEV_COL
     return false;
 }
 template <int MW>
@@ -1111,6 +1112,455 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     PROF_FLUSH(16);
     __syncthreads();
     long long* fr = counters + FPL_OFF_FR(C);
+    for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x)
+        if (acc.fr[i]) atomicAdd((u64*)&fr[i], acc.fr[i]);
+    for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x)
+        if (acc.key[i]) atomicAdd((u64*)&keyh[i], (u64)acc.key[i]);
+}
+
+/* -----------------------------------------------------------------------------------------
+ * k_trim_ends_batched: the same result as k_trim_ends<MODE 1> (no FASTA list, command-line adapters of 16..32 bases,
+ * A / C / G / T only) with the edit-distance confirmations taken out of the per-read stream.
+ *
+ * k_trim_ends runs every confirmation (src/adaptertrimmer.cpp:126-131 / :100-107 / :218-233 / :288-299) as a wave-wide
+ * Myers recurrence on broadcast words: all of it wave-uniform, so it lands on the CU's one scalar unit -- ~30 scalar
+ * instructions per column, up to four confirmations of 16..32 columns per read, and the scalar unit is what bounds the
+ * kernel (1.6e9 scalar against 1.5e9 vector wave-instructions on the bench batch).  Here a wave takes 64 reads at a time
+ * and alternates between per-read steps (lanes = candidate positions, as before) and per-lane steps (lane j = read j of
+ * the group): the per-read steps only FIND the window a confirmation is about and park it in lane j; one lane-parallel
+ * Myers pass (lev_lanes32: every lane its own text, pattern slice and threshold) then confirms 64 of them at once, and
+ * the arithmetic that follows a search (trimming extension, key length, Read::trimFront / resize) is per-lane work too.
+ *
+ *   per read   P1  stage head + tail, trimAndCut, polyX, start adapter: window Hamming scan -> hit | candidate
+ *   per lane   P2  confirm the candidates                                   (:126-131)
+ *   per read   P3  (no full match) partial-pattern search at the start      (:202-216)
+ *   per lane   P4  confirm the partial matches, finish the start trim       (:185-193, :218-233)
+ *   per read   P5  end adapter: window Hamming scan -> hit | candidate      (:84-107)
+ *   per lane   P6  confirm
+ *   per read   P7  (no full match) partial-pattern search at the end        (:273-286)
+ *   per lane   P8  confirm, finish the end trim, write the ReadState records (:256-264, :288-299)
+ * --------------------------------------------------------------------------------------- */
+
+/* Global edit distance <= thr? between the adapter slice [shift, shift + m) (m <= 32; peqf = word 0 of the adapter's Peq
+ * table, in LDS) and the m text bytes at `text`, one problem per lane (need = this lane has one).  The exact distance
+ * as the reference's edit_distance computes it (src/editdistance.cpp:30-61), compared per lane. */
+__device__ __forceinline__ bool lev_lanes32(const u8* __restrict__ text, int m, int shift, int thr, bool need,
+                                            const uint64_t (*__restrict__ peqf)[1], const u8* __restrict__ seq_end) {
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (need) {
+        const u32x4 a = load16_guard(text, seq_end), b = load16_guard(text + 16, seq_end);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    }
+    const int mm = need ? m : 0;
+    const u32 mask = mm >= 32 ? ~0u : ((1u << mm) - 1u);
+    const u32 topsh = mm > 0 ? (u32)(mm - 1) : 0u;
+    const int mmax = (int)wave_max_u32((u32)mm);
+    u32 Pv = ~0u, Mv = 0;
+    int score = mm;
+#pragma unroll
+    for (int t = 0; t < 32; t++) {
+        if (t < mmax) { /* wave-uniform */
+            const u32 c = (w[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+            const u32 Eq = (u32)(peqf[c][0] >> shift) & mask;
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            const int sc = score + (int)((Ph >> topsh) & 1u) - (int)((Mh >> topsh) & 1u);
+            Ph = (Ph << 1) | 1u;
+            Mh <<= 1;
+            const bool act = t < mm; /* this lane's text has a column t */
+            score = act ? sc : score;
+            const u32 nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
+            Pv = act ? nPv : Pv;
+            Mv = act ? nMv : Mv;
+        }
+    }
+    return need && score <= thr;
+}
+
+/* Can the 16-base partial pattern (peq16 = its Peq table, in LDS) match ANY 16-byte window of the n text bytes at
+ * `text` with an edit distance <= thr?  One problem per lane.  Myers' search recurrence (the first DP row is all zero:
+ * a match may start anywhere) gives, for every text position j, the best distance of the pattern against any substring
+ * that ENDS at j; the global distance of the pattern against the window [j - 16, j) -- what the partial-pattern searches
+ * of trimBySequenceStart / End compute per window, src/adaptertrimmer.cpp:202-216, 273-286 -- cannot be smaller.  So
+ * "no j reaches thr" proves that the search finds nothing, at 1/12 of its cost and for 64 reads at once; "some j does"
+ * proves nothing, and the read takes the exact search. */
+__device__ __forceinline__ bool partial16_possible(const u8* __restrict__ text, int n, int thr, bool need,
+                                                   const uint16_t* __restrict__ peq16, const u8* __restrict__ seq_end) {
+    const int nn = need ? n : 0;
+    const int nmax = (int)wave_max_u32((u32)nn);
+    u32 Pv = 0xFFFFu, Mv = 0;
+    int score = 16, best = 16;
+    for (int c0 = 0; c0 < nmax; c0 += 16) { /* wave-uniform */
+        u32 w[4] = {0, 0, 0, 0};
+        if (c0 < nn) {
+            const u32x4 a = load16_guard(text + c0, seq_end);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const u32 c = (w[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+            const u32 Eq = peq16[c];
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            const int sc = score + (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
+            Ph <<= 1; /* (no "| 1": the row above the pattern is zero everywhere) */
+            Mh <<= 1;
+            const bool act = c0 + t < nn;
+            const u32 nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv; /* (what gathers above bit 15 never comes back down) */
+            score = act ? sc : score;
+            Pv = act ? nPv : Pv;
+            Mv = act ? nMv : Mv;
+            best = min(best, score);
+        }
+    }
+    return need && best <= thr;
+}
+
+/* the value lane j holds, as a wave-uniform value / set lane j's value */
+__device__ __forceinline__ int lane_get(int v, int j) { return readlane_i32(v, j); }
+__device__ __forceinline__ void lane_set(int& v, int j, int x) { v = lane_id() == j ? x : v; }
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, FPL_TRIM_WAVES_PER_SIMD_SHORT)
+k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
+                    uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
+                    ReadState* __restrict__ state, long long* __restrict__ counters, u32 C, u32* __restrict__ group_ctr) {
+    __shared__ TrimBlockAcc acc;
+    __shared__ TrimLds<WAVES> lds;
+    __shared__ int thr_lds[40]; /* DevConfig::thr[0..32] */
+    const int lane = lane_id();
+    for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x) acc.fr[i] = 0;
+    for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x) acc.key[i] = 0;
+    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
+        lds.peq16[0][i] = (uint16_t)ads[0].peq16_start[i];
+        lds.peq16[1][i] = (uint16_t)ads[1].peq16_end[i];
+        lds.peqf[0][i][0] = ads[0].peq_full[i][0];
+        lds.peqf[1][i][0] = ads[1].peq_full[i][0];
+    }
+    for (u32 i = threadIdx.x; i < 40; i += blockDim.x) thr_lds[i] = i <= 32 ? cfg->thr[i] : 0;
+    __syncthreads();
+    const u8* seq_end = seq + n_bytes;
+    const u8* qual_end = qual + n_bytes;
+    u32* const win_s = lds.win[wave_in_block()][0];
+    u32* const win_e = lds.win[wave_in_block()][1];
+    u32* const win_hq = lds.win[wave_in_block()][2];
+    u32* const win_tq = lds.win[wave_in_block()][3];
+    u32* const win4_s = lds.win4[wave_in_block()][0];
+    u32* const win4_e = lds.win4[wave_in_block()][1];
+    const bool do_ad = cfg->adapter_enabled != 0;
+    const bool do_start = do_ad && cfg->has_start, do_end = do_ad && cfg->has_end;
+    const int ext = cfg->ext;
+    const int alen0 = ads[0].len, alen1 = ads[1].len;
+    constexpr int plen = FPL_PATTERN_LEN; /* (both adapters have >= 16 bases here) */
+    const int thrA0 = cfg->thr[alen0], thrA1 = cfg->thr[alen1], thrP = cfg->thr[plen];
+    u32 ad1h0[4], ad1h1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ad1h0[k] = uniform_u32(ads[0].onehot[k]);
+        ad1h1[k] = uniform_u32(ads[1].onehot[k]);
+    }
+
+    /* groups of 64 reads are handed out through one counter (zeroed before the batch): the grid is what the chip holds
+       at once, and no wave idles while another still has rounds to go */
+    const u32 n_groups = (n_reads + 63) / 64;
+    for (;;) {
+        u32 grp = 0;
+        if (lane == 0) grp = atomicAdd(group_ctr, 1u);
+        grp = readlane_u32(grp, 0);
+        if (grp >= n_groups) break;
+        const u32 g0 = grp * 64;
+        const int gn = (int)min(64u, n_reads - g0);
+        /* lane j = read g0 + j */
+        uint64_t v_o0 = 0;
+        int v_l = 0;
+        if (lane < gn) {
+            v_o0 = off[g0 + lane];
+            v_l = (int)(off[g0 + lane + 1] - v_o0);
+        }
+        int v_s = 0, v_e = 0, v_alive = 0, v_trim = 0;
+        int v_mpos = -1; /* full match decided at this r1 position */
+        int v_cand = -1; /* candidate of the window scan that still needs its edit distance */
+
+        /* ---- P1: trimAndCut, polyX, start adapter window scan */
+        for (int j = 0; j < gn; j++) {
+            const uint64_t o0 = readlane_u64(v_o0, j);
+            const int l = lane_get(v_l, j);
+            const u8* sq = seq + o0;
+            const u8* ql = qual + o0;
+            const int tail0 = max(0, l - TRIM_WIN);
+            stage_ends<true>(win_s, win_e, win_hq, win_tq, win4_s, win4_e, sq, ql, l, tail0, seq_end, qual_end);
+            const EndsView vs = {sq, (const u8*)win_s, (const u8*)win_e, tail0};
+            const EndsView vq = {ql, (const u8*)win_hq, (const u8*)win_tq, tail0};
+            int s, e;
+            const bool alive = trim_and_cut_wave(vs, vq, l, cfg, s, e);
+            if (alive && cfg->polyx) { /* src/seprocessor.cpp:198-201 */
+                int poly, tl;
+                const int nl = trim_polyx_wave(vs, s, e - s, cfg->polyx_min_len, poly, tl);
+                e = s + nl;
+                if (poly >= 0 && lane == 0) {
+                    atomicAdd(&acc.fr[FPL_FR_POLYX_READS + poly], (u64)1);
+                    atomicAdd(&acc.fr[FPL_FR_POLYX_BASES + poly], (u64)tl);
+                }
+            }
+            int mpos = -1, cand = -1;
+            const int rlen = e - s;
+            if (alive && do_start && rlen >= FPL_PATTERN_LEN) { /* searchAdapter, asRightAsPossible (:109-131) */
+                const int searchEnd = min(rlen, FPL_END_WINDOW);
+                if (alen0 <= rlen && searchEnd > alen0) {
+                    const int wl = searchEnd;
+                    int bias = -s;
+                    if (s + wl > TRIM_WIN) {
+                        stage_window(win_s, sq + s, wl, seq_end, win4_s);
+                        bias = 0;
+                    }
+                    const int npos = searchEnd - alen0 + 1;
+                    int hit = -1;
+                    u64 best = ~0ull;
+                    for (int p0 = 0; p0 < npos; p0 += 64) {
+                        const int p = p0 + lane;
+                        int mm = 0x7fffffff;
+                        if (p < npos) mm = hamming_onehot<4>(win4_s, p - bias, ad1h0, alen0);
+                        const u64 m = wave_ballot(p < npos && mm <= thrA0);
+                        if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
+                        if (p < npos) {
+                            const u64 k = ((u64)(u32)mm << 32) | (u32)p; /* ties: leftmost (descending scan, <=) */
+                            best = k < best ? k : best;
+                        }
+                    }
+                    if (hit >= 0) mpos = hit;
+                    else {
+                        best = wave_min_u64(best);
+                        if (best != ~0ull) cand = (int)(u32)best;
+                    }
+                }
+            }
+            lane_set(v_s, j, s);
+            lane_set(v_e, j, e);
+            lane_set(v_alive, j, alive ? 1 : 0);
+            lane_set(v_mpos, j, mpos);
+            lane_set(v_cand, j, cand);
+        }
+        /* ---- P2: the candidates' edit distance, 64 reads at once */
+        if (do_start) {
+            const bool need = v_cand >= 0;
+            if (wave_ballot(need)) {
+                const bool ok = lev_lanes32(seq + v_o0 + v_s + v_cand, alen0, 0, thrA0, need, lds.peqf[0], seq_end);
+                v_mpos = ok ? v_cand : v_mpos;
+            }
+        }
+        /* ---- P3: partial-pattern search at the start for the reads without a full match (:202-216) */
+        int v_ppos = -1;
+        if (do_start) {
+            /* (the windows the search looks at are r1[p, p + 16) for p < lim: the first lim + 15 bytes of r1) */
+            const int rl = v_e - v_s;
+            const bool wants = v_alive && v_mpos < 0 && rl >= FPL_PATTERN_LEN;
+            bool may = wants;
+            if (FPL_OPT_SGFILTER && wave_ballot(wants))
+                may = partial16_possible(seq + v_o0 + v_s, min(rl, FPL_END_WINDOW), thrP, wants, lds.peq16[0], seq_end);
+            u64 todo = wave_ballot(may);
+            while (todo) {
+                const int j = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                const uint64_t o0 = readlane_u64(v_o0, j);
+                const int s = lane_get(v_s, j), e = lane_get(v_e, j), rlen = e - s;
+                const u8* sq = seq + o0;
+                stage_window(win_s, sq + s, min(rlen, FPL_END_WINDOW), seq_end, nullptr);
+                const Win<true> win = {nullptr, win_s, 0, rlen, nullptr};
+                const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
+                u64 best = ~0ull;
+                for (int p0 = 0; p0 < lim; p0 += 192) {
+                    int pp[3], ed[3];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) pp[u] = p0 + 64 * u + lane;
+#pragma unroll
+                    for (int u = 0; u < 3; u++) ed[u] = lev16_win<true>(win, min(pp[u], lim - 1), lds.peq16[0], 16, 16);
+#pragma unroll
+                    for (int u = 0; u < 3; u++)
+                        if (pp[u] < lim && ed[u] <= thrP) {
+                            const u64 k = ((u64)(u32)ed[u] << 32) | (u32)pp[u];
+                            best = k < best ? k : best;
+                        }
+                }
+                best = wave_min_u64(best);
+                lane_set(v_ppos, j, best != ~0ull ? (int)(u32)best : -1);
+            }
+        }
+        /* ---- P4: confirm the partial matches; finish the start trim (:185-193, :218-233) */
+        if (do_start) {
+            const int rlen = v_e - v_s;
+            const int cmplen = min(v_ppos + plen, alen0);
+            const bool need = v_ppos >= 0;
+            bool pok = false;
+            if (wave_ballot(need))
+                pok = lev_lanes32(seq + v_o0 + v_s + v_ppos + plen - cmplen, cmplen, alen0 - cmplen, thr_lds[need ? cmplen : 0], need,
+                                  lds.peqf[0], seq_end);
+            int kl = 0, got = 0;
+            if (v_mpos >= 0) {
+                const int mp = min(v_mpos + ext, rlen - alen0);
+                kl = alen0;
+                v_s += min(rlen - 1, mp + alen0); /* Read::trimFront */
+                got = mp + alen0;
+            } else if (pok) {
+                const int pos = min(v_ppos + ext, rlen - alen0);
+                kl = cmplen;
+                const int n = min(rlen - 1, pos + plen); /* Read::trimFront; negative erases everything */
+                if (n < 0) v_s = v_e;
+                else v_s += n;
+                got = pos + plen;
+            }
+            v_trim += got;
+            if (kl > 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
+        }
+        /* ---- P5: end adapter window scan (searchAdapter, asLeftAsPossible, :84-107) */
+        v_mpos = -1;
+        v_cand = -1;
+        if (do_end) {
+            u64 todo = wave_ballot(v_alive && (v_e - v_s) >= FPL_PATTERN_LEN);
+            while (todo) {
+                const int j = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                const uint64_t o0 = readlane_u64(v_o0, j);
+                const int s = lane_get(v_s, j), e = lane_get(v_e, j), rlen = e - s;
+                const u8* sq = seq + o0;
+                int mpos = -1, cand = -1;
+                const int ss = max(0, rlen - FPL_END_WINDOW);
+                if (ss + alen1 <= rlen) {
+                    const int wl = min(rlen, FPL_END_WINDOW);
+                    stage_window(win_e, sq + e - wl, wl, seq_end, win4_e);
+                    const int bias = rlen - wl;
+                    const int pend = rlen - alen1; /* p in [ss, pend) : the last position is never tested */
+                    int hit = -1;
+                    u64 best = ~0ull;
+                    for (int p0 = ss; p0 < pend; p0 += 64) {
+                        const int p = p0 + lane;
+                        int mm = 0x7fffffff;
+                        if (p < pend) mm = hamming_onehot<4>(win4_e, p - bias, ad1h1, alen1);
+                        const u64 m = wave_ballot(p < pend && mm <= thrA1);
+                        if (m) {
+                            hit = p0 + __ffsll(m) - 1; /* leftmost hit, returned at once (:98-101) */
+                            break;
+                        }
+                        if (p < pend) {
+                            const u64 k = ((u64)(u32)mm << 32) | (u32)(0xFFFFFFFFu - (u32)p); /* ties: rightmost (<=) */
+                            best = k < best ? k : best;
+                        }
+                    }
+                    if (hit >= 0) mpos = hit;
+                    else {
+                        best = wave_min_u64(best);
+                        if (best != ~0ull) cand = (int)(0xFFFFFFFFu - (u32)best);
+                    }
+                }
+                lane_set(v_mpos, j, mpos);
+                lane_set(v_cand, j, cand);
+            }
+        }
+        /* ---- P6 */
+        if (do_end) {
+            const bool need = v_cand >= 0;
+            if (wave_ballot(need)) {
+                const bool ok = lev_lanes32(seq + v_o0 + v_s + v_cand, alen1, 0, thrA1, need, lds.peqf[1], seq_end);
+                v_mpos = ok ? v_cand : v_mpos;
+            }
+        }
+        /* ---- P7: partial-pattern search walking in from the tail (:273-286) */
+        v_ppos = -1;
+        if (do_end) {
+            /* (the windows are r1[rlen - 16 - p, rlen - p) for p < lim: the last lim + 15 bytes of r1) */
+            const int rl = v_e - v_s, wlf = min(rl, FPL_END_WINDOW);
+            const bool wants = v_alive && v_mpos < 0 && rl >= FPL_PATTERN_LEN;
+            bool may = wants;
+            if (FPL_OPT_SGFILTER && wave_ballot(wants))
+                may = partial16_possible(seq + v_o0 + v_e - wlf, wlf, thrP, wants, lds.peq16[1], seq_end);
+            u64 todo = wave_ballot(may);
+            while (todo) {
+                const int j = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                const uint64_t o0 = readlane_u64(v_o0, j);
+                const int s = lane_get(v_s, j), e = lane_get(v_e, j), rlen = e - s;
+                const u8* sq = seq + o0;
+                const int wl = min(rlen, FPL_END_WINDOW);
+                stage_window(win_e, sq + e - wl, wl, seq_end, nullptr);
+                const Win<true> win = {nullptr, win_e, rlen - wl, rlen, nullptr};
+                const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
+                int pos = -1, mined = -1;
+                bool stop = false;
+                int ed3[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+                    ed3[u] = lim > 0 ? lev16_win<true>(win, rlen - 16 - min(64 * u + lane, lim - 1), lds.peq16[1], 16, 16) : 0x7fffffff;
+                for (int p0 = 0; p0 < lim && !stop; p0 += 64) {
+                    const int p = p0 + lane;
+                    const int edr = p0 == 0 ? ed3[0] : (p0 == 64 ? ed3[1] : ed3[2]);
+                    const int ed = p < lim ? edr : 0x7fffffff;
+                    u64 q = wave_ballot(p < lim && ed <= thrP);
+                    while (q && !stop) {
+                        const int b = __ffsll(q) - 1;
+                        q &= q - 1;
+                        const int edb = readlane_i32(ed, b);
+                        if (pos < 0) {
+                            pos = p0 + b;
+                            mined = edb;
+                        } else if (edb > mined) {
+                            stop = true;
+                        } else {
+                            pos = p0 + b;
+                            mined = edb;
+                        }
+                    }
+                }
+                lane_set(v_ppos, j, pos > 0 ? pos : -1); /* :288 strict */
+            }
+        }
+        /* ---- P8: confirm; finish the end trim (:256-264, :288-299); the records */
+        if (do_end) {
+            const int rlen = v_e - v_s;
+            const int cmplen = min(v_ppos + plen, alen1);
+            const bool need = v_ppos >= 0;
+            bool pok = false;
+            if (wave_ballot(need))
+                pok = lev_lanes32(seq + v_o0 + v_s + (rlen - plen - v_ppos), cmplen, 0, thr_lds[need ? cmplen : 0], need, lds.peqf[1],
+                                  seq_end);
+            int kl = 0, got = 0;
+            if (v_mpos >= 0) {
+                const int mp = max(0, v_mpos - ext);
+                kl = alen1;
+                v_e = v_s + mp; /* Read::resize */
+                got = rlen - mp;
+            } else if (pok) {
+                const int pos = min(v_ppos + ext, rlen - plen);
+                kl = cmplen;
+                v_e = v_s + (rlen - plen - pos); /* Read::resize */
+                got = pos + plen;
+            }
+            v_trim += got;
+            if (kl > 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
+        }
+        if (do_ad) { /* FilterResult::addReadTrimmed */
+            const u64 nt = wave_ballot(v_trim > 0);
+            const u32 tb = wave_sum_u32((u32)v_trim);
+            if (nt && lane == 0) {
+                atomicAdd(&acc.fr[FPL_FR_ADAPTER_READS], (u64)__popcll(nt));
+                atomicAdd(&acc.fr[FPL_FR_ADAPTER_BASES], (u64)tb);
+            }
+        }
+        if (lane < gn) {
+            ReadState st;
+            st.s = v_alive ? (u32)v_s : 0;
+            st.e = v_alive ? (u32)v_e : 0;
+            st.dropped = v_alive ? 0 : 1;
+            st.pad = 0;
+            state[g0 + lane] = st;
+        }
+    }
+    __syncthreads();
+    long long* fr = counters + FPL_OFF_FR(C);
+    long long* keyh = counters + FPL_OFF_KEYHIST(C);
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x)
         if (acc.fr[i]) atomicAdd((u64*)&fr[i], acc.fr[i]);
     for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x)

@@ -75,7 +75,7 @@ struct BatchArgs {
     bool scan_short = false; /* DevConfig::scan_short on the host side */
     long long* counters;
     u32 C;
-    u32* work_ctr; /* two words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count */
+    u32* work_ctr; /* four words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count, [2] k_trim_ends_batched group counter */
     u64* stats_scratch;   /* stats_scratch_slabs() x FS_SLAB u64 */
     u8* stats_flags;      /* n_tiles tile flags + one byte per slab, zeroed before each statistics pass */
     u32 n_cu;      /* compute units of the device (grid sizing) */
@@ -159,7 +159,17 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         const u32 cap = FPL_TRIM_BLOCKS_PER_CU * a.n_cu;
         if (blocks > cap) blocks = cap;
         /* the usual adapter sets have their own, much smaller instantiations (DevConfig::trim_mode) */
-        if (a.trim_mode == 1)
+#ifndef FPL_OPT_BATCH
+#define FPL_OPT_BATCH 1 /* the usual adapter set goes through k_trim_ends_batched (confirmations 64 reads at a time) */
+#endif
+        if (a.trim_mode == 1 && FPL_OPT_BATCH) {
+            /* a wave takes 64 reads per round: enough waves to fill the chip, few enough to keep every wave a few rounds long */
+            u32 gblocks = cdiv(cdiv(n, 64u), KWAVES);
+            const u32 gcap = FPL_TRIM_WAVES_PER_SIMD_SHORT * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
+            if (gblocks > gcap) gblocks = gcap;
+            FPL_LAUNCH((k_trim_ends_batched<KWAVES>), dim3(gblocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+                       a.ads, a.state, a.counters, a.C, a.work_ctr + 2);
+        } else if (a.trim_mode == 1)
             FPL_LAUNCH((k_trim_ends<KWAVES, 1>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                        a.ads, a.state, a.counters, a.C);
         else if (a.trim_mode == 2)

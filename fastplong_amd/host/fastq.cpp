@@ -1,4 +1,5 @@
 #include "fastq.h"
+#include "split.h"
 
 #include <fcntl.h>
 #include <immintrin.h>
@@ -190,7 +191,7 @@ class GzMembers {
 
    private:
     struct Result {
-        vector<char> out;
+        RawBuf out;
         size_t end = 0; /* file offset behind the member's trailer */
         int state = 0;  /* 1 = a whole member, 2 = too large to buffer, -1 = not a member */
     };
@@ -211,42 +212,14 @@ class GzMembers {
         });
         for (auto& v : found) cands_.insert(cands_.end(), v.begin(), v.end());
     }
-    void inflate_at(size_t off, Result& r) const {
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        r.state = -1;
-        if (inflateInit2(&zs, 15 + 16) != Z_OK) return;
-        zs.next_in = (Bytef*)(base_ + off);
-        size_t in_left = size_ - off;
-        r.out.resize(min<size_t>(4u << 20, cap_));
-        size_t produced = 0;
-        for (;;) {
-            if (zs.avail_in == 0 && in_left > 0) {
-                zs.avail_in = (uInt)min<size_t>(in_left, 1u << 30);
-                in_left -= zs.avail_in;
-            }
-            if (produced == r.out.size()) {
-                if (r.out.size() >= cap_) {
-                    r.state = 2;
-                    break;
-                }
-                r.out.resize(r.out.size() * 2);
-            }
-            zs.next_out = (Bytef*)r.out.data() + produced;
-            zs.avail_out = (uInt)min<size_t>(r.out.size() - produced, 1u << 30);
-            const uInt before = zs.avail_out;
-            const int rc = inflate(&zs, Z_NO_FLUSH);
-            produced += before - zs.avail_out;
-            if (rc == Z_STREAM_END) {
-                r.state = 1;
-                r.end = (size_t)((const unsigned char*)zs.next_in - base_);
-                break;
-            }
-            if (rc != Z_OK || (zs.avail_in == 0 && in_left == 0 && zs.avail_out != 0)) break; /* bad data / truncated */
-        }
-        inflateEnd(&zs);
-        if (r.state == 1) r.out.resize(produced);
-        else r.out = vector<char>();
+    void inflate_at(size_t off, Result& r) const { /* (libdeflate when the system has it, else zlib: split.cpp) */
+        size_t used = 0;
+        /* a first guess of the inflated size: four times the distance to the next candidate header */
+        auto nx = std::upper_bound(cands_.begin(), cands_.end(), off);
+        const size_t span = (nx == cands_.end() ? size_ : *nx) - off;
+        const int st = gunzip_member(base_ + off, size_ - off, r.out, cap_, &used, span * 4 + (64u << 10));
+        r.state = st == 1 ? 1 : (st == 2 ? 2 : -1);
+        r.end = off + used;
     }
     /* make the member at pos_ current; false at the end of the input */
     bool next_member() {
@@ -292,7 +265,7 @@ class GzMembers {
     size_t cap_ = 512ull << 20; /* largest inflated member that is buffered */
     vector<size_t> cands_;
     std::map<size_t, Result> done_;
-    vector<char> cur_;
+    RawBuf cur_;
     gzFile stream_ = nullptr;
     uint64_t n_parallel_ = 0;
     int err_ = 0;

@@ -1,8 +1,11 @@
 #include "split.h"
 
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+
+#include <algorithm>
 
 #include <ctype.h>
 #include <iostream>
@@ -16,11 +19,78 @@ static void error_exit(const string& msg) { /* src/util.h:270-273 */
     exit(-1);
 }
 
+/* libdeflate, loaded on first use (its API is a handful of C functions; declared here, the image ships the library
+   without a header on the default include path) */
+namespace {
+struct Deflate {
+    void* lib = nullptr;
+    void* (*alloc_compressor)(int) = nullptr;
+    size_t (*gzip_compress)(void*, const void*, size_t, void*, size_t) = nullptr;
+    size_t (*gzip_compress_bound)(void*, size_t) = nullptr;
+    void (*free_compressor)(void*) = nullptr;
+    void* (*alloc_decompressor)() = nullptr;
+    int (*gzip_decompress_ex)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;
+    void (*free_decompressor)(void*) = nullptr;
+    Deflate() {
+        if (getenv("FPLH_NO_LIBDEFLATE")) return; /* test hook: the zlib paths */
+        for (const char* name : {"libdeflate.so.0", "libdeflate.so", "/usr/lib/x86_64-linux-gnu/libdeflate.so.0"}) {
+            lib = dlopen(name, RTLD_NOW);
+            if (lib) break;
+        }
+        if (!lib) return;
+        alloc_compressor = (decltype(alloc_compressor))dlsym(lib, "libdeflate_alloc_compressor");
+        gzip_compress = (decltype(gzip_compress))dlsym(lib, "libdeflate_gzip_compress");
+        gzip_compress_bound = (decltype(gzip_compress_bound))dlsym(lib, "libdeflate_gzip_compress_bound");
+        free_compressor = (decltype(free_compressor))dlsym(lib, "libdeflate_free_compressor");
+        alloc_decompressor = (decltype(alloc_decompressor))dlsym(lib, "libdeflate_alloc_decompressor");
+        gzip_decompress_ex = (decltype(gzip_decompress_ex))dlsym(lib, "libdeflate_gzip_decompress_ex");
+        free_decompressor = (decltype(free_decompressor))dlsym(lib, "libdeflate_free_decompressor");
+        if (!alloc_compressor || !gzip_compress || !gzip_compress_bound || !free_compressor || !alloc_decompressor ||
+            !gzip_decompress_ex || !free_decompressor)
+            lib = nullptr;
+    }
+};
+const Deflate& deflate_lib() {
+    static const Deflate d;
+    return d;
+}
+/* one compressor / decompressor per thread and level (they are not thread-safe, and allocating one costs more than a
+   small member) */
+struct ThreadCodec {
+    void* comp = nullptr;
+    int level = -1;
+    void* decomp = nullptr;
+    ~ThreadCodec() {
+        const Deflate& d = deflate_lib();
+        if (comp) d.free_compressor(comp);
+        if (decomp) d.free_decompressor(decomp);
+    }
+};
+}  // namespace
+
+bool have_libdeflate() { return deflate_lib().lib != nullptr; }
+
 /* The deflated bytes go through a buffer the calling thread keeps (the pool's workers are persistent): dozens of
    threads allocating and releasing multi-megabyte strings per slice spend their time in the kernel's address-space
    lock instead. */
 void gzip_into(const string& in, int level, string& out) {
     static thread_local vector<char> scratch;
+    const Deflate& d = deflate_lib();
+    if (d.lib) {
+        static thread_local ThreadCodec tc;
+        if (!tc.comp || tc.level != level) {
+            if (tc.comp) d.free_compressor(tc.comp);
+            tc.comp = d.alloc_compressor(level);
+            tc.level = level;
+            if (!tc.comp) error_exit("libdeflate_alloc_compressor failed");
+        }
+        const size_t bound = d.gzip_compress_bound(tc.comp, in.size());
+        if (scratch.size() < bound) scratch.resize(bound);
+        const size_t n = d.gzip_compress(tc.comp, in.data(), in.size(), scratch.data(), bound);
+        if (n == 0) error_exit("libdeflate_gzip_compress failed");
+        out.assign(scratch.data(), n);
+        return;
+    }
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) error_exit("deflateInit2 failed");
@@ -34,6 +104,75 @@ void gzip_into(const string& in, int level, string& out) {
     const size_t n = zs.total_out;
     deflateEnd(&zs);
     out.assign(scratch.data(), n); /* (when out is the input itself: shrinks inside its own allocation) */
+}
+
+int gunzip_member(const unsigned char* in, size_t in_len, RawBuf& out, size_t cap, size_t* consumed, size_t hint) {
+    const Deflate& d = deflate_lib();
+    out.clear();
+    if (d.lib) {
+        static thread_local ThreadCodec tc;
+        if (!tc.decomp) tc.decomp = d.alloc_decompressor();
+        if (!tc.decomp) return 0;
+        /* the member's own trailer says how long it inflates to (mod 2^32), but where the member ends is what is being
+           found out: start from the caller's guess and grow (a wrong guess costs one more pass over the member) */
+        /* (untouched pages of a generous buffer cost nothing, a second pass over the member does) */
+        size_t guess = min<size_t>(cap, max<size_t>(64u << 20, hint));
+        for (;;) {
+            out.reserve(guess);
+            size_t used = 0, produced = 0;
+            const int rc = d.gzip_decompress_ex(tc.decomp, in, in_len, out.p, guess, &used, &produced);
+            if (rc == 0) {
+                out.n = produced;
+                if (consumed) *consumed = used;
+                return 1;
+            }
+            if (rc != 3) { /* bad data / truncated */
+                out.release();
+                return 0;
+            }
+            if (guess >= cap) { /* LIBDEFLATE_INSUFFICIENT_SPACE at the cap */
+                out.release();
+                return 2;
+            }
+            guess = min(cap, guess * 2);
+        }
+    }
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return 0;
+    zs.next_in = (Bytef*)in;
+    size_t in_left = in_len;
+    out.reserve(min<size_t>(max<size_t>(4u << 20, hint), cap));
+    size_t produced = 0;
+    int state = 0;
+    for (;;) {
+        if (zs.avail_in == 0 && in_left > 0) {
+            zs.avail_in = (uInt)min<size_t>(in_left, 1u << 30);
+            in_left -= zs.avail_in;
+        }
+        if (produced == out.cap) {
+            if (out.cap >= cap) {
+                state = 2;
+                break;
+            }
+            out.reserve(min(cap, out.cap * 2));
+        }
+        zs.next_out = (Bytef*)out.p + produced;
+        zs.avail_out = (uInt)min<size_t>(out.cap - produced, 1u << 30);
+        const uInt before = zs.avail_out;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        produced += before - zs.avail_out;
+        if (rc == Z_STREAM_END) {
+            state = 1;
+            if (consumed) *consumed = (size_t)((const unsigned char*)zs.next_in - in);
+            break;
+        }
+        if (rc != Z_OK || (zs.avail_in == 0 && in_left == 0 && zs.avail_out != 0)) break; /* bad data / truncated */
+    }
+    inflateEnd(&zs);
+    if (state == 1) out.n = produced;
+    else out.release();
+    return state;
 }
 string gzip_member(const string& in, int level) {
     string o;

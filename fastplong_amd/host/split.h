@@ -6,7 +6,9 @@
 #define FPLH_SPLIT_H
 
 #include <stdio.h>
+#include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <ostream>
 #include <string>
@@ -14,9 +16,50 @@
 
 namespace fplh {
 
-/* one complete gzip member holding `in` (any gzip reader takes a concatenation of members as one stream) */
+/* one complete gzip member holding `in` (any gzip reader takes a concatenation of members as one stream).  Whole-buffer
+ * work: libdeflate does it (the library the reference's Writer uses, src/writer.cpp:110-133; loaded at run time when
+ * the system has libdeflate.so.0), zlib otherwise. */
 void gzip_into(const std::string& in, int level, std::string& out);
 std::string gzip_member(const std::string& in, int level);
+/* bytes without std::vector's zero fill (an inflate target is overwritten anyway, and its size is a guess) */
+struct RawBuf {
+    char* p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf&) = delete;
+    RawBuf& operator=(const RawBuf&) = delete;
+    RawBuf(RawBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr, o.n = o.cap = 0; }
+    RawBuf& operator=(RawBuf&& o) noexcept {
+        swap(o);
+        return *this;
+    }
+    ~RawBuf() { free(p); }
+    void swap(RawBuf& o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(cap, o.cap);
+    }
+    void reserve(size_t c) {
+        if (c > cap) {
+            p = (char*)realloc(p, c);
+            cap = c;
+        }
+    }
+    void release() {
+        free(p);
+        p = nullptr;
+        n = cap = 0;
+    }
+    char* data() { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+};
+/* the gzip member that starts at in[0]: inflated into out, *consumed = its compressed length.  hint = a guess of the
+   inflated size (0 = none).  1 = a whole member, 0 = not a (complete, undamaged) member, 2 = it inflates to more than
+   cap bytes */
+int gunzip_member(const unsigned char* in, size_t in_len, RawBuf& out, size_t cap, size_t* consumed, size_t hint = 0);
+bool have_libdeflate();
 
 /* --split / --split_by_lines.  Each of the reference's workers owns a writer and walks through the file numbers
  * t, t + T, t + 2T, ... as its current file fills up (ThreadConfig::initWriterForSplit / markProcessed /

@@ -58,7 +58,7 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     std::vector<fpl_fragment> frags((size_t)frag_cap + 1);
     std::vector<fpl_region> regs((size_t)reg_cap + 1);
     u32 bm_counts[4] = {0, 0, 0, 0};
-    uint32_t work_ctr[2] = {0, 0};
+    uint32_t work_ctr[4] = {0, 0, 0, 0};
     /* the kernels never read past n_bytes, but give the buffers an end guard anyway */
     BatchArgs a;
     a.seq = seq;

@@ -68,3 +68,112 @@ def test_shard_range_partitions():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+class _StandInEngine:
+    """An engine for a box without GPUs: the oracle behind the calls bench.py makes (test infrastructure -- the product
+    engine has no CPU path).  The counter buffer is a CPU tensor, so the all-reduce under test really moves it."""
+
+    def __init__(self, opt, ad_start, ad_end, ad_fasta, C):
+        from oracle import oracle
+
+        self.orc = oracle
+        self.cfg = oracle.Config(opt, ad_start, ad_end, ad_fasta)
+        self.C = C
+        self.n_adapters = self.cfg.n_adapters
+        self.cnt = torch.zeros(abi.counters_len(C, self.n_adapters), dtype=torch.int64)
+        self.calls = 0
+
+    def process_device(self, seq_t, qual_t, off_t, max_len, res_t, stream):
+        _, c = self.orc.process_batch(self.cfg, seq_t.numpy(), qual_t.numpy(), off_t.numpy().astype(np.uint64), max_cycles=self.C)
+        self.cnt += torch.from_numpy(c)
+        self.calls += 1
+
+    def reset_counters(self):
+        self.cnt.zero_()
+
+    def enable_timing(self, on):
+        self.calls = 0
+
+    def kernel_times(self):
+        return {"k_trim_ends": 1.0 * self.calls, "k_scan": 2.0 * self.calls, "k_stats": 1.5 * self.calls}, self.calls
+
+    def counters_tensor(self):
+        return self.cnt
+
+    def counters(self):
+        return self.cnt.numpy().copy()
+
+    def close(self):
+        pass
+
+
+def _bench_rank(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Rig(bench.Rig):
+        backend = "gloo"
+
+        def device(self, local_rank):
+            return torch.device("cpu")
+
+        def synchronize(self, dev):
+            pass
+
+        def stream(self, dev):
+            return 0
+
+        def make_batch(self, wl, n_reads, rank_, dev):
+            # every rank its own reads (seeded by the rank, as bench.make_batch does), of different maximum length
+            seq, qual, off = synth.ont_like(n_reads, seed=1 + rank_, median_len=500 + 300 * rank_, p_middle=0.1)
+            return (torch.from_numpy(seq), torch.from_numpy(qual), torch.from_numpy(off.astype(np.int64)),
+                    int(np.diff(off.astype(np.int64)).max()), synth.START_ADAPTER, synth.END_ADAPTER, [])
+
+        def engine(self, opt, ad_start, ad_end, ad_fasta, local_rank, C):
+            return _StandInEngine(opt, ad_start, ad_end, ad_fasta, C)
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--reads", "25", "--cpu-bases", "0",
+                    "--e2e-reads", "0"], rig=Rig())
+    with open(os.path.join(outdir, "out_%d.txt" % rank), "w") as f:
+        f.write(buf.getvalue())
+
+
+def test_bench_rank_code_path_gloo(orc, tmp_path):
+    """bench.py's own N > 1 code -- per-rank shard, agree_capacity, the timed region with its barriers, the counter
+    all-reduce, the MAX / SUM reductions behind the JSON line -- with world_size 2 over gloo on CPU tensors"""
+    import json
+
+    world, steps, reads = 2, 3, 25
+    mp.spawn(_bench_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "out_1.txt").read().strip() == ""  # only rank 0 prints
+    line = json.loads(open(tmp_path / "out_0.txt").read().strip())
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["scaling"] == "weak" and line["unit"] == "Gbases/s"
+    # what the line must add up to: both ranks' reads, `steps` times, through one all-reduce
+    cfg_opt = abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
+                                     complexity_filter=1)
+    tot_reads = tot_bases = tot_out = 0
+    C = 0
+    shards = []
+    for r in range(world):
+        seq, qual, off = synth.ont_like(reads, seed=1 + r, median_len=500 + 300 * r, p_middle=0.1)
+        shards.append((seq, qual, off))
+        C = max(C, int(np.diff(off.astype(np.int64)).max()))
+    for seq, qual, off in shards:
+        _, cnt = orc.process_batch(orc.Config(cfg_opt, synth.START_ADAPTER, synth.END_ADAPTER), seq, qual, off, max_cycles=C)
+        v = abi.CountersView(cnt, C, 2)
+        tot_reads += int(v.pre.reads)
+        tot_bases += int(v.pre.length_sum)
+        tot_out += int(v.post.reads)
+    cc = line["counters_check"]
+    assert cc["reads_in"] == steps * tot_reads == steps * world * reads
+    assert cc["bases_in"] == steps * tot_bases and cc["fragments_out"] == steps * tot_out
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 1e9 - tot_bases) < 1e-6 * tot_bases  # value = all ranks' bases / time
+    assert line["roofline"]["kernel"] == "k_scan" and line["config"]["reads_per_gpu"] == reads
