@@ -60,6 +60,9 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_OPT_NB6
 #define FPL_OPT_NB6 1 /* six count planes instead of seven when both adapters have <= 32 bases */
 #endif
+#ifndef FPL_OPT_SCANBATCH
+#define FPL_OPT_SCANBATCH 1 /* k_scan: the middle-adapter confirmations of up to 32 reads in one lane-parallel pass */
+#endif
 #ifndef FPL_OPT_SGFILTER
 #define FPL_OPT_SGFILTER 1 /* k_trim_ends_batched: a lane-parallel Myers search pass decides which reads need the
                               partial-pattern search at all (partial16_possible) */
@@ -2634,6 +2637,44 @@ __device__ __forceinline__ void lev_pair32_run(const u32 (*__restrict__ peq4)[4]
     ed1 = readlane_i32(res, 1);
 }
 
+/* The confirmation of lev_pair32_run for many reads at once: every lane its own window (m text bytes at `text`) against
+ * the whole adapter `a` (m = its length <= 32, A / C / G / T only; peq4 = its four Peq words, in LDS).  True when the
+ * global edit distance is <= thr. */
+__device__ __forceinline__ bool lev_lanes32_acgt(const u8* __restrict__ text, int m, int thr, bool need,
+                                                 const u32* __restrict__ peq4row, const u8* __restrict__ seq_end) {
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (need) {
+        const u32x4 a = load16_guard(text, seq_end), b = load16_guard(text + 16, seq_end);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    }
+    const int mm = need ? m : 0;
+    const u32 topsh = mm > 0 ? (u32)(mm - 1) : 0u;
+    const int mmax = (int)wave_max_u32((u32)mm);
+    u32 Pv = ~0u, Mv = 0;
+    int score = mm;
+#pragma unroll
+    for (int t = 0; t < 32; t++) {
+        if (t < mmax) { /* wave-uniform */
+            const u32 c = (w[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+            const u32 Eq = peq4_lookup(peq4row, c);
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            const int sc = score + (int)((Ph >> topsh) & 1u) - (int)((Mh >> topsh) & 1u);
+            Ph = (Ph << 1) | 1u;
+            Mh <<= 1;
+            const bool act = t < mm;
+            score = act ? sc : score;
+            const u32 nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
+            Pv = act ? nPv : Pv;
+            Mv = act ? nMv : Mv;
+        }
+    }
+    return need && score <= thr;
+}
+
 /* SHORT: adapter trimming is on and both command-line adapters are ACGT-only and <= 32 bases (DevConfig::scan_short):
    the byte-wise scan and the multi-word Levenshtein are left out of that instantiation */
 template <int WAVES, bool SHORT>
@@ -2688,21 +2729,79 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         wave_sync();
         nbuf = 0;
     };
-    for (;;) {
-        if (chunk_next >= chunk_end) {
+    /* Deferred confirmations (FPL_OPT_SCANBATCH, both adapters <= 32 bases).  A read whose middle-adapter candidates
+       still need their edit distance is resolved as "no middle adapter" -- what nearly all of them turn out to be -- and
+       its two windows are parked in lanes 2k / 2k + 1 (k = the wave's k-th pending read); every 32 reads ONE lane-parallel
+       Myers pass (lev_lanes32_acgt) settles all 64 windows.  The rare read that does have a middle adapter comes back
+       through the loop below as a REDO item: same scan, the unsplit bookkeeping taken back, the confirmed positions
+       forced. */
+    constexpr bool BATCH = FPL_OPT_SCANBATCH != 0;
+    uint64_t v_text = 0; /* lane 2k + a: the window of adapter a of pending read k (global address of its first byte) */
+    int v_pos = -1;      /*             its position in r1 */
+    u32 v_ri = 0;        /*             the read */
+    u32 v_flags = 0;     /* bit 0: the window needs its edit distance; bit 1 (even lanes): the read, if it stays unsplit, still has to go on the EXTRA list */
+    u32 npend = 0;       /* pending reads (wave-uniform) */
+    u64 redo_mask = 0;   /* bit 2k / 2k + 1: pending read k has a middle adapter 0 / 1 and waits for its second pass */
+    auto flush_pending = [&]() {
+        if (npend == 0) return;
+        const int a = lane & 1;
+        const bool need = (u32)lane < 2 * npend && (v_flags & 1u);
+        const bool ok = lev_lanes32_acgt((const u8*)v_text, a ? ads[1].len : ads[0].len, cfg->thr[a ? ads[1].len : ads[0].len], need,
+                                         peq4[a], seq_end);
+        redo_mask = wave_ballot(ok);
+        /* reads that stay as they are and were promised a place on the EXTRA list: their r1 passes unsplit, but starts
+           too far into the read for the single statistics pass */
+        const bool okn = shfl_down_u32(ok ? 1u : 0u, 1) != 0;
+        const bool want = (u32)lane < 2 * npend && a == 0 && (v_flags & 2u) && !ok && !okn;
+        const u64 wm = wave_ballot(want);
+        if (wm) {
             u32 base = 0;
-            if (lane == 0) base = atomicAdd(work_ctr, chunk);
+            if (lane == 0) base = atomicAdd(frag_count, (u32)__popcll(wm));
             base = readlane_u32(base, 0);
-            if (base >= n_reads) break;
-            chunk_next = base;
-            chunk_end = min(n_reads, base + chunk);
-            have_next = false;
+            if (want) { /* the fragment is r1 itself: [s, e) of k_trim_ends' record (this kernel only rewrites its `pad`) */
+                const ReadState rs = state[v_ri];
+                const u32 slot = base + (u32)__popcll(wm & ((1ull << lane) - 1ull));
+                frag_off[slot] = off[v_ri] + rs.s;
+                frag_len[slot] = rs.e - rs.s;
+            }
         }
-        const u32 ri = chunk_next++;
+        npend = 0;
+    };
+    for (;;) {
+        /* ---- the next read: a redo item first, else the next of the chunk, else a new chunk */
+        bool redo = false;
+        int f_sp = -1, f_ep = -1;
+        u32 ri;
+        if (BATCH && redo_mask) {
+            const int k = (__ffsll(redo_mask) - 1) >> 1;
+            const u64 bits = (redo_mask >> (2 * k)) & 3ull;
+            redo_mask &= ~(3ull << (2 * k));
+            ri = readlane_u32(v_ri, 2 * k);
+            if (bits & 1ull) f_sp = readlane_i32(v_pos, 2 * k);
+            if (bits & 2ull) f_ep = readlane_i32(v_pos, 2 * k + 1);
+            redo = true;
+        } else {
+            if (chunk_next >= chunk_end) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(work_ctr, chunk);
+                base = readlane_u32(base, 0);
+                if (base >= n_reads) {
+                    if (BATCH && npend) { /* the last windows; their redo items, if any, still go through the loop */
+                        flush_pending();
+                        if (redo_mask) continue;
+                    }
+                    break;
+                }
+                chunk_next = base;
+                chunk_end = min(n_reads, base + chunk);
+                have_next = false;
+            }
+            ri = chunk_next++;
+        }
         /* this read's metadata: loaded while the previous read was being processed, when possible */
         uint64_t o0, o1;
         ReadState st;
-        if (have_next) {
+        if (have_next && !redo) {
             o0 = nx_o0;
             o1 = nx_o1;
             st = nx_st;
@@ -2718,11 +2817,13 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         st.s = uniform_u32(st.s);
         st.e = uniform_u32(st.e);
         st.dropped = uniform_u32(st.dropped);
-        have_next = chunk_next < chunk_end;
-        if (have_next) { /* the next read of the chunk */
-            nx_o0 = o1;
-            nx_o1 = off[ri + 2];
-            nx_st = state[ri + 1];
+        if (!redo) {
+            have_next = chunk_next < chunk_end;
+            if (have_next) { /* the next read of the chunk */
+                nx_o0 = o1;
+                nx_o1 = off[ri + 2];
+                nx_st = state[ri + 1];
+            }
         }
         const int l = (int)(o1 - o0);
         const u8* rb = seq + o0;
@@ -2753,8 +2854,12 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         const int thr0 = ham ? cfg->thr[ads[0].len] : 0, thr1 = ham ? cfg->thr[ads[1].len] : 0;
         const bool need0 = ham && key0 != ~0ull && (int)(key0 >> 32) > thr0;
         const bool need1 = ham && key1 != ~0ull && (int)(key1 >> 32) > thr1;
+        /* (a read with a candidate accepted outright AND one pending is rare and would need its split taken back: it
+           gets its edit distance on the spot) */
+        const bool direct = ham && ((key0 != ~0ull && !need0) || (key1 != ~0ull && !need1));
+        const bool defer_confirm = BATCH && pair32 && !redo && (need0 || need1) && !direct && !cfg->defer;
         LevPairText ltxt = {0, 0};
-        if (pair32 && (need0 || need1))
+        if (pair32 && (need0 || need1) && !defer_confirm && !redo)
             ltxt = lev_pair32_fetch(rb + s + (int)(u32)key0, ads[0].len, need0, rb + s + (int)(u32)key1, ads[1].len, need1);
         PROF(2) /* body scan */
         u32 hb0, hb1;
@@ -2792,16 +2897,34 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         PROF(5)
         int med_pre = 0;
         if (l > 0) med_pre = hist_median(ht0, ht1, (u32)l);
-        /* pre-filter Stats scalars, src/stats.cpp:265-271,352-374 */
-        if (ht0) atomicAdd(&acc.bqh[0][2 * lane], (u64)ht0);
-        if (ht1) atomicAdd(&acc.bqh[0][2 * lane + 1], (u64)ht1);
-        if (lane == 0) {
-            if (l > 0) {
-                atomicAdd(&acc.medh[0][med_pre], (u64)1);
-                atomicAdd(&acc.medb[0][med_pre], (u64)l);
+        /* pre-filter Stats scalars, src/stats.cpp:265-271,352-374 (counted in the read's first pass) */
+        if (!redo) {
+            if (ht0) atomicAdd(&acc.bqh[0][2 * lane], (u64)ht0);
+            if (ht1) atomicAdd(&acc.bqh[0][2 * lane + 1], (u64)ht1);
+            if (lane == 0) {
+                if (l > 0) {
+                    atomicAdd(&acc.medh[0][med_pre], (u64)1);
+                    atomicAdd(&acc.medb[0][med_pre], (u64)l);
+                }
+                atomicAdd(&acc.reads[0], (u64)1);
+                atomicAdd(&acc.lensum[0], (u64)l);
             }
-            atomicAdd(&acc.reads[0], (u64)1);
-            atomicAdd(&acc.lensum[0], (u64)l);
+        } else {
+            /* the first pass booked r1 as one unsplit fragment: take that back (the same sums and histogram give the
+               same filter code and median) before the fragments are booked */
+            const int code_u = filter_code(cfg, blen, sm);
+            if (lane == 0) atomicAdd(&acc.fr[code_u], (u64)0 - (u64)1);
+            if (code_u == FPL_PASS_FILTER) {
+                const int med_u = hist_median(hb0, hb1, (u32)blen);
+                if (hb0) atomicAdd(&acc.bqh[1][2 * lane], (u64)0 - (u64)hb0);
+                if (hb1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)0 - (u64)hb1);
+                if (lane == 0) {
+                    atomicAdd(&acc.medh[1][med_u], (u64)0 - (u64)1);
+                    atomicAdd(&acc.medb[1][med_u], (u64)0 - (u64)blen);
+                    atomicAdd(&acc.reads[1], (u64)0 - (u64)1);
+                    atomicAdd(&acc.lensum[1], (u64)0 - (u64)blen);
+                }
+            }
         }
 
         PROF(6) /* median + block accumulators */
@@ -2820,7 +2943,13 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 const int p0 = (int)(u32)key0, p1 = (int)(u32)key1;
                 int ed0 = 0, ed1 = 0;
                 PROF(10)
-                if (SHORT || pair32) {
+                if (redo) { /* second pass: the lane-parallel confirmation has spoken */
+                    ed0 = f_sp >= 0 ? 0 : thr0 + 1;
+                    ed1 = f_ep >= 0 ? 0 : thr1 + 1;
+                } else if (defer_confirm) { /* resolved as "no middle adapter" for now */
+                    ed0 = thr0 + 1;
+                    ed1 = thr1 + 1;
+                } else if (SHORT || pair32) {
                     if (need0 || need1) lev_pair32_run(peq4, ltxt, al0, thr0, need0, al1, thr1, need1, ed0, ed1);
                     PROF(11)
                 } else {
@@ -2930,7 +3059,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                post-only EXTRA list (through this wave's buffer; the order is irrelevant) */
             state[ri].pad = to_post ? PLAN_TO_POST : 0u;
             u32 slot = nbuf;
-            if (pass0 && !to_post) {
+            if (pass0 && !to_post && !defer_confirm) {
                 wl->fbuf_off[slot] = o0 + r_fs0;
                 wl->fbuf_len[slot] = r_fl0;
                 slot++;
@@ -2940,8 +3069,19 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 wl->fbuf_len[slot] = r_fl1;
             }
         }
-        nbuf += ((pass0 && !to_post) ? 1u : 0u) + (pass1 ? 1u : 0u);
+        nbuf += ((pass0 && !to_post && !defer_confirm) ? 1u : 0u) + (pass1 ? 1u : 0u);
         if (nbuf > SC_FBUF - 2) flush_frags();
+        if (defer_confirm) { /* park the two windows; the read's EXTRA entry (if it is owed one) waits with them */
+            const int la = 2 * (int)npend;
+            if (lane == la || lane == la + 1) {
+                const bool second = lane != la;
+                v_pos = (int)(u32)(second ? key1 : key0);
+                v_text = (uint64_t)(rb + s + v_pos);
+                v_ri = ri;
+                v_flags = ((second ? need1 : need0) ? 1u : 0u) | ((!second && pass0 && !to_post) ? 2u : 0u);
+            }
+            if (++npend == 32) flush_pending();
+        }
         PROF(9) /* result record, plan, fragment buffer */
     }
     PROF_FLUSH(0);
