@@ -31,6 +31,12 @@ struct DevAdapter {
     /* one-hot nibbles of the first 64 bases (A 1, C 2, G 4, T 8; base i in bits 4i..4i+3 of word i / 8), zero behind the
        adapter: the window Hamming scans of k_trim_ends count matches as popcount(text nibbles & these) */
     uint32_t onehot[8];
+    /* the Peq words of the letters A, C, T, G (code = (ASCII >> 1) & 3) in one place, for the lane-per-adapter filter of
+       the FASTA chain (k_trim_ends, fasta_may_trim): the whole adapter (first 64 columns), its last 16 bases (start
+       trim's partial pattern) and its first 16 (end trim's) */
+    uint64_t peq4_full[4];
+    uint32_t peq4_s16[4];
+    uint32_t peq4_e16[4];
 };
 
 /* Options as the kernels consume them: integers only. */
@@ -89,6 +95,14 @@ inline void build_adapter(DevAdapter* a, const char* seq, int len) {
     for (int j = 0; j < a->plen; j++) {
         a->peq16_start[(uint8_t)seq[len - a->plen + j]] |= 1u << j;
         a->peq16_end[(uint8_t)seq[j]] |= 1u << j;
+    }
+    {
+        static const uint8_t letters[4] = {'A', 'C', 'T', 'G'};
+        for (int c = 0; c < 4; c++) {
+            a->peq4_full[c] = a->peq_full[letters[c]][0];
+            a->peq4_s16[c] = a->peq16_start[letters[c]];
+            a->peq4_e16[c] = a->peq16_end[letters[c]];
+        }
     }
 }
 

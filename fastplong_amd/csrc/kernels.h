@@ -63,6 +63,10 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_OPT_SCANBATCH
 #define FPL_OPT_SCANBATCH 1 /* k_scan: the middle-adapter confirmations of up to 32 reads in one lane-parallel pass */
 #endif
+#ifndef FPL_OPT_FASTAFILTER
+#define FPL_OPT_FASTAFILTER 1 /* k_trim_ends<2>: a lane-per-adapter Myers search pass over the two end windows decides which
+                                 adapters of the FASTA list get the exact trims at all (fasta_may_trim) */
+#endif
 #ifndef FPL_OPT_SGFILTER
 #define FPL_OPT_SGFILTER 1 /* k_trim_ends_batched: a lane-parallel Myers search pass decides which reads need the
                               partial-pattern search at all (partial16_possible) */
@@ -959,6 +963,81 @@ __device__ __forceinline__ void stage_ends(u32* __restrict__ hs, u32* __restrict
     wave_sync();
 }
 
+/* The FASTA chain (trimByMultiSequences, src/adaptertrimmer.cpp:42-57) tries every adapter at both ends of every read;
+ * with 64 adapters nearly all of those 128 trims find nothing, at full price.  Lane = adapter: ONE pass of Myers' search
+ * recurrence over the <= 200 window bytes (the same byte for every lane, each lane its own Peq words) gives, per adapter,
+ * the smallest edit distance of (a) the whole adapter and (b) its 16-base partial pattern against ANY substring of the
+ * window.  A trim needs a window position whose GLOBAL distance (full adapter: Hamming <= thr, or the candidate's edit
+ * distance <= thr, :84-131; partial pattern: :202-216 / :273-286) is within the threshold, and no global distance is
+ * smaller than the search distance at the window's last byte -- so an adapter whose two minima both stay above their
+ * thresholds cannot trim this end, and the chain skips it.  Anything else gets the exact code, unchanged.
+ * FastaPeqLds: the Peq words of a group of 64 adapters, [letter code | 4 = any other byte: zero][field][lane]. */
+struct FastaPeqLds {
+    u32 w[5][4][64]; /* field 0 / 1: whole adapter, low / high word; 2: last 16 bases; 3: first 16 bases */
+};
+/* this lane's adapter into the table (a_ok: the lane has one) */
+__device__ __forceinline__ void fasta_peq_store(FastaPeqLds* __restrict__ t, const DevAdapter* __restrict__ ad, bool a_ok) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint64_t f = a_ok ? ad->peq4_full[c] : 0ull;
+        t->w[c][0][lane] = (u32)f;
+        t->w[c][1][lane] = (u32)(f >> 32);
+        t->w[c][2][lane] = a_ok ? ad->peq4_s16[c] : 0u;
+        t->w[c][3][lane] = a_ok ? ad->peq4_e16[c] : 0u;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; f++) t->w[4][f][lane] = 0u;
+}
+/* can this lane's adapter (length alen in 16..64, thresholds thrA / thrP) trim at this end?  win = the window bytes in
+   LDS (window byte j at win[j + boff]), n of them; START: the start trim (partial pattern = the adapter's last 16 bases) */
+template <bool START>
+__device__ __forceinline__ bool fasta_may_trim(const FastaPeqLds* __restrict__ t, const u8* __restrict__ win, int boff, int n,
+                                               int alen, int thrA, int thrP, bool a_ok) {
+    const int lane = lane_id();
+    u32 PvL = ~0u, PvH = ~0u, MvL = 0, MvH = 0; /* whole adapter: 64 columns in two words */
+    u32 Pv = 0xFFFFu, Mv = 0;                   /* partial pattern: 16 columns */
+    int scF = alen, scP = 16, bestF = alen, bestP = 16;
+    const u32 topF = (u32)(alen - 1); /* bit of the adapter's last column, 15..63 */
+    for (int j = 0; j < n; j++) {
+        const u32 c = uniform_u32((u32)win[j + boff]); /* the same byte for every lane */
+        const u32 code = (c >> 1) & 3u;
+        const u32 row = (((0x47544341u >> (8 * code)) & 0xFFu) == c) ? code : 4u; /* exactly A / C / T / G, else the zero row */
+        const u32 EqL = t->w[row][0][lane], EqH = t->w[row][1][lane], Eq = t->w[row][START ? 2 : 3][lane];
+        { /* 64 columns; the row above the pattern is all zero (a match may start anywhere) */
+            const u32 XvL = EqL | MvL, XvH = EqH | MvH;
+            const u64 sum = (((u64)(EqH & PvH) << 32) | (EqL & PvL)) + (((u64)PvH << 32) | PvL);
+            const u32 XhL = ((u32)sum ^ PvL) | EqL, XhH = ((u32)(sum >> 32) ^ PvH) | EqH;
+            u32 PhL = MvL | ~(XhL | PvL), PhH = MvH | ~(XhH | PvH);
+            u32 MhL = PvL & XhL, MhH = PvH & XhH;
+            const u64 ph = ((u64)PhH << 32) | PhL, mh = ((u64)MhH << 32) | MhL;
+            scF += (int)((ph >> topF) & 1ull) - (int)((mh >> topF) & 1ull);
+            PhH = (PhH << 1) | (PhL >> 31);
+            PhL <<= 1;
+            MhH = (MhH << 1) | (MhL >> 31);
+            MhL <<= 1;
+            PvL = MhL | ~(XvL | PhL);
+            PvH = MhH | ~(XvH | PhH);
+            MvL = PhL & XvL;
+            MvH = PhH & XvH;
+            bestF = min(bestF, scF);
+        }
+        { /* 16 columns */
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            scP += (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
+            Ph <<= 1;
+            Mh <<= 1;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+            bestP = min(bestP, scP);
+        }
+    }
+    return a_ok && (bestF <= thrA || bestP <= thrP);
+}
+
 /* MODE (DevConfig::trim_mode, chosen by the host): 0 = anything; 1 = no FASTA adapters and command-line adapters of
    16..32 bases; 2 = every adapter (command-line and FASTA) has 16..64 bases.  Modes 1 and 2 leave the global-memory
    paths, the short-pattern variants and the multi-word Levenshtein out (mode 1 also the FASTA chain): a fraction of
@@ -970,6 +1049,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
             ReadState* __restrict__ state, long long* __restrict__ counters, u32 C) {
     __shared__ TrimBlockAcc acc;
     __shared__ TrimLds<WAVES> lds;
+    constexpr bool FILT = MODE == 2 && FPL_OPT_FASTAFILTER != 0;
+    __shared__ FastaPeqLds fpeq[FILT ? WAVES : 1]; /* per wave: the Peq words of the FASTA adapters being filtered */
     const int lane = lane_id();
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x) acc.fr[i] = 0;
     for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x) acc.key[i] = 0;
@@ -982,6 +1063,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     __syncthreads();
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
+    FastaPeqLds* const fp = &fpeq[FILT ? wave_in_block() : 0];
+    int fp_group = -1; /* the group of 64 FASTA adapters whose words fp holds */
     u32* const win_s = lds.win[wave_in_block()][0];  /* head of the read, bases (later: the start trim's window) */
     u32* const win_e = lds.win[wave_in_block()][1];  /* tail of the read, bases (later: the end trim's window) */
     u32* const win_hq = lds.win[wave_in_block()][2]; /* head / tail, qualities */
@@ -1059,6 +1142,33 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                each adapter's 16-column Peq table is copied next to them (4 loads per lane) */
             bool stale_s = true, stale_e = true;
             uint16_t* const pq = lds.peq16w[wave_in_block()];
+            /* which adapters of the current group of 64 can trim the start / the end of r1 as it is now (fasta_may_trim) */
+            u64 may_s = ~0ull, may_e = ~0ull;
+            bool masks_ok = false;
+            auto refresh_masks = [&](int a) {
+                const int g = a >> 6, ai = g * 64 + lane;
+                const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
+                masks_ok = true;
+                if (rlen < FPL_PATTERN_LEN) { /* (no trim looks at an r1 this short) */
+                    may_s = may_e = 0;
+                    return;
+                }
+                if (stale_s) stage_window(win_s, sq + s, wl, seq_end, win4_s);
+                if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end, win4_e);
+                stale_s = stale_e = false;
+                const bool a_ok = ai < cfg->n_fasta;
+                const DevAdapter* la = &ads[2 + (a_ok ? ai : a)];
+                if (g != fp_group) {
+                    wave_sync();
+                    fasta_peq_store(fp, la, a_ok);
+                    wave_sync();
+                    fp_group = g;
+                }
+                const int alen = la->len;
+                const int thrA = cfg->thr[alen], thrP = cfg->thr[FPL_PATTERN_LEN];
+                may_s = wave_ballot(fasta_may_trim<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok));
+                may_e = wave_ballot(fasta_may_trim<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok));
+            };
             for (int a = 0; MODE != 1 && a < cfg->n_fasta; a++) {
                 const DevAdapter* ad = &ads[2 + a];
                 if (MODE == 0 && ad->len > FPL_END_WINDOW) { /* longer than the window: work on the read in global memory */
@@ -1071,7 +1181,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     stale_s = stale_e = true;
                     continue;
                 }
-                {
+                if (FILT && (!masks_ok || (a >> 6) != fp_group)) refresh_masks(a);
+                if (!FILT || ((may_s >> (a & 63)) & 1ull)) {
                     if (stale_s) stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end, win4_s);
                     stale_s = false;
                     wave_sync();
@@ -1081,9 +1192,13 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     const Win<true> wn = {nullptr, win_s, 0, e - s, win4_s};
                     trimmed += trim_start_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
-                    if (s != s0 || e != e0) stale_s = stale_e = true;
+                    if (s != s0 || e != e0) {
+                        stale_s = stale_e = true;
+                        masks_ok = false; /* r1 moved: what can trim it has to be asked again */
+                    }
                 }
-                {
+                if (FILT && !masks_ok) refresh_masks(a);
+                if (!FILT || ((may_e >> (a & 63)) & 1ull)) {
                     const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
                     if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end, win4_e);
                     stale_e = false;
@@ -1094,7 +1209,10 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     const Win<true> wn = {nullptr, win_e, rlen - wl, rlen, win4_e};
                     trimmed += trim_end_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
-                    if (s != s0 || e != e0) stale_s = stale_e = true;
+                    if (s != s0 || e != e0) {
+                        stale_s = stale_e = true;
+                        masks_ok = false;
+                    }
                 }
             }
             if (trimmed > 0 && lane == 0) { /* FilterResult::addReadTrimmed */
@@ -2736,32 +2854,41 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
        through the loop below as a REDO item: same scan, the unsplit bookkeeping taken back, the confirmed positions
        forced. */
     constexpr bool BATCH = FPL_OPT_SCANBATCH != 0;
-    uint64_t v_text = 0; /* lane 2k + a: the window of adapter a of pending read k (global address of its first byte) */
-    int v_pos = -1;      /*             its position in r1 */
-    u32 v_ri = 0;        /*             the read */
-    u32 v_flags = 0;     /* bit 0: the window needs its edit distance; bit 1 (even lanes): the read, if it stays unsplit, still has to go on the EXTRA list */
+    /* lane 2k + a: the window of adapter a of pending read k -- two registers, everything else is read back from the
+       batch when the windows are settled (the wave keeps them through the whole scan loop: every register here is one
+       the scan cannot have) */
+    int v_pos = -1; /* the window's position in r1 */
+    u32 v_rf = 0;   /* the read (bits 0..29; n_reads < 2^30) | bit 30: the window needs its edit distance | bit 31 (even
+                       lanes): the read, if it stays unsplit, still has to go on the EXTRA list */
     u32 npend = 0;       /* pending reads (wave-uniform) */
     u64 redo_mask = 0;   /* bit 2k / 2k + 1: pending read k has a middle adapter 0 / 1 and waits for its second pass */
     auto flush_pending = [&]() {
         if (npend == 0) return;
         const int a = lane & 1;
-        const bool need = (u32)lane < 2 * npend && (v_flags & 1u);
-        const bool ok = lev_lanes32_acgt((const u8*)v_text, a ? ads[1].len : ads[0].len, cfg->thr[a ? ads[1].len : ads[0].len], need,
-                                         peq4[a], seq_end);
+        const bool mine = (u32)lane < 2 * npend;
+        const u32 v_ri = v_rf & 0x3FFFFFFFu;
+        const bool need = mine && (v_rf & 0x40000000u);
+        uint64_t o_r = 0;
+        ReadState rs = {0, 0, 0, 0};
+        if (mine) {
+            o_r = off[v_ri];
+            rs = state[v_ri]; /* (s and e are k_trim_ends' values; this kernel only rewrites `pad`) */
+        }
+        const bool ok = lev_lanes32_acgt(seq + o_r + rs.s + (need ? v_pos : 0), a ? ads[1].len : ads[0].len,
+                                         cfg->thr[a ? ads[1].len : ads[0].len], need, peq4[a], seq_end);
         redo_mask = wave_ballot(ok);
         /* reads that stay as they are and were promised a place on the EXTRA list: their r1 passes unsplit, but starts
            too far into the read for the single statistics pass */
         const bool okn = shfl_down_u32(ok ? 1u : 0u, 1) != 0;
-        const bool want = (u32)lane < 2 * npend && a == 0 && (v_flags & 2u) && !ok && !okn;
+        const bool want = mine && a == 0 && (v_rf & 0x80000000u) && !ok && !okn;
         const u64 wm = wave_ballot(want);
         if (wm) {
             u32 base = 0;
             if (lane == 0) base = atomicAdd(frag_count, (u32)__popcll(wm));
             base = readlane_u32(base, 0);
-            if (want) { /* the fragment is r1 itself: [s, e) of k_trim_ends' record (this kernel only rewrites its `pad`) */
-                const ReadState rs = state[v_ri];
+            if (want) { /* the fragment is r1 itself */
                 const u32 slot = base + (u32)__popcll(wm & ((1ull << lane) - 1ull));
-                frag_off[slot] = off[v_ri] + rs.s;
+                frag_off[slot] = o_r + rs.s;
                 frag_len[slot] = rs.e - rs.s;
             }
         }
@@ -2776,7 +2903,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             const int k = (__ffsll(redo_mask) - 1) >> 1;
             const u64 bits = (redo_mask >> (2 * k)) & 3ull;
             redo_mask &= ~(3ull << (2 * k));
-            ri = readlane_u32(v_ri, 2 * k);
+            ri = readlane_u32(v_rf, 2 * k) & 0x3FFFFFFFu;
             if (bits & 1ull) f_sp = readlane_i32(v_pos, 2 * k);
             if (bits & 2ull) f_ep = readlane_i32(v_pos, 2 * k + 1);
             redo = true;
@@ -3076,9 +3203,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             if (lane == la || lane == la + 1) {
                 const bool second = lane != la;
                 v_pos = (int)(u32)(second ? key1 : key0);
-                v_text = (uint64_t)(rb + s + v_pos);
-                v_ri = ri;
-                v_flags = ((second ? need1 : need0) ? 1u : 0u) | ((!second && pass0 && !to_post) ? 2u : 0u);
+                v_rf = ri | ((second ? need1 : need0) ? 0x40000000u : 0u) | ((!second && pass0 && !to_post) ? 0x80000000u : 0u);
             }
             if (++npend == 32) flush_pending();
         }
