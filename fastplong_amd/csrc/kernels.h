@@ -47,8 +47,10 @@ __device__ unsigned long long g_fpl_prof[64];
 
 /* compile-time A/B switches of individual optimisations (tools/ab_bench.py builds the variants; the defaults ship) */
 #ifndef FPL_OPT_HIST
-#define FPL_OPT_HIST 0 /* histogram counter address by v_and_or_b32 on a 4 KiB-aligned slice (hist_bump): 32 VALU fewer per
-                          tile and 2.5 % SLOWER side by side (profiles/r02_ab): the asm pins the counter updates in place */
+#define FPL_OPT_HIST 2 /* histogram counter address = (bin bits) | (4 KiB-aligned slice + lane copy), hist_bump.  2: written in
+                          plain C, the compiler picks v_and_or_b32 (32 VALU fewer per tile, k_scan 1.4 % faster side by
+                          side); 1: the same through inline asm -- 2.5 % SLOWER (profiles/r02_ab: the asm pins the counter
+                          updates in place); 0: index arithmetic */
 #endif
 #ifndef FPL_OPT_PREFETCH
 #define FPL_OPT_PREFETCH 0 /* k_scan touches the lines of a read's next tile one tile ahead (range_scan_fast): 2 % slower side by side --
@@ -1043,7 +1045,10 @@ __device__ __forceinline__ bool fasta_may_trim(const FastaPeqLds* __restrict__ t
    paths, the short-pattern variants and the multi-word Levenshtein out (mode 1 also the FASTA chain): a fraction of
    the code, fewer scalar registers to spill */
 template <int WAVES, int MODE>
-__global__ void __launch_bounds__(WAVES * 64, MODE == 1 ? FPL_TRIM_WAVES_PER_SIMD_SHORT : FPL_TRIM_WAVES_PER_SIMD)
+/* (MODE 2 with the adapter filter holds two 64-column Myers states per lane next to the exact trims' registers: 4 waves
+   per SIMD, up to 128 VGPRs) */
+__global__ void __launch_bounds__(WAVES * 64, MODE == 1 ? FPL_TRIM_WAVES_PER_SIMD_SHORT
+                                              : (MODE == 2 && FPL_OPT_FASTAFILTER) ? 4 : FPL_TRIM_WAVES_PER_SIMD)
 k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
             uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
             ReadState* __restrict__ state, long long* __restrict__ counters, u32 C) {
@@ -1927,8 +1932,9 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                     SG[g] = readlane_u32(S, bit);
                     EG[g] = readlane_u32(E, bit);
                     TG[g] = readlane_u32(TP, bit);
-                    const uint64_t start = readlane_u64(st, bit);
-                    if (LG[g] > c0 && (!EXTRA || c0 + 8 > SG[g])) {
+                    uint64_t start = readlane_u64(st, bit);
+                    if (FPL_ABL & 8) start &= ~(uint64_t)127; /* (timing experiment: rows on cache-line boundaries) */
+                    if ((FPL_ABL & 16) ? lane == 0 : LG[g] > c0 && (!EXTRA || c0 + 8 > SG[g])) {
                         svG[g] = load8_guard(seq + start + c0, seq_end);
                         qvG[g] = load8_guard(qual + start + c0, qual_end);
                     }
@@ -1984,11 +1990,14 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                 /* one byte.  DO_PRE / DO_POST / FULL are compile-time; FULL: all 8 bytes of every lane belong to
                    the item and (with DO_POST) to r1, 5-mer windows included.  Otherwise bit k of bodymask /
                    kbodymask says whether byte k (its window) lies inside r1. */
+/* the increment of byte k + 1 is fetched before the updates of byte k are issued: LDS operations of a wave finish in
+   order, so a table read issued AFTER three atomics (and waited for) would stall the wave for all of them, eight times
+   per row */
+#define FPL_FS_Q(k) ((qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF)
+                u64 inc_n = inc_of[FPL_FS_Q(0)];
 #define FPL_FS_BYTE(k, DO_PRE, DO_POST, FULL)                                                                     \
     if (FULL || (k) < nvalid) {                                                                                   \
         const u32 bb = (sw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                    \
-        const u32 q = (qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                     \
-        const u64 inc = inc_of[q];                                                                                \
         const u32 cell = mad_u24(bb & 7u, FS_STRIDE, lane);                                                       \
         if (DO_PRE && !(FPL_ABL & 1)) atomicAdd(&tbl[cell + (k)*64], inc);                                        \
         if (DO_POST && !(FPL_ABL & 2)) {                                                                          \
@@ -2014,10 +2023,18 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                     const u32 bodymask = range_mask8(s - p0, e - p0), kbodymask = range_mask8(s + 4 - p0, e - p0);
                     if ((int)tile_start >= s + 4 && itemL >= tile_start + FS_T) {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, false, true, true)
+                        for (int k = 0; k < 8; k++) {
+                            const u64 inc = inc_n;
+                            if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];
+                            FPL_FS_BYTE(k, false, true, true)
+                        }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, false, true, false)
+                        for (int k = 0; k < 8; k++) {
+                            const u64 inc = inc_n;
+                            if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];
+                            FPL_FS_BYTE(k, false, true, false)
+                        }
                     }
                 } else if (tp && (int)tile_start >= s + 4 && (int)(tile_start + FS_T) <= e) {
                     /* wave-uniform: the whole tile lies inside r1 (and inside the read) */
@@ -2025,24 +2042,41 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                     (void)bodymask;
                     (void)kbodymask;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, true, true)
+                    for (int k = 0; k < 8; k++) {
+                            const u64 inc = inc_n;
+                            if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];
+                            FPL_FS_BYTE(k, true, true, true)
+                        }
                 } else if (tp) { /* a tile that straddles an end of r1 */
                     const u32 bodymask = range_mask8(s - p0, e - p0), kbodymask = range_mask8(s + 4 - p0, e - p0);
 #pragma unroll
-                    for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, true, false)
+                    for (int k = 0; k < 8; k++) {
+                            const u64 inc = inc_n;
+                            if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];
+                            FPL_FS_BYTE(k, true, true, false)
+                        }
                 } else { /* pre only (dropped, failed, split or far-trimmed read) */
                     const u32 bodymask = 0, kbodymask = 0;
                     (void)bodymask;
                     (void)kbodymask;
                     if (itemL >= tile_start + FS_T) {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, false, true)
+                        for (int k = 0; k < 8; k++) {
+                            const u64 inc = inc_n;
+                            if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];
+                            FPL_FS_BYTE(k, true, false, true)
+                        }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) FPL_FS_BYTE(k, true, false, false)
+                        for (int k = 0; k < 8; k++) {
+                            const u64 inc = inc_n;
+                            if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];
+                            FPL_FS_BYTE(k, true, false, false)
+                        }
                     }
                 }
 #undef FPL_FS_BYTE
+#undef FPL_FS_Q
             }
         }
     }
@@ -2463,7 +2497,11 @@ __device__ __forceinline__ void hist_bump(const HistLane& hl, u32 qd) {
 #else
     typedef __attribute__((address_space(3))) u32 lds_u32;
     const u32 sh = K == 0 ? (qd << 5) : (qd >> (8 * K - 5));
+#if FPL_OPT_HIST == 2
+    const u32 a = (sh & 0xfe0u) | hl.addr; /* (plain C: the compiler picks v_and_or_b32 and keeps its freedom to schedule) */
+#else
     const u32 a = and_or(sh, 0xfe0u, hl.addr);
+#endif
     __hip_atomic_fetch_add((lds_u32*)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 }

@@ -106,6 +106,30 @@ def test_hifi_like_64_adapters_bit_exact(orc, engine_mod):
     _run_both(orc, engine_mod, cfgd, seq, qual, off, fasta=sorted(ads))
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_FUZZ_FASTA", "8")))))
+def test_random_fasta_sets_of_16_to_64_mers_bit_exact(orc, engine_mod, seed):
+    """adapter sets made of 16..64-base ACGT adapters only (k_trim_ends<2>: the lane-per-adapter filter in front of the exact
+    trims, fasta_may_trim) -- 1, 3, 64, 65 and 130 FASTA adapters (one, two and three groups of 64 lanes), mutated /
+    truncated copies near both ends, every ed_max; FPL_FUZZ_FASTA=<n> widens it for a soak"""
+    rng = np.random.default_rng(52000 + seed)
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, int(n)))  # noqa: E731
+    n_fa = int(rng.choice([1, 3, 64, 65, 130]))
+    fasta = [rnd(rng.choice([16, 17, 24, 31, 32, 33, 40, 48, 63, 64])) for _ in range(n_fa)]
+    if rng.random() < 0.5:  # near-duplicates: several adapters of a group can trim the same end, the first in list order wins
+        fasta += [f[:int(rng.integers(16, len(f) + 1))] for f in fasta[:4]]
+    start, end = rnd(rng.choice([16, 24, 32, 33, 64])), rnd(rng.choice([16, 27, 32, 45, 64]))
+    opt = dict(ed_max=float(rng.choice([0.0, 0.1, 0.25, 0.4])), trimming_extension=int(rng.choice([0, 10, 30])),
+               cut_front=int(rng.integers(2)), polyx=int(rng.integers(2)))
+    a = synth.adversarial(400, seed=seed, start_adapter=start, end_adapter=end, fasta=fasta)
+    b = synth.hifi_like(12, seed=seed, mean_len=3000, sd_len=800, n_adapters=4)[:3]
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
+    res, cnt = _run_both(orc, engine_mod, dict(opt=opt, start=start, end=end), seq, qual, off, fasta=fasta)
+    assert (res["r1_start"] > 0).any()
+
+
 def _lowq_ont_like(n, seed, median_len=3000):
     """ONT-like reads whose qualities dip far below the --break / --mask thresholds in stretches"""
     rng = np.random.default_rng(seed)
