@@ -38,6 +38,11 @@ struct fpl_ctx {
     u32* d_frag_cyc = nullptr;
     BmLists bm = {nullptr, nullptr, 0, 0, 0, nullptr};
     size_t scratch_slabs = 0;
+    u32* d_sort_ws = nullptr;       /* k_stats_sorted: bucket counters and the slice table */
+    size_t sort_ws_cap = 0;         /* words */
+    uint64_t* d_st_off = nullptr;   /* the reads in sorted order (ws_reads each) */
+    u32* d_st_len = nullptr;
+    u32* d_st_e = nullptr;
     u64* d_stats_scratch = nullptr;
     u8* d_stats_flags = nullptr;
     /* staging for the host-pointer entry points: FPL_MAX_IN_FLIGHT slots, so that the copies of one batch
@@ -205,7 +210,8 @@ void fpl_destroy(fpl_ctx* ctx) {
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->d_cfg, ctx->d_ads, ctx->d_counters, ctx->d_state, ctx->d_frag_off, ctx->d_frag_len,
                     ctx->d_work_ctr, ctx->d_stats_scratch,
-                    ctx->d_stats_flags, ctx->d_frag_cyc, ctx->bm.frags, ctx->bm.regs, ctx->bm.counts};
+                    ctx->d_stats_flags, ctx->d_frag_cyc, ctx->bm.frags, ctx->bm.regs, ctx->bm.counts,
+                    ctx->d_sort_ws, ctx->d_st_off, ctx->d_st_len, ctx->d_st_e};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& sl : ctx->slot) {
@@ -390,6 +396,20 @@ static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_r
     return FPL_OK;
 }
 
+static int ensure_sort_ws(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes) {
+    const u32 per = stats_items_per_slice(n_reads, n_reads ? (u32)(n_bytes / n_reads) : 0, ctx->n_cu, ctx->tune);
+    const size_t words = sort_ws_words(stats_sorted_max_slices(n_reads, per, ctx->tune), n_reads);
+    if (words <= ctx->sort_ws_cap) return FPL_OK;
+    FPL_HIP(hipDeviceSynchronize());
+    if (ctx->d_sort_ws) (void)hipFree(ctx->d_sort_ws);
+    ctx->d_sort_ws = nullptr;
+    ctx->sort_ws_cap = 0;
+    const size_t cap = words + words / 4;
+    FPL_HIP(hipMalloc((void**)&ctx->d_sort_ws, cap * sizeof(u32)));
+    ctx->sort_ws_cap = cap;
+    return FPL_OK;
+}
+
 /* the fragment / region / piece lists of k_break_mask: capacities grow (25 % headroom) and never shrink, so that a
    run whose batches differ a little in size does not reallocate -- and wait for the device -- on every batch */
 static int ensure_break_mask(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes) {
@@ -432,6 +452,14 @@ static int ensure_workspace(fpl_ctx* ctx, u32 n_reads) {
     ctx->d_state = nullptr;
     ctx->ws_reads = 0;
     FPL_HIP(hipMalloc((void**)&ctx->d_state, sizeof(ReadState) * (size_t)n_reads));
+    if (ctx->d_st_off) (void)hipFree(ctx->d_st_off);
+    if (ctx->d_st_len) (void)hipFree(ctx->d_st_len);
+    if (ctx->d_st_e) (void)hipFree(ctx->d_st_e);
+    ctx->d_st_off = nullptr;
+    ctx->d_st_len = ctx->d_st_e = nullptr;
+    FPL_HIP(hipMalloc((void**)&ctx->d_st_off, sizeof(uint64_t) * (size_t)n_reads));
+    FPL_HIP(hipMalloc((void**)&ctx->d_st_len, sizeof(u32) * (size_t)n_reads));
+    FPL_HIP(hipMalloc((void**)&ctx->d_st_e, sizeof(u32) * (size_t)n_reads));
     if (!ctx->hcfg.defer) { /* (with --break / --mask the item list is sized by ensure_break_mask) */
         if (ctx->d_frag_off) (void)hipFree(ctx->d_frag_off);
         if (ctx->d_frag_len) (void)hipFree(ctx->d_frag_len);
@@ -461,6 +489,8 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         if (r != FPL_OK) return r;
         r = ensure_scratch(ctx, n_reads, n_bytes, max_read_len);
         if (r != FPL_OK) return r;
+        r = ensure_sort_ws(ctx, n_reads, n_bytes);
+        if (r != FPL_OK) return r;
         r = ensure_break_mask(ctx, n_reads, n_bytes);
         if (r != FPL_OK) return r;
         FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, 4 * sizeof(u32), stream));
@@ -487,6 +517,10 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.counters = ctx->d_counters;
     a.C = ctx->C;
     a.work_ctr = ctx->d_work_ctr;
+    a.sort_ws = ctx->d_sort_ws;
+    a.st_off = ctx->d_st_off;
+    a.st_len = ctx->d_st_len;
+    a.st_e = ctx->d_st_e;
     a.stats_scratch = ctx->d_stats_scratch;
     a.stats_flags = ctx->d_stats_flags;
     a.n_cu = ctx->n_cu;
@@ -689,5 +723,11 @@ extern "C" int fpl_debug_prof(unsigned long long* out, int n) {
     memset(tmp, 0, sizeof(tmp));
     if (hipMemcpyToSymbol(HIP_SYMBOL(fpl::g_fpl_prof), tmp, sizeof(tmp)) != hipSuccess) return -1;
     return 0;
+}
+#endif
+
+#ifdef FPL_PROF_BLOCKS
+extern "C" int fpl_debug_read_blockprof(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fpl::g_blockprof), bytes) == hipSuccess ? 0 : -1;
 }
 #endif

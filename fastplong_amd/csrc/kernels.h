@@ -52,6 +52,10 @@ __device__ unsigned long long g_fpl_prof[64];
                           side); 1: the same through inline asm -- 2.5 % SLOWER (profiles/r02_ab: the asm pins the counter
                           updates in place); 0: index arithmetic */
 #endif
+#ifndef FPL_OPT_SORTSTATS
+#define FPL_OPT_SORTSTATS 1 /* the statistics pass walks the reads sorted by their front trim: one table update per base instead
+                               of two (k_stats_sorted) */
+#endif
 #ifndef FPL_OPT_PREFETCH
 #define FPL_OPT_PREFETCH 0 /* k_scan touches the lines of a read's next tile one tile ahead (range_scan_fast): 2 % slower side by side --
                               the other waves of the SIMD already cover the trip to HBM */
@@ -1789,7 +1793,7 @@ __device__ __forceinline__ void fs_hand_over(const u64* tbl, const u32* kpre, co
         flags[gridDim.y + slab] = 1;
         flags[blockIdx.y] = 1; /* this tile has at least one slab */
     }
-    for (u32 i = threadIdx.x; i < 1024; i += blockDim.x) {
+    for (u32 i = threadIdx.x; i < 1024 && !(FPL_ABL & 64); i += blockDim.x) {
         const u32 both = kpost[i], pre_only = EXTRA ? 0u : kpre[i]; /* (EXTRA: kpost is post-only) */
         if (!EXTRA && both + pre_only) atomicAdd((u64*)&kg0[i], (u64)both + pre_only);
         if (both) atomicAdd((u64*)&kg1[i], (u64)both);
@@ -1820,6 +1824,7 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
     u32& any_work = kpost[0]; /* (2 x 81920 bytes of LDS per CU: no room for one more word) */
     const int lane = lane_id();
     if (EXTRA) n_items = *n_items_dev;
+    if ((FPL_ABL & 32) && !EXTRA && blockIdx.y >= 48) return;
     const u32 tile_start = blockIdx.y * FS_T;
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
@@ -3251,6 +3256,420 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     flush_frags();
     __syncthreads();
     scan_acc_flush(acc, counters, C);
+}
+
+/* =========================================================================================
+ * The statistics pass over reads SORTED BY THEIR FRONT TRIM (FPL_OPT_SORTSTATS).
+ *
+ * k_stats above spends two table updates per base: pre cycle p and post cycle p - s.  The second one exists only because
+ * s differs from read to read.  Statistics are sums, so the reads may be taken in any order and in any grouping: when
+ * every read of a slice has the SAME front trim s, the slice's post-filter table is its pre-filter table shifted by s,
+ * minus the bases behind the reads' ends e -- so a block keeps the pre table (one update per base, as before) and a
+ * "not post" table that only the bases at p >= e touch, and k_stats_reduce_sorted computes
+ *      pre[c]  += slab.pre[c]           post[c - s] += slab.pre[c] - slab.notpost[c]   (c >= s)
+ * per slab.  Buckets: front trim 0..FS_SMAX (a read k_scan marked PLAN_TO_POST), and one for the reads that are not
+ * counted post-filter by this pass at all (dropped, failed, split or far-trimmed reads).  A front trim that too few reads
+ * of the batch share (StatsTune::min_bucket) is not worth a slab per cycle tile: those reads are filed under "not post"
+ * and handed to the EXTRA pass instead, like the far-trimmed ones.
+ *   k_bucket_count    reads per bucket
+ *   k_bucket_plan     bucket -> range of the sorted order, ranges -> slices of <= `per` reads (device-side table)
+ *   k_bucket_scatter  (start, length, e) of every read into its bucket's range (order inside a bucket: arbitrary)
+ *   k_stats_sorted    block = (slice, cycle tile)
+ *   k_stats_reduce_sorted
+ * ======================================================================================= */
+constexpr int FS_NB = FS_SMAX + 2;        /* buckets */
+constexpr int FS_B_NOPOST = FS_SMAX + 1;  /* the bucket of the reads this pass does not count post-filter */
+/* sort workspace (u32 words; the first SW_SLICES are zeroed before every batch) */
+constexpr int SW_CNT = 0;                /* [FS_NB] reads per bucket */
+constexpr int SW_CUR = FS_NB;            /* [FS_NB] next free position of the range of bucket b */
+constexpr int SW_MAP = 2 * FS_NB;        /* [FS_NB] the bucket that bucket b is filed under: b, or FS_B_NOPOST when too small */
+constexpr int SW_NSLICES = 3 * FS_NB;    /* slices in the table */
+constexpr int SW_WORK = 3 * FS_NB + 1;   /* k_stats_sorted: the next (tile, slice) item */
+constexpr int SW_SLICES = 3 * FS_NB + 2; /* [slices][4]: begin, end (positions of the sorted order), front trim + 1 (0: not
+                                            post-filter), unused */
+constexpr int FS_BSTRIDE = 2 * FS_T;     /* LDS cells per base class: [FS_T pre | FS_T not-post] */
+
+__device__ __forceinline__ u32 plan_bucket(const ReadState& st) {
+    return (st.pad & PLAN_TO_POST) ? st.s : (u32)FS_B_NOPOST; /* (PLAN_TO_POST implies s <= FS_SMAX) */
+}
+
+/* one block per FS_SORT_BLK consecutive reads; blkcnt[b][block] = the block's reads of bucket b */
+constexpr int FS_SORT_BLK = 256;
+__global__ void __launch_bounds__(FS_SORT_BLK)
+k_bucket_count(const ReadState* __restrict__ plan, u32 n_reads, u32* __restrict__ sw, u32* __restrict__ blkcnt) {
+    __shared__ u32 h[FS_NB];
+    if (threadIdx.x < FS_NB) h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 it = blockIdx.x * FS_SORT_BLK + threadIdx.x;
+    if (it < n_reads) atomicAdd(&h[plan_bucket(plan[it])], 1u);
+    __syncthreads();
+    if (threadIdx.x < FS_NB) {
+        blkcnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+        if (h[threadIdx.x]) atomicAdd(&sw[SW_CNT + threadIdx.x], h[threadIdx.x]);
+    }
+}
+
+/* blkcnt[b][*] -> its exclusive prefix sums: where, inside bucket b's range, the reads of every block go.  The sorted
+   order is then ascending in the input inside every bucket -- a slice walks the batch front to back like the unsorted
+   pass does, instead of hopping between whatever blocks happened to reserve their places one after another (measured
+   with 18 GB batches: the hopping costs more address-translation misses than the saved table updates are worth) */
+__global__ void __launch_bounds__(256)
+k_bucket_scan(u32* __restrict__ blkcnt, u32 nblk) {
+    __shared__ u32 wsum[4];
+    u32* row = blkcnt + (size_t)blockIdx.x * nblk;
+    const u32 chunk = (nblk + 255u) / 256u;
+    const u32 lo = min(nblk, threadIdx.x * chunk), hi = min(nblk, lo + chunk);
+    u32 sum = 0;
+    for (u32 i = lo; i < hi; i++) sum += row[i];
+    const u32 incl = wave_scan_incl_u32(sum);
+    if (lane_id() == 63) wsum[wave_in_block()] = incl;
+    __syncthreads();
+    u32 run = incl - sum;
+    for (int w = 0; w < wave_in_block(); w++) run += wsum[w];
+    for (u32 i = lo; i < hi; i++) {
+        const u32 v = row[i];
+        row[i] = run;
+        run += v;
+    }
+}
+
+/* one thread: 98 buckets */
+__global__ void __launch_bounds__(128)
+k_bucket_plan(u32* __restrict__ sw, u32 per, u32 min_bucket, u32 max_slices) {
+    __shared__ u32 cnt[FS_NB];
+    for (u32 b = threadIdx.x; b < (u32)FS_NB; b += blockDim.x) cnt[b] = sw[SW_CNT + b];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    u32 nopost = cnt[FS_B_NOPOST];
+    for (int b = 0; b <= FS_SMAX; b++) {
+        const u32 c = cnt[b];
+        const bool own = c >= min_bucket && c > 0;
+        sw[SW_MAP + b] = own ? (u32)b : (u32)FS_B_NOPOST;
+        if (!own) {
+            nopost += c;
+            cnt[b] = 0;
+        }
+    }
+    sw[SW_MAP + FS_B_NOPOST] = FS_B_NOPOST;
+    cnt[FS_B_NOPOST] = nopost;
+    u32 pos = 0, ns = 0;
+    for (int b = 0; b < FS_NB; b++) {
+        const u32 c = cnt[b];
+        sw[SW_CUR + b] = pos;
+        if (c) {
+            const u32 k = (c + per - 1) / per;
+            const u32 pb = (((c + k - 1) / k) + 63u) / 64u * 64u; /* <= per: per is a multiple of 64 */
+            for (u32 i = 0; i < k; i++) {
+                const u32 begin = pos + i * pb, end = min(pos + c, begin + pb);
+                if (begin < end && ns < max_slices) {
+                    u32* e = sw + SW_SLICES + 4 * ns++;
+                    e[0] = begin;
+                    e[1] = end;
+                    e[2] = b == FS_B_NOPOST ? 0u : (u32)b + 1u;
+                    e[3] = 0;
+                }
+            }
+        }
+        pos += c;
+    }
+    sw[SW_NSLICES] = ns;
+}
+
+__global__ void __launch_bounds__(FS_SORT_BLK)
+k_bucket_scatter(const uint64_t* __restrict__ off, const ReadState* __restrict__ plan, u32 n_reads, u32* __restrict__ sw,
+                 const u32* __restrict__ blkoff,
+                 uint64_t* __restrict__ st_off, u32* __restrict__ st_len, u32* __restrict__ st_e,
+                 uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, u32* __restrict__ frag_count) {
+    __shared__ u32 h[FS_NB], base[FS_NB], nextra, xbase;
+    if (threadIdx.x < FS_NB) h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) nextra = 0;
+    __syncthreads();
+    const u32 it = blockIdx.x * blockDim.x + threadIdx.x;
+    ReadState st = {0, 0, 0, 0};
+    u32 b = 0, rank = 0, xr = 0;
+    bool handed = false; /* a passing read whose front trim is too rare for a slice of its own: post-filter through EXTRA */
+    if (it < n_reads) {
+        st = plan[it];
+        const u32 b0 = plan_bucket(st);
+        b = sw[SW_MAP + b0];
+        rank = atomicAdd(&h[b], 1u);
+        handed = b0 != (u32)FS_B_NOPOST && b == (u32)FS_B_NOPOST;
+        if (handed) xr = atomicAdd(&nextra, 1u);
+    }
+    __syncthreads();
+    /* a bucket with slices of its own: this block's place in the range (k_bucket_scan); "not post" collects reads of
+       several source buckets and hands its places out as the blocks come (few reads, any order) */
+    if (threadIdx.x < FS_NB && h[threadIdx.x])
+        base[threadIdx.x] = threadIdx.x == FS_B_NOPOST ? atomicAdd(&sw[SW_CUR + FS_B_NOPOST], h[threadIdx.x])
+                                                       : sw[SW_CUR + threadIdx.x] + blkoff[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+    if (threadIdx.x == 0 && nextra) xbase = atomicAdd(frag_count, nextra);
+    __syncthreads();
+    if (it < n_reads) {
+        const u32 pos = base[b] + rank;
+        const uint64_t o = off[it];
+        st_off[pos] = o;
+        st_len[pos] = (u32)(off[it + 1] - o);
+        st_e[pos] = st.e;
+        if (handed) {
+            frag_off[xbase + xr] = o + st.s;
+            frag_len[xbase + xr] = st.e - st.s;
+        }
+    }
+}
+
+#ifdef FPL_PROF_BLOCKS
+/* profiling only: when every block of k_stats_sorted ran, and where (tools/block_timeline.py) */
+__device__ unsigned long long g_blockprof[1 << 17][2];
+#endif
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, (2 * WAVES + 3) / 4)
+k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_bytes,
+               const uint64_t* __restrict__ st_off, const u32* __restrict__ st_len, const u32* __restrict__ st_e,
+               u32* __restrict__ sw, u32 max_slices, u32 n_tiles, long long* __restrict__ counters,
+               u64* __restrict__ scratch, u8* __restrict__ flags, u32 C) {
+    (void)C;
+    __shared__ u64 lds_all[1024 + 256 + 8 * FS_BSTRIDE];
+    static_assert(sizeof(u64) * (1024 + 256 + 8 * FS_BSTRIDE) <= 81920, "two blocks per CU");
+    u32* const kmer = (u32*)lds_all; /* [0,1024): 5-mers counted pre-filter only; [1024,2048): pre- AND post-filter */
+    u64* const inc_of = lds_all + 1024;
+    u64* const tbl = inc_of + 256; /* [8][FS_T pre | FS_T not-post] */
+    u32* const kpre = kmer;
+    u32* const kpost = kmer + 1024;
+    __shared__ u32 any_work, cur_item;
+    const int lane = lane_id();
+    const u8* seq_end = seq + n_bytes;
+    const u8* qual_end = qual + n_bytes;
+    long long* kg0 = counters + FPL_OFF_PRE(C) + FPL_ST_KMER(C);
+    long long* kg1 = counters + FPL_OFF_POST(C) + FPL_ST_KMER(C);
+    for (u32 q = threadIdx.x; q < 256; q += blockDim.x)
+        inc_of[q] = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);
+    const u32 n_slices = uniform_u32(sw[SW_NSLICES]);
+    const u32 n_items = n_slices * n_tiles;
+    /* The blocks are persistent (two per CU) and take (tile, slice) items off one counter, tile by tile -- the heavy low
+       tiles first.  A grid of one block per item leaves a fifth of the chip idle: the hardware hands blocks to the XCDs
+       in turn and in order, so every XCD waits for the one whose slots are all taken by long blocks (block timeline in
+       profiles/r02_ab) */
+    for (;;) {
+    __syncthreads(); /* (everybody is done with the previous item's tables and cur_item) */
+    if (threadIdx.x == 0) {
+        cur_item = atomicAdd(&sw[SW_WORK], 1u);
+        any_work = 0;
+    }
+    __syncthreads();
+    const u32 item = cur_item;
+    if (item >= n_items) break; /* block-uniform */
+    const u32 tile = item / n_slices, slice = item - tile * n_slices;
+#ifdef FPL_PROF_BLOCKS
+    const unsigned long long prof_t0 = wall_clock64();
+#endif
+    const u32 i_begin = uniform_u32(sw[SW_SLICES + 4 * slice]), i_end = uniform_u32(sw[SW_SLICES + 4 * slice + 1]);
+    const u32 sp1 = uniform_u32(sw[SW_SLICES + 4 * slice + 2]);
+    const bool tp = sp1 != 0;            /* the slice's reads pass unsplit, all with ... */
+    const int s = tp ? (int)sp1 - 1 : 0; /* ... this front trim */
+    const u32 tile_start = tile * FS_T;
+    const u32 c0 = tile_start + 8 * lane;
+    {
+        bool mine = false;
+        for (u32 it = i_begin + threadIdx.x; it < i_end; it += blockDim.x) mine = mine || (st_len[it] > tile_start);
+        if (wave_ballot(mine) && lane == 0) any_work = 1;
+    }
+    __syncthreads();
+    if (!any_work) continue; /* block-uniform */
+    for (u32 i = threadIdx.x; i < 8 * FS_BSTRIDE; i += blockDim.x) tbl[i] = 0;
+    for (u32 i = threadIdx.x; i < 2048; i += blockDim.x) kmer[i] = 0;
+    __syncthreads();
+
+    for (u32 ib = i_begin + 64 * wave_in_block(); ib < i_end; ib += 64 * WAVES) {
+        const u32 it = ib + lane;
+        u32 L = 0, E = 0;
+        uint64_t st = 0;
+        if (it < i_end) {
+            st = st_off[it];
+            L = st_len[it];
+            E = st_e[it];
+        }
+        u64 m = wave_ballot(L > tile_start);
+        while (m) {
+            u32x2 svG[CS_GROUP], qvG[CS_GROUP];
+            u32 haloG[CS_GROUP], LG[CS_GROUP], EG[CS_GROUP];
+#pragma unroll
+            for (int g = 0; g < CS_GROUP; g++) {
+                svG[g] = {0, 0};
+                qvG[g] = {0, 0};
+                haloG[g] = 0;
+                LG[g] = EG[g] = 0;
+                if (m) {
+                    const int bit = __ffsll(m) - 1;
+                    m &= m - 1;
+                    LG[g] = readlane_u32(L, bit);
+                    EG[g] = readlane_u32(E, bit);
+                    const uint64_t start = readlane_u64(st, bit);
+                    if (LG[g] > c0) {
+                        svG[g] = load8_guard(seq + start + c0, seq_end);
+                        qvG[g] = load8_guard(qual + start + c0, qual_end);
+                    }
+                    if (lane == 0 && tile_start >= 4) haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < CS_GROUP; g++) {
+                const u32 itemL = uniform_u32(LG[g]);
+                if (itemL <= tile_start) continue; /* wave-uniform: empty slot of the last group */
+                const u32 sw2[2] = {svG[g].x, svG[g].y};
+                const u32 qw[2] = {qvG[g].x, qvG[g].y};
+                const int e = (int)uniform_u32(EG[g]);
+                const int nvalid = itemL > c0 ? (int)min(8u, itemL - c0) : 0;
+                const u32 up = shfl_up_u32(sw2[1], 1);
+                const bool have_halo = lane > 0 || tile_start >= 4;
+                const u32 halo = lane > 0 ? up : haloG[g];
+                const u32 vh = kmer_codes(halo), v0 = kmer_codes(sw2[0]), v1 = kmer_codes(sw2[1]);
+                const u32 W = perm_b32(kmer_pack(vh), perm_b32(kmer_pack(v0), kmer_pack(v1), 0x0c0c0703u), 0x0c070100u);
+                u32 okmask;
+                {
+                    const u32 m0 = perm_lo(0x47435441u, v0), m1 = perm_lo(0x47435441u, v1), mh = perm_lo(0x47435441u, vh);
+                    u32 bad = (m0 ^ sw2[0]) | (m1 ^ sw2[1]);
+                    if (have_halo) bad |= mh ^ halo;
+                    if (!wave_ballot(nvalid > 0 && bad != 0)) {
+                        okmask = have_halo ? 0xFFu : 0xF0u;
+                    } else {
+                        const u32 ih = have_halo ? invalid_nibble(mh, halo) : 0xFu;
+                        const u32 inv = lshl_or<8>(invalid_nibble(m1, sw2[1]), lshl_or<4>(invalid_nibble(m0, sw2[0]), ih));
+                        const u32 r = inv | (inv >> 1) | (inv >> 2) | (inv >> 3) | (inv >> 4);
+                        okmask = ~r & 0xFFu;
+                    }
+                    okmask &= (1u << nvalid) - 1u;
+                }
+                const int p0 = (int)c0;
+                /* one byte.  NPM: bit k of npmask says whether byte k lies behind the end of r1 (it then also goes to the
+                   not-post table); KM: the byte's 5-mer window is counted 0 pre-filter only, 1 pre- and post-filter, 2 as
+                   bit k of kbodymask says */
+#define FPL_FS_Q(k) ((qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF)
+                u64 inc_n = inc_of[FPL_FS_Q(0)];
+#define FPL_FB_BYTE(k, NPM, KM, FULL)                                                                             \
+    if (FULL || (k) < nvalid) {                                                                                   \
+        const u32 bb = (sw2[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                   \
+        const u32 cell = mad_u24(bb & 7u, FS_BSTRIDE, lane);                                                      \
+        atomicAdd(&tbl[cell + (k)*64], inc);                                                                      \
+        if (NPM && ((npmask >> (k)) & 1u)) atomicAdd(&tbl[cell + (k)*64 + FS_T], inc);                            \
+        const u32 kidx = (W >> (2 * (7 - (k)))) & 0x3FFu;                                                         \
+        const u32 kval = (okmask >> (k)) & 1u;                                                                    \
+        if (KM == 1)                                                                                              \
+            atomicAdd(&kmer[1024u + kidx], kval);                                                                 \
+        else if (KM == 0)                                                                                         \
+            atomicAdd(&kmer[kidx], kval);                                                                         \
+        else                                                                                                      \
+            atomicAdd(&kmer[(((kbodymask >> (k)) & 1u) << 10) + kidx], kval);                                     \
+    }
+#define FPL_FB_ROW(NPM, KM, FULL)                                                                                 \
+    _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                               \
+        const u64 inc = inc_n;                                                                                    \
+        if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];                                                               \
+        FPL_FB_BYTE(k, NPM, KM, FULL)                                                                             \
+    }
+                if (tp && (int)tile_start >= s + 4 && (int)(tile_start + FS_T) <= e) {
+                    /* wave-uniform: the whole tile lies inside r1 (and inside the read) */
+                    const u32 npmask = 0, kbodymask = 0xFFu;
+                    (void)npmask;
+                    (void)kbodymask;
+                    FPL_FB_ROW(false, 1, true)
+                } else if (tp) { /* a tile that holds an end of r1 */
+                    const u32 npmask = ~range_mask8(-1, e - p0) & 0xFFu, kbodymask = range_mask8(s + 4 - p0, e - p0);
+                    FPL_FB_ROW(true, 2, false)
+                } else { /* not counted post-filter */
+                    const u32 npmask = 0, kbodymask = 0;
+                    (void)npmask;
+                    (void)kbodymask;
+                    if (itemL >= tile_start + FS_T) {
+                        FPL_FB_ROW(false, 0, true)
+                    } else {
+                        FPL_FB_ROW(false, 0, false)
+                    }
+                }
+#undef FPL_FB_ROW
+#undef FPL_FB_BYTE
+#undef FPL_FS_Q
+            }
+        }
+    }
+    __syncthreads();
+    /* hand-over: the two tables as one slab (pre cells, then not-post cells, both in LDS slot order) */
+    const size_t slab = (size_t)tile * max_slices + slice;
+    u64* dst = scratch + slab * FS_SLAB;
+    for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) {
+        const u32 cell = (i / FS_T) * FS_BSTRIDE + (i % FS_T);
+        dst[i] = tbl[cell];
+        if (tp) dst[8 * FS_T + i] = tbl[cell + FS_T];
+    }
+    if (threadIdx.x == 0) {
+        flags[n_tiles + slab] = 1;
+        flags[tile] = 1;
+#ifdef FPL_PROF_BLOCKS
+        if (item < (1u << 17)) {
+            g_blockprof[item][0] = prof_t0;
+            g_blockprof[item][1] = (wall_clock64() << 8) | (__builtin_amdgcn_s_getreg(6164) & 0xF);
+        }
+#endif
+    }
+    for (u32 i = threadIdx.x; i < 1024 && !(FPL_ABL & 64); i += blockDim.x) {
+        const u32 both = kpost[i], pre_only = kpre[i];
+        if (both + pre_only) atomicAdd((u64*)&kg0[i], (u64)both + pre_only);
+        if (both) atomicAdd((u64*)&kg1[i], (u64)both);
+    }
+    }
+}
+
+/* Sum the slabs of one k_stats_sorted launch into the per-cycle counters (grid as k_stats_reduce: x = chunk of 256 cells,
+ * y = tile).  A post cycle c of tile t takes, from every slice with a front trim s, cycle c + s of the slice's slab of tile
+ * t or t + 1: pre minus not-post. */
+__global__ void __launch_bounds__(256)
+k_stats_reduce_sorted(const u64* __restrict__ scratch, const u8* __restrict__ flags, const u32* __restrict__ sw,
+                      u32 max_slices, u32 n_tiles, long long* __restrict__ counters, u32 C) {
+    const u32 tile = blockIdx.y;
+    const u32 cell = blockIdx.x * 256 + threadIdx.x;
+    const bool is_post = cell >= 8 * FS_T;
+    const u8* slab_flags = flags + n_tiles;
+    const bool here = flags[tile] != 0, next = tile + 1 < n_tiles && flags[tile + 1] != 0;
+    if (!here && !next) return;
+    const u32 n_slices = sw[SW_NSLICES];
+    const u32 cc = is_post ? cell - 8 * FS_T : cell;
+    const u32 cls = cc / FS_T, x = cc % FS_T;
+    u64 qsum = 0, cnt = 0, q20 = 0, q30 = 0;
+    if (!is_post) {
+        if (!here) return;
+        const u32 slot = (x & 7) * 64 + (x >> 3);
+        for (u32 sl = 0; sl < n_slices; sl++) {
+            const size_t slab = (size_t)tile * max_slices + sl;
+            if (!slab_flags[slab]) continue;
+            fs_unpack_add(scratch[slab * FS_SLAB + cls * FS_T + slot], qsum, cnt, q20, q30);
+        }
+    } else {
+        u64 nsum = 0, ncnt = 0, n20 = 0, n30 = 0; /* what lies behind the reads' ends */
+        for (u32 sl = 0; sl < n_slices; sl++) {
+            const u32 sp1 = sw[SW_SLICES + 4 * sl + 2];
+            if (!sp1) continue;
+            const u32 xs = x + (sp1 - 1);
+            const u32 tt = tile + (xs >= (u32)FS_T ? 1u : 0u);
+            if (tt >= n_tiles) continue;
+            const size_t slab = (size_t)tt * max_slices + sl;
+            if (!slab_flags[slab]) continue;
+            const u32 xx = xs & (u32)(FS_T - 1);
+            const u32 slot = (xx & 7) * 64 + (xx >> 3);
+            fs_unpack_add(scratch[slab * FS_SLAB + cls * FS_T + slot], qsum, cnt, q20, q30);
+            fs_unpack_add(scratch[slab * FS_SLAB + 8 * FS_T + cls * FS_T + slot], nsum, ncnt, n20, n30);
+        }
+        qsum -= nsum;
+        cnt -= ncnt;
+        q20 -= n20;
+        q30 -= n30;
+    }
+    const u32 c = tile * FS_T + x;
+    if (cnt && c < C) {
+        long long* st = counters + (is_post ? FPL_OFF_POST(C) : FPL_OFF_PRE(C));
+        st[FPL_ST_CYC(c, 0, cls)] += (long long)cnt;
+        st[FPL_ST_CYC(c, 1, cls)] += (long long)qsum - 33ll * (long long)cnt;
+        st[FPL_ST_CYC(c, 2, cls)] += (long long)q20;
+        st[FPL_ST_CYC(c, 3, cls)] += (long long)q30;
+    }
 }
 
 /* =========================================================================================

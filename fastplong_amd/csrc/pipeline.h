@@ -37,10 +37,11 @@ typedef hipStream_t fpl_stream_t;
 #endif
 
 /* Tuning / test hooks of the statistics passes (FPL_STATS_PER, FPL_STATS_EXTRA_PER, FPL_STATS_EXTRA_BLOCKS,
- * FPL_STATS_EXTRA_ACC in the environment; 0 = built-in choice).  The library reads them ONCE, in fpl_create(); the
+ * FPL_STATS_EXTRA_ACC, FPL_STATS_MIN_BUCKET in the environment; 0 = built-in choice).  The library reads them ONCE, in fpl_create(); the
  * per-batch path only sees this struct. */
 struct StatsTune {
     u32 per = 0, extra_per = 0, extra_blocks = 0, extra_acc = 0;
+    u32 min_bucket = 0; /* FPL_STATS_MIN_BUCKET: reads that must share a front trim to get slices of their own (k_stats_sorted) */
 };
 inline StatsTune stats_tune_from_env() {
     auto get = [](const char* name) -> u32 {
@@ -52,6 +53,7 @@ inline StatsTune stats_tune_from_env() {
     t.extra_per = get("FPL_STATS_EXTRA_PER");
     t.extra_blocks = get("FPL_STATS_EXTRA_BLOCKS");
     t.extra_acc = get("FPL_STATS_EXTRA_ACC");
+    t.min_bucket = get("FPL_STATS_MIN_BUCKET");
     return t;
 }
 
@@ -76,6 +78,10 @@ struct BatchArgs {
     long long* counters;
     u32 C;
     u32* work_ctr; /* four words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count, [2] k_trim_ends_batched group counter */
+    u32* sort_ws = nullptr;       /* k_stats_sorted: sort_ws_words(stats_sorted_max_slices()) words */
+    uint64_t* st_off = nullptr;   /* ... and (start, length, end of r1) of the reads in sorted order, n_reads each */
+    u32* st_len = nullptr;
+    u32* st_e = nullptr;
     u64* stats_scratch;   /* stats_scratch_slabs() x FS_SLAB u64 */
     u8* stats_flags;      /* n_tiles tile flags + one byte per slab, zeroed before each statistics pass */
     u32 n_cu;      /* compute units of the device (grid sizing) */
@@ -130,12 +136,27 @@ inline u32 stats_extra_blocks(u32 n_reads, const StatsTune& tune) {
 }
 /* items a block may accumulate before it must empty its tables (test hook: force that path) */
 inline u32 stats_extra_max_acc(const StatsTune& tune) { return tune.extra_acc ? tune.extra_acc : CS_MAX_ITEMS_PER_SLICE; }
+/* k_stats_sorted: a front trim shared by fewer reads than this is not given slices of its own (every slice costs one slab
+ * hand-over per cycle tile its reads reach) */
+constexpr u32 FS_MIN_BUCKET = 256;
+inline u32 stats_min_bucket(const StatsTune& tune) { return tune.min_bucket ? tune.min_bucket : FS_MIN_BUCKET; }
+/* upper bound of the slices k_bucket_plan can make: sum over buckets of ceil(count / per) */
+inline u32 stats_sorted_max_slices(u32 n_reads, u32 per, const StatsTune& tune) {
+    const u32 own = n_reads / stats_min_bucket(tune) + 1; /* buckets with slices of their own, "not post" included */
+    /* (odd: block x + y * slices runs on XCD (x + y * slices) % 8 -- with a multiple of 8 every slice would stay on one XCD
+       for all its tiles, and the XCDs, which take their blocks in turn, wait for the one that got the larger slices) */
+    return (n_reads / per + 1 + (own < (u32)FS_NB ? own : (u32)FS_NB)) | 1u;
+}
+inline size_t sort_ws_words(u32 max_slices, u32 n_reads) {
+    return (size_t)SW_SLICES + 4 * (size_t)max_slices + (size_t)FS_NB * cdiv(n_reads ? n_reads : 1, FS_SORT_BLK);
+}
 /* slabs (tiles x slices) the scratch buffer must hold for a batch */
 inline size_t stats_scratch_slabs(u32 n_reads, uint64_t n_bytes, u32 max_read_len, u32 n_cu, const StatsTune& tune) {
     const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, FS_T);
     const u32 mean_len = n_reads ? (u32)(n_bytes / n_reads) : 0;
     const u32 per = stats_items_per_slice(n_reads, mean_len, n_cu, tune);
     u32 slices = cdiv(n_reads ? n_reads : 1, per);
+    if (FPL_OPT_SORTSTATS) slices = stats_sorted_max_slices(n_reads, per, tune);
     if (slices < FS_EXTRA_BLOCKS) slices = FS_EXTRA_BLOCKS;
     return (size_t)slices * n_tiles;
 }
@@ -207,7 +228,26 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     }
     mark(2);
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
-    {
+    if (FPL_OPT_SORTSTATS && !a.defer) {
+        /* (with --break / --mask no read is counted post-filter by this pass: the plain walk below does) */
+        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
+        const u32 max_slices = stats_sorted_max_slices(n, per, a.tune);
+        FPL_MEMSET(a.sort_ws, (size_t)SW_SLICES * sizeof(u32), stream);
+        FPL_MEMSET(a.stats_flags, (size_t)max_slices * n_tiles + n_tiles, stream);
+        const u32 nblk = cdiv(n, FS_SORT_BLK);
+        u32* const blkcnt = a.sort_ws + SW_SLICES + 4 * (size_t)max_slices;
+        FPL_LAUNCH(k_bucket_count, dim3(nblk), dim3(FS_SORT_BLK), stream, (const ReadState*)a.state, n, a.sort_ws, blkcnt);
+        FPL_LAUNCH(k_bucket_plan, dim3(1), dim3(128), stream, a.sort_ws, per, stats_min_bucket(a.tune), max_slices);
+        FPL_LAUNCH(k_bucket_scan, dim3(FS_NB), dim3(256), stream, blkcnt, nblk);
+        FPL_LAUNCH(k_bucket_scatter, dim3(nblk), dim3(FS_SORT_BLK), stream, a.off, (const ReadState*)a.state, n, a.sort_ws,
+                   (const u32*)blkcnt, a.st_off, a.st_len, a.st_e, a.frag_off, a.frag_len, a.work_ctr + 1);
+        /* persistent blocks, two per CU (what the LDS tables allow) */
+        FPL_LAUNCH((k_stats_sorted<SWAVES>), dim3(2 * a.n_cu), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
+                   (const uint64_t*)a.st_off, (const u32*)a.st_len, (const u32*)a.st_e, a.sort_ws, max_slices, n_tiles, a.counters,
+                   a.stats_scratch, a.stats_flags, a.C);
+        FPL_LAUNCH(k_stats_reduce_sorted, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
+                   (const u8*)a.stats_flags, (const u32*)a.sort_ws, max_slices, n_tiles, a.counters, a.C);
+    } else {
         const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
         const u32 n_slices = cdiv(n, per);
         FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles + n_tiles, stream);

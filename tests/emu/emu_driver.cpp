@@ -87,6 +87,14 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     std::vector<u64> scratch(slabs * (size_t)FS_SLAB + 1);
     std::vector<u8> sflags(slabs + slabs / 8 + 4096);
     a.stats_scratch = scratch.data();
+    const u32 per_s = stats_items_per_slice(n_reads, n_reads ? (u32)(n_bytes / n_reads) : 0, a.n_cu, a.tune);
+    std::vector<u32> sort_ws(sort_ws_words(stats_sorted_max_slices(n_reads, per_s, a.tune), n_reads) + 1, 0xA5A5A5A5u);
+    std::vector<uint64_t> st_off(n_reads + 1);
+    std::vector<u32> st_len(n_reads + 1), st_e(n_reads + 1);
+    a.sort_ws = sort_ws.data();
+    a.st_off = st_off.data();
+    a.st_len = st_len.data();
+    a.st_e = st_e.data();
     a.stats_flags = sflags.data();
     enqueue_batch(a, nullptr, [](int) {});
     g_frags.clear();

@@ -13,10 +13,13 @@ ap.add_argument("--reads", type=int, default=1_000_000)
 ap.add_argument("--workload", default="c3_full_pipeline")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--median-len", type=int, default=0)
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 wl = bench.WORKLOADS[a.workload]
+if a.median_len:
+    wl = dict(wl, gen=dict(wl["gen"], median_len=a.median_len))
 opt = abi.FplOptions.default(**wl["opt"])
 seq_t, qual_t, off_t, max_len, s_ad, e_ad, fasta = bench.make_batch(wl, a.reads, 0, dev)
 n = off_t.numel() - 1
