@@ -3271,7 +3271,8 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
  * counted post-filter by this pass at all (dropped, failed, split or far-trimmed reads).  A front trim that too few reads
  * of the batch share (StatsTune::min_bucket) is not worth a slab per cycle tile: those reads are filed under "not post"
  * and handed to the EXTRA pass instead, like the far-trimmed ones.
- *   k_bucket_count    reads per bucket
+ *   k_bucket_count    reads per (block of 256 reads, bucket)
+ *   k_bucket_scan     their prefix sums along the blocks, and the buckets' totals
  *   k_bucket_plan     bucket -> range of the sorted order, ranges -> slices of <= `per` reads (device-side table)
  *   k_bucket_scatter  (start, length, e) of every read into its bucket's range (order inside a bucket: arbitrary)
  *   k_stats_sorted    block = (slice, cycle tile)
@@ -3296,17 +3297,14 @@ __device__ __forceinline__ u32 plan_bucket(const ReadState& st) {
 /* one block per FS_SORT_BLK consecutive reads; blkcnt[b][block] = the block's reads of bucket b */
 constexpr int FS_SORT_BLK = 256;
 __global__ void __launch_bounds__(FS_SORT_BLK)
-k_bucket_count(const ReadState* __restrict__ plan, u32 n_reads, u32* __restrict__ sw, u32* __restrict__ blkcnt) {
+k_bucket_count(const ReadState* __restrict__ plan, u32 n_reads, u32* __restrict__ blkcnt) {
     __shared__ u32 h[FS_NB];
     if (threadIdx.x < FS_NB) h[threadIdx.x] = 0;
     __syncthreads();
     const u32 it = blockIdx.x * FS_SORT_BLK + threadIdx.x;
     if (it < n_reads) atomicAdd(&h[plan_bucket(plan[it])], 1u);
     __syncthreads();
-    if (threadIdx.x < FS_NB) {
-        blkcnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
-        if (h[threadIdx.x]) atomicAdd(&sw[SW_CNT + threadIdx.x], h[threadIdx.x]);
-    }
+    if (threadIdx.x < FS_NB) blkcnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
 /* blkcnt[b][*] -> its exclusive prefix sums: where, inside bucket b's range, the reads of every block go.  The sorted
@@ -3314,7 +3312,7 @@ k_bucket_count(const ReadState* __restrict__ plan, u32 n_reads, u32* __restrict_
    pass does, instead of hopping between whatever blocks happened to reserve their places one after another (measured
    with 18 GB batches: the hopping costs more address-translation misses than the saved table updates are worth) */
 __global__ void __launch_bounds__(256)
-k_bucket_scan(u32* __restrict__ blkcnt, u32 nblk) {
+k_bucket_scan(u32* __restrict__ blkcnt, u32 nblk, u32* __restrict__ sw) {
     __shared__ u32 wsum[4];
     u32* row = blkcnt + (size_t)blockIdx.x * nblk;
     const u32 chunk = (nblk + 255u) / 256u;
@@ -3326,6 +3324,7 @@ k_bucket_scan(u32* __restrict__ blkcnt, u32 nblk) {
     __syncthreads();
     u32 run = incl - sum;
     for (int w = 0; w < wave_in_block(); w++) run += wsum[w];
+    if (threadIdx.x == 255) sw[SW_CNT + blockIdx.x] = run + sum; /* reads in the bucket */
     for (u32 i = lo; i < hi; i++) {
         const u32 v = row[i];
         row[i] = run;
@@ -3431,12 +3430,13 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     __shared__ u64 lds_all[1024 + 256 + 8 * FS_BSTRIDE];
     static_assert(sizeof(u64) * (1024 + 256 + 8 * FS_BSTRIDE) <= 81920, "two blocks per CU");
     u32* const kmer = (u32*)lds_all; /* [0,1024): 5-mers counted pre-filter only; [1024,2048): pre- AND post-filter */
-    u64* const inc_of = lds_all + 1024;
-    u64* const tbl = inc_of + 256; /* [8][FS_T pre | FS_T not-post] */
+    u64* const inc_of = lds_all + 1024; /* the packed increment of every quality byte */
+    u64* const tbl = inc_of + 256;      /* [8][FS_T pre | FS_T not-post] */
     u32* const kpre = kmer;
     u32* const kpost = kmer + 1024;
     __shared__ u32 any_work, cur_item;
     const int lane = lane_id();
+    const u32 lane8 = 8u * (u32)lane;
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
     long long* kg0 = counters + FPL_OFF_PRE(C) + FPL_ST_KMER(C);
@@ -3525,12 +3525,14 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                 const u32 vh = kmer_codes(halo), v0 = kmer_codes(sw2[0]), v1 = kmer_codes(sw2[1]);
                 const u32 W = perm_b32(kmer_pack(vh), perm_b32(kmer_pack(v0), kmer_pack(v1), 0x0c0c0703u), 0x0c070100u);
                 u32 okmask;
+                bool allok = false; /* wave-uniform */
                 {
                     const u32 m0 = perm_lo(0x47435441u, v0), m1 = perm_lo(0x47435441u, v1), mh = perm_lo(0x47435441u, vh);
                     u32 bad = (m0 ^ sw2[0]) | (m1 ^ sw2[1]);
                     if (have_halo) bad |= mh ^ halo;
                     if (!wave_ballot(nvalid > 0 && bad != 0)) {
                         okmask = have_halo ? 0xFFu : 0xF0u;
+                        allok = tile_start >= 4; /* every window of every lane counts: the 5-mer updates add a constant */
                     } else {
                         const u32 ih = have_halo ? invalid_nibble(mh, halo) : 0xFu;
                         const u32 inv = lshl_or<8>(invalid_nibble(m1, sw2[1]), lshl_or<4>(invalid_nibble(m0, sw2[0]), ih));
@@ -3543,16 +3545,20 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                 /* one byte.  NPM: bit k of npmask says whether byte k lies behind the end of r1 (it then also goes to the
                    not-post table); KM: the byte's 5-mer window is counted 0 pre-filter only, 1 pre- and post-filter, 2 as
                    bit k of kbodymask says */
+                /* (the increment of byte k + 1 is fetched before the updates of byte k are issued, as in k_stats.  Building it
+                   on the vector unit instead -- bit 7 of q + 75 / q + 65 as the Q20 / Q30 tests, two v_perm per byte --
+                   measured the same: this kernel issues 20 vector instructions per 64 bytes and the vector unit is what it
+                   waits for, profiles/r02_ab) */
 #define FPL_FS_Q(k) ((qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF)
                 u64 inc_n = inc_of[FPL_FS_Q(0)];
 #define FPL_FB_BYTE(k, NPM, KM, FULL)                                                                             \
     if (FULL || (k) < nvalid) {                                                                                   \
         const u32 bb = (sw2[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                   \
-        const u32 cell = mad_u24(bb & 7u, FS_BSTRIDE, lane);                                                      \
-        atomicAdd(&tbl[cell + (k)*64], inc);                                                                      \
-        if (NPM && ((npmask >> (k)) & 1u)) atomicAdd(&tbl[cell + (k)*64 + FS_T], inc);                            \
+        u64* const cellp = (u64*)((char*)tbl + mad_u24(bb & 7u, 8 * FS_BSTRIDE, lane8)); /* (byte offset: one op) */ \
+        atomicAdd(&cellp[(k)*64], inc);                                                                           \
+        if (NPM && ((npmask >> (k)) & 1u)) atomicAdd(&cellp[(k)*64 + FS_T], inc);                                 \
         const u32 kidx = (W >> (2 * (7 - (k)))) & 0x3FFu;                                                         \
-        const u32 kval = (okmask >> (k)) & 1u;                                                                    \
+        const u32 kval = (FULL && allok) ? 1u : ((okmask >> (k)) & 1u);                                           \
         if (KM == 1)                                                                                              \
             atomicAdd(&kmer[1024u + kidx], kval);                                                                 \
         else if (KM == 0)                                                                                         \
@@ -3571,7 +3577,11 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                     const u32 npmask = 0, kbodymask = 0xFFu;
                     (void)npmask;
                     (void)kbodymask;
-                    FPL_FB_ROW(false, 1, true)
+                    if (allok) {
+                        FPL_FB_ROW(false, 1, true)
+                    } else {
+                        FPL_FB_ROW(false, 1, true)
+                    }
                 } else if (tp) { /* a tile that holds an end of r1 */
                     const u32 npmask = ~range_mask8(-1, e - p0) & 0xFFu, kbodymask = range_mask8(s + 4 - p0, e - p0);
                     FPL_FB_ROW(true, 2, false)

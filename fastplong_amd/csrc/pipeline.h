@@ -236,9 +236,9 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_MEMSET(a.stats_flags, (size_t)max_slices * n_tiles + n_tiles, stream);
         const u32 nblk = cdiv(n, FS_SORT_BLK);
         u32* const blkcnt = a.sort_ws + SW_SLICES + 4 * (size_t)max_slices;
-        FPL_LAUNCH(k_bucket_count, dim3(nblk), dim3(FS_SORT_BLK), stream, (const ReadState*)a.state, n, a.sort_ws, blkcnt);
+        FPL_LAUNCH(k_bucket_count, dim3(nblk), dim3(FS_SORT_BLK), stream, (const ReadState*)a.state, n, blkcnt);
+        FPL_LAUNCH(k_bucket_scan, dim3(FS_NB), dim3(256), stream, blkcnt, nblk, a.sort_ws);
         FPL_LAUNCH(k_bucket_plan, dim3(1), dim3(128), stream, a.sort_ws, per, stats_min_bucket(a.tune), max_slices);
-        FPL_LAUNCH(k_bucket_scan, dim3(FS_NB), dim3(256), stream, blkcnt, nblk);
         FPL_LAUNCH(k_bucket_scatter, dim3(nblk), dim3(FS_SORT_BLK), stream, a.off, (const ReadState*)a.state, n, a.sort_ws,
                    (const u32*)blkcnt, a.st_off, a.st_len, a.st_e, a.frag_off, a.frag_len, a.work_ctr + 1);
         /* persistent blocks, two per CU (what the LDS tables allow) */
