@@ -3406,7 +3406,7 @@ k_bucket_scatter(const uint64_t* __restrict__ off, const ReadState* __restrict__
     if (it < n_reads) {
         const u32 pos = base[b] + rank;
         const uint64_t o = off[it];
-        st_off[pos] = o;
+        st_off[pos] = (FPL_ABL & 8) ? (o & ~(uint64_t)127) : o; /* (timing experiment: rows on cache-line boundaries) */
         st_len[pos] = (u32)(off[it + 1] - o);
         st_e[pos] = st.e;
         if (handed) {
