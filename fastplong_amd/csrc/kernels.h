@@ -56,6 +56,9 @@ __device__ unsigned long long g_fpl_prof[64];
 #define FPL_OPT_SORTSTATS 1 /* the statistics pass walks the reads sorted by their front trim: one table update per base instead
                                of two (k_stats_sorted) */
 #endif
+#ifndef FPL_OPT_ACGT
+#define FPL_OPT_ACGT 1 /* k_scan: tiles made of A, C, G, T, N only take three code bit-planes through the scan (range_scan_fast) */
+#endif
 #ifndef FPL_OPT_PREFETCH
 #define FPL_OPT_PREFETCH 0 /* k_scan touches the lines of a read's next tile one tile ahead (range_scan_fast): 2 % slower side by side --
                               the other waves of the SIMD already cover the trip to HBM */
@@ -2347,6 +2350,53 @@ __device__ inline void range_scan_bytes(const u8* __restrict__ rb, const u8* __r
  * Letter bit-planes of 32 bases held as 8 dwords: bit j of P_X = (base j == X), X in A C T G,
  * compared as raw bytes (lower case, N, U, ... match nothing).  byte -> bit compaction with
  * v_dot4_u32_u8 against power-of-two weights: 4 bases per instruction and plane. */
+/* three bit-planes of 32 bases that are all exactly A, C, G, T or N: bit j of L / H / N = ASCII bit 1 / 2 / 3 of base j
+   (A 000, C 001 -- L set --, T 010, G 011; bit 3 is set for N = 0x4E alone, whose L and H bits read like G's) */
+__device__ __forceinline__ void code_planes(const u32 s[8], u32& L, u32& H, u32& N) {
+    L = 0;
+    H = 0;
+    N = 0;
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+        u32 lb = 0, hb = 0, nb = 0;
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const u32 w = s[2 * pr + hh];
+            const u32 wt = hh ? 0x80402010u : 0x08040201u;
+            lb = udot4((w >> 1) & 0x01010101u, wt, lb);
+            hb = udot4((w >> 2) & 0x01010101u, wt, hb);
+            nb = udot4((w >> 3) & 0x01010101u, wt, nb);
+        }
+        L |= lb << (8 * pr);
+        H |= hb << (8 * pr);
+        N |= nb << (8 * pr);
+    }
+}
+/* non-zero when one of the 32 bytes is not exactly A, C, G, T or N: ASCII bits 1..3 pick the letter the byte would have
+   to be out of a table (codes 4..6 pick a zero byte, which no base is) */
+__device__ __forceinline__ u32 not_acgtn(const u32 s[8]) {
+    u32 bad = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) bad |= perm_b32(0x4E000000u, 0x47544341u, (s[d] >> 1) & 0x07070707u) ^ s[d];
+    return bad;
+}
+/* sums32 for a full chunk of 32 bases that are all A, C, G, T or N (L, H, N = code_planes): the N count is one
+   popcount, and "differs from its predecessor" (Filter::passLowComplexityFilter, src/filter.cpp:66-81) one XOR of each
+   plane with itself shifted by one position -- 16 instead of 104 vector instructions.  The predecessor of base 0 (the
+   byte in front of the chunk) may be any byte: that one comparison is made on the bytes. */
+__device__ __forceinline__ void sums32_acgtn(const u32 s0, const u32 q[8], u32 L, u32 H, u32 N, u32 prev_dword, u32 qqrep,
+                                             u32& lowq, u32& nn, u32& totq, u32& diff) {
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const u32 t = (q[d] | 0x80808080u) - qqrep;
+        lowq = FPL_OPT_BCNT ? popc_acc(~t & 0x80808080u, lowq) : lowq + popc32(~t & 0x80808080u);
+        totq = sum_bytes(q[d], totq);
+    }
+    nn = FPL_OPT_BCNT ? popc_acc(N, nn) : nn + popc32(N);
+    const u32 dm = ((L ^ (L << 1)) | (H ^ (H << 1)) | (N ^ (N << 1))) & ~1u;
+    const u32 d0 = ((s0 & 0xFFu) != (prev_dword >> 24)) ? 1u : 0u;
+    diff = (FPL_OPT_BCNT ? popc_acc(dm, diff) : diff + popc32(dm)) + d0;
+}
 __device__ __forceinline__ void build_planes(const u32 s[8], u32& PA, u32& PC, u32& PT, u32& PG) {
     u32 L = 0, H = 0, X = 0;
 #pragma unroll
@@ -2597,10 +2647,24 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
         /* the last tile of a range is ragged (some lane holds fewer than 32 bytes): the whole wave then takes
            the byte-masked variants, so that no lane falls back to a byte-by-byte loop */
-        if (!LEAN && !wave_ballot(nstat > 0 && nstat < SC_CHUNK)) {
+        /* a full tile whose bytes are all exactly A, C, G, T or N -- nearly every tile -- is scanned on three code
+           bit-planes: no per-byte validity test, the N count and the complexity sum from the planes.  Every other tile
+           (ragged, or holding a lower-case letter, a U, ...) takes the byte-masked variants below, whole wave
+           (wave-uniform choice) */
+        const bool ragged = wave_ballot(nstat > 0 && nstat < SC_CHUNK) != 0;
+        bool acgt = false;
+        u32 cL = 0, cH = 0, cN = 0;
+        if (FPL_OPT_ACGT && !LEAN && !ragged && (SUMS || HAM)) {
+            acgt = !wave_ballot(not_acgtn(s) != 0);
+            if (acgt) code_planes(s, cL, cH, cN);
+        }
+        if (!LEAN && !ragged && (acgt || !FPL_OPT_ACGT || !(SUMS || HAM))) {
             if (nstat == SC_CHUNK) {
                 if (!FPL_DBG(dbg, 1)) hist32<false>(hl, q, SC_CHUNK);
-                if (SUMS && !FPL_DBG(dbg, 2)) sums32<false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
+                if (SUMS && !FPL_DBG(dbg, 2)) {
+                    if (FPL_OPT_ACGT) sums32_acgtn(s[0], q, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
+                    else sums32<false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
+                }
                 if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
             }
         } else if (nstat > 0) {
@@ -2610,7 +2674,14 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         if (HAM) {
             if ((npos0 > t0 || npos1 > t0) && !FPL_DBG(dbg, 16)) { /* wave-uniform: some window of this tile is tested */
                 u32 PA, PC, PT, PG;
-                build_planes(s, PA, PC, PT, PG);
+                if (acgt) {
+                    PA = ~(cH | cL); /* (an N has both bits set) */
+                    PC = ~cH & cL;
+                    PT = cH & ~cL;
+                    PG = cH & cL & ~cN;
+                } else {
+                    build_planes(s, PA, PC, PT, PG);
+                }
                 wave_sync(); /* previous tile's plane reads are done */
                 w->planes[0][lane] = PA;
                 w->planes[1][lane] = PC;
