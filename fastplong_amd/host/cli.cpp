@@ -18,6 +18,8 @@
 #include <string.h>
 #include <time.h>
 #include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -416,6 +418,8 @@ int main(int argc, char* argv[]) {
        back in order and checks every chunk's guessed start against its predecessor.  Everything else -- gzip,
        pipes, --reads_to_process -- goes through the one sequential reader. */
     int chunkFd = -1;
+    const char* chunkMem = nullptr; /* the input's text in memory (a mapping of the file / inflated gzip members) instead of a descriptor */
+    bool chunkMemMapped = false;    /* ... a file mapping: its pages go back to the kernel as the reader passes them */
     uint64_t chunkFileSize = 0;
     if (!fromStdin && in != "/dev/stdin" && readsToProcess == 0 && !getenv("FPLH_NO_CHUNKS")) {
         const int fd = open(in.c_str(), O_RDONLY);
@@ -425,8 +429,45 @@ int main(int argc, char* argv[]) {
             !(magic[0] == 0x1f && magic[1] == 0x8b)) {
             chunkFd = fd;
             chunkFileSize = (uint64_t)st.st_size;
+            /* the parsers take the file's bytes in place from a mapping (18 GB of page cache: pipeline 0.76 -> 0.58 s
+               against pread into per-thread windows, and no first-touch penalty on a file this process has not read before);
+               the pages are handed back as the sequencer passes them.  (FPLH_NO_MMAP_INPUT: measurement hook.)  A file cut
+               short under the mapping raises SIGBUS where pread would have returned an error: same message, same exit code */
+            if (!getenv("FPLH_NO_MMAP_INPUT")) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+                if (m != MAP_FAILED) {
+                    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                    chunkMem = (const char*)m;
+                    chunkMemMapped = true;
+                    struct sigaction sa;
+                    memset(&sa, 0, sizeof(sa));
+                    sa.sa_handler = [](int) {
+                        static const char msg[] = "ERROR: reading the input failed (file truncated while it was being read?)\n";
+                        ssize_t r = write(2, msg, sizeof(msg) - 1);
+                        (void)r;
+                        _exit(1);
+                    };
+                    sigaction(SIGBUS, &sa, nullptr);
+                }
+            }
         } else if (fd >= 0) {
+            const bool gz_file = S_ISREG(st.st_mode) && magic[0] == 0x1f && magic[1] == 0x8b;
             close(fd);
+            /* a gzip file made of several members (bgzip, a `cat` of per-chunk files, what fastp / fastplong / this host
+               write): the members are inflated side by side into anonymous memory, which the chunk parsers then take like
+               a mapped file.  One deflate stream, or more text than a third of the machine's memory: the sequential
+               reader and its stream.  (FPLH_NO_GZ_EXPAND: measurement / test hook) */
+            if (gz_file && !getenv("FPLH_NO_GZ_EXPAND")) {
+                const double t0 = clk();
+                const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
+                uint64_t sz = 0, reserved = 0;
+                chunkMem = fplh::gunzip_members_to_memory(in, max(16, min(64, hw / 4)), phys / 3, &sz, &reserved);
+                if (chunkMem) { /* (the mapping lives until the process ends) */
+                    chunkFileSize = sz;
+                    if (cmd.exist("verbose"))
+                        cerr << "gzip members inflated into memory: " << sz << " bytes of text in " << clk() - t0 << " s" << endl;
+                }
+            }
         }
     }
     uint64_t chunkBytes = (uint64_t)max(1L, cmd.l("chunk_mb")) << 20;
@@ -434,7 +475,7 @@ int main(int argc, char* argv[]) {
         if (atol(e) > 0) chunkBytes = (uint64_t)atol(e);
     int readerThreads = cmd.i("reader_threads");
     if (readerThreads <= 0) readerThreads = max(2, min(16, hw / 8));
-    const bool chunked = chunkFd >= 0 && chunkFileSize > chunkBytes;
+    const bool chunked = (chunkFd >= 0 || chunkMem) && (chunkFileSize > chunkBytes || chunkMem);
     fplh::FastqReader* reader = nullptr;
     /* Work objects bound what is in flight: one per parser, FPL_MAX_IN_FLIGHT per device in the copy / kernel stage,
        one per device being formatted, two waiting for the writer */
@@ -533,12 +574,21 @@ int main(int argc, char* argv[]) {
                 return it;
             };
             auto release = [&](fplh::ChunkedReader::Item it) { freeq.push((Work*)it.token); };
-            fplh::ChunkedReader cr(chunkFd, chunkFileSize, chunkBytes, readerThreads, acquire, release);
+            fplh::ChunkedReader cr(chunkFd, chunkFileSize, chunkBytes, readerThreads, acquire, release, chunkMem);
             fplh::ChunkedReader::Item it;
+            uint64_t unmapped = 0;
             while (cr.next(it)) {
                 Work* w = (Work*)it.token;
                 w->seq_no = nBatches++;
                 devq[w->seq_no % nGpus].push(w);
+                if (chunkMem) { /* pages no parser looks at again (unmapping 18 GB at exit costs 0.2 s of process time) */
+                    const uint64_t dead = cr.dead_below() & ~(uint64_t)((2u << 20) - 1);
+                    if (dead > unmapped) {
+                        if (chunkMemMapped) munmap((void*)(chunkMem + unmapped), (size_t)(dead - unmapped));
+                        else madvise((void*)(chunkMem + unmapped), (size_t)(dead - unmapped), MADV_DONTNEED);
+                        unmapped = dead;
+                    }
+                }
             }
             inputError = cr.malformed_text();
             ioError = cr.io_error_text();

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -186,6 +187,42 @@ class GzMembers {
         }
         return got;
     }
+    /* The next members of the chain, inflated (at most `threads` of them at a time), in file order; false when the chain
+       cannot be followed this way any further -- the end of the input (`*at_end`), or a member that is too large to
+       buffer / damaged (the caller goes back to the stream) */
+    bool next_group(vector<RawBuf>& out, bool* at_end) {
+        out.clear();
+        *at_end = false;
+        if (stream_) return false;
+        if (pos_ >= size_ || size_ - pos_ < 18 || !looks_like_header(base_ + pos_)) {
+            *at_end = true;
+            return false;
+        }
+        vector<size_t> todo;
+        for (auto c = std::lower_bound(cands_.begin(), cands_.end(), pos_); c != cands_.end() && (int)todo.size() < threads_; ++c)
+            if (!done_.count(*c)) todo.push_back(*c);
+        if (!done_.count(pos_) && (todo.empty() || todo[0] != pos_)) todo.insert(todo.begin(), pos_);
+        vector<Result> res(todo.size());
+        parallel_run((int)todo.size(), [&](int i) { inflate_at(todo[i], res[i]); });
+        for (size_t i = 0; i < todo.size(); i++) done_[todo[i]] = std::move(res[i]);
+        for (;;) {
+            auto it = done_.find(pos_);
+            if (it == done_.end()) break;
+            if (it->second.state != 1) return !out.empty(); /* (the next call reports the member that cannot be taken) */
+            const size_t end = it->second.end;
+            out.emplace_back(std::move(it->second.out));
+            for (auto d = done_.begin(); d != done_.end();)
+                d = d->first < end ? done_.erase(d) : std::next(d);
+            pos_ = end;
+            n_parallel_++;
+            delivered++;
+        }
+        if (out.empty()) { /* pos_ is there and cannot be taken */
+            auto it = done_.find(pos_);
+            if (it != done_.end() && it->second.state != 1) return false;
+        }
+        return !out.empty();
+    }
     uint64_t members_inflated_in_parallel() const { return n_parallel_; }
     int error() const { return err_; } /* zlib's code when the stream turned out damaged or truncated, else 0 */
 
@@ -272,6 +309,49 @@ class GzMembers {
 };
 
 std::atomic<uint64_t> GzMembers::delivered{0};
+
+/* A gzip file made of several members -> its inflated text in anonymous memory, so that the chunk-parallel reader can
+ * take it like a mapped file (the members are inflated on `threads` workers and copied into place side by side; address
+ * space for `max_bytes` is reserved up front, pages are only touched as the text arrives).  nullptr when the file is not
+ * of that kind, a member cannot be buffered or checked, or the text would take more than `max_bytes`: the caller then
+ * reads the input through the sequential stream as before.  The caller owns the mapping (`*reserved` bytes). */
+char* gunzip_members_to_memory(const string& path, int threads, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved) {
+    GzMembers* g = GzMembers::open(path, threads);
+    if (!g) return nullptr;
+    const uint64_t span = max_bytes + (4u << 20);
+    char* base = (char*)mmap(nullptr, (size_t)span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (base == (char*)MAP_FAILED) {
+        delete g;
+        return nullptr;
+    }
+    uint64_t total = 0;
+    bool ok = true, at_end = false;
+    vector<RawBuf> group;
+    while (ok && g->next_group(group, &at_end)) {
+        vector<uint64_t> at(group.size());
+        for (size_t i = 0; i < group.size(); i++) {
+            at[i] = total;
+            total += group[i].n;
+        }
+        if (total > max_bytes) {
+            ok = false;
+            break;
+        }
+        parallel_run((int)group.size(), [&](int i) {
+            memcpy(base + at[i], group[i].p, group[i].n);
+            group[i].release();
+        });
+    }
+    if (!at_end || g->error()) ok = false;
+    delete g;
+    if (!ok || total == 0) {
+        munmap(base, (size_t)span);
+        return nullptr;
+    }
+    *size_out = total;
+    *reserved = span;
+    return base;
+}
 
 /* FAILED_TYPES, src/common.h:55-64 */
 static const char* failed_type(int code) {
@@ -735,7 +815,7 @@ void FastqReader::scan_parallel(uint64_t& bases, uint64_t max_bases, uint32_t& r
 }
 
 bool FastqReader::parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b, bool exact, vector<char>& window,
-                              Batch& out, ChunkInfo& info, int threads) {
+                              Batch& out, ChunkInfo& info, int threads, const char* mem) {
     info = ChunkInfo();
     if (out.off.empty()) {
         out.off.push_back(0);
@@ -752,8 +832,10 @@ bool FastqReader::parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b
         const double t_begin = now_s();
         const uint64_t w1 = min<uint64_t>(file_size, b + slack);
         const size_t n = (size_t)(w1 - w0);
-        if (window.size() < n) window.resize(n);
-        {
+        const char* wp = mem ? mem + w0 : nullptr; /* the bytes [w0, w1): in place when the input is in memory */
+        if (!mem) {
+            if (window.size() < n) window.resize(n);
+            wp = window.data();
             const int T = (int)max<size_t>(1, min<size_t>((size_t)threads, n / (8u << 20)));
             std::atomic<bool> ok{true};
             parallel_run(T, [&](int t) {
@@ -774,12 +856,12 @@ bool FastqReader::parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b
             }
         }
         const double t_read = now_s();
-        FastqReader m(window.data(), n, w1 >= file_size);
+        FastqReader m(wp, n, w1 >= file_size);
         m.copy_threads_ = threads;
         size_t pos = (size_t)(a - w0);
         if (!exact && a > 0) { /* the first header at or behind the cut that validates (see scan_parallel) */
             Line ln;
-            if (window[pos - 1] != '\n' && window[pos - 1] != '\r') m.scan_line(pos, ln); /* finish the line we fell into */
+            if (wp[pos - 1] != '\n' && wp[pos - 1] != '\r') m.scan_line(pos, ln); /* finish the line we fell into */
             for (;;) {
                 const size_t cand = m.next_at_line(pos);
                 if (cand >= n) {
@@ -804,7 +886,7 @@ bool FastqReader::parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b
         string err;
         const int rc = m.scan_records(pos, (size_t)(b - w0), bases, ~0ull, reads, 0xFFFFFFFFu, recs, err);
         if (rc == 1) continue; /* the window ends inside a record although the file goes on */
-        if (!recs.empty()) info.first = w0 + (uint64_t)(recs[0].name.p - window.data());
+        if (!recs.empty()) info.first = w0 + (uint64_t)(recs[0].name.p - wp);
         const double t_scan = now_s();
         m.copy_records(out, recs);
         if (g_timing) {
@@ -889,6 +971,7 @@ uint32_t FastqReader::fill(Batch& b, uint64_t max_bases, uint32_t max_reads) {
 
 struct ChunkedReader::Impl {
     int fd;
+    const char* mem = nullptr;
     uint64_t file_size, chunk_bytes, n_chunks;
     std::function<Item()> acquire;
     std::function<void(Item)> release;
@@ -907,9 +990,10 @@ struct ChunkedReader::Impl {
 };
 
 ChunkedReader::ChunkedReader(int fd, uint64_t file_size, uint64_t chunk_bytes, int threads, std::function<Item()> acquire,
-                             std::function<void(Item)> release) {
+                             std::function<void(Item)> release, const char* mem) {
     d_ = new Impl;
     d_->fd = fd;
+    d_->mem = mem;
     d_->file_size = file_size;
     d_->chunk_bytes = chunk_bytes ? chunk_bytes : 1;
     d_->n_chunks = (file_size + d_->chunk_bytes - 1) / d_->chunk_bytes;
@@ -944,7 +1028,7 @@ ChunkedReader::ChunkedReader(int fd, uint64_t file_size, uint64_t chunk_bytes, i
                 ps.item.batch->clear();
                 const auto t0 = std::chrono::steady_clock::now();
                 FastqReader::parse_chunk(D.fd, D.file_size, k * D.chunk_bytes, (k + 1) * D.chunk_bytes, false, window,
-                                         *ps.item.batch, ps.info, 1);
+                                         *ps.item.batch, ps.info, 1, D.mem);
                 D.busy[t] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 {
                     lock_guard<mutex> g(D.parsed_mu);
@@ -963,6 +1047,10 @@ ChunkedReader::~ChunkedReader() {
     for (auto& t : d_->threads) t.join();
     for (auto& kv : d_->parsed) d_->release(kv.second.item);
     delete d_;
+}
+
+uint64_t ChunkedReader::dead_below() const {
+    return d_->seq_chunk >= 2 ? (d_->seq_chunk - 2) * d_->chunk_bytes : 0; /* (seq_chunk - 1 was taken last; one chunk of margin) */
 }
 
 double ChunkedReader::busiest_parser_seconds() const {
@@ -997,7 +1085,7 @@ bool ChunkedReader::next(Item& out) {
             } else {
                 const int hw = (int)std::thread::hardware_concurrency();
                 FastqReader::parse_chunk(D.fd, D.file_size, max(a, D.expected), b, true, D.window, *ps.item.batch, ps.info,
-                                         max(1, min(8, hw / 2)));
+                                         max(1, min(8, hw / 2)), D.mem);
             }
             t_redo_ += now_s() - t0;
             n_redo_++;
@@ -1219,7 +1307,13 @@ void* fplh_batch_read_chunked(const char* path, uint64_t chunk_bytes, int thread
             cv.notify_all();
         };
         {
-            fplh::ChunkedReader cr(fd, (uint64_t)st.st_size, chunk_bytes, threads, acquire, release);
+            /* FPLH_CHUNK_MEM (test hook): the parsers take the file's bytes from a mapping, as they take inflated gzip members */
+            const char* mem = nullptr;
+            if (getenv("FPLH_CHUNK_MEM") && st.st_size > 0) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) mem = (const char*)m;
+            }
+            fplh::ChunkedReader cr(mem ? -1 : fd, (uint64_t)st.st_size, chunk_bytes, threads, acquire, release, mem);
             fplh::ChunkedReader::Item it;
             while (cr.next(it)) {
                 const fplh::Batch& t = *it.batch;
@@ -1293,6 +1387,13 @@ int fplh_read_error(const char* path, char* msg, int msg_len) {
 }
 uint64_t fplh_parallel_records(void) { return fplh::g_parallel_records.exchange(0); }
 uint64_t fplh_gz_members(void) { return fplh::GzMembers::delivered.exchange(0); }
+/* test hook: descriptor of the in-memory file with the inflated text of a multi-member gzip file, or -1 */
+char* fplh_gunzip_to_memory(const char* path, int threads, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved) {
+    return fplh::gunzip_members_to_memory(path, threads, max_bytes, size_out, reserved);
+}
+void fplh_gunzip_release(char* base, uint64_t reserved) {
+    if (base) munmap(base, (size_t)reserved);
+}
 uint32_t fplh_batch_n(void* b) { return ((fplh::Batch*)b)->n(); }
 uint64_t fplh_batch_bytes(void* b) { return ((fplh::Batch*)b)->seq.size(); }
 const uint8_t* fplh_batch_seq(void* b) { return ((fplh::Batch*)b)->seq.data(); }

@@ -100,8 +100,9 @@ class FastqReader {
         int status = 0;        /* 0 = more input follows, 2 = end of input reached, 3 = malformed record, 4 = read error (message in err) */
         std::string err;
     };
+    /* (mem != nullptr: the input's bytes [0, file_size) are in memory there and are parsed in place; fd is not used) */
     static bool parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b, bool exact, std::vector<char>& window,
-                            Batch& out, ChunkInfo& info, int threads);
+                            Batch& out, ChunkInfo& info, int threads, const char* mem = nullptr);
     bool ok() const { return fp_ != nullptr; }
     /* append records until the batch holds >= max_bases bases or max_reads reads; returns the
      * number of records appended (0 at end of input) */
@@ -164,12 +165,15 @@ class ChunkedReader {
         void* token = nullptr; /* the caller's handle for the batch (e.g. the Work object it lives in) */
     };
     ChunkedReader(int fd, uint64_t file_size, uint64_t chunk_bytes, int threads, std::function<Item()> acquire,
-                  std::function<void(Item)> release);
+                  std::function<void(Item)> release, const char* mem = nullptr);
     ~ChunkedReader();
     /* the next batch in input order; false at the end of the input (or behind a malformed record / read error) */
     bool next(Item& out);
     const std::string& malformed_text() const { return malformed_; } /* "" or the reference's message for a bad record */
     const std::string& io_error_text() const { return io_error_; }
+    /* input offset below which no parser will look again (the chunks in front of the one the sequencer took last): the
+       owner of an in-memory input may give those pages back */
+    uint64_t dead_below() const;
     uint64_t chunks_parsed_again() const { return n_redo_; }
     double redo_seconds() const { return t_redo_; }
     double busiest_parser_seconds() const;
@@ -181,6 +185,9 @@ class ChunkedReader {
     uint64_t n_redo_ = 0;
     double t_redo_ = 0;
 };
+
+/* multi-member gzip -> the inflated text in anonymous memory (fastq.cpp); nullptr when that does not apply */
+char* gunzip_members_to_memory(const std::string& path, int threads, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved);
 
 /* --break / --mask: the outcome list of a batch (fpl_get_fragments: sorted by read, then seq_no) and where
  * each read's records start */
@@ -216,6 +223,8 @@ int fplh_write_fastq(const char* path, const uint8_t* seq, const uint8_t* qual, 
                      const char* prefix, int threads);
 uint64_t fplh_parallel_records(void); /* records the multi-threaded scan contributed since the last call */
 uint64_t fplh_gz_members(void);       /* gzip members inflated on the worker pool since the last call */
+char* fplh_gunzip_to_memory(const char* path, int threads, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved);
+void fplh_gunzip_release(char* base, uint64_t reserved);
 uint32_t fplh_batch_n(void* b);
 uint64_t fplh_batch_bytes(void* b);
 const uint8_t* fplh_batch_seq(void* b);

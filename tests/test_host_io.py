@@ -284,11 +284,56 @@ def test_multi_member_gzip_input(hostlib, tmp_path, monkeypatch, variant):
         assert n == 0
 
 
+@pytest.mark.parametrize("variant", ["members", "false_header", "big_member", "trailing_zeros", "single", "truncated", "cap"])
+def test_gzip_members_inflated_into_memory(hostlib, tmp_path, monkeypatch, variant):
+    """the CLI's fast lane for multi-member gzip input: the members are inflated side by side into anonymous memory (the
+    chunk parsers then take it like a mapped file).  The text must be exactly what zlib's stream delivers; whatever cannot
+    be taken that way -- a single member, a member too large to buffer, a damaged tail, more text than allowed -- is
+    refused (-1) and left to the sequential reader"""
+    import gzip
+    rng = np.random.default_rng(6)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(synth._ACGT[rng.integers(0, 4, n)]), bytes(rng.integers(35, 70, n).astype(np.uint8)))
+                    for i, n in enumerate(rng.integers(50, 3000, 300)))
+    if variant == "false_header":
+        text = text.replace(b"@r37\n", b"@r37 \x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03 looks like a member\n", 1)
+    cuts = sorted(set(int(x) for x in rng.integers(0, len(text), 11)) | {0, len(text)})
+    parts = [text[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    level = 0 if variant == "false_header" else 6
+    blob = _gz_member(text) if variant == "single" else b"".join(_gz_member(p_, level) for p_ in parts[:5]) + _gz_member(b"") + b"".join(
+        _gz_member(p_, level) for p_ in parts[5:])
+    if variant == "trailing_zeros":
+        blob += b"\0" * 1000
+    if variant == "truncated":
+        blob = blob[:-20]
+    if variant == "big_member":
+        monkeypatch.setenv("FPLH_GZ_MEMBER_CAP", str(16 << 10))
+    p = tmp_path / "in.fq.gz"
+    p.write_bytes(blob)
+    hostlib.fplh_gunzip_to_memory.restype = C.c_void_p
+    hostlib.fplh_gunzip_to_memory.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    hostlib.fplh_gunzip_release.argtypes = [C.c_void_p, C.c_uint64]
+    size, reserved = C.c_uint64(0), C.c_uint64(0)
+    cap = 1000 if variant == "cap" else 2 ** 32
+    for threads in (1, 3, 16):
+        base = hostlib.fplh_gunzip_to_memory(str(p).encode(), threads, cap, C.byref(size), C.byref(reserved))
+        if variant in ("single", "truncated", "big_member", "cap"):
+            assert not base
+            continue
+        assert base and size.value == len(text)
+        got = C.string_at(base, size.value)
+        hostlib.fplh_gunzip_release(base, reserved.value)
+        assert got == text == gzip.decompress(blob[:-1000] if variant == "trailing_zeros" else blob)
+
+
+@pytest.mark.parametrize("source", ["file", "memory"])
 @pytest.mark.parametrize("variant", ["clean", "crlf", "junk", "at_quals", "malformed", "long_record", "noeol"])
-def test_chunked_reader_equals_sequential(hostlib, tmp_path, variant):
+def test_chunked_reader_equals_sequential(hostlib, tmp_path, monkeypatch, variant, source):
     """the chunk-parallel reader of the CLI (FastqReader::parse_chunk + ChunkedReader): parser threads guess where
     the first record of their chunk starts, the sequencer checks every guess against the chunk in front and parses
-    again where they differ -- whatever the chunk size, the records are those of the sequential reader"""
+    again where they differ -- whatever the chunk size, the records are those of the sequential reader.  source =
+    memory: the parsers take the bytes in place from a mapping (how inflated gzip members reach them)"""
+    if source == "memory":
+        monkeypatch.setenv("FPLH_CHUNK_MEM", "1")
     rng = np.random.default_rng(33)
     reads = []
     for i in range(300):
