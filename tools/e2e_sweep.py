@@ -22,16 +22,15 @@ base = [build.CLI, "-i", fq, "-o", "/dev/null", "-s", synth.START_ADAPTER, "-e",
         "-W", "5", "-x", "-y", "-j", "/dev/shm/e2e.json", "-h", "/dev/shm/e2e.html", "-V"]
 configs = [
     ("seq reader (round 1 path), pinned", ["--reader_threads", "1"], {"FPLH_NO_CHUNKS": "1"}),
-    ("chunks R=4  32MB", ["--reader_threads", "4"], {}),
+    ("chunks R=16 32MB pread", ["--reader_threads", "16"], {"FPLH_NO_MMAP_INPUT": "1"}),
     ("chunks R=8  32MB", ["--reader_threads", "8"], {}),
-    ("chunks R=12 32MB", ["--reader_threads", "12"], {}),
     ("chunks R=16 32MB", ["--reader_threads", "16"], {}),
     ("chunks R=24 32MB", ["--reader_threads", "24"], {}),
-    ("chunks R=32 32MB", ["--reader_threads", "32"], {}),
-    ("chunks R=16 16MB", ["--reader_threads", "16", "--chunk_mb", "16"], {}),
     ("chunks R=16 64MB", ["--reader_threads", "16", "--chunk_mb", "64"], {}),
     ("chunks R=16 128MB", ["--reader_threads", "16", "--chunk_mb", "128"], {}),
-    ("chunks R=16 32MB pageable", ["--reader_threads", "16"], {"FPLH_NO_PIN": "1"}),
+    ("chunks R=16 256MB", ["--reader_threads", "16", "--chunk_mb", "256"], {}),
+    ("chunks R=8 256MB", ["--reader_threads", "8", "--chunk_mb", "256"], {}),
+    ("chunks R=16 512MB", ["--reader_threads", "16", "--chunk_mb", "512"], {}),
     ("chunks default", [], {}),
     ("chunks default -> /dev/shm file", ["-o", "/dev/shm/e2e_out.fq"], {}),
 ]
