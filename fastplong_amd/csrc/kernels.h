@@ -57,7 +57,9 @@ __device__ unsigned long long g_fpl_prof[64];
                                of two (k_stats_sorted) */
 #endif
 #ifndef FPL_OPT_ACGT
-#define FPL_OPT_ACGT 1 /* k_scan: tiles made of A, C, G, T, N only take three code bit-planes through the scan (range_scan_fast) */
+#define FPL_OPT_ACGT 1 /* k_scan: full tiles made of A, C, G, T, N only take three code bit-planes through the scan (range_scan_fast).
+                          2: the ragged last tile of a range too -- measured the same (6.756 vs 6.753 ms, 2 kb reads 10.62 vs
+                          10.54 ms, profiles/r02_ab), so the ragged tile keeps the byte-masked variants */
 #endif
 #ifndef FPL_OPT_PREFETCH
 #define FPL_OPT_PREFETCH 0 /* k_scan touches the lines of a read's next tile one tile ahead (range_scan_fast): 2 % slower side by side --
@@ -2384,18 +2386,38 @@ __device__ __forceinline__ u32 not_acgtn(const u32 s[8]) {
    popcount, and "differs from its predecessor" (Filter::passLowComplexityFilter, src/filter.cpp:66-81) one XOR of each
    plane with itself shifted by one position -- 16 instead of 104 vector instructions.  The predecessor of base 0 (the
    byte in front of the chunk) may be any byte: that one comparison is made on the bytes. */
-__device__ __forceinline__ void sums32_acgtn(const u32 s0, const u32 q[8], u32 L, u32 H, u32 N, u32 prev_dword, u32 qqrep,
-                                             u32& lowq, u32& nn, u32& totq, u32& diff) {
+/* MASKED: only the first nvalid (1..32) bases of the chunk count */
+template <bool MASKED>
+__device__ __forceinline__ void sums32_acgtn(const u32 s0, const u32 q[8], int nvalid, u32 L, u32 H, u32 N, u32 prev_dword,
+                                             u32 qqrep, u32& lowq, u32& nn, u32& totq, u32& diff) {
 #pragma unroll
     for (int d = 0; d < 8; d++) {
+        u32 bm = ~0u, fm = 0x80808080u;
+        if (MASKED) {
+            const int c = nvalid - 4 * d;
+            bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
+            fm &= bm;
+        }
         const u32 t = (q[d] | 0x80808080u) - qqrep;
-        lowq = FPL_OPT_BCNT ? popc_acc(~t & 0x80808080u, lowq) : lowq + popc32(~t & 0x80808080u);
-        totq = sum_bytes(q[d], totq);
+        lowq = FPL_OPT_BCNT ? popc_acc(~t & fm, lowq) : lowq + popc32(~t & fm);
+        totq = sum_bytes(q[d] & bm, totq);
     }
-    nn = FPL_OPT_BCNT ? popc_acc(N, nn) : nn + popc32(N);
-    const u32 dm = ((L ^ (L << 1)) | (H ^ (H << 1)) | (N ^ (N << 1))) & ~1u;
+    const u32 vm = (!MASKED || nvalid >= 32) ? ~0u : ((1u << nvalid) - 1u);
+    nn = FPL_OPT_BCNT ? popc_acc(N & vm, nn) : nn + popc32(N & vm);
+    const u32 dm = ((L ^ (L << 1)) | (H ^ (H << 1)) | (N ^ (N << 1))) & ~1u & vm;
     const u32 d0 = ((s0 & 0xFFu) != (prev_dword >> 24)) ? 1u : 0u;
     diff = (FPL_OPT_BCNT ? popc_acc(dm, diff) : diff + popc32(dm)) + d0;
+}
+/* not_acgtn over the first nvalid (0..32) bytes only */
+__device__ __forceinline__ u32 not_acgtn_masked(const u32 s[8], int nvalid) {
+    u32 bad = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const int c = nvalid - 4 * d;
+        const u32 bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
+        bad |= (perm_b32(0x4E000000u, 0x47544341u, (s[d] >> 1) & 0x07070707u) ^ s[d]) & bm;
+    }
+    return bad;
 }
 __device__ __forceinline__ void build_planes(const u32 s[8], u32& PA, u32& PC, u32& PT, u32& PG) {
     u32 L = 0, H = 0, X = 0;
@@ -2654,22 +2676,27 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         const bool ragged = wave_ballot(nstat > 0 && nstat < SC_CHUNK) != 0;
         bool acgt = false;
         u32 cL = 0, cH = 0, cN = 0;
-        if (FPL_OPT_ACGT && !LEAN && !ragged && (SUMS || HAM)) {
-            acgt = !wave_ballot(not_acgtn(s) != 0);
+        if (FPL_OPT_ACGT && !LEAN && (SUMS || HAM) && (!ragged || FPL_OPT_ACGT > 1)) {
+            /* (a ragged tile: the bytes behind the end of the range are not looked at -- no window that is tested reaches
+               them, and the sums mask them) */
+            acgt = !wave_ballot((ragged ? not_acgtn_masked(s, nstat) : not_acgtn(s)) != 0);
             if (acgt) code_planes(s, cL, cH, cN);
         }
         if (!LEAN && !ragged && (acgt || !FPL_OPT_ACGT || !(SUMS || HAM))) {
             if (nstat == SC_CHUNK) {
                 if (!FPL_DBG(dbg, 1)) hist32<false>(hl, q, SC_CHUNK);
                 if (SUMS && !FPL_DBG(dbg, 2)) {
-                    if (FPL_OPT_ACGT) sums32_acgtn(s[0], q, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
+                    if (FPL_OPT_ACGT) sums32_acgtn<false>(s[0], q, SC_CHUNK, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
                     else sums32<false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
                 }
                 if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
             }
         } else if (nstat > 0) {
             hist32<true>(hl, q, nstat);
-            if (SUMS) sums32<true>(s, q, nstat, prevd, qqrep, lowq, nn, totq, diff);
+            if (SUMS) {
+                if (FPL_OPT_ACGT > 1 && acgt) sums32_acgtn<true>(s[0], q, nstat, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
+                else sums32<true>(s, q, nstat, prevd, qqrep, lowq, nn, totq, diff);
+            }
         }
         if (HAM) {
             if ((npos0 > t0 || npos1 > t0) && !FPL_DBG(dbg, 16)) { /* wave-uniform: some window of this tile is tested */
