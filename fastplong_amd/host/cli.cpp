@@ -411,7 +411,7 @@ int main(int argc, char* argv[]) {
     /* the CSR arrays of every batch are page-locked (fpl_host_alloc), so the DMA engines read them in place */
     if (!getenv("FPLH_NO_PIN")) /* (measurement hook: pageable batches, the runtime stages the copies) */
         fplh::ByteBuf::set_allocator(fpl_host_alloc, fpl_host_free);
-    const int hw = max(1, (int)thread::hardware_concurrency());
+    const int hw = max(1, fplh::effective_cpus()); /* (what the scheduler lets this process use: affinity and cgroup quota) */
     /* How the input is read.  A regular uncompressed file is cut into chunks of --chunk_mb that --reader_threads
        workers parse at the same time (FastqReader::parse_chunk: each worker reads its chunk from the page cache,
        locates the records and copies their lines into a page-locked batch); the sequencer below puts the chunks
@@ -461,7 +461,7 @@ int main(int argc, char* argv[]) {
                 const double t0 = clk();
                 const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
                 uint64_t sz = 0, reserved = 0;
-                chunkMem = fplh::gunzip_members_to_memory(in, max(16, min(64, hw / 4)), phys / 3, &sz, &reserved);
+                chunkMem = fplh::gunzip_members_to_memory(in, max(4, min(64, hw)), phys / 3, &sz, &reserved);
                 if (chunkMem) { /* (the mapping lives until the process ends) */
                     chunkFileSize = sz;
                     if (cmd.exist("verbose"))
@@ -474,12 +474,14 @@ int main(int argc, char* argv[]) {
     if (const char* e = getenv("FPLH_CHUNK_BYTES")) /* test hook: tiny chunks put every cut inside some record */
         if (atol(e) > 0) chunkBytes = (uint64_t)atol(e);
     int readerThreads = cmd.i("reader_threads");
-    if (readerThreads <= 0) readerThreads = max(2, min(16, hw / 8));
+    if (readerThreads <= 0) readerThreads = max(2, min(16, hw / 2)); /* (half of the CPUs parse, the rest formats, copies and writes) */
     const bool chunked = (chunkFd >= 0 || chunkMem) && (chunkFileSize > chunkBytes || chunkMem);
     fplh::FastqReader* reader = nullptr;
     /* Work objects bound what is in flight: one per parser, FPL_MAX_IN_FLIGHT per device in the copy / kernel stage,
        one per device being formatted, two waiting for the writer */
-    const int nWork = (chunked ? readerThreads : 1) + (FPL_MAX_IN_FLIGHT + 1) * nGpus + 2;
+    auto gz_name = [](const string& p) { return p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0; };
+    const bool gzOut = !splitEnabled && (gz_name(out) || gz_name(failedOut)); /* (then up to four batches are formatted at a time) */
+    const int nWork = (chunked ? readerThreads : 1) + (FPL_MAX_IN_FLIGHT + 1) * nGpus + 2 + (gzOut ? 3 : 0);
     if (chunked) /* a chunk holds about half its bytes in bases: one block each for the bases and the qualities of a batch */
         fplh::ByteBuf::set_arena((size_t)(chunkBytes / 2 + chunkBytes / 16 + (2u << 20)), 2 * (size_t)nWork);
     if (!chunked) {
@@ -528,7 +530,12 @@ int main(int argc, char* argv[]) {
     /* slices a batch's output is formatted in (one worker each); gzip outputs are deflated per slice, which is compute-
        bound, so they get more, smaller slices */
     const bool anyGz = (fout && fout.gz) || (ffail && ffail.gz);
-    const int fmtThreads = max(1, min(anyGz ? 64 : 16, hw / max(1, nGpus) - 1));
+    /* formatter stage threads: one per device -- or four when the output is deflated, each with a quarter of the helpers:
+       a batch of one chunk (32 MB of text) cut into 64 members keeps 64 helpers busy for a few milliseconds between two
+       thread hand-offs (measured: 25 ms per batch, 1.3 GB/s), four batches side by side in 16 members each do not wait
+       for one another */
+    const int nFmt = anyGz ? max(nGpus, 4) : nGpus;
+    const int fmtThreads = max(1, min(anyGz ? max(8, 64 / nFmt * nGpus) : 16, hw / max(1, nGpus) - 1));
     vector<Work> pool(nWork);
     Channel<Work*> freeq, fmtq, doneq;
     vector<Channel<Work*>> devq(nGpus);
@@ -539,7 +546,7 @@ int main(int argc, char* argv[]) {
     const double tStart = now();
     double tParse = 0, tWrite = 0, tRedo = 0;
     uint64_t nRedo = 0;
-    vector<double> tGpu(nGpus, 0), tFormat(nGpus, 0);
+    vector<double> tGpu(nGpus, 0), tFormat(nFmt, 0);
     string inputError; /* a malformed record: reported the way the sequential reader does, the input ends there */
     string ioError;    /* the input could not be read / decompressed to its end: the run fails (src/fastqreader.cpp:92-137) */
 
@@ -658,7 +665,7 @@ int main(int argc, char* argv[]) {
     /* ---- stage 3: the output text of a batch, on helper threads (the writer below only writes) */
     vector<thread> fmtStage;
     std::atomic<int> devEnded{0};
-    for (int f = 0; f < nGpus; f++)
+    for (int f = 0; f < nFmt; f++)
         fmtStage.emplace_back([&, f]() {
             for (;;) {
                 Work* w = fmtq.pop();
@@ -666,7 +673,7 @@ int main(int argc, char* argv[]) {
                     /* one end marker per device thread; the formatter that sees the last one wakes the others */
                     if (devEnded.load() >= nGpus) break;
                     if (++devEnded == nGpus) {
-                        for (int i = 0; i + 1 < nGpus; i++) fmtq.push(nullptr);
+                        for (int i = 0; i + 1 < nFmt; i++) fmtq.push(nullptr);
                         break;
                     }
                     continue;
@@ -735,7 +742,7 @@ int main(int argc, char* argv[]) {
     { /* writer: this thread, in input order */
         map<uint64_t, Work*> ready;
         uint64_t next = 0;
-        int live = nGpus;
+        int live = nFmt;
         while (live > 0) {
             Work* w = doneq.pop();
             if (!w) {
@@ -771,7 +778,8 @@ int main(int argc, char* argv[]) {
     if (!ioError.empty()) error_exit(ioError);
     if (cmd.exist("verbose")) {
         double g = 0, f = 0;
-        for (int d = 0; d < nGpus; d++) g = max(g, tGpu[d]), f = max(f, tFormat[d]);
+        for (int d = 0; d < nGpus; d++) g = max(g, tGpu[d]);
+        for (int d = 0; d < nFmt; d++) f = max(f, tFormat[d]);
         cerr << "host pipeline: " << nBatches << " batches, wall " << now() - tStart << " s; busy: parse " << tParse
              << " s" << (chunked ? " (busiest of " + to_string(readerThreads) + " chunk parsers; " + to_string(nRedo) + " chunks parsed again, " + to_string(tRedo) + " s)" : string())
              << ", copies + kernels (waits) " << g << " s, format (" << fmtThreads << " threads) " << f << " s, write " << tWrite

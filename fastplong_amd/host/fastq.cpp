@@ -5,6 +5,7 @@
 #include <immintrin.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/syscall.h>
 #include <sys/stat.h>
@@ -29,12 +30,44 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 static const bool g_timing = getenv("FPLH_TIMING") != nullptr;
 static std::atomic<uint64_t> g_chunk_us[3]; /* FPLH_TIMING: microseconds the chunk parsers spent reading / locating / copying */
 
+int effective_cpus() {
+    static const int cached = []() {
+        if (const char* e = getenv("FPLH_CPUS"))
+            if (atoi(e) > 0) return atoi(e);
+        int n = max(1, (int)std::thread::hardware_concurrency());
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = min(n, (int)CPU_COUNT(&set));
+        auto quota = [](const char* path, bool v2) -> double {
+            FILE* f = fopen(path, "r");
+            if (!f) return 0;
+            char a[64] = {0}, b[64] = {0};
+            double q = 0;
+            if (v2) { /* "max 100000" or "<quota> <period>" */
+                if (fscanf(f, "%63s %63s", a, b) == 2 && strcmp(a, "max") != 0 && atof(b) > 0) q = atof(a) / atof(b);
+            } else if (fscanf(f, "%63s", a) == 1) {
+                q = atof(a); /* microseconds per period, -1 = none */
+            }
+            fclose(f);
+            return q;
+        };
+        double q = quota("/sys/fs/cgroup/cpu.max", true);
+        if (q <= 0) {
+            const double us = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false), per = quota("/sys/fs/cgroup/cpu/cpu.cfs_period_us", false);
+            if (us > 0 && per > 0) q = us / per;
+        }
+        if (q > 0) n = min(n, max(1, (int)(q + 0.5)));
+        return n;
+    }();
+    return cached;
+}
+
 namespace {
 class Pool {
    public:
     Pool() {
-        const int hw = (int)std::thread::hardware_concurrency();
-        int n = min(64, max(1, hw - 2));
+        const int hw = effective_cpus();
+        int n = min(64, max(1, hw - 1));
         if (const char* e = getenv("FPLH_POOL_THREADS"))
             if (atoi(e) >= 0) n = atoi(e);
         for (int i = 0; i < n; i++) workers_.emplace_back([this]() { work(); });
@@ -1083,7 +1116,7 @@ bool ChunkedReader::next(Item& out) {
                 ps.item.batch->off.push_back(0);
                 ps.item.batch->name_off.push_back(0);
             } else {
-                const int hw = (int)std::thread::hardware_concurrency();
+                const int hw = effective_cpus();
                 FastqReader::parse_chunk(D.fd, D.file_size, max(a, D.expected), b, true, D.window, *ps.item.batch, ps.info,
                                          max(1, min(8, hw / 2)), D.mem);
             }

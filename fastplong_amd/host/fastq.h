@@ -25,6 +25,10 @@ namespace fplh {
  * as much as the work.  run(n, fn) executes fn(0) .. fn(n-1) on the workers and the calling thread and returns when
  * all are done; any number of threads may call it at the same time. */
 void parallel_run(int tasks, const std::function<void(int)>& fn);
+/* CPUs this process may actually use: the hardware threads, cut down to the scheduler affinity mask and to the cgroup's
+   CPU bandwidth quota (cpu.max / cpu.cfs_quota_us) -- a container on a 256-thread node with a 16-CPU quota is throttled,
+   not sped up, by 64 busy threads (FPLH_CPUS overrides) */
+int effective_cpus();
 
 /* growable byte array without the zero fill of std::vector::resize (batches are hundreds of megabytes and
  * every byte is overwritten by the parser's copy threads).  The memory comes from a process-wide allocator pair the
