@@ -414,6 +414,7 @@ struct Arena {
     size_t block = 0, n = 0;
     vector<uint8_t*> free_blocks;
     mutex mu;
+    bool released = false;
     bool owns(const uint8_t* p) const { return base && p >= base && p < base + block * n; }
 } g_arena;
 }  // namespace
@@ -428,6 +429,12 @@ void ByteBuf::set_arena(size_t block_bytes, size_t n_blocks) {
     g_arena.block = block_bytes;
     g_arena.n = n_blocks;
     for (size_t i = n_blocks; i-- > 0;) g_arena.free_blocks.push_back(g_arena.base + i * block_bytes);
+}
+void ByteBuf::release_arena() {
+    lock_guard<mutex> g(g_arena.mu);
+    if (g_arena.base && g_free && !g_arena.released) g_free(g_arena.base);
+    g_arena.released = true; /* (owns() stays true for stale pointers: their release is then a no-op push) */
+    g_arena.free_blocks.clear();
 }
 static void buf_release(uint8_t* p) {
     if (g_arena.owns(p)) {

@@ -43,6 +43,7 @@ class ByteBuf {
        memory is slow and does not scale over threads: 24 parser threads allocating their first batches spent 13 s in
        it for 5 GB); a buffer that needs more than a block, or finds none free, falls back to the allocator */
     static void set_arena(size_t block_bytes, size_t n_blocks);
+    static void release_arena(); /* give the arena back (no buffer of it may be used afterwards) */
     ByteBuf() = default;
     ByteBuf(const ByteBuf&) = delete;
     ByteBuf& operator=(const ByteBuf&) = delete;

@@ -8,7 +8,9 @@
 
 #include <algorithm>
 #include <fstream>
+#include <charconv>
 #include <sstream>
+#include <type_traits>
 
 #include "report.h"
 #include "report_internal.h"
@@ -100,6 +102,17 @@ string div_name(const string& subsection, bool colons_too) { /* replace(s, " ", 
 }
 template <class T>
 string joined(const vector<T>& v) { /* Stats::list2string(T*, long) */
+    if constexpr (std::is_integral<T>::value) { /* (the density plots list two numbers per read: operator<< costs 0.2 s per million reads) */
+        string out;
+        out.resize(v.size() * 21 + 1);
+        char* p = &out[0];
+        for (size_t i = 0; i < v.size(); i++) {
+            p = std::to_chars(p, p + 21, (long long)v[i]).ptr;
+            if (i + 1 < v.size()) *p++ = ',';
+        }
+        out.resize((size_t)(p - out.data()));
+        return out;
+    }
     stringstream ss;
     for (size_t i = 0; i < v.size(); i++) {
         ss << v[i];
