@@ -228,9 +228,12 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     }
     mark(2);
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
-    if (FPL_OPT_SORTSTATS && !a.defer) {
+    const u32 per_sorted = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
+    /* (the persistent blocks number their (tile, slice) items with 32 bits; a batch beyond that -- hundreds of millions of
+       reads next to a read of hundreds of megabases -- takes the plain walk) */
+    if (FPL_OPT_SORTSTATS && !a.defer && (uint64_t)stats_sorted_max_slices(n, per_sorted, a.tune) * n_tiles < 0xFFFFFFF0ull) {
         /* (with --break / --mask no read is counted post-filter by this pass: the plain walk below does) */
-        const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
+        const u32 per = per_sorted;
         const u32 max_slices = stats_sorted_max_slices(n, per, a.tune);
         FPL_MEMSET(a.sort_ws, (size_t)SW_SLICES * sizeof(u32), stream);
         FPL_MEMSET(a.stats_flags, (size_t)max_slices * n_tiles + n_tiles, stream);
