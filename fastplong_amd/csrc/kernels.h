@@ -1736,7 +1736,8 @@ constexpr u32 CS_MAX_ITEMS_PER_SLICE = 16383;
 #define FPL_ABL 0 /* profiling only (-DFPL_ABL=bits): 1 no pre-table, 2 no post-table, 4 no 5-mer updates in k_stats */
 #endif
 constexpr int CS_GROUP = 4; /* items whose loads are in flight together, per wave */
-constexpr u32 PLAN_TO_POST = 1u; /* ReadState::pad bit: r1 passes unsplit and s <= FS_SMAX */
+constexpr u32 PLAN_TO_POST = 1u; /* ReadState::pad bit: the read has ONE output read, it passes, and it starts <= FS_SMAX bases into the read
+                                    (ReadState::s / e then hold that output read's window) */
 
 /* 2-bit base codes of the four bytes of d, one per byte (Stats::base2val: A0 T/U1 C2 G3; other letters give
    some code and are caught by the validity mask) */
@@ -3013,7 +3014,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         ReadState rs = {0, 0, 0, 0};
         if (mine) {
             o_r = off[v_ri];
-            rs = state[v_ri]; /* (s and e are k_trim_ends' values; this kernel only rewrites `pad`) */
+            rs = state[v_ri]; /* (s and e are still k_trim_ends' values: a pending read has not been split) */
         }
         const bool ok = lev_lanes32_acgt(seq + o_r + rs.s + (need ? v_pos : 0), a ? ads[1].len : ads[0].len,
                                          cfg->thr[a ? ads[1].len : ads[0].len], need, peq4[a], seq_end);
@@ -3307,7 +3308,11 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             }
         }
         PROF(8) /* filter + fragment statistics */
-        const bool to_post = !dropped && !split && pass0 && s <= FS_SMAX;
+        /* one passing output read that starts within FS_SMAX bases of the read's start -- r1 itself, or the only fragment a
+           middle adapter close to an end leaves (Read::breakByGap drops an empty side; with empty command-line adapters
+           and --adapter_fasta EVERY read is "split" at position 0 like that, src/adaptertrimmer.cpp:13-40): its post-filter
+           statistics are those of the window [start, start + len) of the read, which the single statistics pass counts */
+        const bool to_post = !dropped && nf == 1 && pass0 && r_fs0 <= (u32)FS_SMAX;
         if (lane == 0) {
             fpl_read_result res;
             res.r1_start = dropped ? 0 : (u32)s;
@@ -3326,6 +3331,10 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                tables straight from the single statistics pass; every other passing fragment goes to the
                post-only EXTRA list (through this wave's buffer; the order is irrelevant) */
             state[ri].pad = to_post ? PLAN_TO_POST : 0u;
+            if (to_post && split) { /* the window the statistics pass works on is the fragment, not r1 */
+                state[ri].s = r_fs0;
+                state[ri].e = r_fs0 + r_fl0;
+            }
             u32 slot = nbuf;
             if (pass0 && !to_post && !defer_confirm) {
                 wl->fbuf_off[slot] = o0 + r_fs0;

@@ -97,6 +97,11 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.st_e = st_e.data();
     a.stats_flags = sflags.data();
     enqueue_batch(a, nullptr, [](int) {});
+    if (getenv("FPL_EMU_DEBUG_PLAN")) { /* how the reads were planned for the statistics passes */
+        u32 tp = 0;
+        for (uint32_t i = 0; i < n_reads; i++) tp += state[i].pad & 1u;
+        fprintf(stderr, "emu: %u reads, %u planned to-post, EXTRA list %u, sort slices %u\n", n_reads, tp, work_ctr[1], sort_ws[SW_NSLICES]);
+    }
     g_frags.clear();
     g_regs.clear();
     if (cfg.defer) {
