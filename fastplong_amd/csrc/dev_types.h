@@ -37,6 +37,11 @@ struct DevAdapter {
     uint64_t peq4_full[4];
     uint32_t peq4_s16[4];
     uint32_t peq4_e16[4];
+    /* ... and for its cheaper form (FPL_OPT_FASTAFILTER 2): the first min(32, len) bases in reading order (end trim) and the
+       last min(32, len) bases in REVERSE order (start trim, whose window is then walked backwards): in both the trim's
+       16-base partial pattern is the first 16 columns */
+    uint32_t peq4_e32[4];
+    uint32_t peq4_s32r[4];
 };
 
 /* Options as the kernels consume them: integers only. */
@@ -102,6 +107,13 @@ inline void build_adapter(DevAdapter* a, const char* seq, int len) {
             a->peq4_full[c] = a->peq_full[letters[c]][0];
             a->peq4_s16[c] = a->peq16_start[letters[c]];
             a->peq4_e16[c] = a->peq16_end[letters[c]];
+            a->peq4_e32[c] = 0;
+            a->peq4_s32r[c] = 0;
+            const int m = len < 32 ? len : 32;
+            for (int i = 0; i < m; i++) {
+                if ((uint8_t)seq[i] == letters[c]) a->peq4_e32[c] |= 1u << i;
+                if ((uint8_t)seq[len - 1 - i] == letters[c]) a->peq4_s32r[c] |= 1u << i;
+            }
         }
     }
 }

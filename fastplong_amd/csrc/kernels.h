@@ -75,8 +75,10 @@ __device__ unsigned long long g_fpl_prof[64];
 #define FPL_OPT_SCANBATCH 1 /* k_scan: the middle-adapter confirmations of up to 32 reads in one lane-parallel pass */
 #endif
 #ifndef FPL_OPT_FASTAFILTER
-#define FPL_OPT_FASTAFILTER 1 /* k_trim_ends<2>: a lane-per-adapter Myers search pass over the two end windows decides which
-                                 adapters of the FASTA list get the exact trims at all (fasta_may_trim) */
+#define FPL_OPT_FASTAFILTER 2 /* k_trim_ends<2>: a lane-per-adapter Myers search pass over the two end windows decides which
+                                 adapters of the FASTA list get the exact trims at all.  1: a 64-column run for the whole adapter
+                                 and a 16-column run for the partial pattern (fasta_may_trim); 2: one 32-column run with two
+                                 score taps (fasta_may_trim32) */
 #endif
 #ifndef FPL_OPT_SGFILTER
 #define FPL_OPT_SGFILTER 1 /* k_trim_ends_batched: a lane-parallel Myers search pass decides which reads need the
@@ -999,6 +1001,49 @@ __device__ __forceinline__ void fasta_peq_store(FastaPeqLds* __restrict__ t, con
     }
 #pragma unroll
     for (int f = 0; f < 4; f++) t->w[4][f][lane] = 0u;
+#if FPL_OPT_FASTAFILTER == 2
+#pragma unroll
+    for (int c = 0; c < 4; c++) { /* (the cheaper form only needs fields 2 and 3) */
+        t->w[c][2][lane] = a_ok ? ad->peq4_s32r[c] : 0u;
+        t->w[c][3][lane] = a_ok ? ad->peq4_e32[c] : 0u;
+    }
+#endif
+}
+/* The cheaper form of the test below (FPL_OPT_FASTAFILTER 2): ONE 32-column semi-global Myers run per end with two score
+   taps.  If the whole adapter matches somewhere within thrA edits, so does any prefix or suffix of it, and if the 16-base
+   partial pattern matches a window within thrP edits, the search variant finds a substring at least that close: the end
+   trim searches for the adapter's first min(32, len) bases (tap at their last column) and reads the partial pattern's
+   score off column 15 of the same run; the start trim does the same with the adapter's last bases REVERSED over the
+   window read backwards (an edit script read backwards is an edit script), so that its partial pattern -- the adapter's
+   last 16 bases -- is again the first 16 columns.  18 vector instructions per window byte instead of 49; what it lets
+   through that the two-run form would have stopped only costs an exact trim that finds nothing. */
+template <bool START>
+__device__ __forceinline__ bool fasta_may_trim32(const FastaPeqLds* __restrict__ t, const u8* __restrict__ win, int boff, int n,
+                                                 int alen, int thrA, int thrP, bool a_ok) {
+    const int lane = lane_id();
+    const int m = min(alen, 32);
+    u32 Pv = m >= 32 ? ~0u : ((1u << m) - 1u), Mv = 0;
+    int scF = m, scP = 16, bestF = m, bestP = 16;
+    const u32 topF = (u32)(m - 1);
+    for (int j = 0; j < n; j++) {
+        const u32 c = uniform_u32((u32)win[(START ? n - 1 - j : j) + boff]); /* the same byte for every lane */
+        const u32 code = (c >> 1) & 3u;
+        const u32 row = (((0x47544341u >> (8 * code)) & 0xFFu) == c) ? code : 4u;
+        const u32 Eq = t->w[row][START ? 2 : 3][lane];
+        const u32 Xv = Eq | Mv;
+        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        u32 Ph = Mv | ~(Xh | Pv);
+        u32 Mh = Pv & Xh;
+        scF += (int)((Ph >> topF) & 1u) - (int)((Mh >> topF) & 1u);
+        scP += (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
+        Ph <<= 1; /* (no "| 1": a match may start anywhere) */
+        Mh <<= 1;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+        bestF = min(bestF, scF);
+        bestP = min(bestP, scP);
+    }
+    return a_ok && (bestF <= thrA || bestP <= thrP);
 }
 /* can this lane's adapter (length alen in 16..64, thresholds thrA / thrP) trim at this end?  win = the window bytes in
    LDS (window byte j at win[j + boff]), n of them; START: the start trim (partial pattern = the adapter's last 16 bases) */
@@ -1180,8 +1225,13 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 }
                 const int alen = la->len;
                 const int thrA = cfg->thr[alen], thrP = cfg->thr[FPL_PATTERN_LEN];
+#if FPL_OPT_FASTAFILTER == 2
+                may_s = wave_ballot(fasta_may_trim32<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok));
+                may_e = wave_ballot(fasta_may_trim32<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok));
+#else
                 may_s = wave_ballot(fasta_may_trim<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok));
                 may_e = wave_ballot(fasta_may_trim<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok));
+#endif
             };
             for (int a = 0; MODE != 1 && a < cfg->n_fasta; a++) {
                 const DevAdapter* ad = &ads[2 + a];
