@@ -985,6 +985,9 @@ __device__ __forceinline__ void stage_ends(u32* __restrict__ hs, u32* __restrict
  * smaller than the search distance at the window's last byte -- so an adapter whose two minima both stay above their
  * thresholds cannot trim this end, and the chain skips it.  Anything else gets the exact code, unchanged.
  * FastaPeqLds: the Peq words of a group of 64 adapters, [letter code | 4 = any other byte: zero][field][lane]. */
+#ifdef FPL_EMU_FILTER_STATS
+static unsigned long long g_filter_stats[4]; /* emulator only: mask refreshes, adapters flagged at the start / at the end */
+#endif
 struct FastaPeqLds {
     u32 w[5][4][64]; /* field 0 / 1: whole adapter, low / high word; 2: last 16 bases; 3: first 16 bases */
 };
@@ -1225,12 +1228,24 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 }
                 const int alen = la->len;
                 const int thrA = cfg->thr[alen], thrP = cfg->thr[FPL_PATTERN_LEN];
+                if (FPL_DBG(cfg->dbg, 2048)) { /* (timing experiment: no filter, no exact trims) */
+                    may_s = may_e = 0;
+                    return;
+                }
 #if FPL_OPT_FASTAFILTER == 2
                 may_s = wave_ballot(fasta_may_trim32<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok));
                 may_e = wave_ballot(fasta_may_trim32<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok));
 #else
                 may_s = wave_ballot(fasta_may_trim<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok));
                 may_e = wave_ballot(fasta_may_trim<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok));
+#endif
+                if (FPL_DBG(cfg->dbg, 1024)) may_s = may_e = 0; /* (timing experiment: the filter, but no exact trims) */
+#ifdef FPL_EMU_FILTER_STATS
+                if (lane == 0) {
+                    __atomic_fetch_add(&g_filter_stats[0], 1ull, __ATOMIC_RELAXED);
+                    __atomic_fetch_add(&g_filter_stats[1], (unsigned long long)__builtin_popcountll(may_s), __ATOMIC_RELAXED);
+                    __atomic_fetch_add(&g_filter_stats[2], (unsigned long long)__builtin_popcountll(may_e), __ATOMIC_RELAXED);
+                }
 #endif
             };
             for (int a = 0; MODE != 1 && a < cfg->n_fasta; a++) {

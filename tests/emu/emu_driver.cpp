@@ -97,6 +97,10 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.st_e = st_e.data();
     a.stats_flags = sflags.data();
     enqueue_batch(a, nullptr, [](int) {});
+#ifdef FPL_EMU_FILTER_STATS
+    fprintf(stderr, "emu: filter refreshes %llu, flagged start %llu, end %llu (reads %u)\n", fpl::g_filter_stats[0], fpl::g_filter_stats[1],
+            fpl::g_filter_stats[2], n_reads);
+#endif
     if (getenv("FPL_EMU_DEBUG_PLAN")) { /* how the reads were planned for the statistics passes */
         u32 tp = 0;
         for (uint32_t i = 0; i < n_reads; i++) tp += state[i].pad & 1u;
