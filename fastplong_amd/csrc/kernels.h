@@ -678,7 +678,11 @@ template <int MODE, bool LDSWIN, class PT, int PW>
 __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                                const PT* __restrict__ peq16,
                                                const uint64_t (*__restrict__ peqf)[PW],
-                                               const DevConfig* __restrict__ cfg, int& keylen) {
+                                               const DevConfig* __restrict__ cfg, int& keylen,
+                                               bool may_full = true, bool may_part = true) {
+    /* may_full / may_part (wave-uniform): false when the caller has PROOF that the whole-adapter search / the partial-
+       pattern search finds nothing here (fasta_may_trim32) -- the search, and the Levenshtein run on its best window, are
+       then left out */
     const int lane = lane_id();
     const int rlen = e - s;
     keylen = 0;
@@ -695,7 +699,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
     for (int k = 0; k < NW1H; k++) ad1h[k] = (MODE != 0 && FPL_OPT_ONEHOT) ? uniform_u32(ad->onehot[k]) : 0u;
     int mpos = -1;
     const int searchEnd = min(rlen, FPL_END_WINDOW);
-    if (alen <= rlen && searchEnd > alen) {
+    if (may_full && alen <= rlen && searchEnd > alen) {
         const int npos = searchEnd - alen + 1; /* p = searchEnd-alen .. 0 */
         int hit = -1;
         u64 best = ~0ull;
@@ -730,7 +734,7 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
         return mpos + alen;
     }
     /* partial match of the last plen adapter bases, :202-216: first minimum among ed <= thr */
-    const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
+    const int lim = may_part ? min(rlen - plen, FPL_END_WINDOW - plen) : 0;
     const int thrP = cfg->thr[plen];
     u64 best = ~0ull;
     /* lim <= 184: three positions per lane, evaluated as three independent chains in one straight-line
@@ -778,7 +782,8 @@ template <int MODE, bool LDSWIN, class PT, int PW>
 __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int& e, const DevAdapter* __restrict__ ad,
                                              const PT* __restrict__ peq16,
                                              const uint64_t (*__restrict__ peqf)[PW],
-                                             const DevConfig* __restrict__ cfg, int& keylen) {
+                                             const DevConfig* __restrict__ cfg, int& keylen,
+                                             bool may_full = true, bool may_part = true) { /* (see trim_start_wave) */
     const int lane = lane_id();
     const int rlen = e - s;
     keylen = 0;
@@ -793,7 +798,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     for (int k = 0; k < NW1H; k++) ad1h[k] = (MODE != 0 && FPL_OPT_ONEHOT) ? uniform_u32(ad->onehot[k]) : 0u;
     const int ss = max(0, rlen - FPL_END_WINDOW);
     int mpos = -1;
-    if (ss + alen <= rlen) {
+    if (may_full && ss + alen <= rlen) {
         const int pend = rlen - alen; /* p in [ss, pend) : the last position is never tested */
         int hit = -1;
         u64 best = ~0ull;
@@ -832,7 +837,7 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     }
     /* partial match of the first plen adapter bases walking in from the tail, :273-286:
        qualifying positions in ascending p; stop at the first increase; ties take the later */
-    const int lim = min(rlen - plen, FPL_END_WINDOW - plen);
+    const int lim = may_part ? min(rlen - plen, FPL_END_WINDOW - plen) : 0;
     const int thrP = cfg->thr[plen];
     int pos = -1, mined = -1;
     bool stop = false;
@@ -1021,7 +1026,7 @@ __device__ __forceinline__ void fasta_peq_store(FastaPeqLds* __restrict__ t, con
    last 16 bases -- is again the first 16 columns.  18 vector instructions per window byte instead of 49; what it lets
    through that the two-run form would have stopped only costs an exact trim that finds nothing. */
 template <bool START>
-__device__ __forceinline__ bool fasta_may_trim32(const FastaPeqLds* __restrict__ t, const u8* __restrict__ win, int boff, int n,
+__device__ __forceinline__ u32 fasta_may_trim32(const FastaPeqLds* __restrict__ t, const u8* __restrict__ win, int boff, int n,
                                                  int alen, int thrA, int thrP, bool a_ok) {
     const int lane = lane_id();
     const int m = min(alen, 32);
@@ -1046,7 +1051,7 @@ __device__ __forceinline__ bool fasta_may_trim32(const FastaPeqLds* __restrict__
         bestF = min(bestF, scF);
         bestP = min(bestP, scP);
     }
-    return a_ok && (bestF <= thrA || bestP <= thrP);
+    return a_ok ? ((bestF <= thrA ? 1u : 0u) | (bestP <= thrP ? 2u : 0u)) : 0u; /* bit 0: the whole adapter may match, 1: its partial pattern */
 }
 /* can this lane's adapter (length alen in 16..64, thresholds thrA / thrP) trim at this end?  win = the window bytes in
    LDS (window byte j at win[j + boff]), n of them; START: the start trim (partial pattern = the adapter's last 16 bases) */
@@ -1206,6 +1211,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
             uint16_t* const pq = lds.peq16w[wave_in_block()];
             /* which adapters of the current group of 64 can trim the start / the end of r1 as it is now (fasta_may_trim) */
             u64 may_s = ~0ull, may_e = ~0ull;
+            u64 full_s = ~0ull, part_s = ~0ull, full_e = ~0ull, part_e = ~0ull; /* ... and which of its two searches could succeed */
             bool masks_ok = false;
             auto refresh_masks = [&](int a) {
                 const int g = a >> 6, ai = g * 64 + lane;
@@ -1233,8 +1239,16 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     return;
                 }
 #if FPL_OPT_FASTAFILTER == 2
-                may_s = wave_ballot(fasta_may_trim32<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok));
-                may_e = wave_ballot(fasta_may_trim32<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok));
+                {
+                    const u32 fs_ = fasta_may_trim32<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok);
+                    const u32 fe_ = fasta_may_trim32<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok);
+                    full_s = wave_ballot((fs_ & 1u) != 0);
+                    part_s = wave_ballot((fs_ & 2u) != 0);
+                    full_e = wave_ballot((fe_ & 1u) != 0);
+                    part_e = wave_ballot((fe_ & 2u) != 0);
+                    may_s = full_s | part_s;
+                    may_e = full_e | part_e;
+                }
 #else
                 may_s = wave_ballot(fasta_may_trim<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok));
                 may_e = wave_ballot(fasta_may_trim<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok));
@@ -1269,7 +1283,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_s, 0, e - s, win4_s};
-                    trimmed += trim_start_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
+                    trimmed += trim_start_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl, ((full_s >> (a & 63)) & 1ull) != 0,
+                                                     ((part_s >> (a & 63)) & 1ull) != 0);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
                     if (s != s0 || e != e0) {
                         stale_s = stale_e = true;
@@ -1286,7 +1301,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_e, rlen - wl, rlen, win4_e};
-                    trimmed += trim_end_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl);
+                    trimmed += trim_end_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl, ((full_e >> (a & 63)) & 1ull) != 0,
+                                                   ((part_e >> (a & 63)) & 1ull) != 0);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
                     if (s != s0 || e != e0) {
                         stale_s = stale_e = true;
