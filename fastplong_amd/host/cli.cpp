@@ -417,6 +417,9 @@ int main(int argc, char* argv[]) {
        locates the records and copies their lines into a page-locked batch); the sequencer below puts the chunks
        back in order and checks every chunk's guessed start against its predecessor.  Everything else -- gzip,
        pipes, --reads_to_process -- goes through the one sequential reader. */
+    uint64_t chunkBytes = (uint64_t)max(1L, cmd.l("chunk_mb")) << 20;
+    if (const char* e = getenv("FPLH_CHUNK_BYTES")) /* test hook: tiny chunks put every cut inside some record */
+        if (atol(e) > 0) chunkBytes = (uint64_t)atol(e);
     int chunkFd = -1;
     const char* chunkMem = nullptr; /* the input's text in memory (a mapping of the file / inflated gzip members) instead of a descriptor */
     bool chunkMemMapped = false;    /* ... a file mapping: its pages go back to the kernel as the reader passes them */
@@ -433,7 +436,7 @@ int main(int argc, char* argv[]) {
                against pread into per-thread windows, and no first-touch penalty on a file this process has not read before);
                the pages are handed back as the sequencer passes them.  (FPLH_NO_MMAP_INPUT: measurement hook.)  A file cut
                short under the mapping raises SIGBUS where pread would have returned an error: same message, same exit code */
-            if (!getenv("FPLH_NO_MMAP_INPUT")) {
+            if (!getenv("FPLH_NO_MMAP_INPUT") && chunkFileSize > chunkBytes) { /* (a file of one chunk goes through the sequential reader) */
                 void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
                 if (m != MAP_FAILED) {
                     madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
@@ -457,11 +460,15 @@ int main(int argc, char* argv[]) {
                write): the members are inflated side by side into anonymous memory, which the chunk parsers then take like
                a mapped file.  One deflate stream, or more text than a third of the machine's memory: the sequential
                reader and its stream.  (FPLH_NO_GZ_EXPAND: measurement / test hook) */
-            if (gz_file && !getenv("FPLH_NO_GZ_EXPAND")) {
+            if (gz_file && !getenv("FPLH_NO_GZ_EXPAND") && (uint64_t)st.st_size > chunkBytes / 8) { /* (small inputs: the stream) */
                 const double t0 = clk();
                 const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
                 uint64_t sz = 0, reserved = 0;
                 chunkMem = fplh::gunzip_members_to_memory(in, max(4, min(64, hw)), phys / 3, &sz, &reserved);
+                if (chunkMem && sz <= chunkBytes) { /* one chunk of text: not worth the parsers */
+                    munmap((void*)chunkMem, (size_t)reserved);
+                    chunkMem = nullptr;
+                }
                 if (chunkMem) { /* (the mapping lives until the process ends) */
                     chunkFileSize = sz;
                     if (cmd.exist("verbose"))
@@ -470,12 +477,9 @@ int main(int argc, char* argv[]) {
             }
         }
     }
-    uint64_t chunkBytes = (uint64_t)max(1L, cmd.l("chunk_mb")) << 20;
-    if (const char* e = getenv("FPLH_CHUNK_BYTES")) /* test hook: tiny chunks put every cut inside some record */
-        if (atol(e) > 0) chunkBytes = (uint64_t)atol(e);
     int readerThreads = cmd.i("reader_threads");
     if (readerThreads <= 0) readerThreads = max(2, min(16, hw / 2)); /* (half of the CPUs parse, the rest formats, copies and writes) */
-    const bool chunked = (chunkFd >= 0 || chunkMem) && (chunkFileSize > chunkBytes || chunkMem);
+    const bool chunked = (chunkFd >= 0 || chunkMem) && chunkFileSize > chunkBytes;
     fplh::FastqReader* reader = nullptr;
     /* Work objects bound what is in flight: one per parser, FPL_MAX_IN_FLIGHT per device in the copy / kernel stage,
        one per device being formatted, two waiting for the writer */
