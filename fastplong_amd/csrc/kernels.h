@@ -61,6 +61,10 @@ __device__ unsigned long long g_fpl_prof[64];
                           2: the ragged last tile of a range too -- measured the same (6.756 vs 6.753 ms, 2 kb reads 10.62 vs
                           10.54 ms, profiles/r02_ab), so the ragged tile keeps the byte-masked variants */
 #endif
+#ifndef FPL_OPT_ROWGUARD
+#define FPL_OPT_ROWGUARD 0 /* k_stats_sorted: one wave-uniform bounds test per row instead of one per lane and load -- 9 % SLOWER
+                              side by side (5.92 -> 6.44 ms): the second copy of the loads costs four more spilled registers */
+#endif
 #ifndef FPL_OPT_PREFETCH
 #define FPL_OPT_PREFETCH 0 /* k_scan touches the lines of a read's next tile one tile ahead (range_scan_fast): 2 % slower side by side --
                               the other waves of the SIMD already cover the trip to HBM */
@@ -3693,8 +3697,15 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                     EG[g] = readlane_u32(E, bit);
                     const uint64_t start = readlane_u64(st, bit);
                     if (LG[g] > c0) {
-                        svG[g] = load8_guard(seq + start + c0, seq_end);
-                        qvG[g] = load8_guard(qual + start + c0, qual_end);
+                        /* (wave-uniform: the whole row lies inside the batch -- every row but the last few of the last read --
+                           so the lanes need no bounds test of their own) */
+                        if (FPL_OPT_ROWGUARD && start + tile_start + FS_T <= n_bytes) {
+                            __builtin_memcpy(&svG[g], seq + start + c0, 8);
+                            __builtin_memcpy(&qvG[g], qual + start + c0, 8);
+                        } else {
+                            svG[g] = load8_guard(seq + start + c0, seq_end);
+                            qvG[g] = load8_guard(qual + start + c0, qual_end);
+                        }
                     }
                     if (lane == 0 && tile_start >= 4) haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
                 }
