@@ -65,6 +65,9 @@ __device__ unsigned long long g_fpl_prof[64];
 #define FPL_OPT_ROWGUARD 0 /* k_stats_sorted: one wave-uniform bounds test per row instead of one per lane and load -- 9 % SLOWER
                               side by side (5.92 -> 6.44 ms): the second copy of the loads costs four more spilled registers */
 #endif
+#ifndef FPL_OPT_CSA16
+#define FPL_OPT_CSA16 1 /* k_scan match counts: carry-save groups of sixteen adapter bases where the adapter has them */
+#endif
 #ifndef FPL_OPT_PREFETCH
 #define FPL_OPT_PREFETCH 0 /* k_scan touches the lines of a read's next tile one tile ahead (range_scan_fast): 2 % slower side by side --
                               the other waves of the SIMD already cover the trip to HBM */
@@ -2546,7 +2549,8 @@ __device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane,
 #endif
 #pragma unroll
     for (int b = 0; b < NB; b++) B[b] = 0;
-    for (int i0 = 0; i0 < alen; i0 += 8) {
+    /* the eights carry of eight terms (B[0..2] take their ones, twos and fours) */
+    auto group8 = [&](int i0) -> u32 {
         u32 m[8], tw[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) tw[k] = ad->term[i0 + k]; /* terms past alen point at the all-zero plane row */
@@ -2588,14 +2592,29 @@ __device__ __forceinline__ void match_counts(const u32* __restrict__ plane_lane,
         csa(t4, B[0], B[0], m[6], m[7]);
         csa(f2, B[1], B[1], t3, t4);
         csa(e, B[2], B[2], f1, f2);
-        u32 c = e; /* ripple the eights carry upwards */
+        return e;
+    };
+    /* ripple a carry of weight 2^lvl upwards */
+    auto ripple = [&](u32 c, int lvl) {
 #pragma unroll
         for (int b = 3; b < NB; b++) {
+            if (b < lvl) continue;
             const u32 t = B[b] & c;
             B[b] ^= c;
             c = t;
         }
+    };
+    int i0 = 0;
+#if FPL_OPT_CSA16
+    for (; i0 + 8 < alen; i0 += 16) { /* sixteen terms: the two eights carries go through one more adder before they ripple */
+        const u32 ea = group8(i0);
+        const u32 eb = group8(i0 + 8);
+        u32 c16;
+        csa(c16, B[3], B[3], ea, eb);
+        ripple(c16, 4);
     }
+#endif
+    for (; i0 < alen; i0 += 8) ripple(group8(i0), 3);
 }
 
 /* largest count among the positions in `cand` (non-zero) and the first position holding it */
