@@ -37,11 +37,14 @@ typedef hipStream_t fpl_stream_t;
 #endif
 
 /* Tuning / test hooks of the statistics passes (FPL_STATS_PER, FPL_STATS_EXTRA_PER, FPL_STATS_EXTRA_BLOCKS,
- * FPL_STATS_EXTRA_ACC, FPL_STATS_MIN_BUCKET in the environment; 0 = built-in choice).  The library reads them ONCE, in fpl_create(); the
+ * FPL_STATS_EXTRA_ACC, FPL_STATS_MIN_BUCKET, FPL_STATS_SORT_MIN, FPL_TRIM_BATCH_MIN in the environment; 0 = built-in choice).  The library reads them ONCE, in fpl_create(); the
  * per-batch path only sees this struct. */
 struct StatsTune {
     u32 per = 0, extra_per = 0, extra_blocks = 0, extra_acc = 0;
     u32 min_bucket = 0; /* FPL_STATS_MIN_BUCKET: reads that must share a front trim to get slices of their own (k_stats_sorted) */
+    u32 sort_min = 0;   /* FPL_STATS_SORT_MIN: batches of fewer reads take the unsorted statistics pass */
+    u32 trim_batch_min = 0; /* FPL_TRIM_BATCH_MIN: batches of fewer reads take k_trim_ends<1> (a wave per read) instead of
+                               k_trim_ends_batched (64 reads per wave) */
 };
 inline StatsTune stats_tune_from_env() {
     auto get = [](const char* name) -> u32 {
@@ -54,6 +57,8 @@ inline StatsTune stats_tune_from_env() {
     t.extra_blocks = get("FPL_STATS_EXTRA_BLOCKS");
     t.extra_acc = get("FPL_STATS_EXTRA_ACC");
     t.min_bucket = get("FPL_STATS_MIN_BUCKET");
+    t.sort_min = get("FPL_STATS_SORT_MIN");
+    t.trim_batch_min = get("FPL_TRIM_BATCH_MIN");
     return t;
 }
 
@@ -147,6 +152,16 @@ inline u32 stats_sorted_max_slices(u32 n_reads, u32 per, const StatsTune& tune) 
        for all its tiles, and the XCDs, which take their blocks in turn, wait for the one that got the larger slices) */
     return (n_reads / per + 1 + (own < (u32)FS_NB ? own : (u32)FS_NB)) | 1u;
 }
+/* The sorted pass pays for its bucket kernels and for one slab per (slice, tile) of every front trim: measured against the
+ * unsorted pass it wins from about 200 k reads of 9 kb on (1 M: 6.7 -> 5.9 ms, 300 k: 2.19 -> 2.05, 100 k: 0.87 -> 1.00), and a
+ * batch of a few thousand reads would hand nearly every read to the EXTRA pass (no front trim is shared by 256 of them).
+ * A test hook that sets the bucket threshold asks for the sorted pass whatever the size. */
+constexpr u32 FS_SORT_MIN_READS = 150000;
+inline bool stats_use_sorted(u32 n_reads, const StatsTune& tune) {
+    if (tune.sort_min) return n_reads >= tune.sort_min;
+    if (tune.min_bucket) return true;
+    return n_reads >= FS_SORT_MIN_READS;
+}
 inline size_t sort_ws_words(u32 max_slices, u32 n_reads) {
     return (size_t)SW_SLICES + 4 * (size_t)max_slices + (size_t)FS_NB * cdiv(n_reads ? n_reads : 1, FS_SORT_BLK);
 }
@@ -183,7 +198,10 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
 #ifndef FPL_OPT_BATCH
 #define FPL_OPT_BATCH 1 /* the usual adapter set goes through k_trim_ends_batched (confirmations 64 reads at a time) */
 #endif
-        if (a.trim_mode == 1 && FPL_OPT_BATCH) {
+        /* (a wave of the batched kernel walks its 64 reads one after the other through the per-read phases: 0.4 ms however few
+           groups there are -- 2 000 reads: 0.42 ms against 0.03 for a wave per read; the two meet at about 100 k reads) */
+        const u32 batch_min = a.tune.trim_batch_min ? a.tune.trim_batch_min : 65536u;
+        if (a.trim_mode == 1 && FPL_OPT_BATCH && n >= batch_min) {
             /* a wave takes 64 reads per round: enough waves to fill the chip, few enough to keep every wave a few rounds long */
             u32 gblocks = cdiv(cdiv(n, 64u), KWAVES);
             const u32 gcap = FPL_TRIM_WAVES_PER_SIMD_SHORT * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
@@ -231,7 +249,8 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     const u32 per_sorted = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
     /* (the persistent blocks number their (tile, slice) items with 32 bits; a batch beyond that -- hundreds of millions of
        reads next to a read of hundreds of megabases -- takes the plain walk) */
-    if (FPL_OPT_SORTSTATS && !a.defer && (uint64_t)stats_sorted_max_slices(n, per_sorted, a.tune) * n_tiles < 0xFFFFFFF0ull) {
+    if (FPL_OPT_SORTSTATS && !a.defer && stats_use_sorted(n, a.tune) &&
+        (uint64_t)stats_sorted_max_slices(n, per_sorted, a.tune) * n_tiles < 0xFFFFFFF0ull) {
         /* (with --break / --mask no read is counted post-filter by this pass: the plain walk below does) */
         const u32 per = per_sorted;
         const u32 max_slices = stats_sorted_max_slices(n, per, a.tune);

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The library picks k_trim_ends_batched (64 reads per wave) for batches of >= 65 536 reads and the wave-per-read kernel
+    # below that.  The test batches are small: by default they go through the batched kernel -- the one the bench and any
+    # large batch take -- and the tests named *_wave_per_read_* clear the hook to cover the other one.
+    os.environ.setdefault("FPL_TRIM_BATCH_MIN", "1")
 
 
 @pytest.fixture(scope="session")

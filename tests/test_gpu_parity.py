@@ -92,6 +92,40 @@ def test_ont_like_reads_bit_exact(orc, engine_mod, name):
     assert (res["n_frag"] == 2).any()
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_wave_per_read_trim_kernel_bit_exact(orc, engine_mod, monkeypatch, name):
+    """batches of fewer than 65 536 reads take k_trim_ends<1> (a wave per read) instead of k_trim_ends_batched; the test suite
+    forces the batched kernel everywhere else (tests/conftest.py)"""
+    monkeypatch.delenv("FPL_TRIM_BATCH_MIN", raising=False)
+    a = synth.adversarial(1500, seed=300 + len(name))
+    b = synth.ont_like(300, seed=7, median_len=3000, p_middle=0.05)
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
+    _run_both(orc, engine_mod, CASES[name], seq, qual, off)
+
+
+@pytest.mark.parametrize("min_bucket,per", [(1, 0), (8, 128), (0, 0)])
+def test_sorted_statistics_pass_bit_exact(orc, engine_mod, monkeypatch, min_bucket, per):
+    """k_stats_sorted is what batches of >= 150 000 reads take (test_large_batch_properties runs one); here it is forced on
+    a batch the oracle can check in full -- every front trim in slices of its own, several slices per bucket with the rare
+    front trims handed to the EXTRA pass, and (0, 0) the built-in thresholds with the size limit lifted"""
+    if min_bucket:
+        monkeypatch.setenv("FPL_STATS_MIN_BUCKET", str(min_bucket))
+    else:
+        monkeypatch.setenv("FPL_STATS_SORT_MIN", "1")
+    if per:
+        monkeypatch.setenv("FPL_STATS_PER", str(per))
+    a = synth.ont_like(1500, seed=41, median_len=2500, p_middle=0.05)
+    b = synth.adversarial(1500, seed=42)
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
+    _run_both(orc, engine_mod, CASES["full_pipeline"], seq, qual, off, via="device")
+
+
 def test_multi_adapter_fasta_bit_exact(orc, engine_mod):
     fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA",
              "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG",
@@ -280,13 +314,18 @@ def test_capacity_growth_and_accumulation(orc, engine_mod):
     parity.assert_counters_equal(got, want, C, 2)
 
 
-def test_large_batch_properties(engine_mod):
+def test_large_batch_properties(engine_mod, monkeypatch):
     """BASELINE-sized reads without the oracle: size-independent properties.
     (1) conservation: every read is dropped or yields fragments inside r1 inside the read;
     (2) idempotence of the statistics: post-filter Stats of a run == pre-filter Stats of a run
         over exactly the passing fragments with trimming/filters off;
-    (3) partition invariance: counters of one batch == sum of counters of its two halves."""
+    (3) partition invariance: counters of one batch == sum of counters of its two halves.
+    The whole batch goes through the statistics pass over sorted reads (k_stats_sorted, with the built-in bucket threshold;
+    batches of >= 150 000 reads take it by themselves), the halves and the fragment batch through the unsorted pass: (2)
+    and (3) also hold the two implementations against each other."""
     import torch
+
+    monkeypatch.setenv("FPL_STATS_SORT_MIN", "1")
 
     opt = abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
                                  complexity_filter=1)
@@ -299,6 +338,7 @@ def test_large_batch_properties(engine_mod):
     cnt = eng.counters()
     C = eng.max_cycles
     eng.close()
+    monkeypatch.delenv("FPL_STATS_SORT_MIN")  # (the library reads it when a context is created)
     off = off_t.cpu().numpy().astype(np.int64)
     lens = np.diff(off)
     v = abi.CountersView(cnt, C, 2)

@@ -90,6 +90,43 @@ def test_emulated_kernels_match_oracle_ont_like(orc):
     assert (want_res["n_frag"] == 2).any()  # the middle-adapter split path ran
 
 
+def test_emulated_wave_per_read_trim_kernel(orc, monkeypatch):
+    """k_trim_ends<1>, what batches of fewer than 65 536 reads take (the suite forces k_trim_ends_batched elsewhere)"""
+    monkeypatch.delenv("FPL_TRIM_BATCH_MIN", raising=False)
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
+                                            complexity_filter=1), synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = synth.adversarial(90, seed=77)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
+@pytest.mark.parametrize("min_bucket,per", [(1, 0), (3, 64), (40, 0)])
+def test_emulated_sorted_statistics_pass(orc, monkeypatch, min_bucket, per):
+    """k_stats_sorted (the statistics pass over the reads sorted by front trim: bucket kernels, persistent blocks, the
+    shifted reduce) is what batches of >= 150 000 reads take; FPL_STATS_MIN_BUCKET forces it for a small batch.
+    min_bucket 1: every front trim gets slices of its own; 3 with slices of 64 reads: several slices per bucket, rare front
+    trims handed to the EXTRA pass; 40: nearly everything handed over"""
+    monkeypatch.setenv("FPL_STATS_MIN_BUCKET", str(min_bucket))
+    if per:
+        monkeypatch.setenv("FPL_STATS_PER", str(per))
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
+                                            complexity_filter=1), synth.START_ADAPTER, synth.END_ADAPTER)
+    a = synth.ont_like(90, seed=12, median_len=700, p_middle=0.1, p_polya=0.2)
+    b = synth.adversarial(60, seed=13)
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
 def test_emulated_kernels_multi_adapter(orc):
     fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA", "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG"]
     cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER, fasta)
