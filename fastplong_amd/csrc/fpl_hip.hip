@@ -726,6 +726,48 @@ extern "C" int fpl_debug_prof(unsigned long long* out, int n) {
 }
 #endif
 
+int fpl_count_end_kmers(int32_t device, const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int32_t side, int32_t shift_tail,
+                        uint32_t* counts, uint64_t* position_acc, uint64_t* total) {
+    if (!off || !counts || !position_acc || !total || (n_reads && !seq) || side < 0 || side > 1 || shift_tail < 0) return FPL_ERR_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) return FPL_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FPL_ERR_NO_DEVICE;
+    const size_t n_keys = (size_t)1 << 20;
+    const uint64_t n_bytes = n_reads ? off[n_reads] : 0;
+    u8* d_seq = nullptr;
+    uint64_t* d_off = nullptr;
+    u32* d_counts = nullptr;
+    unsigned long long *d_pos = nullptr, *d_total = nullptr;
+    int rc = FPL_OK;
+    auto ok = [&](hipError_t e) {
+        if (e != hipSuccess && rc == FPL_OK) rc = FPL_ERR_HIP;
+        return e == hipSuccess;
+    };
+    if (ok(hipMalloc((void**)&d_seq, n_bytes ? n_bytes : 1)) && ok(hipMalloc((void**)&d_off, sizeof(uint64_t) * ((size_t)n_reads + 1))) &&
+        ok(hipMalloc((void**)&d_counts, sizeof(u32) * n_keys)) && ok(hipMalloc((void**)&d_pos, sizeof(unsigned long long) * n_keys)) &&
+        ok(hipMalloc((void**)&d_total, sizeof(unsigned long long)))) {
+        ok(hipMemcpy(d_seq, seq, n_bytes, hipMemcpyHostToDevice));
+        ok(hipMemcpy(d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice));
+        ok(hipMemset(d_counts, 0, sizeof(u32) * n_keys));
+        ok(hipMemset(d_pos, 0, sizeof(unsigned long long) * n_keys));
+        ok(hipMemset(d_total, 0, sizeof(unsigned long long)));
+        if (rc == FPL_OK && n_reads) {
+            u32 blocks = (n_reads + 3) / 4;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(k_count_end_kmers, dim3(blocks), dim3(256), 0, 0, (const u8*)d_seq, (const uint64_t*)d_off, n_reads, (int)side,
+                               (int)shift_tail, d_counts, d_pos, d_total);
+            ok(hipGetLastError());
+        }
+        ok(hipMemcpy(counts, d_counts, sizeof(u32) * n_keys, hipMemcpyDeviceToHost));
+        ok(hipMemcpy(position_acc, d_pos, sizeof(unsigned long long) * n_keys, hipMemcpyDeviceToHost));
+        ok(hipMemcpy(total, d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    void* ptrs[] = {d_seq, d_off, d_counts, d_pos, d_total};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    return rc;
+}
+
 #ifdef FPL_PROF_BLOCKS
 extern "C" int fpl_debug_read_blockprof(void* dst, size_t bytes) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fpl::g_blockprof), bytes) == hipSuccess ? 0 : -1;

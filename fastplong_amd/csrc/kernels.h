@@ -3901,6 +3901,50 @@ k_stats_reduce_sorted(const u64* __restrict__ scratch, const u8* __restrict__ fl
 }
 
 /* =========================================================================================
+ * k_count_end_kmers: the counting loops of the adapter auto-detection (Evaluator::evalAdapterAndReadNum,
+ * src/evaluator.cpp:300-345).  For every read of the evaluation prefix (<= 64 Ki reads) the 10-mers that start at the first
+ * 128 positions (side 0) or at the last 129 positions in front of the skipped tail (side 1) are counted: counts[key]++,
+ * position_acc[key] += pos (side 0) / rlen - pos (side 1), total++ -- a key is valid when its ten bases are A, T/U, C, G
+ * (the reference rolls the key and starts over behind an invalid base: the same set of keys).  One wave per read,
+ * lanes = positions; the 4^10 counters live in HBM (the host keeps getTopKey / extendKeyToAdapter, which walk them).
+ * ======================================================================================= */
+__global__ void __launch_bounds__(256)
+k_count_end_kmers(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_reads, int side, int shift_tail,
+                  u32* __restrict__ counts, unsigned long long* __restrict__ position_acc, unsigned long long* __restrict__ total) {
+    constexpr int KEYLEN = 10;
+    const int lane = lane_id();
+    u32 mine = 0;
+    for (u32 ri = blockIdx.x * (blockDim.x / 64) + wave_in_block(); ri < n_reads; ri += gridDim.x * (blockDim.x / 64)) {
+        const uint64_t o = off[ri];
+        const long long rlen = (long long)(off[ri + 1] - o);
+        const long long last = rlen - KEYLEN - shift_tail; /* the last position that is looked at */
+        if (last < 0) continue;
+        const long long first = side == 0 ? 0 : (last - 128 > 0 ? last - 128 : 0);
+        const long long end = side == 0 ? (last < 127 ? last : 127) : last;
+        const u8* data = seq + o;
+        for (long long p0 = first; p0 <= end; p0 += 64) {
+            const long long pos = p0 + lane;
+            if (pos > end) continue;
+            u32 key = 0;
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < KEYLEN; i++) {
+                const u32 c = data[pos + i];
+                const u32 code = c == 'A' ? 0u : ((c == 'T' || c == 'U') ? 1u : (c == 'C' ? 2u : (c == 'G' ? 3u : 4u)));
+                ok = ok && code < 4u;
+                key = (key << 2) | (code & 3u);
+            }
+            if (!ok) continue;
+            atomicAdd(&counts[key], 1u);
+            atomicAdd(&position_acc[key], (unsigned long long)(side == 0 ? pos : rlen - pos));
+            mine++;
+        }
+    }
+    const u32 t = wave_sum_u32(mine);
+    if (lane == 0 && t) atomicAdd(total, (unsigned long long)t);
+}
+
+/* =========================================================================================
  * k_break_mask: --break and --mask, src/seprocessor.cpp:234-281.
  *
  * Runs only when one of the two options is on (DevConfig::defer); k_scan then stops after the

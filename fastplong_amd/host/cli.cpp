@@ -379,6 +379,13 @@ int main(int argc, char* argv[]) {
     if (o.adapter_enabled && (startAd == "auto" || endAd == "auto")) {
         if (fromStdin || in == "/dev/stdin") cerr << "Adapter auto-detection is disabled for STDIN mode" << endl;
         else {
+            /* the 10-mer counting of the detection runs on the first device (fpl_count_end_kmers); what the reference does
+               with the counters stays on the host.  (FPLH_HOST_KMERS: count on the host -- test / measurement hook) */
+            if (!getenv("FPLH_HOST_KMERS"))
+                fplh::set_kmer_counter([&](const uint8_t* sq, const uint64_t* of, uint32_t n, int side, int shift, uint32_t* cnt,
+                                           uint64_t* pos, uint64_t* tot) {
+                    return fpl_count_end_kmers(0, sq, of, n, side, shift, cnt, pos, tot) == FPL_OK; /* (device 0: the first of --gpus) */
+                });
             fplh::detect_adapters(in, o.trim_tail, isRNA, startAd, endAd, &readNum);
             cerr << endl;
         }

@@ -239,6 +239,45 @@ long evaluate_read_num(const string& path) {
 }
 
 /* Evaluator::evalAdapterAndReadNum, src/evaluator.cpp:105-266 */
+static KmerCounter g_kmer_counter;
+void set_kmer_counter(KmerCounter f) { g_kmer_counter = std::move(f); }
+
+/* Evaluator::evalAdapterAndReadNum's counting loops, src/evaluator.cpp:300-345 */
+void count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail, uint32_t* counts,
+                          uint64_t* position_acc, uint64_t* total) {
+    const int keylen = 10;
+    const size_t size = (size_t)1 << (keylen * 2);
+    fill(counts, counts + size, 0u);
+    fill(position_acc, position_acc + size, (uint64_t)0);
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        const char* data = (const char*)seq + off[i];
+        const int rlen = (int)(off[i + 1] - off[i]);
+        int key = -1;
+        if (side == 0) {
+            for (int pos = 0; pos <= rlen - keylen - shift_tail && pos < 128; pos++) {
+                key = seq2int(data, rlen, pos, keylen, key);
+                if (key >= 0) {
+                    counts[key]++;
+                    position_acc[key] += (uint64_t)pos;
+                    t++;
+                }
+            }
+        } else {
+            const int startpos = max(0, rlen - keylen - shift_tail - 128);
+            for (int pos = startpos; pos <= rlen - keylen - shift_tail; pos++) {
+                key = seq2int(data, rlen, pos, keylen, key);
+                if (key >= 0) {
+                    counts[key]++;
+                    position_acc[key] += (uint64_t)(rlen - pos);
+                    t++;
+                }
+            }
+        }
+    }
+    *total = t;
+}
+
 void detect_adapters(const string& path, int trim_tail, bool is_rna, string& start, string& end, long* read_num) {
     if (start != "auto" && end != "auto") return;
     const long READ_LIMIT = 64 * 1024;
@@ -262,32 +301,15 @@ void detect_adapters(const string& path, int trim_tail, bool is_rna, string& sta
         cerr << (side == 0 ? "Trying to detect adapter sequence at read start" : "Trying to detect adapter sequence at read end") << endl;
         long total = 0;
         int total_key = 0;
-        fill(counts.begin(), counts.end(), 0u);
-        fill(position_acc.begin(), position_acc.end(), 0ul);
-        for (long i = 0; i < records; i++) {
-            const char* data = (const char*)b.seq.data() + b.off[i];
-            const int rlen = (int)(b.off[i + 1] - b.off[i]);
-            int key = -1;
-            if (side == 0) {
-                for (int pos = 0; pos <= rlen - keylen - shift_tail && pos < 128; pos++) {
-                    key = seq2int(data, rlen, pos, keylen, key);
-                    if (key >= 0) {
-                        counts[key]++;
-                        position_acc[key] += pos;
-                        total++;
-                    }
-                }
-            } else {
-                const int startpos = max(0, rlen - keylen - shift_tail - 128);
-                for (int pos = startpos; pos <= rlen - keylen - shift_tail; pos++) {
-                    key = seq2int(data, rlen, pos, keylen, key);
-                    if (key >= 0) {
-                        counts[key]++;
-                        position_acc[key] += rlen - pos;
-                        total++;
-                    }
-                }
-            }
+        {
+            /* the counting loops: on the device when the caller has plugged one in (fpl_count_end_kmers), else here */
+            uint64_t t = 0;
+            static_assert(sizeof(unsigned long) == sizeof(uint64_t), "position_acc is handed over as uint64_t");
+            if (!(g_kmer_counter && g_kmer_counter(b.seq.data(), b.off.data(), (uint32_t)records, side, shift_tail, counts.data(),
+                                                   (uint64_t*)position_acc.data(), &t)))
+                count_end_kmers_host(b.seq.data(), b.off.data(), (uint32_t)records, side, shift_tail, counts.data(),
+                                     (uint64_t*)position_acc.data(), &t);
+            total = (long)t;
         }
         for (int k = 0; k < size; k++)
             if (counts[k] > 0) total_key++;
@@ -321,6 +343,10 @@ void fplh_int2seq(unsigned int val, int seqlen, int is_rna, char* out) {
     memcpy(out, s.c_str(), s.size() + 1);
 }
 long fplh_evaluate_read_num(const char* path) { return fplh::evaluate_read_num(path); }
+void fplh_count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail, uint32_t* counts,
+                               uint64_t* position_acc, uint64_t* total) {
+    fplh::count_end_kmers_host(seq, off, n_reads, side, shift_tail, counts, position_acc, total);
+}
 long fplh_detect_read_num(const char* path) {
     std::string s = "auto", e = "auto";
     long n = 0;

@@ -11,9 +11,20 @@
 #ifndef FPLH_EVALUATOR_H
 #define FPLH_EVALUATOR_H
 
+#include <cstdint>
+#include <functional>
 #include <string>
 
 namespace fplh {
+
+/* The counting loops of the detection (src/evaluator.cpp:300-345) over the first / last 128 positions of every read of the
+ * evaluation prefix: 4^10 counters and position sums, overwritten.  count_end_kmers_host is the host form; set_kmer_counter
+ * plugs in another one (the CLI hands over the C-ABI's fpl_count_end_kmers, which counts on the GPU) -- it returns false when it
+ * could not run, and the host form takes over. */
+void count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail, uint32_t* counts,
+                          uint64_t* position_acc, uint64_t* total);
+using KmerCounter = std::function<bool(const uint8_t*, const uint64_t*, uint32_t, int, int, uint32_t*, uint64_t*, uint64_t*)>;
+void set_kmer_counter(KmerCounter f);
 
 std::string int2seq(unsigned int val, int seqlen, bool is_rna = false);
 int seq2int(const char* seq, int rlen, int pos, int keylen, int last_val = -1);
@@ -40,6 +51,8 @@ void fplh_int2seq(unsigned int val, int seqlen, int is_rna, char* out);
 /* out_start / out_end: buffers of >= 128 bytes, NUL-terminated results ("auto" when nothing was detected) */
 void fplh_detect_adapters(const char* path, int trim_tail, int is_rna, char* out_start, char* out_end);
 long fplh_evaluate_read_num(const char* path);
+void fplh_count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail, uint32_t* counts,
+                               uint64_t* position_acc, uint64_t* total);
 long fplh_detect_read_num(const char* path); /* the estimate detect_adapters gives */
 }
 #endif

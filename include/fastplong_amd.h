@@ -326,6 +326,15 @@ int fpl_get_counters(fpl_ctx* ctx, int64_t* host_buf, size_t n);
  * fpl_counters_device_ptr() themselves (bench.py does, through torch.distributed) after agreeing on C.
  */
 int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n);
+
+/* The counting loops of the adapter auto-detection, Evaluator::evalAdapterAndReadNum (src/evaluator.cpp:300-345), on the
+ * device: for the reads of the evaluation prefix (host CSR arrays; the reference looks at <= 64 Ki reads / 512 Mbases) count
+ * the 10-mers starting at the first 128 positions (side 0) or at the last 129 positions in front of the `shift_tail` skipped
+ * bases (side 1).  counts / position_acc: host arrays of 4^10 entries, overwritten; *total = keys counted.  What the reference
+ * does with the counters (getTopKey :268-326, extendKeyToAdapter :328-404) stays with the caller.  No context is needed: the
+ * detection runs before the adapters -- and with them the contexts -- exist (src/main.cpp:270-277). */
+int fpl_count_end_kmers(int32_t device, const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int32_t side, int32_t shift_tail,
+                        uint32_t* counts, uint64_t* position_acc, uint64_t* total);
 int fpl_reset_counters(fpl_ctx* ctx);
 int fpl_synchronize(fpl_ctx* ctx);
 

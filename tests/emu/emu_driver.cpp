@@ -119,6 +119,15 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     return 0;
 }
 
+/* k_count_end_kmers (the counting of the adapter auto-detection) on the emulator: counts / position_acc of 4^10 entries */
+extern "C" void emu_count_end_kmers(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail,
+                                    uint32_t* counts, unsigned long long* position_acc, unsigned long long* total) {
+    memset(counts, 0, sizeof(uint32_t) << 20);
+    memset(position_acc, 0, sizeof(unsigned long long) << 20);
+    *total = 0;
+    emu_launch(k_count_end_kmers, dim3(3), dim3(256), seq, off, n_reads, side, shift_tail, counts, position_acc, total);
+}
+
 /* direct hooks for unit tests of the bit-parallel Levenshtein code */
 extern "C" int emu_lev_bp64(const char* adapter, int alen, int shift, int m, const char* text, int n) {
     static DevAdapter ad;

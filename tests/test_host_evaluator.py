@@ -124,3 +124,81 @@ def test_read_number_estimate(hostlib, tmp_path):
     _write_reads(p, 80000, 200, gz=True)
     got = L.fplh_detect_read_num(p.encode())
     assert abs(got - 80000) < 25000, got
+
+
+def _kmer_case(seed):
+    """reads of 0..600 bases (incl. shorter than a key), with N / lower-case bytes and U, planted adapters at both ends"""
+    import numpy as np
+    from fastplong_amd import synth
+    rng = np.random.default_rng(seed)
+    reads = []
+    ad = np.frombuffer(b"AAGGATTCATTCCCACGGTAACAC", np.uint8)
+    for i in range(300):
+        n = int(rng.choice([0, 5, 9, 10, 11, 12, 137, 138, 139, 140])) if rng.random() < 0.3 else int(rng.integers(0, 600))
+        s = synth._ACGT[rng.integers(0, 4, n)].astype(np.uint8)
+        if n > 60 and rng.random() < 0.5:
+            s[:24] = ad
+        if n > 60 and rng.random() < 0.5:
+            s[-24:] = ad[::-1]
+        for _ in range(int(rng.integers(0, 3))):
+            if n:
+                s[int(rng.integers(0, n))] = int(rng.choice([ord("N"), ord("a"), ord("U"), ord("t")]))
+        reads.append((s, np.full(n, 40, np.uint8)))
+    return synth.pack(reads)
+
+
+def _host_counts(L, seq, off, side, shift):
+    import ctypes as C
+    import numpy as np
+    cnt = np.zeros(1 << 20, np.uint32)
+    pos = np.zeros(1 << 20, np.uint64)
+    tot = C.c_uint64(0)
+    L.fplh_count_end_kmers_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.fplh_count_end_kmers_host(seq.ctypes.data, off.ctypes.data, len(off) - 1, side, shift, cnt.ctypes.data, pos.ctypes.data, C.byref(tot))
+    return cnt, pos, tot.value
+
+
+@pytest.mark.parametrize("side,shift", [(0, 1), (1, 1), (0, 7), (1, 30)])
+def test_emulated_kmer_counting_kernel_equals_host(side, shift):
+    """k_count_end_kmers (what fpl_count_end_kmers runs on the GPU for the adapter auto-detection) on the CPU emulator against
+    the host's counting loops (Evaluator::evalAdapterAndReadNum, src/evaluator.cpp:300-345): counters, position sums, total"""
+    import ctypes as C
+    import numpy as np
+    from fastplong_amd import build
+    from tests.emu import emu
+    build.build_host()
+    H = C.CDLL(build.HOST_LIB)
+    seq, _, off = _kmer_case(100 + side)
+    seq = np.ascontiguousarray(np.concatenate([seq, np.zeros(16, np.uint8)]))
+    off = np.ascontiguousarray(off.astype(np.uint64))
+    want = _host_counts(H, seq, off, side, shift)
+    E = emu.lib()
+    cnt = np.zeros(1 << 20, np.uint32)
+    pos = np.zeros(1 << 20, np.uint64)
+    tot = C.c_uint64(0)
+    E.emu_count_end_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    E.emu_count_end_kmers(seq.ctypes.data, off.ctypes.data, len(off) - 1, side, shift, cnt.ctypes.data, pos.ctypes.data, C.byref(tot))
+    assert tot.value == want[2] > 0
+    assert np.array_equal(cnt, want[0]) and np.array_equal(pos, want[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,shift", [(0, 1), (1, 1), (1, 30)])
+def test_device_kmer_counting_equals_host(side, shift):
+    """fpl_count_end_kmers through the C-ABI on the GPU against the host's counting loops"""
+    import ctypes as C
+    import numpy as np
+    from fastplong_amd import build, engine
+    build.build_host()
+    H = C.CDLL(build.HOST_LIB)
+    L = engine.load_library()
+    seq, _, off = _kmer_case(200 + side)
+    off = np.ascontiguousarray(off.astype(np.uint64))
+    seq = np.ascontiguousarray(seq)
+    want = _host_counts(H, np.concatenate([seq, np.zeros(16, np.uint8)]), off, side, shift)
+    cnt = np.zeros(1 << 20, np.uint32)
+    pos = np.zeros(1 << 20, np.uint64)
+    tot = C.c_uint64(0)
+    rc = L.fpl_count_end_kmers(0, seq.ctypes.data, off.ctypes.data, len(off) - 1, side, shift, cnt.ctypes.data, pos.ctypes.data, C.byref(tot))
+    assert rc == 0 and tot.value == want[2] > 0
+    assert np.array_equal(cnt, want[0]) and np.array_equal(pos, want[1])
