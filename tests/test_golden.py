@@ -168,6 +168,18 @@ def test_cli_detects_adapters_when_left_at_auto(tmp_path):
     assert err.count("Detected: ") == 2, err
     js = json.loads((tmp_path / "out.json").read_text().replace("},\n}", "}\n}"))
     assert js["adapter_cutting"]["adapter_trimmed_reads"] > 200
+    # the 10-mer counting ran on the device (fpl_count_end_kmers); with the host's loops instead (FPLH_HOST_KMERS) the run must
+    # detect the same two sequences and write the same bytes
+    import os
+    p2 = subprocess.run([build.CLI, "-i", str(inp), "-o", str(tmp_path / "out2.fq"), "-j", str(tmp_path / "out2.json"), "-h",
+                         str(tmp_path / "out2.html")], env=dict(os.environ, FPLH_HOST_KMERS="1"),
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p2.returncode == 0, p2.stderr.decode()[-2000:]
+    det = lambda t: [ln for ln in t.splitlines() if ln.startswith("Detected: ")]  # noqa: E731
+    assert det(p2.stderr.decode()) == det(err) and len(det(err)) == 2
+    assert (tmp_path / "out2.fq").read_bytes() == (tmp_path / "out.fq").read_bytes()
+    strip = lambda t: "\n".join(ln for ln in t.splitlines() if '"command"' not in ln)  # noqa: E731
+    assert strip((tmp_path / "out2.json").read_text()) == strip((tmp_path / "out.json").read_text())
 
 
 def _per_read_outputs(seq, qual, off, names, strands, res):
