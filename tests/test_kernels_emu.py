@@ -114,8 +114,8 @@ def test_emulated_sorted_statistics_pass(orc, monkeypatch, min_bucket, per):
         monkeypatch.setenv("FPL_STATS_PER", str(per))
     cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
                                             complexity_filter=1), synth.START_ADAPTER, synth.END_ADAPTER)
-    a = synth.ont_like(90, seed=12, median_len=700, p_middle=0.1, p_polya=0.2)
-    b = synth.adversarial(60, seed=13)
+    a = synth.ont_like(60, seed=12, median_len=700, p_middle=0.1, p_polya=0.2)
+    b = synth.adversarial(40, seed=13)
     reads = []
     for (s_, q_, o_) in (a, b):
         reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
