@@ -8,10 +8,12 @@
 
 #include <algorithm>
 #include <fstream>
+#include <memory>
 #include <charconv>
 #include <sstream>
 #include <type_traits>
 
+#include "fastq.h"
 #include "report.h"
 #include "report_internal.h"
 
@@ -158,23 +160,39 @@ struct Side {
     /* Stats::calcLengthHistogram, src/stats.cpp:377-409, run lengths of the sorted list standing in for the
        map<int,int>; `first * second` is an int product there and is kept one */
     void length_stats() {
-        vector<int32_t> v(lists->len);
-        sort(v.begin(), v.end());
-        if (v.empty()) return;
-        min_len = v.front();
-        max_len = v.back();
+        const vector<int32_t>& len = lists->len;
+        if (len.empty()) return;
+        int32_t lo = len[0], hi = len[0];
+        for (int32_t x : len) {
+            lo = min(lo, x);
+            hi = max(hi, x);
+        }
+        min_len = lo;
+        max_len = hi;
         long totalBase = 0;
         int readnum = 0;
-        const size_t n = v.size();
-        for (size_t i = 0; i < n;) {
-            size_t j = i;
-            while (j < n && v[j] == v[i]) j++;
-            const int first = v[i], second = (int)(j - i);
+        const size_t n = len.size();
+        auto step = [&](int first, int second) { /* one (length, count) pair of the map, ascending; true = done */
             totalBase += (int)((unsigned)first * (unsigned)second);
             if (n50_len == 0 && totalBase > sm.length_sum / 2) n50_len = first;
             readnum += second;
             if (median_len == 0 && (size_t)readnum > n / 2) median_len = first;
-            if (median_len > 0 && n50_len > 0) break;
+            return median_len > 0 && n50_len > 0;
+        };
+        if (lo >= 0 && (uint64_t)hi - (uint64_t)lo < (64u << 20)) {
+            /* a histogram by length instead of sorting a million lengths (0.08 s per side) */
+            vector<uint32_t> hist((size_t)(hi - lo) + 1, 0u);
+            for (int32_t x : len) hist[(size_t)(x - lo)]++;
+            for (size_t k = 0; k < hist.size(); k++)
+                if (hist[k] && step((int)(lo + (int32_t)k), (int)hist[k])) break;
+            return;
+        }
+        vector<int32_t> v(len);
+        sort(v.begin(), v.end());
+        for (size_t i = 0; i < n;) {
+            size_t j = i;
+            while (j < n && v[j] == v[i]) j++;
+            if (step(v[i], (int)(j - i))) break;
             i = j;
         }
     }
@@ -440,8 +458,15 @@ bool write_html(const string& path, const ReportInputs& in, const HtmlInputs& h)
     if (!o.is_open()) return false;
     const uint32_t C = in.C;
     const int threads = max(1, min(16, h.threads));
-    const Side pre(in.counters + FPL_OFF_PRE(C), C, &h.pre, threads, in.is_rna, "Before filtering");
-    const Side post(in.counters + FPL_OFF_POST(C), C, &h.post, threads, in.is_rna, "After filtering");
+    /* the two sides (length statistics, curve sampling) are prepared side by side (rendering the sections into strings on
+       several threads and writing those was slower than streaming them: the density lists are 8 MB each) */
+    std::unique_ptr<Side> sides[2];
+    parallel_run(2, [&](int i) {
+        sides[i].reset(i == 0 ? new Side(in.counters + FPL_OFF_PRE(C), C, &h.pre, threads, in.is_rna, "Before filtering")
+                              : new Side(in.counters + FPL_OFF_POST(C), C, &h.post, threads, in.is_rna, "After filtering"));
+    });
+    const Side& pre = *sides[0];
+    const Side& post = *sides[1];
     const int64_t* fr = in.counters + FPL_OFF_FR(C);
     const string stamp = h.timestamp.empty() ? now_text() : h.timestamp;
 
