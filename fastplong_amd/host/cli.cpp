@@ -21,6 +21,7 @@
 #include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 #include <atomic>
@@ -157,9 +158,92 @@ struct Work {
     vector<fpl_read_result> res;
     fplh::FragmentList frags; /* --break / --mask */
     vector<string> outs, faileds;
+    vector<struct iovec> gather; /* --out as a gather list over the batch's own arrays (plain output, see build_gather) */
+    string gather_text;          /* the few bytes of it that exist nowhere yet: names with a split prefix */
     int rc = 0;
     string err;
 };
+/* The passing reads of a batch as they go to --out (Read::appendToString, src/read.cpp:119-143), NOT copied together: every
+ * line is a slice of what the batch already holds -- names and '+' lines in Batch::text, bases and qualities in the
+ * page-locked arrays -- so the writer hands the kernel a gather list (writev) instead of a second copy of the data.
+ * Formatting 18 GB of output text was 4.5 of the pipeline's 9 CPU-seconds, and the CPU quota is what bounds it.
+ * (Plain --out only: gzip members, --failed_out, --split* and --break / --mask output go through format_batch_parallel.) */
+static void build_gather(const fplh::Batch& b, const fpl_read_result* res, vector<struct iovec>& iov, string& text) {
+    static const char* prefix[3] = {"", "split-by-adapter-left-", "split-by-adapter-right-"}; /* src/read.cpp:199,208 */
+    static const char nl_byte = '\n';
+    const uint32_t n = b.n();
+    iov.clear();
+    text.clear();
+    size_t need = 0; /* bytes of prefixed names: reserved up front, the list points into the string */
+    for (uint32_t i = 0; i < n; i++) {
+        const fpl_read_result& r = res[i];
+        if (r.dropped) continue;
+        for (int f = 0; f < r.n_frag; f++)
+            if (r.code[f] == FPL_PASS_FILTER && r.kind[f] >= 1 && r.kind[f] <= 2 && b.name_len[i] > 0)
+                need += b.name_len[i] + strlen(prefix[r.kind[f]]);
+    }
+    text.reserve(need + 1);
+    auto put = [&](const void* p, size_t len) {
+        struct iovec v;
+        v.iov_base = const_cast<void*>(p);
+        v.iov_len = len;
+        iov.push_back(v);
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const fpl_read_result& r = res[i];
+        if (r.dropped) continue;
+        const char* name = b.text.data() + b.name_off[i];
+        const uint32_t nl = b.name_len[i], sl = b.strand_len[i];
+        const char* strand = name + nl;
+        const uint8_t* sq = b.seq.data() + b.off[i];
+        const uint8_t* ql = b.qual.data() + b.off[i];
+        for (int f = 0; f < r.n_frag; f++) {
+            if (r.code[f] != FPL_PASS_FILTER) continue;
+            const char* pf = prefix[r.kind[f] <= 2 ? r.kind[f] : 0];
+            if (*pf && nl > 0) { /* name->insert(1, prefix) */
+                const size_t at = text.size();
+                text.append(name, 1);
+                text.append(pf);
+                text.append(name + 1, nl - 1);
+                put(text.data() + at, text.size() - at);
+            } else {
+                put(name, nl);
+            }
+            put(&nl_byte, 1);
+            put(sq + r.frag_start[f], r.frag_len[f]);
+            put(&nl_byte, 1);
+            put(strand, sl);
+            put(&nl_byte, 1);
+            put(ql + r.frag_start[f], r.frag_len[f]);
+            put(&nl_byte, 1);
+        }
+    }
+}
+/* all of a gather list to fd (writev takes 1024 entries and about 2 GiB at a time, and may stop short) */
+static bool write_gather(int fd, vector<struct iovec>& iov) {
+    size_t k = 0;
+    while (k < iov.size()) {
+        const int cnt = (int)min<size_t>(1024, iov.size() - k);
+        ssize_t w = writev(fd, iov.data() + k, cnt);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        while (w > 0 && k < iov.size()) { /* skip what went out, trim the entry it stopped in */
+            if ((size_t)w >= iov[k].iov_len) {
+                w -= (ssize_t)iov[k].iov_len;
+                k++;
+            } else {
+                iov[k].iov_base = (char*)iov[k].iov_base + w;
+                iov[k].iov_len -= (size_t)w;
+                w = 0;
+            }
+        }
+        while (k < iov.size() && iov[k].iov_len == 0) k++;
+    }
+    return true;
+}
+
 template <class T>
 class Channel {
    public:
@@ -541,6 +625,17 @@ int main(int argc, char* argv[]) {
     /* slices a batch's output is formatted in (one worker each); gzip outputs are deflated per slice, which is compute-
        bound, so they get more, smaller slices */
     const bool anyGz = (fout && fout.gz) || (ffail && ffail.gz);
+    /* Plain --out alone that is NOT a regular file -- a pipe into an aligner or a compressor (--stdout, /dev/stdout), /dev/null --
+       is written as gather lists over the batches' own arrays (build_gather): nothing is formatted.  Into a regular file the
+       one writer thread's copy into the page cache is the bottleneck either way (18 GB: 2.9 s from formatted pieces, 3.6 s
+       from eight small entries per read), so files keep the pieces the formatter threads put together side by side.
+       FPLH_NO_GATHER / FPLH_GATHER_FILES: measurement hooks */
+    bool gatherOut = fout && !fout.gz && !ffail && !fragmentMode && !split && !getenv("FPLH_NO_GATHER");
+    if (gatherOut && !getenv("FPLH_GATHER_FILES")) {
+        struct stat ost;
+        if (fstat(fileno(fout.f), &ost) == 0 && S_ISREG(ost.st_mode)) gatherOut = false;
+    }
+    if (gatherOut) fflush(fout.f); /* (from here on the descriptor is written directly) */
     /* formatter stage threads: one per device -- or four when the output is deflated, each with a quarter of the helpers:
        a batch of one chunk (32 MB of text) cut into 64 members keeps 64 helpers busy for a few milliseconds between two
        thread hand-offs (measured: 25 ms per batch, 1.3 GB/s), four batches side by side in 16 members each do not wait
@@ -690,7 +785,9 @@ int main(int argc, char* argv[]) {
                     continue;
                 }
                 const double t1 = now();
-                if (w->rc == FPL_OK && !split) { /* (--split* output is cut per pack of 16 reads by the writer) */
+                if (w->rc == FPL_OK && !split && gatherOut) {
+                    build_gather(w->batch, w->res.data(), w->gather, w->gather_text);
+                } else if (w->rc == FPL_OK && !split) { /* (--split* output is cut per pack of 16 reads by the writer) */
                     fplh::format_batch_parallel(w->batch, w->res.data(), fmtThreads, w->outs, ffail ? &w->faileds : nullptr,
                                                 fragmentMode ? &w->frags : nullptr);
                     if (fout && fout.gz) gzip_pieces(w->outs);
@@ -766,7 +863,12 @@ int main(int argc, char* argv[]) {
                 ready.erase(ready.begin());
                 if (r->rc != FPL_OK) error_exit("fpl_process_batch: " + r->err);
                 const double t0 = now();
-                if (fout) write_pieces(fout, r->outs);
+                if (fout && gatherOut) {
+                    if (!r->gather.empty()) {
+                        if (!write_gather(fileno(fout.f), r->gather)) error_exit("write failed");
+                        fout.wrote = true;
+                    }
+                } else if (fout) write_pieces(fout, r->outs);
                 if (ffail) write_pieces(ffail, r->faileds);
                 if (split) split_reads(*r);
                 note_reads(*r);

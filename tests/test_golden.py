@@ -127,6 +127,31 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("how", ["stdout_pipe", "file_forced"])
+def test_cli_gather_output_reproduces_golden_on_gpu(tmp_path, case, how):
+    """plain --out without --failed_out that is not a regular file (here: --stdout into a pipe) is written as gather lists
+    over the batches' own arrays (writev, nothing is formatted); FPLH_GATHER_FILES forces the same for a file.  Same bytes
+    as the formatted output (the cases with --break / --mask keep the formatter: they must still agree)"""
+    build.build_all()
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    flags = [f if f != "ADAPTERS.fa" else os.path.join(GOLD, case, "ADAPTERS.fa") for f in meta["flags"]]
+    cmd = [build.CLI, "-i", str(inp), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"), "--reader_threads", "3"] + flags
+    env = dict(os.environ, FPLH_CHUNK_BYTES="30000")
+    if how == "stdout_pipe":
+        cmd += ["--stdout"]
+    else:
+        cmd += ["-o", str(tmp_path / "out.fq")]
+        env["FPLH_GATHER_FILES"] = "1"
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = p.stdout if how == "stdout_pipe" else (tmp_path / "out.fq").read_bytes()
+    assert got == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+
+
+@pytest.mark.gpu
 def test_cli_gzip_outputs_on_gpu(tmp_path):
     """names ending in .gz are written as concatenated gzip members (one per formatted slice, deflated in parallel)"""
     case = "c3_full"
