@@ -348,15 +348,81 @@ std::atomic<uint64_t> GzMembers::delivered{0};
  * space for `max_bytes` is reserved up front, pages are only touched as the text arrives).  nullptr when the file is not
  * of that kind, a member cannot be buffered or checked, or the text would take more than `max_bytes`: the caller then
  * reads the input through the sequential stream as before.  The caller owns the mapping (`*reserved` bytes). */
+/* A gzip file that is ONE member (a plain `gzip` of a whole run): no two workers can share a deflate stream, but libdeflate
+ * inflates a whole member 2.3 times faster than zlib streams it, and the text can then be parsed by all the chunk parsers.
+ * The member's trailer gives its inflated size modulo 4 GiB; the candidates size, size + 4 GiB, ... are tried in turn (a
+ * wrong one fails with "no space" at the end of the output).  nullptr: not a single clean member, no libdeflate, or more
+ * text than max_bytes. */
+static char* gunzip_single_to_memory(const string& path, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) {
+        close(fd);
+        return nullptr;
+    }
+    const size_t fsize = (size_t)st.st_size;
+    const unsigned char* in = (const unsigned char*)mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (in == (const unsigned char*)MAP_FAILED) return nullptr;
+    char* result = nullptr;
+    if (in[0] == 0x1f && in[1] == 0x8b && in[2] == 8) {
+        size_t tail = fsize; /* zlib ignores zero padding behind the last member: so does this */
+        while (tail > 18 && in[tail - 1] == 0 && tail > fsize - 4096) tail--;
+        for (int pad = 0; pad < 4 && !result; pad++) { /* (the size field itself may end in zero bytes) */
+            const size_t end = min(fsize, tail + (size_t)pad);
+            if (end < 18) break;
+            const uint64_t isize = (uint64_t)in[end - 4] | ((uint64_t)in[end - 3] << 8) | ((uint64_t)in[end - 2] << 16) | ((uint64_t)in[end - 1] << 24);
+            for (uint64_t want = isize; want <= max_bytes && !result; want += 1ull << 32) {
+                if (want == 0) continue;
+                const uint64_t span = want + (4u << 20);
+                char* base = (char*)mmap(nullptr, (size_t)span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+                if (base == (char*)MAP_FAILED) break;
+                madvise(base, (size_t)span, MADV_HUGEPAGE); /* (one fault per 2 MiB instead of per 4 KiB as the text arrives) */
+                size_t used = 0, made = 0;
+                const int rc = gunzip_member_into(in, end, base, (size_t)want, &used, &made);
+                if (rc == 1 && made == want && used == end) {
+                    result = base;
+                    *size_out = want;
+                    *reserved = span;
+                    break;
+                }
+                munmap(base, (size_t)span);
+                if (rc != 2) break; /* damaged, several members, no libdeflate: not for this lane */
+            }
+        }
+    }
+    munmap((void*)in, fsize);
+    return result;
+}
+
 char* gunzip_members_to_memory(const string& path, int threads, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved) {
+    /* The size field at the end of the file belongs to its LAST member.  When it says "at least as much text as the whole file
+       has bytes", the file is almost certainly one member: that lane first (bytes that look like a member header inside the
+       compressed data would otherwise send it through the member chain, whose size guesses for a member this large cost
+       several passes).  Otherwise the chain first, the single-member lane if the chain finds only one. */
+    bool single_first = false;
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        struct stat st;
+        unsigned char t[4];
+        if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 18 && pread(fd, t, 4, st.st_size - 4) == 4) {
+            const uint64_t isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+            single_first = isize >= (uint64_t)st.st_size;
+        }
+        if (fd >= 0) close(fd);
+    }
+    if (single_first)
+        if (char* one = gunzip_single_to_memory(path, max_bytes, size_out, reserved)) return one;
     GzMembers* g = GzMembers::open(path, threads);
-    if (!g) return nullptr;
+    if (!g) return single_first ? nullptr : gunzip_single_to_memory(path, max_bytes, size_out, reserved);
     const uint64_t span = max_bytes + (4u << 20);
     char* base = (char*)mmap(nullptr, (size_t)span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (base == (char*)MAP_FAILED) {
         delete g;
         return nullptr;
     }
+    madvise(base, (size_t)span, MADV_HUGEPAGE); /* (one fault per 2 MiB instead of per 4 KiB as the text arrives) */
     uint64_t total = 0;
     bool ok = true, at_end = false;
     vector<RawBuf> group;
@@ -1431,6 +1497,7 @@ uint64_t fplh_gz_members(void) { return fplh::GzMembers::delivered.exchange(0); 
 char* fplh_gunzip_to_memory(const char* path, int threads, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved) {
     return fplh::gunzip_members_to_memory(path, threads, max_bytes, size_out, reserved);
 }
+int fplh_have_libdeflate(void) { return fplh::have_libdeflate() ? 1 : 0; }
 void fplh_gunzip_release(char* base, uint64_t reserved) {
     if (base) munmap(base, (size_t)reserved);
 }

@@ -230,6 +230,7 @@ uint64_t fplh_parallel_records(void); /* records the multi-threaded scan contrib
 uint64_t fplh_gz_members(void);       /* gzip members inflated on the worker pool since the last call */
 char* fplh_gunzip_to_memory(const char* path, int threads, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved);
 void fplh_gunzip_release(char* base, uint64_t reserved);
+int fplh_have_libdeflate(void);
 uint32_t fplh_batch_n(void* b);
 uint64_t fplh_batch_bytes(void* b);
 const uint8_t* fplh_batch_seq(void* b);

@@ -106,6 +106,22 @@ void gzip_into(const string& in, int level, string& out) {
     out.assign(scratch.data(), n); /* (when out is the input itself: shrinks inside its own allocation) */
 }
 
+int gunzip_member_into(const unsigned char* in, size_t in_len, char* out, size_t out_cap, size_t* consumed, size_t* produced) {
+    const Deflate& d = deflate_lib();
+    if (!d.lib) return -1;
+    static thread_local ThreadCodec tc;
+    if (!tc.decomp) tc.decomp = d.alloc_decompressor();
+    if (!tc.decomp) return -1;
+    size_t used = 0, made = 0;
+    const int rc = d.gzip_decompress_ex(tc.decomp, in, in_len, out, out_cap, &used, &made);
+    if (rc == 0) {
+        if (consumed) *consumed = used;
+        if (produced) *produced = made;
+        return 1;
+    }
+    return rc == 3 ? 2 : 0;
+}
+
 int gunzip_member(const unsigned char* in, size_t in_len, RawBuf& out, size_t cap, size_t* consumed, size_t hint) {
     const Deflate& d = deflate_lib();
     out.clear();

@@ -60,6 +60,9 @@ struct RawBuf {
    cap bytes */
 int gunzip_member(const unsigned char* in, size_t in_len, RawBuf& out, size_t cap, size_t* consumed, size_t hint = 0);
 bool have_libdeflate();
+/* one whole member straight into caller-owned memory (libdeflate only): 1 = done (*consumed input bytes, *produced output
+   bytes), 2 = out_cap is too small, 0 = damaged / truncated, -1 = libdeflate is not there */
+int gunzip_member_into(const unsigned char* in, size_t in_len, char* out, size_t out_cap, size_t* consumed, size_t* produced);
 
 /* --split / --split_by_lines.  Each of the reference's workers owns a writer and walks through the file numbers
  * t, t + T, t + 2T, ... as its current file fills up (ThreadConfig::initWriterForSplit / markProcessed /

@@ -128,7 +128,7 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("how", ["stdout_pipe", "file_forced"])
+@pytest.mark.parametrize("how", ["stdout_pipe", "file_forced", "gz_input"])
 def test_cli_gather_output_reproduces_golden_on_gpu(tmp_path, case, how):
     """plain --out without --failed_out that is not a regular file (here: --stdout into a pipe) is written as gather lists
     over the batches' own arrays (writev, nothing is formatted); FPLH_GATHER_FILES forces the same for a file.  Same bytes
@@ -137,18 +137,22 @@ def test_cli_gather_output_reproduces_golden_on_gpu(tmp_path, case, how):
     meta = json.load(open(os.path.join(GOLD, case, "case.json")))
     inp = tmp_path / "in.fq"
     inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    if how == "gz_input":  # the fixture as it is: ONE gzip member, inflated in one piece into memory and parsed in chunks there
+        inp = os.path.join(GOLD, case, "in.fq.gz")
     flags = [f if f != "ADAPTERS.fa" else os.path.join(GOLD, case, "ADAPTERS.fa") for f in meta["flags"]]
-    cmd = [build.CLI, "-i", str(inp), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"), "--reader_threads", "3"] + flags
+    cmd = [build.CLI, "-i", str(inp), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"), "--reader_threads", "3", "-V"] + flags
     env = dict(os.environ, FPLH_CHUNK_BYTES="30000")
-    if how == "stdout_pipe":
+    if how != "file_forced":
         cmd += ["--stdout"]
     else:
         cmd += ["-o", str(tmp_path / "out.fq")]
         env["FPLH_GATHER_FILES"] = "1"
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    got = p.stdout if how == "stdout_pipe" else (tmp_path / "out.fq").read_bytes()
+    got = p.stdout if how != "file_forced" else (tmp_path / "out.fq").read_bytes()
     assert got == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    if how == "gz_input":
+        assert b"gzip members inflated into memory" in p.stderr and b"chunk parsers" in p.stderr
 
 
 @pytest.mark.gpu
