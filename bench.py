@@ -45,7 +45,10 @@ WORKLOADS = {
                      reads_desc="lognormal lengths (sigma 0.9, clipped to [300, 200000], N50 ~15 kb), Q~N(18,8)"),
     # BASELINE.json configs[4]: HiFi-like reads, --adapter_fasta of 64 adapters visited in header order
     # (src/adaptertrimmer.cpp:42-57), no command-line adapters
-    "c5_hifi64": dict(opt=dict(), flags="--adapter_fasta (64 random 30-45-mers), defaults otherwise", config=4, reads=500_000,
+    # With -a alone the reference leaves -s / -e on "auto" (src/options.cpp:209-214); SURVEY 8(d): pass them explicitly --
+    # here the first FASTA adapter and its reverse complement, as tests/test_gpu_parity.py does for the same reads.
+    "c5_hifi64": dict(opt=dict(), flags="--adapter_fasta (64 random 30-45-mers), -s <first adapter> -e <its reverse complement>, "
+                      "defaults otherwise", config=4, reads=500_000,
                       gen=dict(kind="hifi", mean_len=20000, sd_len=2000, n_adapters=64, seed0=5),
                       reads_desc="N(20 kb, 2 kb) lengths, Q~N(35,6), 30 % of the reads with one FASTA adapter at an end, 1 % in the middle"),
 }
@@ -60,7 +63,7 @@ def make_batch(wl, n_reads, rank, dev):
     seed = g.pop("seed0", 1) + rank
     if kind == "hifi":
         seq_t, qual_t, off_t, max_len, ads = synth.device_batch_hifi(n_reads, seed=seed, device=dev, **g)
-        return seq_t, qual_t, off_t, max_len, "", "", ads
+        return seq_t, qual_t, off_t, max_len, ads[0], synth.revcomp(ads[0]), ads
     seq_t, qual_t, off_t, max_len = synth.device_batch(n_reads, seed=seed, device=dev, **g)
     return seq_t, qual_t, off_t, max_len, synth.START_ADAPTER, synth.END_ADAPTER, []
 
@@ -103,20 +106,90 @@ def cpu_baseline(opt, adapters, seq_t, qual_t, off_t, target_bases, max_threads=
                 n, nb, threads, dt)}
 
 
+def parity_sample(rig, opt, adapters, seq_t, qual_t, off_t, local_rank, n_sample=2000):
+    """Outside the timed region: the first reads of the bench batch through a fresh context of the HIP library,
+    records AND counters compared bit for bit with the oracle (the checker; never the thing measured)."""
+    import numpy as np
+    from oracle import oracle
+    from tests import parity
+
+    n = min(n_sample, off_t.numel() - 1)
+    off = off_t[:n + 1].cpu().numpy().astype(np.uint64)
+    nb = int(off[-1])
+    seq, qual = seq_t[:nb].cpu().numpy(), qual_t[:nb].cpu().numpy()
+    C = int(np.diff(off.astype(np.int64)).max())
+    cfg = oracle.Config(opt, adapters[0], adapters[1], adapters[2])
+    want_res, want_cnt = oracle.process_batch(cfg, seq, qual, off, max_cycles=C)
+    eng = rig.engine(opt, adapters[0], adapters[1], adapters[2], local_rank, C)
+    try:
+        rt = eng.process_device(seq_t[:nb], qual_t[:nb], off_t[:n + 1], C)
+        rig.synchronize(seq_t.device)
+        got_res = eng.results_to_numpy(rt, n)
+        got_cnt = eng.counters()
+        nad = eng.n_adapters
+    finally:
+        eng.close()
+    try:
+        parity.assert_results_equal(got_res, want_res, seq, off)
+        parity.assert_counters_equal(got_cnt, want_cnt, C, nad)
+    except AssertionError as e:
+        return "MISMATCH: " + str(e)[:300], n, nb
+    return "ok", n, nb
+
+
+def profile_record(workload):
+    """What the separate rocprofv3 --pmc passes of this workload recorded (profiles/kernel_counters.json, written by
+    profiles/summarize_profile.py): HBM bytes and vector wave-instructions per base and kernel.  {} when there is none."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "kernel_counters.json")))
+        return rec.get("workloads", {}).get(workload, {})
+    except (OSError, ValueError):
+        return {}
+
+
+def mem_headroom():
+    """bytes this process may still put into the page cache / tmpfs: the cgroup's limit (v2 or v1) minus what is in use,
+    and MemAvailable -- whichever is smaller"""
+    lim = None
+    for mx, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                    ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            m = open(mx).read().strip()
+            if m != "max" and int(m) < (1 << 60):
+                lim = int(m) - int(open(cur).read().strip())
+            break
+        except (OSError, ValueError):
+            continue
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    vals = [v for v in (lim, avail) if v is not None]
+    return min(vals) if vals else None
+
+
 CLI_FLAGS = {
     "c3_full_pipeline": ["--cut_front", "--cut_tail", "-W", "5", "-x", "-y"],
     "c4_mixed": ["--cut_front", "--cut_tail", "-W", "5", "-x", "-y"],
     "c2_adapter_only": [],
+    "c5_hifi64": [],
 }
 
 
-def end_to_end(workload, opt, ad_start, ad_end, seq_t, qual_t, off_t, n_reads):
+E2E_RUNS = (("to_dev_null_first_pass", "/dev/null"), ("to_dev_null", "/dev/null"), ("to_file", None))
+
+
+def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1, copies=None, with_pcie=True, run_names=None):
     """End to end around the hot path, on the first n_reads reads of the resident batch -- reported NEXT to `value`,
     never as `value`:
-      (1) the command line bin/fastplong_amd: FASTQ text in the page cache (tmpfs) -> chunk-parallel parse into
-          page-locked CSR batches -> H2D / kernels / D2H two batches deep -> trimmed FASTQ + fastplong.json / .html;
-          wall time of the whole process (HIP start-up, reports and exit included) and of its host pipeline alone;
-      (2) the PCIe-inclusive C-ABI call: fpl_process_batch_async / fpl_wait from page-locked arrays, two deep."""
+      (1) the command line bin/fastplong_amd --gpus n_gpus: FASTQ text in the page cache (tmpfs; `copies` copies of the
+          reads under names of their own, n_gpus by default) -> chunk-parallel parse into page-locked CSR batches ->
+          H2D / kernels / D2H two batches deep per device -> trimmed FASTQ + fastplong.json / .html; wall time of the
+          whole process (HIP start-up, reports and exit included) and of its host pipeline alone;
+      (2) n_gpus == 1: the PCIe-inclusive C-ABI call, fpl_process_batch_async / fpl_wait from page-locked arrays, two deep."""
     import shutil
     import subprocess
 
@@ -126,73 +199,99 @@ def end_to_end(workload, opt, ad_start, ad_end, seq_t, qual_t, off_t, n_reads):
 
     from fastplong_amd import abi, build, engine
 
+    ad_start, ad_end, ad_fasta = adapters
     off = off_t[:n_reads + 1].cpu().numpy().astype(np.uint64)
     nb = int(off[-1])
     seq = seq_t[:nb].cpu().numpy()
     qual = qual_t[:nb].cpu().numpy()
-    res = {"reads": n_reads, "bases": nb, "unit": "Gbases/s"}
+    res = {"reads": n_reads, "bases": nb, "unit": "Gbases/s", "n_gpus": n_gpus}
 
     # (2) first: it needs the arrays page-locked, the file writer below does not care
-    eng = engine.Engine(opt, ad_start, ad_end, device=torch.cuda.current_device(), max_cycles=int(np.diff(off.astype(np.int64)).max()))
-    n_parts = 16
-    n_pcie = min(n_reads, 400_000)  # (page-locking tens of gigabytes takes longer than the measurement)
-    nb_pcie = int(off[n_pcie])
-    cuts = [int(i * n_pcie / n_parts) for i in range(n_parts + 1)]
-    parts = []
-    for i in range(n_parts):
-        a, b = cuts[i], cuts[i + 1]
-        lo, hi = int(off[a]), int(off[b])
-        ps, pq, po = eng.pinned_array(hi - lo), eng.pinned_array(hi - lo), eng.pinned_array(b - a + 1, np.uint64)
-        ps[:], pq[:], po[:] = seq[lo:hi], qual[lo:hi], off[a:b + 1] - off[a]
-        parts.append((ps, pq, po, np.zeros(b - a, dtype=abi.RESULT_DTYPE)))
-    for rep in range(2):  # the first round allocates the staging slots
-        t0 = time.perf_counter()
-        for ps, pq, po, rr in parts:
-            if eng.in_flight() == abi.FPL_MAX_IN_FLIGHT:
+    if with_pcie and n_gpus == 1:
+        eng = engine.Engine(opt, ad_start, ad_end, ad_fasta, device=torch.cuda.current_device(),
+                            max_cycles=int(np.diff(off.astype(np.int64)).max()))
+        n_parts = 16
+        n_pcie = min(n_reads, 400_000)  # (page-locking tens of gigabytes takes longer than the measurement)
+        nb_pcie = int(off[n_pcie])
+        cuts = [int(i * n_pcie / n_parts) for i in range(n_parts + 1)]
+        parts = []
+        for i in range(n_parts):
+            a, b = cuts[i], cuts[i + 1]
+            lo, hi = int(off[a]), int(off[b])
+            ps, pq, po = eng.pinned_array(hi - lo), eng.pinned_array(hi - lo), eng.pinned_array(b - a + 1, np.uint64)
+            ps[:], pq[:], po[:] = seq[lo:hi], qual[lo:hi], off[a:b + 1] - off[a]
+            parts.append((ps, pq, po, np.zeros(b - a, dtype=abi.RESULT_DTYPE)))
+        for rep in range(2):  # the first round allocates the staging slots
+            t0 = time.perf_counter()
+            for ps, pq, po, rr in parts:
+                if eng.in_flight() == abi.FPL_MAX_IN_FLIGHT:
+                    eng.wait()
+                eng.submit_host(ps, pq, po, rr)
+            while eng.in_flight():
                 eng.wait()
-            eng.submit_host(ps, pq, po, rr)
-        while eng.in_flight():
-            eng.wait()
-        dt = time.perf_counter() - t0
-    res["pcie_call"] = {"value": nb_pcie / dt / 1e9, "seconds": dt, "reads": n_pcie, "bases": nb_pcie,
-                        "what": "fpl_process_batch_async/fpl_wait, %d batches from page-locked arrays, two in flight "
-                                "(H2D 2 B/base + kernels + D2H of the records)" % n_parts}
-    eng.close()
-    del parts
+            dt = time.perf_counter() - t0
+        res["pcie_call"] = {"value": nb_pcie / dt / 1e9, "seconds": dt, "reads": n_pcie, "bases": nb_pcie,
+                            "what": "fpl_process_batch_async/fpl_wait, %d batches from page-locked arrays, two in flight "
+                                    "(H2D 2 B/base + kernels + D2H of the records)" % n_parts}
+        eng.close()
+        del parts
 
     # (1)
     build.build_host()
     host = C.CDLL(build.HOST_LIB)
-    host.fplh_write_fastq.restype = C.c_int
-    host.fplh_write_fastq.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_int]
-    need = 2.3 * (2 * nb + 16 * n_reads)
+    host.fplh_write_fastq_ex.restype = C.c_int
+    host.fplh_write_fastq_ex.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int]
+    copies = copies or n_gpus
+    per_copy = 2.0 * nb + 16.0 * n_reads
     tmp = None
+    head = mem_headroom()
     for d in ("/dev/shm", "/tmp"):
         try:
-            if shutil.disk_usage(d).free > need:
-                tmp = d
-                break
+            free = shutil.disk_usage(d).free
         except OSError:
-            pass
+            continue
+        if d == "/dev/shm" and head is not None:
+            free = min(free, head // 2)  # (tmpfs pages count against the container's memory; the run itself needs room too)
+        while copies > 1 and free < 2.3 * per_copy * copies:
+            copies -= 1  # what fits
+        if free > 2.3 * per_copy * copies:
+            tmp = d
+            break
     if tmp is None:
         res["cli"] = None
-        res["note"] = "no scratch directory with %.0f GB free" % (need / 1e9)
+        res["note"] = "no scratch directory with %.0f GB free" % (2.3 * per_copy / 1e9)
         return res
+    res["copies"] = copies
+    res["bases"] = nb * copies
+    res["reads"] = n_reads * copies
     fq = os.path.join(tmp, "fpl_e2e_%d.fq" % os.getpid())
     outp = os.path.join(tmp, "fpl_e2e_%d.out.fq" % os.getpid())
+    fa = os.path.join(tmp, "fpl_e2e_%d.fa" % os.getpid())
     js, html = fq + ".json", fq + ".html"
     try:
         t0 = time.perf_counter()
-        rc = host.fplh_write_fastq(fq.encode(), seq.ctypes.data, qual.ctypes.data, off.ctypes.data, n_reads, b"r", 16)
-        assert rc == 0, "writing %s failed" % fq
-        res["input"] = "%s, %.2f GB of FASTQ text (written in %.1f s, in the page cache)" % (fq, os.path.getsize(fq) / 1e9,
-                                                                                            time.perf_counter() - t0)
+        for c in range(copies):
+            rc = host.fplh_write_fastq_ex(fq.encode(), seq.ctypes.data, qual.ctypes.data, off.ctypes.data, n_reads,
+                                          b"r" if copies == 1 else b"c%d_" % c, 16, 1 if c else 0)
+            assert rc == 0, "writing %s failed" % fq
+        res["input"] = "%s, %.2f GB of FASTQ text (%d x %d reads, written in %.1f s, in the page cache)" % (
+            fq, os.path.getsize(fq) / 1e9, copies, n_reads, time.perf_counter() - t0)
         cmd = [build.CLI, "-i", fq, "-s", ad_start, "-e", ad_end, "-j", js, "-h", html, "-V"] + CLI_FLAGS[workload]
+        if n_gpus > 1:
+            cmd += ["--gpus", str(n_gpus)]
+        if ad_fasta:
+            with open(fa, "w") as f:
+                for i, a in enumerate(ad_fasta):
+                    f.write(">ad%03d\n%s\n" % (i, a))
+            cmd += ["-a", fa]
         runs = {}
         # the first pass over a file that has only just been written pays the kernel's first-touch bookkeeping of its
         # page-cache pages (every read marks them accessed / moves them between LRU lists, under contention from 16
         # parser threads): it is reported, the steady state is the second pass
-        for name, target in (("to_dev_null_first_pass", "/dev/null"), ("to_dev_null", "/dev/null"), ("to_file", outp)):
+        for name, target in E2E_RUNS:
+            if run_names and name not in run_names:
+                continue
+            target = target or outp
             t0 = time.perf_counter()
             p = subprocess.run(cmd + ["-o", target], capture_output=True, text=True,
                                env=dict(os.environ, FPLH_T0=repr(time.time()), FPLH_TIMING="1"))
@@ -204,21 +303,27 @@ def end_to_end(workload, opt, ad_start, ad_end, seq_t, qual_t, off_t, n_reads):
                     pipe = float(line.split("wall ")[1].split(" s")[0])
                 if line.startswith(("host pipeline:", "start-up:", "reports:", "since launch:", "chunk parsers")):
                     keep.append(line)
-            runs[name] = {"rc": p.returncode, "process_seconds": dt, "value": nb / dt / 1e9,
-                          "pipeline_seconds": pipe, "pipeline_value": (nb / pipe / 1e9) if pipe else None, "stages": keep}
+            runs[name] = {"rc": p.returncode, "process_seconds": dt, "value": nb * copies / dt / 1e9,
+                          "pipeline_seconds": pipe, "pipeline_value": (nb * copies / pipe / 1e9) if pipe else None, "stages": keep}
             if p.returncode != 0:
                 runs[name]["stderr_tail"] = p.stderr[-500:]
+            try:
+                os.remove(outp)
+            except OSError:
+                pass
         res["cli"] = runs
         if runs["to_dev_null"]["rc"] == 0:
             res["value"] = runs["to_dev_null"]["value"]
-            res["what"] = ("bin/fastplong_amd -i <FASTQ in tmpfs> -o /dev/null + JSON + HTML: input bases / wall time of the "
+            res["what"] = ("bin/fastplong_amd%s -i <FASTQ in tmpfs> -o /dev/null + JSON + HTML: input bases / wall time of the "
                            "whole process; cli.to_file = the same with the trimmed FASTQ written to tmpfs; "
-                           "pipeline_value = without process start-up (HIP context) and the report writers")
+                           "pipeline_value = without process start-up (HIP context) and the report writers" % (
+                               " --gpus %d" % n_gpus if n_gpus > 1 else ""))
             jr = json.load(open(js))
             res["json_check"] = {"reads_in": jr["summary"]["before_filtering"]["total_reads"],
-                                 "reads_out": jr["summary"]["after_filtering"]["total_reads"]}
+                                 "reads_out": jr["summary"]["after_filtering"]["total_reads"],
+                                 "ok": jr["summary"]["before_filtering"]["total_reads"] == n_reads * copies}
     finally:
-        for f in (fq, outp, js, html):
+        for f in (fq, outp, js, html, fa):
             try:
                 os.remove(f)
             except OSError:
@@ -268,7 +373,11 @@ def main(argv=None, rig=None):
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's own: 1 M for c2/c3, 2.5 M for c4, 0.5 M for c5)")
     ap.add_argument("--median-len", type=int, default=0, help="ablation only: median read length of the ONT-like workloads")
     ap.add_argument("--e2e-reads", type=int, default=1_000_000,
-                    help="N = 1 only: reads of the batch written as FASTQ and run through bin/fastplong_amd (0 = skip)")
+                    help="reads of rank 0's batch written as FASTQ (once per GPU) and run through ONE bin/fastplong_amd --gpus N (0 = skip)")
+    ap.add_argument("--e2e-copies", type=int, default=4,
+                    help="N = 1: a second end-to-end run over this many copies of the reads, so that the process's fixed cost "
+                         "(HIP context, reports, exit) weighs less (0 or 1 = skip)")
+    ap.add_argument("--parity-reads", type=int, default=2000, help="reads of the batch checked against the oracle outside the timed region (0 = skip)")
     ap.add_argument("--workload", default="c3_full_pipeline", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-bases", type=float, default=6e9, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--set", default="", help="ablation only: comma separated fpl_options overrides, e.g. adapter_enabled=0")
@@ -347,23 +456,58 @@ def main(argv=None, rig=None):
     ktimes, nbatches = eng.kernel_times()
     eng.enable_timing(False)
 
+    cpu_group = None
+    if world > 1:  # a CPU-side barrier for the end-to-end leg: the other ranks must not spin on their GPUs meanwhile
+        try:
+            cpu_group = dist.new_group(backend="gloo")
+        except Exception:
+            cpu_group = None
+    n_cu = 256
+    try:
+        n_cu = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == "cuda" else 256
+    except Exception:
+        pass
+    adapters = (ad_start, ad_end, ad_fasta)
+    out = None
     if rank == 0:
         counters = eng.counters()
         v = abi.CountersView(counters, C, eng.n_adapters)
         dom = max(ktimes, key=ktimes.get)
         dom_ms = ktimes[dom] / max(1, nbatches)
         achieved = ALGO_BYTES_PER_BASE * n_bases / (dom_ms * 1e-3) / 1e9
-        # HBM bytes per launch of the dominant kernel: PMC counters come from separate rocprofv3 --pmc
-        # passes of this same command (profiles/hbm_traffic.json records bytes per base, corrected as
-        # MI355X_MICROARCH.md prescribes); --hbm-traffic overrides, otherwise null when nothing is recorded
+        ms_per_step = dt / args.steps * 1e3
+        # HBM bytes and vector wave-instructions per launch: PMC counters come from separate rocprofv3 --pmc passes of
+        # this same command (profiles/kernel_counters.json records them per base, HBM bytes corrected as
+        # MI355X_MICROARCH.md prescribes); --hbm-traffic overrides the dominant kernel's, null when nothing is recorded
+        prof = {} if (args.set or args.median_len) else profile_record(args.workload)
+        hbm_pb, valu_pb = prof.get("hbm_bytes_per_base", {}), prof.get("valu_insts_per_base", {})
+        # (the HIP-event stages group kernels: k_stats = the bucket kernels + k_stats_sorted + its reduce, ...)
+        stage_of = {"k_trim_ends": ("k_trim_ends", "k_trim_ends_batched"), "k_scan": ("k_scan", "k_break_mask"),
+                    "k_stats": ("k_stats", "k_stats_sorted", "k_stats_reduce_sorted", "k_bucket_count", "k_bucket_scan",
+                                "k_bucket_plan", "k_bucket_scatter"),
+                    "k_stats_extra": ("k_stats_extra", "k_stats_reduce")}
+        dom_kernel = {"k_stats": "k_stats_sorted" if "k_stats_sorted" in hbm_pb else "k_stats",
+                      "k_trim_ends": "k_trim_ends_batched" if "k_trim_ends_batched" in hbm_pb else "k_trim_ends"}.get(dom, dom)
         traffic, traffic_src = args.hbm_traffic, "--hbm-traffic"
-        if traffic is None:
-            try:
-                rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-                if rec.get("workload") == args.workload and not args.set and dom in rec["hbm_bytes_per_base"]:
-                    traffic, traffic_src = rec["hbm_bytes_per_base"][dom] * n_bases, rec["source"]
-            except (OSError, ValueError, KeyError):
-                traffic = None
+        if traffic is None and dom_kernel in hbm_pb:
+            traffic, traffic_src = hbm_pb[dom_kernel] * n_bases, prof.get("source")
+        path_bytes = sum(hbm_pb.values()) * n_bases if hbm_pb else None
+        path_achieved = ALGO_BYTES_PER_BASE * n_bases / (ms_per_step * 1e-3) / 1e9
+        # vector issue: one wave-instruction per clock and CU for mixed code (measured, tools/ubench)
+        clock_ghz = 2.4
+        issue = None
+        if dom_kernel in valu_pb:
+            v_insts = valu_pb[dom_kernel] * n_bases
+            issue_ms = v_insts / (n_cu * clock_ghz * 1e9) * 1e3
+            issue = {"kernel": dom_kernel, "valu_wave_insts_per_launch": v_insts, "cus": n_cu, "clock_ghz": clock_ghz,
+                     "issue_ms": issue_ms, "kernel_ms": dom_ms, "frac_of_kernel_time": issue_ms / dom_ms,
+                     "model": "1 vector wave-instruction per clock and CU (mixed code, measured: profiles/r02_ubench)",
+                     "source": prof.get("source")}
+        limited_by = "hbm"
+        if issue and issue["frac_of_kernel_time"] > achieved / HBM_PEAK_GBS:
+            limited_by = "valu_issue"
+        reads_ok = int(v.pre.reads) == args.steps * n * (world if world > 1 else 1) and \
+            int(v.pre.length_sum) == args.steps * total_bases
         out = {
             "metric": "Gbases/s processed (trim+cut+filter)",
             "value": total_bases * args.steps / dt / 1e9,
@@ -371,7 +515,7 @@ def main(argv=None, rig=None):
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -385,24 +529,69 @@ def main(argv=None, rig=None):
                 "parallelism": "shard%d (independent read shards, one RCCL all-reduce of the counters)" % world,
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # priced against the HBM roofline as the contract prescribes (algorithmic bytes / kernel time / 8 TB/s);
+                # `limited_by` says what the counters say the kernel actually waits for
+                "bound": "hbm", "limited_by": limited_by, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BASE * n_bases,
                 "kernel_ms": {k: ktimes[k] / max(1, nbatches) for k in ktimes},
+                "issue": issue,
+                "path": {"what": "the whole launch sequence of a step against the same roofline: 2 B/base x bases / ms_per_step",
+                         "achieved": path_achieved, "frac": path_achieved / HBM_PEAK_GBS,
+                         "measured_bytes_per_base": (path_bytes / n_bases) if path_bytes else None,
+                         "ratio_to_algorithmic": (path_bytes / (ALGO_BYTES_PER_BASE * n_bases)) if path_bytes else None},
             },
             "counters_check": {"reads_in": int(v.pre.reads), "bases_in": int(v.pre.length_sum),
-                               "fragments_out": int(v.post.reads), "bases_out": int(v.post.length_sum)},
+                               "fragments_out": int(v.post.reads), "bases_out": int(v.post.length_sum),
+                               "expected_reads_in": args.steps * n * world if world > 1 else args.steps * n,
+                               "expected_bases_in": args.steps * total_bases, "ok": bool(reads_ok)},
         }
+        if args.parity_reads > 0:
+            verdict, pn, pb = parity_sample(rig, opt, adapters, seq_t, qual_t, off_t, local_rank, args.parity_reads)
+            out["parity_sample"] = verdict
+            out["parity_sample_what"] = ("first %d reads (%d bases) of the bench batch: result records and every counter of a fresh "
+                                         "context, bit for bit against oracle/liboracle.so, outside the timed region" % (pn, pb))
         if args.cpu_bases > 0 and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in the barrier meanwhile)
-            out["cpu_baseline"] = cpu_baseline(opt, (ad_start, ad_end, ad_fasta), seq_t, qual_t, off_t, args.cpu_bases)
-        if args.e2e_reads > 0 and world == 1 and not ad_fasta and not args.set:
-            eng.close()
-            out["e2e"] = end_to_end(args.workload, opt, ad_start, ad_end, seq_t, qual_t, off_t, min(n, args.e2e_reads))
+            out["cpu_baseline"] = cpu_baseline(opt, adapters, seq_t, qual_t, off_t, args.cpu_bases)
+    eng.close()  # (idempotent)
+    run_e2e = args.e2e_reads > 0 and not args.set and dev.type == "cuda"
+    if run_e2e and world > 1:
+        # the end-to-end number the >= 30 Gbases/s target is about: ONE bin/fastplong_amd --gpus N over an N-times larger
+        # FASTQ in tmpfs.  The ranks give their device memory back first and wait on the CPU.
+        keep = None
+        if rank == 0:
+            ne = min(n, args.e2e_reads)
+            keep = (seq_t[:int(off_t[ne].item())].cpu(), qual_t[:int(off_t[ne].item())].cpu(), off_t[:ne + 1].cpu(), ne)
+        del seq_t, qual_t, off_t, res_t
+        torch.cuda.empty_cache()
+        if cpu_group is not None:
+            dist.barrier(group=cpu_group)
+        if rank == 0:
+            try:
+                out["e2e"] = end_to_end(args.workload, opt, adapters, keep[0], keep[1], keep[2], keep[3], n_gpus=world,
+                                        with_pcie=False, run_names=("to_dev_null_first_pass", "to_dev_null"))
+            except Exception as e:  # the line must still be printed
+                out["e2e"] = {"error": repr(e)[:300]}
+        if cpu_group is not None:
+            dist.barrier(group=cpu_group)
+    elif run_e2e and rank == 0:
+        ne = min(n, args.e2e_reads)
+        out["e2e"] = end_to_end(args.workload, opt, adapters, seq_t, qual_t, off_t, ne)
+        if args.e2e_copies > 1:
+            try:
+                big = end_to_end(args.workload, opt, adapters, seq_t, qual_t, off_t, ne, copies=args.e2e_copies,
+                                 with_pcie=False, run_names=("to_dev_null", "to_file"))
+                out["e2e"]["large_input"] = big
+            except Exception as e:
+                out["e2e"]["large_input"] = {"error": repr(e)[:300]}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        if cpu_group is not None:
+            dist.barrier(group=cpu_group)
+        else:
+            dist.barrier()
         dist.destroy_process_group()
-    eng.close()  # (idempotent)
 
 
 if __name__ == "__main__":

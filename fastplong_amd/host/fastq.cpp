@@ -1449,7 +1449,11 @@ void* fplh_batch_read_chunked(const char* path, uint64_t chunk_bytes, int thread
    `threads` threads, slice by slice, and written in order.  0 on success. */
 int fplh_write_fastq(const char* path, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n,
                      const char* prefix, int threads) {
-    FILE* f = fopen(path, "wb");
+    return fplh_write_fastq_ex(path, seq, qual, off, n, prefix, threads, 0);
+}
+int fplh_write_fastq_ex(const char* path, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n,
+                        const char* prefix, int threads, int append) {
+    FILE* f = fopen(path, append ? "ab" : "wb");
     if (!f) return -1;
     if (threads < 1) threads = 1;
     const std::string pre = prefix ? prefix : "r";

@@ -226,6 +226,10 @@ void* fplh_batch_read_chunked(const char* path, uint64_t chunk_bytes, int thread
 int fplh_read_error(const char* path, char* msg, int msg_len);
 int fplh_write_fastq(const char* path, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n,
                      const char* prefix, int threads);
+/* append != 0: the records go behind what the file holds (bench.py builds its N-GPU input out of N copies of a batch, each
+   with a prefix of its own) */
+int fplh_write_fastq_ex(const char* path, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n,
+                        const char* prefix, int threads, int append);
 uint64_t fplh_parallel_records(void); /* records the multi-threaded scan contributed since the last call */
 uint64_t fplh_gz_members(void);       /* gzip members inflated on the worker pool since the last call */
 char* fplh_gunzip_to_memory(const char* path, int threads, uint64_t max_bytes, uint64_t* size_out, uint64_t* reserved);

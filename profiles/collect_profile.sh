@@ -1,19 +1,25 @@
 #!/bin/bash
-# Collect the evidence bench.py's `roofline` object cites, on the GPU box:
-#   1. rocprofv3 --kernel-trace --stats of the default bench command (per-kernel average durations)
-#   2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command -> HBM bytes per launch
-# Usage (from the repo root, through gpurun):  bash profiles/collect_profile.sh r01_v4 [bench args...]
-# Writes gpurun_out/<tag>/{kernel_stats_1M.csv,pmc_hbm_1M.json,bench_1M.json}; copy them to profiles/<tag>/.
+# Collect the evidence bench.py's `roofline` object cites, on the GPU box, for ONE workload:
+#   1. rocprofv3 --kernel-trace --stats of the bench command (per-kernel average durations)
+#   2. separate --pmc passes of the same command: FETCH_SIZE, WRITE_SIZE (HBM bytes per launch) and the SQ instruction
+#      counters (vector / scalar / LDS wave-instructions per launch)
+# Usage (from the repo root, through gpurun):  bash profiles/collect_profile.sh <tag> [<workload> [bench args...]]
+# Writes gpurun_out/<tag>/{kernel_stats_<wl>.csv,pmc_<wl>.json,bench_<wl>.json}; copy them to profiles/<tag>/ and merge
+# pmc_<wl>.json into profiles/kernel_counters.json with `python profiles/summarize_profile.py --merge profiles/<tag>`.
 set -u
 TAG=${1:-prof}; shift || true
+WL=${1:-c3_full_pipeline}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-mkdir -p "$OUT"
+W=$OUT/work_$WL
+rm -rf "$W"; mkdir -p "$W"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --cpu-bases 0 --e2e-reads 0 $*"
-$BENCH --steps 10 --warmup 2 > "$OUT/bench_1M.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH --steps 5 --warmup 1 > "$OUT/stats.log" 2>&1
+BENCH="python $ROOT/bench.py --workload $WL --cpu-bases 0 --e2e-reads 0 --parity-reads 0 $*"
+$BENCH --steps 10 --warmup 2 > "$OUT/bench_$WL.json" 2> "$W/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$W/stats" -- $BENCH --steps 5 --warmup 1 > "$W/stats.log" 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc_$ctr" -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc_$ctr.log" 2>&1
+    rocprofv3 --pmc $ctr --output-format csv -d "$W/pmc_$ctr" -- $BENCH --steps 2 --warmup 1 > "$W/pmc_$ctr.log" 2>&1
 done
-python "$ROOT/profiles/summarize_profile.py" "$OUT"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$W/pmc_SQ" -- $BENCH --steps 2 --warmup 1 > "$W/pmc_SQ.log" 2>&1
+python "$ROOT/profiles/summarize_profile.py" "$OUT" "$WL"
+rm -rf "$W/stats" "$W"/pmc_*/ 2>/dev/null  # (the raw traces are large; the summaries stay)

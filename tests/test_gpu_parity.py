@@ -531,3 +531,39 @@ def test_offsets_beyond_4_gib_bit_exact(orc, engine_mod):
     eng2.close()
     assert np.array_equal(cnt, cnt2)
     parity.assert_results_equal(res2, res)
+
+
+@pytest.mark.parametrize("workload", ["c2_adapter_only", "c3_full_pipeline", "c4_mixed", "c5_hifi64"])
+@pytest.mark.parametrize("forced", [False, True])
+def test_every_bench_workload_bit_exact(orc, engine_mod, monkeypatch, workload, forced):
+    """What bench.py runs, as bench.py builds it (its generators, its option sets, its adapters -- c5 with -s / -e set to the
+    first FASTA adapter and its reverse complement), at a size the oracle checks in full: bench.parity_sample is the very
+    function behind the `parity_sample` field of the bench line.  forced: with the kernels that only batches of bench size
+    take (k_trim_ends_batched, k_stats_sorted) forced on the small batch."""
+    import torch
+
+    import bench
+
+    if forced:
+        monkeypatch.setenv("FPL_TRIM_BATCH_MIN", "1")
+        monkeypatch.setenv("FPL_STATS_SORT_MIN", "1")
+    else:
+        monkeypatch.delenv("FPL_TRIM_BATCH_MIN", raising=False)
+        monkeypatch.delenv("FPL_STATS_SORT_MIN", raising=False)
+    wl = dict(bench.WORKLOADS[workload])
+    g = dict(wl["gen"])
+    if g["kind"] == "hifi":
+        g.update(mean_len=6000, sd_len=1500)
+    elif "max_len" in g:
+        g.update(max_len=40000)
+    else:
+        g.update(median_len=3000)
+    wl["gen"] = g
+    rig = bench.Rig()
+    dev = torch.device("cuda", 0)
+    seq_t, qual_t, off_t, max_len, ad_start, ad_end, ad_fasta = rig.make_batch(wl, 700, 0, dev)
+    if workload == "c5_hifi64":
+        assert ad_start and ad_end == synth.revcomp(ad_start) and len(ad_fasta) == 64
+    opt = abi.FplOptions.default(**wl["opt"])
+    verdict, n, nb = bench.parity_sample(rig, opt, (ad_start, ad_end, ad_fasta), seq_t, qual_t, off_t, 0, 700)
+    assert verdict == "ok" and n == 700, verdict
