@@ -120,6 +120,7 @@ __device__ __forceinline__ u32 dpp_u32(u32 old, u32 v) {
     v = OP(v, (dpp_u32<0x143, 0xc>(ID, v)));
 __device__ __forceinline__ u32 op_add_u32(u32 a, u32 b) { return a + b; }
 __device__ __forceinline__ u32 op_max_u32(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 op_min_u32(u32 a, u32 b) { return a < b ? a : b; }
 #endif
 /* the value of the next lane (lane 63 gets 0): DPP wave_shl:1, no LDS */
 __device__ __forceinline__ u32 wave_next_u32(u32 v) {
@@ -162,6 +163,18 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return v;
 #else
     FPL_DPP_SCAN(op_max_u32, 0u, v)
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+#ifdef FPL_EMU
+    for (int m = 32; m >= 1; m >>= 1) {
+        u32 o = shfl_xor_u32(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+#else
+    FPL_DPP_SCAN(op_min_u32, ~0u, v)
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 #endif
 }

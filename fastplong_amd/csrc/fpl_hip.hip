@@ -30,6 +30,8 @@ struct fpl_ctx {
     /* per-batch workspace, grown on demand */
     u32 ws_reads = 0;
     ReadState* d_state = nullptr;
+    ScanRec* d_recs = nullptr;  /* k_scan -> k_resolve */
+    RedoItem* d_redo = nullptr; /* k_resolve -> k_redo */
     uint64_t* d_frag_off = nullptr;
     u32* d_frag_len = nullptr;
     u32* d_work_ctr = nullptr;
@@ -211,7 +213,7 @@ void fpl_destroy(fpl_ctx* ctx) {
     void* ptrs[] = {ctx->d_cfg, ctx->d_ads, ctx->d_counters, ctx->d_state, ctx->d_frag_off, ctx->d_frag_len,
                     ctx->d_work_ctr, ctx->d_stats_scratch,
                     ctx->d_stats_flags, ctx->d_frag_cyc, ctx->bm.frags, ctx->bm.regs, ctx->bm.counts,
-                    ctx->d_sort_ws, ctx->d_st_off, ctx->d_st_len, ctx->d_st_e};
+                    ctx->d_sort_ws, ctx->d_st_off, ctx->d_st_len, ctx->d_st_e, ctx->d_recs, ctx->d_redo};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& sl : ctx->slot) {
@@ -452,6 +454,12 @@ static int ensure_workspace(fpl_ctx* ctx, u32 n_reads) {
     ctx->d_state = nullptr;
     ctx->ws_reads = 0;
     FPL_HIP(hipMalloc((void**)&ctx->d_state, sizeof(ReadState) * (size_t)n_reads));
+    if (ctx->d_recs) (void)hipFree(ctx->d_recs);
+    if (ctx->d_redo) (void)hipFree(ctx->d_redo);
+    ctx->d_recs = nullptr;
+    ctx->d_redo = nullptr;
+    FPL_HIP(hipMalloc((void**)&ctx->d_recs, sizeof(ScanRec) * (size_t)n_reads));
+    FPL_HIP(hipMalloc((void**)&ctx->d_redo, sizeof(RedoItem) * (size_t)n_reads));
     if (ctx->d_st_off) (void)hipFree(ctx->d_st_off);
     if (ctx->d_st_len) (void)hipFree(ctx->d_st_len);
     if (ctx->d_st_e) (void)hipFree(ctx->d_st_e);
@@ -517,6 +525,8 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.counters = ctx->d_counters;
     a.C = ctx->C;
     a.work_ctr = ctx->d_work_ctr;
+    a.recs = ctx->d_recs;
+    a.redo = ctx->d_redo;
     a.sort_ws = ctx->d_sort_ws;
     a.st_off = ctx->d_st_off;
     a.st_len = ctx->d_st_len;

@@ -2767,41 +2767,61 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
             q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
             q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
         }
+        /* The last tile of a range is ragged: some lane holds fewer than 32 bytes of it.  Those lanes pad themselves -- the
+           bases with copies of their last base, the qualities with zeros -- and the tile then takes the same code as every
+           full tile: a padding base equals its predecessor (nothing for the complexity sum), a padding quality adds nothing
+           to the quality sum and lands in bin 0 of the histogram (hist_dumped: the caller takes it out); what it adds to
+           the low-quality and the N count is taken out of this lane's partial sums right here.  No tested window reaches
+           a padding base (positions p < length - alen).  A lane without any byte of the range pads with 'A'. */
+        if (!LEAN && wave_ballot(navail < SC_CHUNK) != 0) { /* wave-uniform */
+            if (navail < SC_CHUNK) {
+                const int li = navail > 0 ? navail - 1 : 0;
+                u32 lw = s[0];
+#pragma unroll
+                for (int d = 1; d < 8; d++) lw = (li >> 2) == d ? s[d] : lw;
+                const u32 last = navail > 0 ? ((lw >> (8 * (li & 3))) & 0xFFu) : (u32)'A';
+                const u32 rep = 0x01010101u * last;
+#pragma unroll
+                for (int d = 0; d < 8; d++) {
+                    const int c = navail - 4 * d;
+                    const u32 bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
+                    s[d] = (s[d] & bm) | (rep & ~bm);
+                    q[d] &= bm;
+                }
+                if (SUMS && nstat > 0) {
+                    const u32 pad = (u32)(SC_CHUNK - nstat);
+                    lowq -= qqrep ? pad : 0u;
+                    nn -= last == (u32)'N' ? pad : 0u;
+                }
+            }
+        }
         /* predecessor of this chunk's first byte: last dword of the previous lane / previous tile */
         u32 prevd = shfl_up_u32(s[7], 1);
         if (lane == 0) prevd = prev_tile_last;
         prev_tile_last = readlane_u32(s[7], ACTIVE - 1);
         if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
-        /* the last tile of a range is ragged (some lane holds fewer than 32 bytes): the whole wave then takes
-           the byte-masked variants, so that no lane falls back to a byte-by-byte loop */
-        /* a full tile whose bytes are all exactly A, C, G, T or N -- nearly every tile -- is scanned on three code
-           bit-planes: no per-byte validity test, the N count and the complexity sum from the planes.  Every other tile
-           (ragged, or holding a lower-case letter, a U, ...) takes the byte-masked variants below, whole wave
-           (wave-uniform choice) */
-        const bool ragged = wave_ballot(nstat > 0 && nstat < SC_CHUNK) != 0;
+        /* a tile whose bytes are all exactly A, C, G, T or N -- nearly every tile -- is scanned on three code bit-planes:
+           no per-byte validity test, the N count and the complexity sum from the planes.  Any other tile (a lower-case
+           letter, a U, ...) takes the byte-wise sums and builds its letter planes with a validity test, whole wave
+           (wave-uniform choice).  LEAN instances take the byte-masked variants for every tile. */
         bool acgt = false;
         u32 cL = 0, cH = 0, cN = 0;
-        if (FPL_OPT_ACGT && !LEAN && (SUMS || HAM) && (!ragged || FPL_OPT_ACGT > 1)) {
-            /* (a ragged tile: the bytes behind the end of the range are not looked at -- no window that is tested reaches
-               them, and the sums mask them) */
-            acgt = !wave_ballot((ragged ? not_acgtn_masked(s, nstat) : not_acgtn(s)) != 0);
+        if (FPL_OPT_ACGT && !LEAN && (SUMS || HAM)) {
+            acgt = !wave_ballot(not_acgtn(s) != 0);
             if (acgt) code_planes(s, cL, cH, cN);
         }
-        if (!LEAN && !ragged && (acgt || !FPL_OPT_ACGT || !(SUMS || HAM))) {
-            if (nstat == SC_CHUNK) {
+        if (!LEAN) {
+            if (nstat > 0) {
                 if (!FPL_DBG(dbg, 1)) hist32<false>(hl, q, SC_CHUNK);
                 if (SUMS && !FPL_DBG(dbg, 2)) {
-                    if (FPL_OPT_ACGT) sums32_acgtn<false>(s[0], q, SC_CHUNK, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
+                    if (acgt) sums32_acgtn<false>(s[0], q, SC_CHUNK, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
                     else sums32<false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
                 }
                 if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
             }
         } else if (nstat > 0) {
             hist32<true>(hl, q, nstat);
-            if (SUMS) {
-                if (FPL_OPT_ACGT > 1 && acgt) sums32_acgtn<true>(s[0], q, nstat, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
-                else sums32<true>(s, q, nstat, prevd, qqrep, lowq, nn, totq, diff);
-            }
+            if (SUMS) sums32<true>(s, q, nstat, prevd, qqrep, lowq, nn, totq, diff);
         }
         if (HAM) {
             if ((npos0 > t0 || npos1 > t0) && !FPL_DBG(dbg, 16)) { /* wave-uniform: some window of this tile is tested */
@@ -2864,8 +2884,16 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         sums.diff = wave_sum_u32(diff);
     }
     if (HAM) {
-        key0 = wave_min_u64(bm0 < 0 ? ~0ull : (((u64)(u32)(ad0->len - bm0) << 32) | (u32)bp0));
-        key1 = wave_min_u64(bm1 < 0 ? ~0ull : (((u64)(u32)(ad1->len - bm1) << 32) | (u32)bp1));
+        /* the first position with the fewest mismatches = the largest match count, then the smallest position holding it:
+           two 32-bit reductions per adapter (the (mismatches, position) pair as one 64-bit key costs three times that) */
+        key0 = key1 = ~0ull;
+        if (do_ham) { /* wave-uniform */
+            const u32 m0 = wave_max_u32((u32)(bm0 + 1)), m1 = wave_max_u32((u32)(bm1 + 1)); /* 0: no window was tested */
+            const u32 p0 = wave_min_u32((u32)(bm0 + 1) == m0 ? (u32)bp0 : ~0u);
+            const u32 p1 = wave_min_u32((u32)(bm1 + 1) == m1 ? (u32)bp1 : ~0u);
+            if (m0) key0 = ((u64)(u32)(ad0->len - (int)(m0 - 1)) << 32) | p0;
+            if (m1) key1 = ((u64)(u32)(ad1->len - (int)(m1 - 1)) << 32) | p1;
+        }
     }
     return hist_dumped(blen);
 }
@@ -3039,19 +3067,55 @@ __device__ __forceinline__ bool lev_lanes32_acgt(const u8* __restrict__ text, in
     return need && score <= thr;
 }
 
-/* SHORT: adapter trimming is on and both command-line adapters are ACGT-only and <= 32 bases (DevConfig::scan_short):
-   the byte-wise scan and the multi-word Levenshtein are left out of that instantiation */
+/* What k_scan leaves per read for k_resolve: the read's wave has scanned r1 once and reduced what every lane saw; everything
+ * that follows from these numbers -- the Levenshtein confirmations, breakByGap, the result record, the FilterResult and
+ * median counters, the plan for the statistics passes -- is per-read arithmetic that k_resolve runs with LANE = READ. */
+struct alignas(16) ScanRec {
+    u32 lowq, nn, totq, diff; /* the passFilter sums of r1 (src/filter.cpp:27-39, 67-81) */
+    u32 pos0, pos1;           /* Hamming argmin of the two middle-adapter scans, in r1 coordinates */
+    u32 mm;                   /* mismatches there: adapter 0 | adapter 1 << 8; median quality of the read << 16 | of r1 << 24 */
+    u32 flags;                /* SR_TESTED0 / SR_TESTED1: the scan tested at least one window; bits 8..15: passFilter code of r1
+                                 as ONE output read (valid unless the read was dropped or --break / --mask defer the filter) */
+};
+constexpr u32 SR_TESTED0 = 1u, SR_TESTED1 = 2u;
+/* a read whose r1 a middle adapter splits: k_resolve found the gap, k_redo scans the fragments */
+struct alignas(16) RedoItem {
+    u32 ri, gs, glen, pad;
+};
+
+/* the base-quality histograms of one wave of k_scan (bins 2 * lane and 2 * lane + 1, pre- / post-filter), kept in registers and
+   handed to the block's LDS accumulators when they might overflow and when the wave ends */
+struct BqRegs {
+    u32 pre0, pre1, post0, post1;
+    u32 bases; /* bases counted since the last hand-over (wave-uniform) */
+};
+struct ScanBqAcc {
+    u64 bqh[2][128];
+};
+__device__ __forceinline__ void bq_hand_over(BqRegs& r, ScanBqAcc& acc) {
+    const int lane = lane_id();
+    if (r.pre0) atomicAdd(&acc.bqh[0][2 * lane], (u64)r.pre0);
+    if (r.pre1) atomicAdd(&acc.bqh[0][2 * lane + 1], (u64)r.pre1);
+    if (r.post0) atomicAdd(&acc.bqh[1][2 * lane], (u64)r.post0);
+    if (r.post1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)r.post1);
+    r.pre0 = r.pre1 = r.post0 = r.post1 = 0;
+    r.bases = 0;
+}
+
+/* k_scan: ONE pass over r1 of every read -- the quality histogram (medians, base-quality histogram), the passFilter sums,
+ * both middle-adapter Hamming scans -- and nothing else: a wave reduces what its lanes saw to a 32-byte ScanRec and goes on
+ * to the next read.
+ * SHORT: adapter trimming is on and both command-line adapters are ACGT-only and <= 32 bases (DevConfig::scan_short):
+ * the byte-wise scan is left out of that instantiation */
 template <int WAVES, bool SHORT>
 __global__ void __launch_bounds__(WAVES * 64, SCAN_BLOCKS_PER_CU * WAVES / 4)
 k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
        uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
-       ReadState* __restrict__ state, fpl_read_result* __restrict__ results,
-       uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, long long* __restrict__ counters, u32 C,
-       u32* __restrict__ work_ctr, u32 chunk, u32* __restrict__ frag_count) {
+       const ReadState* __restrict__ state, ScanRec* __restrict__ recs, long long* __restrict__ counters, u32 C,
+       u32* __restrict__ work_ctr, u32 chunk) {
     __shared__ alignas(4096) u32 hist_all[WAVES][128 * HIST_COPIES]; /* 4 KiB per wave when HIST_COPIES == 8: hist_bump */
     __shared__ ScanWaveLds wlds[WAVES];
-    __shared__ ScanBlockAcc acc;
-    __shared__ u32 peq4[2][4]; /* Peq words of A, C, T, G for the two command-line adapters (lev_pair32) */
+    __shared__ ScanBqAcc acc;
     const int lane = lane_id();
     ScanWaveLds* const wl = &wlds[wave_in_block()];
     u32* const h = hist_all[wave_in_block()];
@@ -3060,16 +3124,16 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     hist_zero(h); /* from here on every user of the histograms leaves them zeroed */
     wl->ehist[lane] = 0;
     wl->ehist[64 + lane] = 0;
-    if (threadIdx.x < 8) peq4[threadIdx.x >> 2][threadIdx.x & 3] =
-        (u32)ads[threadIdx.x >> 2].peq_full[(0x47544341u >> (8 * (threadIdx.x & 3))) & 0xFFu][0];
     {
         u64* z = (u64*)&acc;
-        for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
+        for (u32 i = threadIdx.x; i < sizeof(ScanBqAcc) / 8; i += blockDim.x) z[i] = 0;
     }
     __syncthreads();
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
     const int qq = cfg->qualified_qual | (cfg->dbg << 8);
+    const bool defer = cfg->defer != 0;
+    BqRegs bq = {0, 0, 0, 0, 0};
 
     /* dynamic work distribution in chunks: one device-scope atomic serves `chunk` reads (a single
        hot counter sustains only ~80 atomics/us, which a per-read dequeue would saturate) */
@@ -3078,103 +3142,21 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     PROF_INIT();
     uint64_t nx_o0 = 0, nx_o1 = 0;
     ReadState nx_st = {0, 0, 0, 0};
-    u32 nbuf = 0; /* entries in this wave's fragment buffer (wave-uniform) */
-    /* hand the buffered fragments to the global list: one atomic per <= SC_FBUF fragments */
-    auto flush_frags = [&]() {
-        if (nbuf == 0) return;
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(frag_count, nbuf);
-        base = readlane_u32(base, 0);
-        wave_sync();
-        if ((u32)lane < nbuf) {
-            frag_off[base + lane] = wl->fbuf_off[lane];
-            frag_len[base + lane] = wl->fbuf_len[lane];
-        }
-        wave_sync();
-        nbuf = 0;
-    };
-    /* Deferred confirmations (FPL_OPT_SCANBATCH, both adapters <= 32 bases).  A read whose middle-adapter candidates
-       still need their edit distance is resolved as "no middle adapter" -- what nearly all of them turn out to be -- and
-       its two windows are parked in lanes 2k / 2k + 1 (k = the wave's k-th pending read); every 32 reads ONE lane-parallel
-       Myers pass (lev_lanes32_acgt) settles all 64 windows.  The rare read that does have a middle adapter comes back
-       through the loop below as a REDO item: same scan, the unsplit bookkeeping taken back, the confirmed positions
-       forced. */
-    constexpr bool BATCH = FPL_OPT_SCANBATCH != 0;
-    /* lane 2k + a: the window of adapter a of pending read k -- two registers, everything else is read back from the
-       batch when the windows are settled (the wave keeps them through the whole scan loop: every register here is one
-       the scan cannot have) */
-    int v_pos = -1; /* the window's position in r1 */
-    u32 v_rf = 0;   /* the read (bits 0..29; n_reads < 2^30) | bit 30: the window needs its edit distance | bit 31 (even
-                       lanes): the read, if it stays unsplit, still has to go on the EXTRA list */
-    u32 npend = 0;       /* pending reads (wave-uniform) */
-    u64 redo_mask = 0;   /* bit 2k / 2k + 1: pending read k has a middle adapter 0 / 1 and waits for its second pass */
-    auto flush_pending = [&]() {
-        if (npend == 0) return;
-        const int a = lane & 1;
-        const bool mine = (u32)lane < 2 * npend;
-        const u32 v_ri = v_rf & 0x3FFFFFFFu;
-        const bool need = mine && (v_rf & 0x40000000u);
-        uint64_t o_r = 0;
-        ReadState rs = {0, 0, 0, 0};
-        if (mine) {
-            o_r = off[v_ri];
-            rs = state[v_ri]; /* (s and e are still k_trim_ends' values: a pending read has not been split) */
-        }
-        const bool ok = lev_lanes32_acgt(seq + o_r + rs.s + (need ? v_pos : 0), a ? ads[1].len : ads[0].len,
-                                         cfg->thr[a ? ads[1].len : ads[0].len], need, peq4[a], seq_end);
-        redo_mask = wave_ballot(ok);
-        /* reads that stay as they are and were promised a place on the EXTRA list: their r1 passes unsplit, but starts
-           too far into the read for the single statistics pass */
-        const bool okn = shfl_down_u32(ok ? 1u : 0u, 1) != 0;
-        const bool want = mine && a == 0 && (v_rf & 0x80000000u) && !ok && !okn;
-        const u64 wm = wave_ballot(want);
-        if (wm) {
-            u32 base = 0;
-            if (lane == 0) base = atomicAdd(frag_count, (u32)__popcll(wm));
-            base = readlane_u32(base, 0);
-            if (want) { /* the fragment is r1 itself */
-                const u32 slot = base + (u32)__popcll(wm & ((1ull << lane) - 1ull));
-                frag_off[slot] = o_r + rs.s;
-                frag_len[slot] = rs.e - rs.s;
-            }
-        }
-        npend = 0;
-    };
     for (;;) {
-        /* ---- the next read: a redo item first, else the next of the chunk, else a new chunk */
-        bool redo = false;
-        int f_sp = -1, f_ep = -1;
-        u32 ri;
-        if (BATCH && redo_mask) {
-            const int k = (__ffsll(redo_mask) - 1) >> 1;
-            const u64 bits = (redo_mask >> (2 * k)) & 3ull;
-            redo_mask &= ~(3ull << (2 * k));
-            ri = readlane_u32(v_rf, 2 * k) & 0x3FFFFFFFu;
-            if (bits & 1ull) f_sp = readlane_i32(v_pos, 2 * k);
-            if (bits & 2ull) f_ep = readlane_i32(v_pos, 2 * k + 1);
-            redo = true;
-        } else {
-            if (chunk_next >= chunk_end) {
-                u32 base = 0;
-                if (lane == 0) base = atomicAdd(work_ctr, chunk);
-                base = readlane_u32(base, 0);
-                if (base >= n_reads) {
-                    if (BATCH && npend) { /* the last windows; their redo items, if any, still go through the loop */
-                        flush_pending();
-                        if (redo_mask) continue;
-                    }
-                    break;
-                }
-                chunk_next = base;
-                chunk_end = min(n_reads, base + chunk);
-                have_next = false;
-            }
-            ri = chunk_next++;
+        if (chunk_next >= chunk_end) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(work_ctr, chunk);
+            base = readlane_u32(base, 0);
+            if (base >= n_reads) break;
+            chunk_next = base;
+            chunk_end = min(n_reads, base + chunk);
+            have_next = false;
         }
+        const u32 ri = chunk_next++;
         /* this read's metadata: loaded while the previous read was being processed, when possible */
         uint64_t o0, o1;
         ReadState st;
-        if (have_next && !redo) {
+        if (have_next) {
             o0 = nx_o0;
             o1 = nx_o1;
             st = nx_st;
@@ -3190,13 +3172,11 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         st.s = uniform_u32(st.s);
         st.e = uniform_u32(st.e);
         st.dropped = uniform_u32(st.dropped);
-        if (!redo) {
-            have_next = chunk_next < chunk_end;
-            if (have_next) { /* the next read of the chunk */
-                nx_o0 = o1;
-                nx_o1 = off[ri + 2];
-                nx_st = state[ri + 1];
-            }
+        have_next = chunk_next < chunk_end;
+        if (have_next) { /* the next read of the chunk */
+            nx_o0 = o1;
+            nx_o1 = off[ri + 2];
+            nx_st = state[ri + 1];
         }
         const int l = (int)(o1 - o0);
         const u8* rb = seq + o0;
@@ -3213,27 +3193,13 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         RangeSums sm = {0, 0, 0, 0};
         u64 key0 = ~0ull, key1 = ~0ull;
         const bool ham = !dropped && cfg->adapter_enabled;
-        u32 dumped = 0; /* bytes the masked tiles of the body scan parked in bin 0 (hist_dumped) */
+        u32 dumped = 0; /* bytes the padded last tile of the body scan parked in bin 0 (hist_dumped) */
         if (SHORT || (ham && cfg->ham_fast)) /* (SHORT: also the reads without an adapter search, through do_ham) */
             dumped = range_scan_fast<true, true, false, NB>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, &ads[0], &ads[1], key0, key1, ham);
         else if (ham) /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
             range_scan_bytes<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
         else
             dumped = range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, nullptr, nullptr, key0, key1);
-        /* candidates of the middle-adapter search that still need their edit distance: fetch the two text
-           windows now, confirm after the histogram work (edit distance <= Hamming distance, so only an argmin
-           worse than the threshold needs it) */
-        const bool pair32 = ham && (SHORT || (cfg->ham_fast && ads[0].len <= 32 && ads[1].len <= 32));
-        const int thr0 = ham ? cfg->thr[ads[0].len] : 0, thr1 = ham ? cfg->thr[ads[1].len] : 0;
-        const bool need0 = ham && key0 != ~0ull && (int)(key0 >> 32) > thr0;
-        const bool need1 = ham && key1 != ~0ull && (int)(key1 >> 32) > thr1;
-        /* (a read with a candidate accepted outright AND one pending is rare and would need its split taken back: it
-           gets its edit distance on the spot) */
-        const bool direct = ham && ((key0 != ~0ull && !need0) || (key1 != ~0ull && !need1));
-        const bool defer_confirm = BATCH && pair32 && !redo && (need0 || need1) && !direct && !cfg->defer;
-        LevPairText ltxt = {0, 0};
-        if (pair32 && (need0 || need1) && !defer_confirm && !redo)
-            ltxt = lev_pair32_fetch(rb + s + (int)(u32)key0, ads[0].len, need0, rb + s + (int)(u32)key1, ads[1].len, need1);
         PROF(2) /* body scan */
         u32 hb0, hb1;
         hist_totals(h, hb0, hb1);
@@ -3242,7 +3208,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         /* ---- the ends: their first SC_END_PF bytes from the prefetched registers into the small histogram,
            any rest (rare) by a scan; pre-filter totals = body + ends */
         u32 ht0 = hb0, ht1 = hb1;
-        {
+        if (s > 0 || e < l) { /* wave-uniform */
             u32* const eh = wl->ehist;
             ends_apply(eh, eb, s, e, l);
             if (s > SC_END_PF || l - e > SC_END_PF) { /* wave-uniform */
@@ -3267,204 +3233,385 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             wave_sync();
         }
         PROF(4) /* ends */
-        PROF(5)
-        int med_pre = 0;
+        /* ---- medians (src/stats.cpp:352-363), the filter code of r1 as one output read, base-quality histograms */
+        if ((u32)l > 0x7FFFFFFFu - bq.bases) bq_hand_over(bq, acc); /* (wave-uniform; the register bins are 32 bits wide) */
+        bq.bases += (u32)l;
+        bq.pre0 += ht0;
+        bq.pre1 += ht1;
+        int med_pre = 0, med_body = 0;
         if (l > 0) med_pre = hist_median(ht0, ht1, (u32)l);
-        /* pre-filter Stats scalars, src/stats.cpp:265-271,352-374 (counted in the read's first pass) */
-        if (!redo) {
-            if (ht0) atomicAdd(&acc.bqh[0][2 * lane], (u64)ht0);
-            if (ht1) atomicAdd(&acc.bqh[0][2 * lane + 1], (u64)ht1);
-            if (lane == 0) {
-                if (l > 0) {
-                    atomicAdd(&acc.medh[0][med_pre], (u64)1);
-                    atomicAdd(&acc.medb[0][med_pre], (u64)l);
-                }
-                atomicAdd(&acc.reads[0], (u64)1);
-                atomicAdd(&acc.lensum[0], (u64)l);
-            }
-        } else {
-            /* the first pass booked r1 as one unsplit fragment: take that back (the same sums and histogram give the
-               same filter code and median) before the fragments are booked */
-            const int code_u = filter_code(cfg, blen, sm);
-            if (lane == 0) atomicAdd(&acc.fr[code_u], (u64)0 - (u64)1);
-            if (code_u == FPL_PASS_FILTER) {
-                const int med_u = hist_median(hb0, hb1, (u32)blen);
-                if (hb0) atomicAdd(&acc.bqh[1][2 * lane], (u64)0 - (u64)hb0);
-                if (hb1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)0 - (u64)hb1);
-                if (lane == 0) {
-                    atomicAdd(&acc.medh[1][med_u], (u64)0 - (u64)1);
-                    atomicAdd(&acc.medb[1][med_u], (u64)0 - (u64)blen);
-                    atomicAdd(&acc.reads[1], (u64)0 - (u64)1);
-                    atomicAdd(&acc.lensum[1], (u64)0 - (u64)blen);
-                }
+        int code = 0;
+        if (!dropped && !defer) {
+            code = uniform_i32(filter_code(cfg, blen, sm));
+            if (code == FPL_PASS_FILTER) { /* (blen > 0 when passing) */
+                /* booked as if r1 stayed in one piece; k_redo takes it back for the few reads a middle adapter splits */
+                med_body = (s == 0 && e == l) ? med_pre : hist_median(hb0, hb1, (u32)blen);
+                bq.post0 += hb0;
+                bq.post1 += hb1;
             }
         }
-
-        PROF(6) /* median + block accumulators */
-        /* per-fragment outcome in scalars (an indexed struct would be demoted to LDS) */
-        int nf = 0;
-        u32 r_fs0 = 0, r_fs1 = 0, r_fl0 = 0, r_fl1 = 0, r_code0 = 0, r_code1 = 0, r_kind0 = 0, r_kind1 = 0, r_med0 = 0, r_med1 = 0;
-        bool pass0 = false, pass1 = false;
-        bool split = false;
-
-        if (!dropped) {
-            /* ---- findMiddleAdapters, src/adaptertrimmer.cpp:13-40 */
-            int gs = 0, glen = 0;
-            if (ham) {
-                const int al0 = ads[0].len, al1 = ads[1].len;
-                int sp = -1, ep = -1;
-                const int p0 = (int)(u32)key0, p1 = (int)(u32)key1;
-                int ed0 = 0, ed1 = 0;
-                PROF(10)
-                if (redo) { /* second pass: the lane-parallel confirmation has spoken */
-                    ed0 = f_sp >= 0 ? 0 : thr0 + 1;
-                    ed1 = f_ep >= 0 ? 0 : thr1 + 1;
-                } else if (defer_confirm) { /* resolved as "no middle adapter" for now */
-                    ed0 = thr0 + 1;
-                    ed1 = thr1 + 1;
-                } else if (SHORT || pair32) {
-                    if (need0 || need1) lev_pair32_run(peq4, ltxt, al0, thr0, need0, al1, thr1, need1, ed0, ed1);
-                    PROF(11)
-                } else {
-                    if (need0) ed0 = lev_wave(ads[0].peq_full, 0, al0, rb + s + p0, al0, thr0);
-                    if (need1) ed1 = lev_wave(ads[1].peq_full, 0, al1, rb + s + p1, al1, thr1);
-                }
-                if (key0 != ~0ull && ed0 <= thr0) sp = p0;
-                if (key1 != ~0ull && ed1 <= thr1) ep = p1;
-                const int ext = cfg->ext;
-                if (sp >= 0 && ep >= 0) {
-                    int gstart = min(sp, ep), gend = max(sp + al0, ep + al1);
-                    gstart = max(0, gstart - ext);
-                    gend = min(blen, gend + ext);
-                    gs = gstart;
-                    glen = gend - gstart;
-                    split = true;
-                } else if (sp >= 0) {
-                    const int gend = min(blen, sp + al0 + ext);
-                    gs = max(0, sp - ext);
-                    glen = gend - gs;
-                    split = true;
-                } else if (ep >= 0) {
-                    const int gend = min(blen, ep + al1 + ext);
-                    gs = max(0, ep - ext);
-                    glen = gend - gs;
-                    split = true;
-                }
-            }
-            PROF(7) /* Levenshtein confirmation of the two Hamming argmins */
-            /* ---- fragments: Read::breakByGap, src/read.cpp:192-215 */
-            int fa[2] = {0, 0}, fb[2] = {0, 0}, fk[2] = {0, 0};
-            if (split) {
-                const int len1 = gs, len2 = blen - gs - glen;
-                if (len1 > 0) {
-                    fa[nf] = s;
-                    fb[nf] = s + len1;
-                    fk[nf++] = 1;
-                }
-                if (len2 > 0) {
-                    fa[nf] = s + gs + glen;
-                    fb[nf] = e;
-                    fk[nf++] = 2;
-                }
-            } else {
-                fa[0] = s;
-                fb[0] = e;
-                fk[0] = 0;
-                nf = 1;
-            }
-            /* ---- passFilter per fragment, counters, post-filter Stats scalars (src/seprocessor.cpp:265-281) */
-            for (int f = 0; f < nf; f++) {
-                const int flen = fb[f] - fa[f];
-                if (cfg->defer) { /* --break / --mask: k_break_mask decides what becomes of the fragment */
-                    if (f == 0) { r_fs0 = (u32)fa[0]; r_fl0 = (u32)flen; r_kind0 = (u32)fk[0]; }
-                    else { r_fs1 = (u32)fa[1]; r_fl1 = (u32)flen; r_kind1 = (u32)fk[1]; }
-                    continue;
-                }
-                u32 t0 = hb0, t1 = hb1;
-                RangeSums fs = sm;
-                if (split) { /* rare: re-derive sums and histogram for this fragment */
-                    u64 d0, d1;
-                    const u32 dmp = range_scan_fast<true, false, true>(rb, qb, fa[f], fb[f], seq_end, qual_end, wl, h, qq, fs, nullptr, nullptr, d0, d1);
-                    hist_totals(h, t0, t1);
-                    if (lane == 0) t0 -= dmp;
-                }
-                const int code = filter_code(cfg, flen, fs);
-                int med = 0;
-                if (code == FPL_PASS_FILTER) med = hist_median(t0, t1, (u32)flen); /* flen > 0 when passing */
-                if (f == 0) {
-                    r_fs0 = (u32)fa[0]; r_fl0 = (u32)flen; r_code0 = (u32)code; r_kind0 = (u32)fk[0]; r_med0 = (u32)med;
-                    pass0 = code == FPL_PASS_FILTER;
-                } else {
-                    r_fs1 = (u32)fa[1]; r_fl1 = (u32)flen; r_code1 = (u32)code; r_kind1 = (u32)fk[1]; r_med1 = (u32)med;
-                    pass1 = code == FPL_PASS_FILTER;
-                }
-                if (lane == 0) atomicAdd(&acc.fr[code], (u64)1);
-                if (code == FPL_PASS_FILTER) {
-                    if (t0) atomicAdd(&acc.bqh[1][2 * lane], (u64)t0);
-                    if (t1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)t1);
-                    if (lane == 0) {
-                        atomicAdd(&acc.medh[1][med], (u64)1);
-                        atomicAdd(&acc.medb[1][med], (u64)flen);
-                        atomicAdd(&acc.reads[1], (u64)1);
-                        atomicAdd(&acc.lensum[1], (u64)flen);
-                    }
-                }
-            }
-        }
-        PROF(8) /* filter + fragment statistics */
-        /* one passing output read that starts within FS_SMAX bases of the read's start -- r1 itself, or the only fragment a
-           middle adapter close to an end leaves (Read::breakByGap drops an empty side; with empty command-line adapters
-           and --adapter_fasta EVERY read is "split" at position 0 like that, src/adaptertrimmer.cpp:13-40): its post-filter
-           statistics are those of the window [start, start + len) of the read, which the single statistics pass counts */
-        const bool to_post = !dropped && nf == 1 && pass0 && r_fs0 <= (u32)FS_SMAX;
+        PROF(6)
         if (lane == 0) {
+            ScanRec r;
+            r.lowq = sm.lowq; r.nn = sm.nn; r.totq = sm.totq; r.diff = sm.diff;
+            r.pos0 = (u32)key0; r.pos1 = (u32)key1;
+            r.mm = ((u32)(key0 >> 32) & 0xFFu) | (((u32)(key1 >> 32) & 0xFFu) << 8) | ((u32)med_pre << 16) | ((u32)med_body << 24);
+            r.flags = (key0 != ~0ull ? SR_TESTED0 : 0u) | (key1 != ~0ull ? SR_TESTED1 : 0u) | ((u32)code << 8);
+            recs[ri] = r;
+        }
+        PROF(9) /* record */
+    }
+    PROF_FLUSH(0);
+    bq_hand_over(bq, acc);
+    __syncthreads();
+    for (int k = 0; k < 2; k++) {
+        long long* st = counters + (k == 0 ? FPL_OFF_PRE(C) : FPL_OFF_POST(C));
+        for (u32 i = threadIdx.x; i < 128; i += blockDim.x)
+            if (acc.bqh[k][i]) atomicAdd((u64*)&st[FPL_ST_BASE_QUAL_HIST(C) + i], acc.bqh[k][i]);
+    }
+}
+
+/* One Levenshtein confirmation per lane, any adapter: the rare configurations (an adapter beyond 32 bases or with bytes
+   outside A / C / G / T) take the wave-cooperative Myers run, one flagged lane after the other.  True in the lanes whose
+   window is within thr of the adapter. */
+__device__ __forceinline__ bool lev_lanes_any(const DevAdapter* __restrict__ ad, const u8* __restrict__ text, int thr, bool need) {
+    bool ok = false;
+    u64 m = wave_ballot(need);
+    const int alen = ad->len;
+    while (m) { /* wave-uniform */
+        const int j = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const u8* t = (const u8*)readlane_u64((u64)(size_t)text, j);
+        const int ed = lev_wave(ad->peq_full, 0, alen, t, alen, thr);
+        if (lane_id() == j) ok = ed <= thr;
+    }
+    return ok;
+}
+
+/* append (offset, length) to the post-only EXTRA list: one device atomic per wave */
+__device__ __forceinline__ void extra_append(bool want, uint64_t o, u32 len, uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len,
+                                             u32* __restrict__ frag_count) {
+    const u64 wm = wave_ballot(want);
+    if (!wm) return;
+    u32 base = 0;
+    if (lane_id() == 0) base = atomicAdd(frag_count, (u32)__popcll(wm));
+    base = readlane_u32(base, 0);
+    if (want) {
+        const u32 slot = base + (u32)__popcll(wm & ((1ull << lane_id()) - 1ull));
+        frag_off[slot] = o;
+        frag_len[slot] = len;
+    }
+}
+
+/* k_resolve: LANE = READ.  From the ScanRec of a read: the Levenshtein confirmation of the two Hamming argmins
+ * (findMiddleAdapters, src/adaptertrimmer.cpp:13-40; searchAdapter's final check, :152-165), the gap; a read that stays in
+ * one piece gets its result record, its FilterResult / median counters (src/seprocessor.cpp:265-281) and its plan for the
+ * statistics passes right here; a read that is split goes on the REDO list (k_redo scans its fragments), or -- with --break /
+ * --mask, where k_break_mask decides the fragments' fate -- gets its record with the two fragments. */
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_resolve(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_reads, uint64_t n_bytes,
+          const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads, ReadState* __restrict__ state,
+          const ScanRec* __restrict__ recs, fpl_read_result* __restrict__ results, uint64_t* __restrict__ frag_off,
+          u32* __restrict__ frag_len, u32* __restrict__ frag_count, RedoItem* __restrict__ redo, u32* __restrict__ redo_count,
+          long long* __restrict__ counters, u32 C) {
+    __shared__ ScanBlockAcc acc;
+    __shared__ u32 peq4[2][4]; /* Peq words of A, C, T, G for the two command-line adapters (lev_lanes32_acgt) */
+    const int lane = lane_id();
+    if (threadIdx.x < 8) peq4[threadIdx.x >> 2][threadIdx.x & 3] =
+        (u32)ads[threadIdx.x >> 2].peq_full[(0x47544341u >> (8 * (threadIdx.x & 3))) & 0xFFu][0];
+    {
+        u64* z = (u64*)&acc;
+        for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
+    }
+    __syncthreads();
+    const u8* seq_end = seq + n_bytes;
+    const bool adapters = cfg->adapter_enabled != 0, defer = cfg->defer != 0;
+    const int al0 = ads[0].len, al1 = ads[1].len;
+    const int thr0 = cfg->thr[al0], thr1 = cfg->thr[al1];
+    const bool pair32 = cfg->ham_fast && al0 <= 32 && al1 <= 32;
+    const int ext = cfg->ext;
+    const u32 n_groups = (n_reads + 63) / 64;
+    for (u32 g = blockIdx.x * WAVES + wave_in_block(); g < n_groups; g += gridDim.x * WAVES) {
+        const u32 ri = g * 64 + (u32)lane;
+        const bool live = ri < n_reads;
+        uint64_t o0 = 0, o1 = 0;
+        ReadState st = {0, 0, 1, 0};
+        ScanRec rec = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) {
+            o0 = off[ri];
+            o1 = off[ri + 1];
+            st = state[ri];
+            rec = recs[ri];
+        }
+        const int l = (int)(o1 - o0);
+        const int s = (int)st.s, e = (int)st.e, blen = e - s;
+        const bool dropped = st.dropped != 0;
+        const int med_pre = (int)((rec.mm >> 16) & 0xFFu), med_body = (int)(rec.mm >> 24);
+        /* pre-filter Stats scalars, src/stats.cpp:265-271,352-374 */
+        if (live) {
+            if (l > 0) {
+                atomicAdd(&acc.medh[0][med_pre], (u64)1);
+                atomicAdd(&acc.medb[0][med_pre], (u64)l);
+            }
+        }
+        {
+            const u32 nl = (u32)__popcll(wave_ballot(live));
+            const u32 lo = wave_sum_u32(live ? ((u32)l & 0xFFFFu) : 0u), hi = wave_sum_u32(live ? ((u32)l >> 16) : 0u);
+            if (lane == 0) {
+                atomicAdd(&acc.reads[0], (u64)nl);
+                atomicAdd(&acc.lensum[0], (u64)lo + ((u64)hi << 16));
+            }
+        }
+        /* ---- findMiddleAdapters: an argmin within the threshold stands (edit distance <= Hamming distance), any other
+           needs its edit distance */
+        const bool ham = live && !dropped && adapters;
+        const bool t0 = ham && (rec.flags & SR_TESTED0), t1 = ham && (rec.flags & SR_TESTED1);
+        const int mm0 = (int)(rec.mm & 0xFFu), mm1 = (int)((rec.mm >> 8) & 0xFFu);
+        const bool need0 = t0 && mm0 > thr0, need1 = t1 && mm1 > thr1;
+        bool ok0 = false, ok1 = false;
+        const u8* w0 = seq + o0 + (uint64_t)s + (need0 ? rec.pos0 : 0u);
+        const u8* w1 = seq + o0 + (uint64_t)s + (need1 ? rec.pos1 : 0u);
+        if (wave_ballot(need0 || need1)) { /* wave-uniform */
+            if (pair32) {
+                ok0 = lev_lanes32_acgt(w0, al0, thr0, need0, peq4[0], seq_end);
+                ok1 = lev_lanes32_acgt(w1, al1, thr1, need1, peq4[1], seq_end);
+            } else {
+                ok0 = lev_lanes_any(&ads[0], w0, thr0, need0);
+                ok1 = lev_lanes_any(&ads[1], w1, thr1, need1);
+            }
+        }
+        const int sp = (t0 && (!need0 || ok0)) ? (int)rec.pos0 : -1;
+        const int ep = (t1 && (!need1 || ok1)) ? (int)rec.pos1 : -1;
+        bool split = false;
+        int gs = 0, glen = 0;
+        if (sp >= 0 && ep >= 0) {
+            const int gstart = max(0, min(sp, ep) - ext), gend = min(blen, max(sp + al0, ep + al1) + ext);
+            gs = gstart;
+            glen = gend - gstart;
+            split = true;
+        } else if (sp >= 0) {
+            gs = max(0, sp - ext);
+            glen = min(blen, sp + al0 + ext) - gs;
+            split = true;
+        } else if (ep >= 0) {
+            gs = max(0, ep - ext);
+            glen = min(blen, ep + al1 + ext) - gs;
+            split = true;
+        }
+        /* ---- the read stays in one piece (or was dropped): everything is known */
+        const bool whole = live && !dropped && !split;
+        const int code = (int)((rec.flags >> 8) & 0xFFu);
+        const bool pass = whole && !defer && code == FPL_PASS_FILTER;
+        if (whole && !defer) {
+            atomicAdd(&acc.fr[code], (u64)1);
+            if (pass) {
+                atomicAdd(&acc.medh[1][med_body], (u64)1);
+                atomicAdd(&acc.medb[1][med_body], (u64)blen);
+                atomicAdd(&acc.reads[1], (u64)1);
+                atomicAdd(&acc.lensum[1], (u64)blen);
+            }
+        }
+        /* one passing output read that starts within FS_SMAX bases of the read's start: the single statistics pass counts it
+           post-filter as the window [start, start + len) of the read; any other passing output read goes on the EXTRA list */
+        const bool to_post = pass && (u32)s <= (u32)FS_SMAX;
+        if (live && !(split && !defer)) {
             fpl_read_result res;
             res.r1_start = dropped ? 0 : (u32)s;
             res.r1_len = dropped ? 0 : (u32)blen;
-            res.frag_start[0] = r_fs0; res.frag_start[1] = r_fs1;
-            res.frag_len[0] = r_fl0; res.frag_len[1] = r_fl1;
+            res.frag_start[0] = res.frag_start[1] = 0;
+            res.frag_len[0] = res.frag_len[1] = 0;
+            res.code[0] = res.code[1] = 0;
+            res.kind[0] = res.kind[1] = 0;
+            res.median_q_post[0] = res.median_q_post[1] = 0;
+            int nf = 0;
+            if (whole) {
+                res.frag_start[0] = (u32)s;
+                res.frag_len[0] = (u32)blen;
+                res.code[0] = defer ? 0 : (u8)code;
+                res.median_q_post[0] = pass ? (u8)med_body : 0;
+                nf = 1;
+            } else if (!dropped) { /* split, --break / --mask: Read::breakByGap, src/read.cpp:192-215 */
+                const int len1 = gs, len2 = blen - gs - glen;
+                if (len1 > 0) {
+                    res.frag_start[nf] = (u32)s;
+                    res.frag_len[nf] = (u32)len1;
+                    res.kind[nf++] = 1;
+                }
+                if (len2 > 0) {
+                    res.frag_start[nf] = (u32)(s + gs + glen);
+                    res.frag_len[nf] = (u32)len2;
+                    res.kind[nf++] = 2;
+                }
+            }
             res.n_frag = (u8)nf;
             res.dropped = dropped ? 1 : 0;
-            res.code[0] = (u8)r_code0; res.code[1] = (u8)r_code1;
-            res.kind[0] = (u8)r_kind0; res.kind[1] = (u8)r_kind1;
             res.median_q_pre = (u8)med_pre;
-            res.median_q_post[0] = (u8)r_med0; res.median_q_post[1] = (u8)r_med1;
             res.reserved[0] = res.reserved[1] = res.reserved[2] = 0;
             results[ri] = res;
-            /* plan for k_stats: a read that passes unsplit with a small front trim feeds the post-filter
-               tables straight from the single statistics pass; every other passing fragment goes to the
-               post-only EXTRA list (through this wave's buffer; the order is irrelevant) */
             state[ri].pad = to_post ? PLAN_TO_POST : 0u;
-            if (to_post && split) { /* the window the statistics pass works on is the fragment, not r1 */
-                state[ri].s = r_fs0;
-                state[ri].e = r_fs0 + r_fl0;
-            }
-            u32 slot = nbuf;
-            if (pass0 && !to_post && !defer_confirm) {
-                wl->fbuf_off[slot] = o0 + r_fs0;
-                wl->fbuf_len[slot] = r_fl0;
-                slot++;
-            }
-            if (pass1) {
-                wl->fbuf_off[slot] = o0 + r_fs1;
-                wl->fbuf_len[slot] = r_fl1;
+        }
+        extra_append(pass && !to_post, o0 + (uint64_t)s, (u32)blen, frag_off, frag_len, frag_count);
+        /* ---- split reads: k_redo scans the fragments */
+        {
+            const bool want = live && split && !dropped && !defer;
+            const u64 wm = wave_ballot(want);
+            if (wm) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(redo_count, (u32)__popcll(wm));
+                base = readlane_u32(base, 0);
+                if (want) {
+                    RedoItem it = {ri, (u32)gs, (u32)glen, 0u};
+                    redo[base + (u32)__popcll(wm & ((1ull << lane) - 1ull))] = it;
+                }
             }
         }
-        nbuf += ((pass0 && !to_post && !defer_confirm) ? 1u : 0u) + (pass1 ? 1u : 0u);
-        if (nbuf > SC_FBUF - 2) flush_frags();
-        if (defer_confirm) { /* park the two windows; the read's EXTRA entry (if it is owed one) waits with them */
-            const int la = 2 * (int)npend;
-            if (lane == la || lane == la + 1) {
-                const bool second = lane != la;
-                v_pos = (int)(u32)(second ? key1 : key0);
-                v_rf = ri | ((second ? need1 : need0) ? 0x40000000u : 0u) | ((!second && pass0 && !to_post) ? 0x80000000u : 0u);
-            }
-            if (++npend == 32) flush_pending();
-        }
-        PROF(9) /* result record, plan, fragment buffer */
     }
-    PROF_FLUSH(0);
-    flush_frags();
+    __syncthreads();
+    scan_acc_flush(acc, counters, C);
+}
+
+/* k_redo: one wave per read that a middle adapter splits (a few per cent of the reads at most).  Scans the fragments
+ * (passFilter sums, quality histogram -> code, median; src/seprocessor.cpp:265-281) and the gap between them -- the three
+ * histograms add up to the one k_scan booked post-filter when r1 passed as a whole, which is taken back here -- and writes the
+ * read's record, counters and plan. */
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t n_bytes,
+       const DevConfig* __restrict__ cfg, ReadState* __restrict__ state, const ScanRec* __restrict__ recs,
+       fpl_read_result* __restrict__ results, uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len,
+       u32* __restrict__ frag_count, const RedoItem* __restrict__ redo, const u32* __restrict__ redo_count,
+       long long* __restrict__ counters, u32 C) {
+    __shared__ alignas(4096) u32 hist_all[WAVES][128 * HIST_COPIES];
+    __shared__ ScanWaveLds wlds[WAVES];
+    __shared__ ScanBlockAcc acc;
+    const int lane = lane_id();
+    ScanWaveLds* const wl = &wlds[wave_in_block()];
+    u32* const h = hist_all[wave_in_block()];
+    hist_zero(h);
+    {
+        u64* z = (u64*)&acc;
+        for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
+    }
+    __syncthreads();
+    const u8* seq_end = seq + n_bytes;
+    const u8* qual_end = qual + n_bytes;
+    const int qq = cfg->qualified_qual;
+    const u32 n_items = *redo_count;
+    for (u32 it = blockIdx.x * WAVES + wave_in_block(); it < n_items; it += gridDim.x * WAVES) {
+        const RedoItem item = redo[it];
+        const u32 ri = uniform_u32(item.ri);
+        const int gs = uniform_i32((int)item.gs), glen = uniform_i32((int)item.glen);
+        const uint64_t o0 = uniform_u64(off[ri]);
+        const ReadState st = state[ri];
+        const int s = uniform_i32((int)st.s), e = uniform_i32((int)st.e), blen = e - s;
+        const ScanRec rec = recs[ri];
+        const u32 rflags = uniform_u32(rec.flags), rmm = uniform_u32(rec.mm);
+        const u8* rb = seq + o0;
+        const u8* qb = qual + o0;
+        /* Read::breakByGap, src/read.cpp:192-215 */
+        const int len1 = gs, len2 = blen - gs - glen;
+        /* per-fragment outcome in scalars (an indexed array would be demoted to scratch): left (L), right (R) */
+        u32 codeL = 0, codeR = 0, medL = 0, medR = 0;
+        bool passL = false, passR = false;
+        /* what k_scan booked post-filter for r1 as a whole comes off again: its histogram is the sum of the three below */
+        const bool undo = ((rflags >> 8) & 0xFFu) == FPL_PASS_FILTER;
+        u32 d0 = 0, d1 = 0; /* this lane's two bins: (passing fragments) - (r1 when it was booked), modulo 2^32 */
+#pragma unroll
+        for (int f = 0; f < 3; f++) { /* left fragment, right fragment, the gap */
+            const int fa = f == 0 ? s : (f == 1 ? s + gs + glen : s + gs);
+            const int flen = f == 0 ? len1 : (f == 1 ? len2 : glen);
+            if (f == 2 ? (!undo || flen <= 0) : flen <= 0) continue; /* wave-uniform */
+            RangeSums fs = {0, 0, 0, 0};
+            u64 k0, k1;
+            u32 t0, t1;
+            const u32 dmp = range_scan_fast<true, false, true>(rb, qb, fa, fa + flen, seq_end, qual_end, wl, h, qq, fs, nullptr, nullptr, k0, k1);
+            hist_totals(h, t0, t1);
+            if (lane == 0) t0 -= dmp;
+            if (undo) {
+                d0 -= t0;
+                d1 -= t1;
+            }
+            if (f == 2) continue;
+            const int code = uniform_i32(filter_code(cfg, flen, fs));
+            const bool pass = code == FPL_PASS_FILTER;
+            int med = 0;
+            if (pass) {
+                med = hist_median(t0, t1, (u32)flen);
+                d0 += t0;
+                d1 += t1;
+            }
+            if (f == 0) { codeL = (u32)code; medL = (u32)med; passL = pass; }
+            else { codeR = (u32)code; medR = (u32)med; passR = pass; }
+            if (lane == 0) {
+                atomicAdd(&acc.fr[code], (u64)1);
+                if (pass) {
+                    atomicAdd(&acc.medh[1][med], (u64)1);
+                    atomicAdd(&acc.medb[1][med], (u64)flen);
+                    atomicAdd(&acc.reads[1], (u64)1);
+                    atomicAdd(&acc.lensum[1], (u64)flen);
+                }
+            }
+        }
+        /* the output reads in order: the left fragment when it has bases, then the right one */
+        const bool hasL = len1 > 0, hasR = len2 > 0;
+        const int nf = (hasL ? 1 : 0) + (hasR ? 1 : 0);
+        const u32 fsL = (u32)s, fsR = (u32)(s + gs + glen);
+        u32 r_fs[2], r_fl[2], r_code[2], r_kind[2], r_med[2];
+        bool r_pass[2];
+        r_fs[0] = hasL ? fsL : (hasR ? fsR : 0u);
+        r_fl[0] = hasL ? (u32)len1 : (hasR ? (u32)len2 : 0u);
+        r_code[0] = hasL ? codeL : (hasR ? codeR : 0u);
+        r_kind[0] = hasL ? 1u : (hasR ? 2u : 0u);
+        r_med[0] = hasL ? medL : (hasR ? medR : 0u);
+        r_pass[0] = hasL ? passL : (hasR && passR);
+        r_fs[1] = (hasL && hasR) ? fsR : 0u;
+        r_fl[1] = (hasL && hasR) ? (u32)len2 : 0u;
+        r_code[1] = (hasL && hasR) ? codeR : 0u;
+        r_kind[1] = (hasL && hasR) ? 2u : 0u;
+        r_med[1] = (hasL && hasR) ? medR : 0u;
+        r_pass[1] = hasL && hasR && passR;
+        if (d0) atomicAdd(&acc.bqh[1][2 * lane], (u64)(long long)(int)d0);
+        if (d1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)(long long)(int)d1);
+        /* one passing output read that starts within FS_SMAX bases of the read's start (Read::breakByGap drops an empty
+           side): the statistics pass counts it post-filter as a window of the read, like an unsplit r1 */
+        const bool to_post = nf == 1 && r_pass[0] && r_fs[0] <= (u32)FS_SMAX;
+        if (lane == 0) {
+            fpl_read_result res;
+            res.r1_start = (u32)s;
+            res.r1_len = (u32)blen;
+            res.frag_start[0] = r_fs[0]; res.frag_start[1] = r_fs[1];
+            res.frag_len[0] = r_fl[0]; res.frag_len[1] = r_fl[1];
+            res.n_frag = (u8)nf;
+            res.dropped = 0;
+            res.code[0] = (u8)r_code[0]; res.code[1] = (u8)r_code[1];
+            res.kind[0] = (u8)r_kind[0]; res.kind[1] = (u8)r_kind[1];
+            res.median_q_pre = (u8)((rmm >> 16) & 0xFFu);
+            res.median_q_post[0] = (u8)r_med[0]; res.median_q_post[1] = (u8)r_med[1];
+            res.reserved[0] = res.reserved[1] = res.reserved[2] = 0;
+            results[ri] = res;
+            ReadState ns = st;
+            ns.pad = to_post ? PLAN_TO_POST : 0u;
+            if (to_post) { /* the window the statistics pass works on is the fragment, not r1 */
+                ns.s = r_fs[0];
+                ns.e = r_fs[0] + r_fl[0];
+            }
+            state[ri] = ns;
+            u32 cnt = (r_pass[0] && !to_post ? 1u : 0u) + (nf > 1 && r_pass[1] ? 1u : 0u);
+            if (cnt) {
+                u32 slot = atomicAdd(frag_count, cnt);
+                if (r_pass[0] && !to_post) {
+                    frag_off[slot] = o0 + r_fs[0];
+                    frag_len[slot] = r_fl[0];
+                    slot++;
+                }
+                if (nf > 1 && r_pass[1]) {
+                    frag_off[slot] = o0 + r_fs[1];
+                    frag_len[slot] = r_fl[1];
+                }
+            }
+        }
+    }
     __syncthreads();
     scan_acc_flush(acc, counters, C);
 }

@@ -4,8 +4,9 @@
  * kernel order are exercised on the CPU too.
  *
  *   1 k_trim_ends              reads  -> r1 window per read (+ polyX / adapter counters)
- *   2 k_scan                   r1 -> middle-adapter split, filter code, result records,
- *                              quality histograms / medians, statistics plan + EXTRA fragment list
+ *   2 k_scan                   r1 -> quality histograms / medians, passFilter sums and code, Hamming argmins (ScanRec per read)
+ *     k_resolve                lane = read: confirmations, middle-adapter split, result records, counters, statistics plan +
+ *                              EXTRA fragment list; k_redo: the fragments of the reads that were split
  *   3 k_stats + k_stats_reduce reads -> pre- AND post-filter per-cycle tables + k-mers in one pass
  *   4 k_stats<EXTRA> + reduce  post-only fragments (split reads, far-trimmed reads)
  */
@@ -82,7 +83,10 @@ struct BatchArgs {
     bool scan_short = false; /* DevConfig::scan_short on the host side */
     long long* counters;
     u32 C;
-    u32* work_ctr; /* four words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count, [2] k_trim_ends_batched group counter */
+    u32* work_ctr; /* four words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count, [2] k_trim_ends_batched
+                      group counter, [3] length of the REDO list */
+    ScanRec* recs = nullptr;  /* n_reads: what k_scan leaves per read for k_resolve */
+    RedoItem* redo = nullptr; /* n_reads: the reads a middle adapter splits (k_resolve -> k_redo) */
     u32* sort_ws = nullptr;       /* k_stats_sorted: sort_ws_words(stats_sorted_max_slices()) words */
     uint64_t* st_off = nullptr;   /* ... and (start, length, end of r1) of the reads in sorted order, n_reads each */
     u32* st_len = nullptr;
@@ -231,10 +235,22 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         if (chunk > 64) chunk = 64;
         if (a.scan_short)
             FPL_LAUNCH((k_scan<KWAVES, true>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
-                       a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk, a.work_ctr + 1);
+                       (const ReadState*)a.state, a.recs, a.counters, a.C, a.work_ctr, chunk);
         else
             FPL_LAUNCH((k_scan<KWAVES, false>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
-                       a.state, a.results, a.frag_off, a.frag_len, a.counters, a.C, a.work_ctr, chunk, a.work_ctr + 1);
+                       (const ReadState*)a.state, a.recs, a.counters, a.C, a.work_ctr, chunk);
+        /* lane = read: confirmations, gaps, records, counters, plan; the reads a middle adapter splits go on the REDO list */
+        u32 rblocks = cdiv(cdiv(n, 64u), KWAVES);
+        if (rblocks > 4 * a.n_cu) rblocks = 4 * a.n_cu;
+        FPL_LAUNCH((k_resolve<KWAVES>), dim3(rblocks), block, stream, a.seq, a.off, n, a.n_bytes, a.cfg, a.ads, a.state,
+                   (const ScanRec*)a.recs, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, a.redo, a.work_ctr + 3, a.counters, a.C);
+        if (!a.defer) { /* (with --break / --mask k_break_mask scans the fragments) */
+            u32 dblocks = cdiv(n, KWAVES); /* the list's length is known on the device only: a grid that walks it */
+            if (dblocks > 2 * a.n_cu) dblocks = 2 * a.n_cu;
+            FPL_LAUNCH((k_redo<KWAVES>), dim3(dblocks), block, stream, a.seq, a.qual, a.off, a.n_bytes, a.cfg, a.state,
+                       (const ScanRec*)a.recs, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, (const RedoItem*)a.redo,
+                       (const u32*)(a.work_ctr + 3), a.counters, a.C);
+        }
     }
     if (a.defer) {
         u32 blocks = cdiv(n, KWAVES);

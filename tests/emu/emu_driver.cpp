@@ -81,6 +81,10 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.counters = (long long*)counters;
     a.C = C;
     a.work_ctr = work_ctr;
+    std::vector<ScanRec> recs(n_reads ? n_reads : 1);
+    std::vector<RedoItem> redo(n_reads ? n_reads : 1);
+    a.recs = recs.data();
+    a.redo = redo.data();
     a.n_cu = n_cu ? n_cu : 2;
     a.tune = stats_tune_from_env(); /* (the tests set the hooks per case) */
     const size_t slabs = stats_scratch_slabs(n_reads, n_bytes, max_len, a.n_cu, a.tune);
