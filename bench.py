@@ -482,7 +482,8 @@ def main(argv=None, rig=None):
         prof = {} if (args.set or args.median_len) else profile_record(args.workload)
         hbm_pb, valu_pb = prof.get("hbm_bytes_per_base", {}), prof.get("valu_insts_per_base", {})
         # (the HIP-event stages group kernels: k_stats = the bucket kernels + k_stats_sorted + its reduce, ...)
-        stage_of = {"k_trim_ends": ("k_trim_ends", "k_trim_ends_batched"), "k_scan": ("k_scan", "k_break_mask"),
+        stage_of = {"k_trim_ends": ("k_trim_ends", "k_trim_ends_batched"), "k_scan": ("k_scan",),
+                    "k_resolve": ("k_resolve", "k_redo", "k_break_mask"),
                     "k_stats": ("k_stats", "k_stats_sorted", "k_stats_reduce_sorted", "k_bucket_count", "k_bucket_scan",
                                 "k_bucket_plan", "k_bucket_scatter"),
                     "k_stats_extra": ("k_stats_extra", "k_stats_reduce")}

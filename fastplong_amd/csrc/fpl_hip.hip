@@ -31,6 +31,7 @@ struct fpl_ctx {
     u32 ws_reads = 0;
     ReadState* d_state = nullptr;
     ScanRec* d_recs = nullptr;  /* k_scan -> k_resolve */
+    ScanWin* d_wins = nullptr;
     RedoItem* d_redo = nullptr; /* k_resolve -> k_redo */
     uint64_t* d_frag_off = nullptr;
     u32* d_frag_len = nullptr;
@@ -189,7 +190,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         FPL_HIP(hipMemcpy(ctx->d_cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
         FPL_HIP(hipMalloc((void**)&ctx->d_ads, sizeof(DevAdapter) * ads.size()));
         FPL_HIP(hipMemcpy(ctx->d_ads, ads.data(), sizeof(DevAdapter) * ads.size(), hipMemcpyHostToDevice));
-        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, 4 * sizeof(u32)));
+        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, WORK_CTR_WORDS * sizeof(u32)));
         ctx->C = max_cycles ? max_cycles : 1;
         int r = alloc_counters(ctx, ctx->C, &ctx->d_counters);
         if (r != FPL_OK) return r;
@@ -213,7 +214,7 @@ void fpl_destroy(fpl_ctx* ctx) {
     void* ptrs[] = {ctx->d_cfg, ctx->d_ads, ctx->d_counters, ctx->d_state, ctx->d_frag_off, ctx->d_frag_len,
                     ctx->d_work_ctr, ctx->d_stats_scratch,
                     ctx->d_stats_flags, ctx->d_frag_cyc, ctx->bm.frags, ctx->bm.regs, ctx->bm.counts,
-                    ctx->d_sort_ws, ctx->d_st_off, ctx->d_st_len, ctx->d_st_e, ctx->d_recs, ctx->d_redo};
+                    ctx->d_sort_ws, ctx->d_st_off, ctx->d_st_len, ctx->d_st_e, ctx->d_recs, ctx->d_redo, ctx->d_wins};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& sl : ctx->slot) {
@@ -456,8 +457,11 @@ static int ensure_workspace(fpl_ctx* ctx, u32 n_reads) {
     FPL_HIP(hipMalloc((void**)&ctx->d_state, sizeof(ReadState) * (size_t)n_reads));
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_redo) (void)hipFree(ctx->d_redo);
+    if (ctx->d_wins) (void)hipFree(ctx->d_wins);
     ctx->d_recs = nullptr;
     ctx->d_redo = nullptr;
+    ctx->d_wins = nullptr;
+    FPL_HIP(hipMalloc((void**)&ctx->d_wins, sizeof(ScanWin) * (size_t)n_reads));
     FPL_HIP(hipMalloc((void**)&ctx->d_recs, sizeof(ScanRec) * (size_t)n_reads));
     FPL_HIP(hipMalloc((void**)&ctx->d_redo, sizeof(RedoItem) * (size_t)n_reads));
     if (ctx->d_st_off) (void)hipFree(ctx->d_st_off);
@@ -501,7 +505,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         if (r != FPL_OK) return r;
         r = ensure_break_mask(ctx, n_reads, n_bytes);
         if (r != FPL_OK) return r;
-        FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, 4 * sizeof(u32), stream));
+        FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, WORK_CTR_WORDS * sizeof(u32), stream));
     }
     if (ctx->hcfg.defer && ctx->bm.counts) FPL_HIP(hipMemsetAsync(ctx->bm.counts, 0, 4 * sizeof(u32), stream));
     BatchArgs a;
@@ -526,6 +530,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.C = ctx->C;
     a.work_ctr = ctx->d_work_ctr;
     a.recs = ctx->d_recs;
+    a.wins = ctx->d_wins;
     a.redo = ctx->d_redo;
     a.sort_ws = ctx->d_sort_ws;
     a.st_off = ctx->d_st_off;

@@ -46,6 +46,12 @@ __device__ unsigned long long g_fpl_prof[64];
 
 
 /* compile-time A/B switches of individual optimisations (tools/ab_bench.py builds the variants; the defaults ship) */
+#ifndef FPL_REDO_PREFETCH
+#define FPL_REDO_PREFETCH 1 /* k_redo: the next tile's cache lines are touched one tile ahead */
+#endif
+#ifndef FPL_REDO_WAVES16
+#define FPL_REDO_WAVES16 1 /* k_redo: blocks of sixteen waves, one per CU (fewer blocks end with global atomics on the same lines) */
+#endif
 #ifndef FPL_OPT_HIST
 #define FPL_OPT_HIST 2 /* histogram counter address = (bin bits) | (4 KiB-aligned slice + lane copy), hist_bump.  2: written in
                           plain C, the compiler picks v_and_or_b32 (32 VALU fewer per tile, k_scan 1.4 % faster side by
@@ -2254,7 +2260,10 @@ k_stats_reduce(const u64* __restrict__ scratch, const u8* __restrict__ flags, u3
 #endif
 constexpr int HIST_COPIES = FPL_HIST_COPIES; /* per-wave quality histogram: 128 bins x this many lane-copies */
 /* k_scan blocks (4 waves) a CU holds: LDS-bound, 10 KiB (16 copies) or 6 KiB (8 copies) per wave */
-constexpr int SCAN_BLOCKS_PER_CU = HIST_COPIES == 16 ? 3 : 5;
+#ifndef FPL_SCAN_BLOCKS
+#define FPL_SCAN_BLOCKS (FPL_HIST_COPIES == 16 ? 3 : 5)
+#endif
+constexpr int SCAN_BLOCKS_PER_CU = FPL_SCAN_BLOCKS;
 constexpr int SC_CHUNK = 32;    /* bases per lane per tile in the bit-sliced scan */
 constexpr int SC_FBUF = 32;     /* fragments a wave gathers per reservation in the global fragment list */
 constexpr int SC_LANES_HAM = 62; /* lanes 62/63 only provide the plane words the last windows reach into */
@@ -2312,6 +2321,14 @@ __device__ __forceinline__ void hist_totals(u32* __restrict__ h, u32& t0, u32& t
         t1 += slot < NSLOT / 2 ? 0u : sum;
     }
     wave_sync(); /* later atomics of other lanes must not overtake these accesses */
+}
+
+/* the two passFilter sums over the qualities of a range from its histogram (t0 / t1 = this lane's bins 2 * lane and
+   2 * lane + 1): bases with a quality below qq, and the sum of the qualities (src/filter.cpp:27-39) */
+__device__ __forceinline__ void hist_quality_sums(u32 t0, u32 t1, int qq, u32& lowq, u32& totq) {
+    const int b0 = 2 * lane_id();
+    lowq = wave_sum_u32((b0 < qq ? t0 : 0u) + (b0 + 1 < qq ? t1 : 0u));
+    totq = wave_sum_u32(t0 * (u32)b0 + t1 * (u32)(b0 + 1));
 }
 
 /* median as Stats::statRead computes it, src/stats.cpp:352-363: smallest q with
@@ -2444,6 +2461,7 @@ __device__ inline void range_scan_bytes(const u8* __restrict__ rb, const u8* __r
 /* three bit-planes of 32 bases that are all exactly A, C, G, T or N: bit j of L / H / N = ASCII bit 1 / 2 / 3 of base j
    (A 000, C 001 -- L set --, T 010, G 011; bit 3 is set for N = 0x4E alone, whose L and H bits read like G's) */
 __device__ __forceinline__ void code_planes(const u32 s[8], u32& L, u32& H, u32& N) {
+    /* the masked bit itself is the multiplicand (2, 4 or 8 per base instead of 1): no shift per dword and plane */
     L = 0;
     H = 0;
     N = 0;
@@ -2454,13 +2472,14 @@ __device__ __forceinline__ void code_planes(const u32 s[8], u32& L, u32& H, u32&
         for (int hh = 0; hh < 2; hh++) {
             const u32 w = s[2 * pr + hh];
             const u32 wt = hh ? 0x80402010u : 0x08040201u;
-            lb = udot4((w >> 1) & 0x01010101u, wt, lb);
-            hb = udot4((w >> 2) & 0x01010101u, wt, hb);
-            nb = udot4((w >> 3) & 0x01010101u, wt, nb);
+            lb = udot4(w & 0x02020202u, wt, lb);
+            hb = udot4(w & 0x04040404u, wt, hb);
+            nb = udot4(w & 0x08080808u, wt, nb);
         }
-        L |= lb << (8 * pr);
-        H |= hb << (8 * pr);
-        N |= nb << (8 * pr);
+        /* lb = 2 * (8 plane bits), hb = 4 * ..., nb = 8 * ...: the factor goes away with the shift that parks the byte */
+        L |= pr ? lb << (8 * pr - 1) : lb >> 1;
+        H |= pr ? hb << (8 * pr - 2) : hb >> 2;
+        N |= pr ? nb << (8 * pr - 3) : nb >> 3;
     }
 }
 /* non-zero when one of the 32 bytes is not exactly A, C, G, T or N: ASCII bits 1..3 pick the letter the byte would have
@@ -2476,11 +2495,12 @@ __device__ __forceinline__ u32 not_acgtn(const u32 s[8]) {
    plane with itself shifted by one position -- 16 instead of 104 vector instructions.  The predecessor of base 0 (the
    byte in front of the chunk) may be any byte: that one comparison is made on the bytes. */
 /* MASKED: only the first nvalid (1..32) bases of the chunk count */
-template <bool MASKED>
+/* QS: also the two sums over the qualities (the main scan leaves them to the histogram: hist_quality_sums) */
+template <bool MASKED, bool QS = true>
 __device__ __forceinline__ void sums32_acgtn(const u32 s0, const u32 q[8], int nvalid, u32 L, u32 H, u32 N, u32 prev_dword,
                                              u32 qqrep, u32& lowq, u32& nn, u32& totq, u32& diff) {
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
+    for (int d = 0; QS && d < 8; d++) {
         u32 bm = ~0u, fm = 0x80808080u;
         if (MASKED) {
             const int c = nvalid - 4 * d;
@@ -2635,7 +2655,7 @@ __device__ __forceinline__ void sliced_max(const u32 (&B)[NB], u32 cand, int& va
  *   lowq: bytes with q < qq          totq: sum of q (v_sad_u8)
  *   nn  : bytes == 'N'               diff: bytes that differ from their predecessor (pw = byte before s[0])
  * MASKED: only the first nvalid bytes count (the ragged last tile of a range). */
-template <bool MASKED>
+template <bool MASKED, bool QS = true>
 __device__ __forceinline__ void sums32(const u32 s[8], const u32 q[8], int nvalid, u32 prev_dword, u32 qqrep, u32& lowq,
                                        u32& nn, u32& totq, u32& diff) {
     u32 pd = prev_dword;
@@ -2647,9 +2667,11 @@ __device__ __forceinline__ void sums32(const u32 s[8], const u32 q[8], int nvali
             bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
             fm &= bm;
         }
-        const u32 t = (q[d] | 0x80808080u) - qqrep; /* per byte, no borrow: bit 7 survives iff q >= qq */
-        lowq = FPL_OPT_BCNT ? popc_acc(~t & fm, lowq) : lowq + popc32(~t & fm);
-        totq = sum_bytes(q[d] & bm, totq);
+        if (QS) {
+            const u32 t = (q[d] | 0x80808080u) - qqrep; /* per byte, no borrow: bit 7 survives iff q >= qq */
+            lowq = FPL_OPT_BCNT ? popc_acc(~t & fm, lowq) : lowq + popc32(~t & fm);
+            totq = sum_bytes(q[d] & bm, totq);
+        }
         const u32 x = s[d] ^ 0x4E4E4E4Eu;
         const u32 zx = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
         nn = FPL_OPT_BCNT ? popc_acc(~zx & fm, nn) : nn + popc32(~zx & fm);
@@ -2724,7 +2746,7 @@ __device__ __forceinline__ u32 hist_dumped(int blen) { return blen > 0 ? (u32)((
 /* NB: bit-planes the match counts need (6 when both adapters have <= 32 bases, else 7).  h = this wave's histogram
  * slice.  Returns the number of bytes the masked tiles parked in bin 0 of the histogram (hist_dumped): the caller takes
  * them out of that bin's total. */
-template <bool SUMS, bool HAM, bool LEAN = false, int NB = 7>
+template <bool SUMS, bool HAM, bool LEAN = false, int NB = 7, bool PREFETCH = (FPL_OPT_PREFETCH != 0)>
 __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
                                                const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
                                                ScanWaveLds* __restrict__ w, u32* __restrict__ h, int qualified_qual, RangeSums& sums,
@@ -2749,7 +2771,7 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
            of every 128-byte line of the NEXT tile (lanes 0..31 the bases, 32..63 the qualities), requested before this
            tile's own loads, brings that tile into the XCD's L2 meanwhile. */
         u32 pf = 0;
-        if (FPL_OPT_PREFETCH && !LEAN) {
+        if (PREFETCH && !LEAN) {
             const int line = 128 * (lane & 31), nx = t0 + ADV + line;
             if (line < ADV + 128 && nx < blen) pf = (u32)(lane < 32 ? rb : qb)[a + nx];
         }
@@ -2757,22 +2779,38 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         const int navail = blen > j0 ? min(SC_CHUNK, blen - j0) : 0; /* bytes of the range in this chunk */
         const int nstat = lane < ACTIVE ? navail : 0;                 /* bytes this lane accounts for */
         u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (navail > 0) {
-            const u32x4 s0 = load16_guard(rb + a + j0, seq_end), s1 = load16_guard(rb + a + j0 + 16, seq_end);
-            s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w;
-            s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
-        }
-        if (nstat > 0) {
-            const u32x4 q0 = load16_guard(qb + a + j0, qual_end), q1 = load16_guard(qb + a + j0 + 16, qual_end);
-            q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
-            q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+        /* a lane loads 32 bytes wherever its chunk starts inside the range: only the chunks of the batch's very last bytes
+           can reach past the buffers (wave-uniform test on the tile's last possible byte), and only those pay for guards */
+        if (LEAN || rb + a + min(blen, t0 + 64 * SC_CHUNK) + SC_CHUNK > seq_end) {
+            if (navail > 0) {
+                const u32x4 s0 = load16_guard(rb + a + j0, seq_end), s1 = load16_guard(rb + a + j0 + 16, seq_end);
+                s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w;
+                s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+            }
+            if (nstat > 0) {
+                const u32x4 q0 = load16_guard(qb + a + j0, qual_end), q1 = load16_guard(qb + a + j0 + 16, qual_end);
+                q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
+                q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+            }
+        } else {
+            if (navail > 0) {
+                const u32x4 s0 = load16(rb + a + j0), s1 = load16(rb + a + j0 + 16);
+                s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w;
+                s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+            }
+            if (nstat > 0) {
+                const u32x4 q0 = load16(qb + a + j0), q1 = load16(qb + a + j0 + 16);
+                q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
+                q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+            }
         }
         /* The last tile of a range is ragged: some lane holds fewer than 32 bytes of it.  Those lanes pad themselves -- the
            bases with copies of their last base, the qualities with zeros -- and the tile then takes the same code as every
            full tile: a padding base equals its predecessor (nothing for the complexity sum), a padding quality adds nothing
-           to the quality sum and lands in bin 0 of the histogram (hist_dumped: the caller takes it out); what it adds to
-           the low-quality and the N count is taken out of this lane's partial sums right here.  No tested window reaches
-           a padding base (positions p < length - alen).  A lane without any byte of the range pads with 'A'. */
+           to the histogram but to bin 0 (hist_dumped: the caller takes it out; the two sums over the qualities come from
+           the histogram), and what a padding N adds to the N count is taken out of this lane's partial sum right here.  No
+           tested window reaches a padding base (positions p < length - alen).  A lane without any byte of the range pads
+           with 'A'. */
         if (!LEAN && wave_ballot(navail < SC_CHUNK) != 0) { /* wave-uniform */
             if (navail < SC_CHUNK) {
                 const int li = navail > 0 ? navail - 1 : 0;
@@ -2788,11 +2826,7 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
                     s[d] = (s[d] & bm) | (rep & ~bm);
                     q[d] &= bm;
                 }
-                if (SUMS && nstat > 0) {
-                    const u32 pad = (u32)(SC_CHUNK - nstat);
-                    lowq -= qqrep ? pad : 0u;
-                    nn -= last == (u32)'N' ? pad : 0u;
-                }
+                if (SUMS && nstat > 0 && last == (u32)'N') nn -= (u32)(SC_CHUNK - nstat);
             }
         }
         /* predecessor of this chunk's first byte: last dword of the previous lane / previous tile */
@@ -2813,9 +2847,9 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         if (!LEAN) {
             if (nstat > 0) {
                 if (!FPL_DBG(dbg, 1)) hist32<false>(hl, q, SC_CHUNK);
-                if (SUMS && !FPL_DBG(dbg, 2)) {
-                    if (acgt) sums32_acgtn<false>(s[0], q, SC_CHUNK, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
-                    else sums32<false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
+                if (SUMS && !FPL_DBG(dbg, 2)) { /* (N count and complexity sum; lowq / totq: hist_quality_sums) */
+                    if (acgt) sums32_acgtn<false, false>(s[0], q, SC_CHUNK, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
+                    else sums32<false, false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
                 }
                 if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
             }
@@ -2872,15 +2906,16 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
             }
         }
 #if !defined(FPL_EMU)
-        if (FPL_OPT_PREFETCH && !LEAN) asm volatile("" ::"v"(pf)); /* (keeps the touch load alive; it has long returned) */
+        if (PREFETCH && !LEAN) asm volatile("" ::"v"(pf)); /* (keeps the touch load alive; it has long returned) */
 #else
         (void)pf;
 #endif
     }
     if (SUMS) {
-        sums.lowq = wave_sum_u32(lowq);
+        /* (the main scan leaves lowq / totq to its caller: hist_quality_sums on the histogram totals) */
+        sums.lowq = LEAN ? wave_sum_u32(lowq) : 0u;
         sums.nn = wave_sum_u32(nn);
-        sums.totq = wave_sum_u32(totq);
+        sums.totq = LEAN ? wave_sum_u32(totq) : 0u;
         sums.diff = wave_sum_u32(diff);
     }
     if (HAM) {
@@ -3029,22 +3064,15 @@ __device__ __forceinline__ void lev_pair32_run(const u32 (*__restrict__ peq4)[4]
     ed1 = readlane_i32(res, 1);
 }
 
-/* The confirmation of lev_pair32_run for many reads at once: every lane its own window (m text bytes at `text`) against
- * the whole adapter `a` (m = its length <= 32, A / C / G / T only; peq4 = its four Peq words, in LDS).  True when the
- * global edit distance is <= thr. */
-__device__ __forceinline__ bool lev_lanes32_acgt(const u8* __restrict__ text, int m, int thr, bool need,
-                                                 const u32* __restrict__ peq4row, const u8* __restrict__ seq_end) {
-    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (need) {
-        const u32x4 a = load16_guard(text, seq_end), b = load16_guard(text + 16, seq_end);
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
-        w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-    }
+/* One Levenshtein confirmation per lane: every lane its own window (the m text bytes in w, m = the adapter's length <= 32,
+ * A / C / G / T only; peq4row = the adapter's four Peq words, in LDS).  True when the global edit distance is <= thr. */
+__device__ __forceinline__ bool lev_lanes32_acgt_w(const u32 (&w)[8], int m, int thr, bool need, const u32* __restrict__ peq4row) {
     const int mm = need ? m : 0;
     const u32 topsh = mm > 0 ? (u32)(mm - 1) : 0u;
     const int mmax = (int)wave_max_u32((u32)mm);
     u32 Pv = ~0u, Mv = 0;
     int score = mm;
+    bool alive = need; /* the window can still end within thr: every remaining column lowers the score by one at most */
 #pragma unroll
     for (int t = 0; t < 32; t++) {
         if (t < mmax) { /* wave-uniform */
@@ -3062,9 +3090,66 @@ __device__ __forceinline__ bool lev_lanes32_acgt(const u8* __restrict__ text, in
             const u32 nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
             Pv = act ? nPv : Pv;
             Mv = act ? nMv : Mv;
+            if ((t & 3) == 3) { /* most windows are hopeless after a dozen columns: leave when every lane's is */
+                alive = alive && score - (mm - 1 - t) <= thr;
+                if (!wave_ballot(alive)) break;
+            }
         }
     }
-    return need && score <= thr;
+    return alive && score <= thr;
+}
+/* ... the window fetched from the read (32 bytes at `text`) */
+__device__ __forceinline__ bool lev_lanes32_acgt(const u8* __restrict__ text, int m, int thr, bool need,
+                                                 const u32* __restrict__ peq4row, const u8* __restrict__ seq_end) {
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (need) {
+        const u32x4 a = load16_guard(text, seq_end), b = load16_guard(text + 16, seq_end);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    }
+    return lev_lanes32_acgt_w(w, m, thr, need, peq4row);
+}
+/* ... and for adapters of up to 64 bases (A / C / G / T only): 64-bit columns, the window fetched 16 bytes at a time */
+__device__ __forceinline__ u64 peq4_lookup64(const u64* __restrict__ tbl, u32 b) {
+    const u32 code = (b >> 1) & 3u; /* A0 C1 T2 G3 */
+    return ((0x47544341u >> (8 * code)) & 0xFFu) == b ? tbl[code] : 0ull;
+}
+__device__ __forceinline__ bool lev_lanes64_acgt(const u8* __restrict__ text, int m, int thr, bool need,
+                                                 const u64* __restrict__ peq4row, const u8* __restrict__ seq_end) {
+    const int mm = need ? m : 0;
+    const u32 topsh = mm > 0 ? (u32)(mm - 1) : 0u;
+    const int mmax = (int)wave_max_u32((u32)mm);
+    u64 Pv = ~0ull, Mv = 0;
+    int score = mm;
+    bool alive = need;
+    for (int t0 = 0; t0 < mmax; t0 += 16) { /* wave-uniform */
+        u32 w[4] = {0, 0, 0, 0};
+        if (need && t0 < mm) {
+            const u32x4 a = load16_guard(text + t0, seq_end);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int t = t0 + u;
+            const u32 c = (w[u >> 2] >> (8 * (u & 3))) & 0xFFu;
+            const u64 Eq = peq4_lookup64(peq4row, c);
+            const u64 Xv = Eq | Mv;
+            const u64 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u64 Ph = Mv | ~(Xh | Pv);
+            u64 Mh = Pv & Xh;
+            const int sc = score + (int)((Ph >> topsh) & 1ull) - (int)((Mh >> topsh) & 1ull);
+            Ph = (Ph << 1) | 1ull;
+            Mh <<= 1;
+            const bool act = t < mm;
+            score = act ? sc : score;
+            const u64 nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
+            Pv = act ? nPv : Pv;
+            Mv = act ? nMv : Mv;
+            if ((u & 3) == 3) alive = alive && (t >= mm || score - (mm - 1 - t) <= thr); /* (columns behind the window count for nothing) */
+        }
+        if (!wave_ballot(alive)) break;
+    }
+    return alive && score <= thr;
 }
 
 /* What k_scan leaves per read for k_resolve: the read's wave has scanned r1 once and reduced what every lane saw; everything
@@ -3078,6 +3163,11 @@ struct alignas(16) ScanRec {
                                  as ONE output read (valid unless the read was dropped or --break / --mask defer the filter) */
 };
 constexpr u32 SR_TESTED0 = 1u, SR_TESTED1 = 2u;
+/* ... and, when both command-line adapters have <= 32 bases, the 32 bytes at each argmin: k_scan still has them in its
+   XCD's L2, k_resolve would have to fetch two scattered cache lines per read */
+struct alignas(16) ScanWin {
+    u32 w[2][8];
+};
 /* a read whose r1 a middle adapter splits: k_resolve found the gap, k_redo scans the fragments */
 struct alignas(16) RedoItem {
     u32 ri, gs, glen, pad;
@@ -3111,11 +3201,12 @@ template <int WAVES, bool SHORT>
 __global__ void __launch_bounds__(WAVES * 64, SCAN_BLOCKS_PER_CU * WAVES / 4)
 k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
        uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
-       const ReadState* __restrict__ state, ScanRec* __restrict__ recs, long long* __restrict__ counters, u32 C,
-       u32* __restrict__ work_ctr, u32 chunk) {
+       const ReadState* __restrict__ state, ScanRec* __restrict__ recs, ScanWin* __restrict__ wins,
+       long long* __restrict__ counters, u32 C, u32* __restrict__ work_ctr, u32 chunk) {
     __shared__ alignas(4096) u32 hist_all[WAVES][128 * HIST_COPIES]; /* 4 KiB per wave when HIST_COPIES == 8: hist_bump */
     __shared__ ScanWaveLds wlds[WAVES];
     __shared__ ScanBqAcc acc;
+    const bool pair32 = SHORT || (cfg->ham_fast && ads[0].len <= 32 && ads[1].len <= 32); /* (k_resolve: the same test) */
     const int lane = lane_id();
     ScanWaveLds* const wl = &wlds[wave_in_block()];
     u32* const h = hist_all[wave_in_block()];
@@ -3194,16 +3285,26 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         u64 key0 = ~0ull, key1 = ~0ull;
         const bool ham = !dropped && cfg->adapter_enabled;
         u32 dumped = 0; /* bytes the padded last tile of the body scan parked in bin 0 (hist_dumped) */
+        bool qsums = true; /* lowq / totq still to come (from the histogram) */
         if (SHORT || (ham && cfg->ham_fast)) /* (SHORT: also the reads without an adapter search, through do_ham) */
             dumped = range_scan_fast<true, true, false, NB>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, &ads[0], &ads[1], key0, key1, ham);
-        else if (ham) /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
+        else if (ham) { /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
             range_scan_bytes<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
-        else
+            qsums = false;
+        } else
             dumped = range_scan_fast<true, false>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, nullptr, nullptr, key0, key1);
+        /* the 32 bytes at the two argmins, for k_resolve's edit distances: dword lane & 7 of window lane >> 3 */
+        u32 wv = 0;
+        const bool wsave = pair32 && ham && (key0 != ~0ull || key1 != ~0ull); /* wave-uniform */
+        if (wsave && lane < 16) {
+            const u64 k = lane < 8 ? key0 : key1;
+            if (k != ~0ull) wv = load4_guard(rb + s + (int)(u32)k + 4 * (lane & 7), seq_end);
+        }
         PROF(2) /* body scan */
         u32 hb0, hb1;
         hist_totals(h, hb0, hb1);
         if (lane == 0) hb0 -= dumped;
+        if (qsums && !dropped && !defer) hist_quality_sums(hb0, hb1, qq & 0x7F, sm.lowq, sm.totq); /* (wave-uniform) */
         PROF(3)
         /* ---- the ends: their first SC_END_PF bytes from the prefetched registers into the small histogram,
            any rest (rare) by a scan; pre-filter totals = body + ends */
@@ -3259,16 +3360,19 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             r.flags = (key0 != ~0ull ? SR_TESTED0 : 0u) | (key1 != ~0ull ? SR_TESTED1 : 0u) | ((u32)code << 8);
             recs[ri] = r;
         }
+        if (wsave && lane < 16) wins[ri].w[lane >> 3][lane & 7] = wv;
         PROF(9) /* record */
     }
     PROF_FLUSH(0);
     bq_hand_over(bq, acc);
     __syncthreads();
+#ifndef FPL_ABL_NOFLUSH /* (timing experiment: what the blocks' closing atomics cost) */
     for (int k = 0; k < 2; k++) {
         long long* st = counters + (k == 0 ? FPL_OFF_PRE(C) : FPL_OFF_POST(C));
         for (u32 i = threadIdx.x; i < 128; i += blockDim.x)
             if (acc.bqh[k][i]) atomicAdd((u64*)&st[FPL_ST_BASE_QUAL_HIST(C) + i], acc.bqh[k][i]);
     }
+#endif
 }
 
 /* One Levenshtein confirmation per lane, any adapter: the rare configurations (an adapter beyond 32 bases or with bytes
@@ -3312,14 +3416,18 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_resolve(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_reads, uint64_t n_bytes,
           const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads, ReadState* __restrict__ state,
-          const ScanRec* __restrict__ recs, fpl_read_result* __restrict__ results, uint64_t* __restrict__ frag_off,
-          u32* __restrict__ frag_len, u32* __restrict__ frag_count, RedoItem* __restrict__ redo, u32* __restrict__ redo_count,
-          long long* __restrict__ counters, u32 C) {
+          const ScanRec* __restrict__ recs, const ScanWin* __restrict__ wins, fpl_read_result* __restrict__ results,
+          uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len, u32* __restrict__ frag_count, RedoItem* __restrict__ redo,
+          u32* __restrict__ redo_count, long long* __restrict__ counters, u32 C) {
     __shared__ ScanBlockAcc acc;
-    __shared__ u32 peq4[2][4]; /* Peq words of A, C, T, G for the two command-line adapters (lev_lanes32_acgt) */
+    __shared__ u64 peq4[2][4]; /* Peq words of A, C, T, G for the two command-line adapters (lev_lanes32 / 64_acgt) */
+    __shared__ u32 peq4lo[2][4];
     const int lane = lane_id();
-    if (threadIdx.x < 8) peq4[threadIdx.x >> 2][threadIdx.x & 3] =
-        (u32)ads[threadIdx.x >> 2].peq_full[(0x47544341u >> (8 * (threadIdx.x & 3))) & 0xFFu][0];
+    if (threadIdx.x < 8) {
+        const u64 v = ads[threadIdx.x >> 2].peq_full[(0x47544341u >> (8 * (threadIdx.x & 3))) & 0xFFu][0];
+        peq4[threadIdx.x >> 2][threadIdx.x & 3] = v;
+        peq4lo[threadIdx.x >> 2][threadIdx.x & 3] = (u32)v;
+    }
     {
         u64* z = (u64*)&acc;
         for (u32 i = threadIdx.x; i < sizeof(ScanBlockAcc) / 8; i += blockDim.x) z[i] = 0;
@@ -3373,9 +3481,19 @@ k_resolve(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_re
         const u8* w0 = seq + o0 + (uint64_t)s + (need0 ? rec.pos0 : 0u);
         const u8* w1 = seq + o0 + (uint64_t)s + (need1 ? rec.pos1 : 0u);
         if (wave_ballot(need0 || need1)) { /* wave-uniform */
-            if (pair32) {
-                ok0 = lev_lanes32_acgt(w0, al0, thr0, need0, peq4[0], seq_end);
-                ok1 = lev_lanes32_acgt(w1, al1, thr1, need1, peq4[1], seq_end);
+            if (pair32) { /* the windows k_scan saved */
+                u32 x0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, x1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (need0 || need1) {
+                    const u32x4* wp = (const u32x4*)&wins[ri];
+                    const u32x4 a = wp[0], b = wp[1], c = wp[2], d = wp[3];
+                    x0[0] = a.x; x0[1] = a.y; x0[2] = a.z; x0[3] = a.w; x0[4] = b.x; x0[5] = b.y; x0[6] = b.z; x0[7] = b.w;
+                    x1[0] = c.x; x1[1] = c.y; x1[2] = c.z; x1[3] = c.w; x1[4] = d.x; x1[5] = d.y; x1[6] = d.z; x1[7] = d.w;
+                }
+                ok0 = lev_lanes32_acgt_w(x0, al0, thr0, need0, peq4lo[0]);
+                ok1 = lev_lanes32_acgt_w(x1, al1, thr1, need1, peq4lo[1]);
+            } else if (cfg->ham_fast) { /* A / C / G / T only, <= 64 bases: a 64-bit column per lane */
+                ok0 = lev_lanes64_acgt(w0, al0, thr0, need0, peq4[0], seq_end);
+                ok1 = lev_lanes64_acgt(w1, al1, thr1, need1, peq4[1], seq_end);
             } else {
                 ok0 = lev_lanes_any(&ads[0], w0, thr0, need0);
                 ok1 = lev_lanes_any(&ads[1], w1, thr1, need1);
@@ -3481,7 +3599,7 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
        const DevConfig* __restrict__ cfg, ReadState* __restrict__ state, const ScanRec* __restrict__ recs,
        fpl_read_result* __restrict__ results, uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len,
        u32* __restrict__ frag_count, const RedoItem* __restrict__ redo, const u32* __restrict__ redo_count,
-       long long* __restrict__ counters, u32 C) {
+       u32* __restrict__ redo_next, long long* __restrict__ counters, u32 C) {
     __shared__ alignas(4096) u32 hist_all[WAVES][128 * HIST_COPIES];
     __shared__ ScanWaveLds wlds[WAVES];
     __shared__ ScanBlockAcc acc;
@@ -3498,6 +3616,10 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     const u8* qual_end = qual + n_bytes;
     const int qq = cfg->qualified_qual;
     const u32 n_items = *redo_count;
+    /* (items off a device counter -- `for (;;) { it = atomicAdd(..); if (it >= n_items) break; ..` -- would even the hundredfold
+       spread of the items' lengths out, but that form of this loop never ended on the GPU (ROCm 7.2, gfx950; the emulator and a
+       fixed stride are fine): the list is walked with a fixed stride) */
+    (void)redo_next;
     for (u32 it = blockIdx.x * WAVES + wave_in_block(); it < n_items; it += gridDim.x * WAVES) {
         const RedoItem item = redo[it];
         const u32 ri = uniform_u32(item.ri);
@@ -3525,9 +3647,11 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             RangeSums fs = {0, 0, 0, 0};
             u64 k0, k1;
             u32 t0, t1;
-            const u32 dmp = range_scan_fast<true, false, true>(rb, qb, fa, fa + flen, seq_end, qual_end, wl, h, qq, fs, nullptr, nullptr, k0, k1);
+            /* (a wave alone with its read: the next tile's lines are requested one tile ahead) */
+            const u32 dmp = range_scan_fast<true, false, false, 7, FPL_REDO_PREFETCH != 0>(rb, qb, fa, fa + flen, seq_end, qual_end, wl, h, qq, fs, nullptr, nullptr, k0, k1);
             hist_totals(h, t0, t1);
             if (lane == 0) t0 -= dmp;
+            if (f != 2) hist_quality_sums(t0, t1, qq & 0x7F, fs.lowq, fs.totq);
             if (undo) {
                 d0 -= t0;
                 d1 -= t1;

@@ -23,11 +23,13 @@ namespace fpl {
 #ifdef FPL_EMU
 constexpr int KWAVES = 2; /* two waves per block keep the emulator's thread count low */
 constexpr int SWAVES = 2;
+constexpr int RWAVES = 2;
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
 #define FPL_MEMSET(ptr, bytes, stream) memset(ptr, 0, bytes)
 typedef void* fpl_stream_t;
 #else
 constexpr int KWAVES = 4;
+constexpr int RWAVES = 16; /* k_resolve */
 #ifndef FPL_SWAVES
 #define FPL_SWAVES 16
 #endif
@@ -63,6 +65,7 @@ inline StatsTune stats_tune_from_env() {
     return t;
 }
 
+constexpr int WORK_CTR_WORDS = 8;
 struct BatchArgs {
     const u8* seq;
     const u8* qual;
@@ -83,9 +86,10 @@ struct BatchArgs {
     bool scan_short = false; /* DevConfig::scan_short on the host side */
     long long* counters;
     u32 C;
-    u32* work_ctr; /* four words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count, [2] k_trim_ends_batched
-                      group counter, [3] length of the REDO list */
+    u32* work_ctr; /* WORK_CTR_WORDS words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count,
+                      [2] k_trim_ends_batched group counter, [3] length of the REDO list, [4] k_redo work counter */
     ScanRec* recs = nullptr;  /* n_reads: what k_scan leaves per read for k_resolve */
+    ScanWin* wins = nullptr;  /* n_reads: ... and the bytes at the two Hamming argmins */
     RedoItem* redo = nullptr; /* n_reads: the reads a middle adapter splits (k_resolve -> k_redo) */
     u32* sort_ws = nullptr;       /* k_stats_sorted: sort_ws_words(stats_sorted_max_slices()) words */
     uint64_t* st_off = nullptr;   /* ... and (start, length, end of r1) of the reads in sorted order, n_reads each */
@@ -98,9 +102,9 @@ struct BatchArgs {
     StatsTune tune; /* tuning / test hooks, read from the environment once by whoever builds the arguments */
 };
 
-constexpr int N_STAGES = 4;
-static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_stats", "k_stats_extra"};
-/* with --break / --mask, k_break_mask runs between k_scan and k_stats and is timed with k_scan */
+constexpr int N_STAGES = 5;
+static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_resolve", "k_stats", "k_stats_extra"};
+/* k_resolve = k_resolve + k_redo (+ k_break_mask with --break / --mask) */
 
 /* capacities of the lists k_break_mask appends to: every region is at least one window long, so an output
    read or a piece costs at least window + 1 bytes of input beyond the two fragments a read starts with */
@@ -235,21 +239,29 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         if (chunk > 64) chunk = 64;
         if (a.scan_short)
             FPL_LAUNCH((k_scan<KWAVES, true>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
-                       (const ReadState*)a.state, a.recs, a.counters, a.C, a.work_ctr, chunk);
+                       (const ReadState*)a.state, a.recs, a.wins, a.counters, a.C, a.work_ctr, chunk);
         else
             FPL_LAUNCH((k_scan<KWAVES, false>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
-                       (const ReadState*)a.state, a.recs, a.counters, a.C, a.work_ctr, chunk);
+                       (const ReadState*)a.state, a.recs, a.wins, a.counters, a.C, a.work_ctr, chunk);
+    }
+    mark(2);
+    {
         /* lane = read: confirmations, gaps, records, counters, plan; the reads a middle adapter splits go on the REDO list */
-        u32 rblocks = cdiv(cdiv(n, 64u), KWAVES);
-        if (rblocks > 4 * a.n_cu) rblocks = 4 * a.n_cu;
-        FPL_LAUNCH((k_resolve<KWAVES>), dim3(rblocks), block, stream, a.seq, a.off, n, a.n_bytes, a.cfg, a.ads, a.state,
-                   (const ScanRec*)a.recs, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, a.redo, a.work_ctr + 3, a.counters, a.C);
+        /* (sixteen waves per block and no more than two blocks per CU: every block ends with a few hundred global atomics on
+           the same dozen cache lines -- its median histograms -- and those serialise: 977 blocks spent 0.1 ms on them) */
+        u32 rblocks = cdiv(cdiv(n, 64u), RWAVES);
+        if (rblocks > 2 * a.n_cu) rblocks = 2 * a.n_cu;
+        FPL_LAUNCH((k_resolve<RWAVES>), dim3(rblocks), dim3(RWAVES * 64), stream, a.seq, a.off, n, a.n_bytes, a.cfg, a.ads, a.state,
+                   (const ScanRec*)a.recs, (const ScanWin*)a.wins, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, a.redo,
+                   a.work_ctr + 3, a.counters, a.C);
         if (!a.defer) { /* (with --break / --mask k_break_mask scans the fragments) */
-            u32 dblocks = cdiv(n, KWAVES); /* the list's length is known on the device only: a grid that walks it */
-            if (dblocks > 2 * a.n_cu) dblocks = 2 * a.n_cu;
-            FPL_LAUNCH((k_redo<KWAVES>), dim3(dblocks), block, stream, a.seq, a.qual, a.off, a.n_bytes, a.cfg, a.state,
+            /* the list's length is known on the device only: waves that take items off a counter; few blocks (see above) */
+            constexpr int DW = FPL_REDO_WAVES16 ? RWAVES : KWAVES;
+            u32 dblocks = cdiv(n, DW);
+            if (dblocks > (FPL_REDO_WAVES16 ? 1u : 4u) * a.n_cu) dblocks = (FPL_REDO_WAVES16 ? 1u : 4u) * a.n_cu;
+            FPL_LAUNCH((k_redo<DW>), dim3(dblocks), dim3(DW * 64), stream, a.seq, a.qual, a.off, a.n_bytes, a.cfg, a.state,
                        (const ScanRec*)a.recs, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, (const RedoItem*)a.redo,
-                       (const u32*)(a.work_ctr + 3), a.counters, a.C);
+                       (const u32*)(a.work_ctr + 3), a.work_ctr + 4, a.counters, a.C);
         }
     }
     if (a.defer) {
@@ -260,7 +272,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_LAUNCH((k_break_mask<KWAVES>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.cfg, a.results, a.bm,
                    a.frag_off, a.frag_len, a.frag_cyc, a.work_ctr + 1, a.counters, a.C);
     }
-    mark(2);
+    mark(3);
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
     const u32 per_sorted = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
     /* (the persistent blocks number their (tile, slice) items with 32 bits; a batch beyond that -- hundreds of millions of
@@ -296,7 +308,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, n_slices, n_tiles, a.counters, a.C, 1);
     }
-    mark(3);
+    mark(4);
     {
         const u32 n_items = a.defer ? a.bm.item_cap : 2 * n; /* upper bound; the kernel reads the real count */
         const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n, a.tune); /* slabs per tile */
@@ -308,7 +320,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, gx, n_tiles, a.counters, a.C, 0);
     }
-    mark(4);
+    mark(5);
 }
 
 }  // namespace fpl

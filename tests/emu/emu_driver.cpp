@@ -58,7 +58,7 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     std::vector<fpl_fragment> frags((size_t)frag_cap + 1);
     std::vector<fpl_region> regs((size_t)reg_cap + 1);
     u32 bm_counts[4] = {0, 0, 0, 0};
-    uint32_t work_ctr[4] = {0, 0, 0, 0};
+    uint32_t work_ctr[WORK_CTR_WORDS] = {0};
     /* the kernels never read past n_bytes, but give the buffers an end guard anyway */
     BatchArgs a;
     a.seq = seq;
@@ -84,6 +84,8 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     std::vector<ScanRec> recs(n_reads ? n_reads : 1);
     std::vector<RedoItem> redo(n_reads ? n_reads : 1);
     a.recs = recs.data();
+    std::vector<ScanWin> wins(n_reads ? n_reads : 1);
+    a.wins = wins.data();
     a.redo = redo.data();
     a.n_cu = n_cu ? n_cu : 2;
     a.tune = stats_tune_from_env(); /* (the tests set the hooks per case) */

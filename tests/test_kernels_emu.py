@@ -157,6 +157,22 @@ def test_emulated_kernels_byte_scan_fallback(orc):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
+def test_emulated_kernels_adapters_of_33_to_64_bases(orc):
+    """A / C / G / T adapters beyond 32 bases: the bit-sliced scan with seven count planes in k_scan, and k_resolve's edit
+    distances on 64-bit columns, one window per lane (lev_lanes64_acgt)"""
+    rng = np.random.default_rng(77)
+    start = "".join("ACGT"[i] for i in rng.integers(0, 4, 45))
+    end = "".join("ACGT"[i] for i in rng.integers(0, 4, 38))
+    cfg = orc.Config(abi.FplOptions.default(ed_max=0.25), start, end)
+    seq, qual, off = synth.adversarial(120, seed=9, start_adapter=start, end_adapter=end)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    assert (want_res["n_frag"] == 2).any()  # some read is split by a middle adapter
+
+
 @pytest.mark.parametrize("acc", [0, 64])
 def test_emulated_stats_extra_pass_accumulates_and_overflows(orc, monkeypatch, acc):
     """k_stats<EXTRA>: one block per tile walks many short slices of the split-fragment list into ONE slab;
