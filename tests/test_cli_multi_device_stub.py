@@ -1,0 +1,124 @@
+"""The HOST side of a multi-device run on a box without GPUs: bin/fastplong_amd --gpus N against tests/stub/libfastplong_amd.so
+(LD_LIBRARY_PATH), a stand-in for the C-ABI library whose "devices" compute with the oracle.  What is under test is the CLI's
+scheduling -- batches dealt round-robin in input order, two in flight per device thread, the formatter stage, the in-order
+writer (positional, parallel file output), the counter merge behind fpl_allreduce_counters -- against the committed golden
+files, which the single-GPU CLI reproduces on hardware (tests/test_golden.py)."""
+import ctypes as C
+import gzip
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from fastplong_amd import abi, build, engine
+from tests import refjson
+from tests.stub import build as stub_build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+CASES = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+
+
+def gz(path):
+    with gzip.open(path, "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="module")
+def stub_env():
+    build.build_host()
+    lib = stub_build.build()
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.dirname(lib) + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    return env
+
+
+def run_cli(tmp_path, case, env, gpus, extra=(), chunk=30000):
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    flags = [f if f != "ADAPTERS.fa" else os.path.join(GOLD, case, "ADAPTERS.fa") for f in meta["flags"]]
+    out = tmp_path / ("g%d" % gpus)
+    out.mkdir(exist_ok=True)
+    log = out / "stub.log"
+    cmd = [build.CLI, "-i", str(inp), "-o", str(out / "out.fq"), "--failed_out", str(out / "failed.fq"), "-j", str(out / "out.json"),
+           "-h", str(out / "out.html"), "--gpus", str(gpus), "--reader_threads", "3", "-V"] + flags + list(extra)
+    e = dict(env, FPL_STUB_DEVICES="3", FPL_STUB_LOG=str(log), FPLH_CHUNK_BYTES=str(chunk))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+    return p, out, log
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cli_three_stub_devices_reproduce_golden(tmp_path, stub_env, case):
+    p, out, log = run_cli(tmp_path, case, stub_env, 3)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert (out / "out.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    assert (out / "failed.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
+    got = [l for l in (out / "out.json").read_bytes().split(b"\n") if not l.startswith(b'\t"command":')]
+    assert got == gz(os.path.join(GOLD, case, "expected.json.gz")).split(b"\n")  # the merged counters of three contexts
+    page = refjson.STAMP.sub(b"<time>", (out / "out.html").read_bytes())
+    page = re.sub(rb"<div id='footer'> <p>.*?</p>", b"<div id='footer'> <p></p>", page, flags=re.S)
+    assert page == gz(os.path.join(GOLD, case, "expected.html.gz"))
+    # scheduling: batch k of the input went to device k mod 3, and the batches are the input cut in order
+    lines = [l.split() for l in open(log).read().splitlines()]
+    assert len(lines) >= 6, "the test input must make several batches per device"
+    per_dev = {d: [l for l in lines if int(l[0]) == d] for d in range(3)}
+    assert all(abs(len(per_dev[d]) - len(lines) / 3) <= 1 for d in range(3))
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    assert sum(int(l[1]) for l in lines) == meta["reads"]
+    # the first bases of every batch, taken in round-robin order over the devices' own submission order, walk the input
+    # front to back: batch k is the k-th cut of the file
+    text = gz(os.path.join(GOLD, case, "in.fq.gz")).split(b"\n")
+    seqs = [text[i + 1] for i in range(0, len(text) - 1, 4)]
+    k, idx = 0, [0, 0, 0]
+    for b in range(len(lines)):
+        d = b % 3
+        dev, n, head = per_dev[d][idx[d]]
+        idx[d] += 1
+        cat = b"".join(seqs[k:k + int(n)])[:16]
+        assert bytes.fromhex(head.decode() if isinstance(head, bytes) else head) == cat, "batch %d is not reads %d.." % (b, k)
+        k += int(n)
+
+
+def test_cli_device_count_is_partition_invariant_and_checked(tmp_path, stub_env):
+    case = "c3_full"
+    p1, out1, _ = run_cli(tmp_path, case, stub_env, 1)
+    p2, out2, _ = run_cli(tmp_path, case, stub_env, 2, chunk=17000)
+    assert p1.returncode == 0 and p2.returncode == 0, (p1.stderr[-500:], p2.stderr[-500:])
+    for f in ("out.fq", "failed.fq"):
+        assert (out1 / f).read_bytes() == (out2 / f).read_bytes()
+    strip = lambda b: [l for l in b.split(b"\n") if not l.startswith(b'\t"command":')]  # noqa: E731
+    assert strip((out1 / "out.json").read_bytes()) == strip((out2 / "out.json").read_bytes())
+    # more devices than there are: the reference-style error, not a crash
+    p4, _, _ = run_cli(tmp_path, case, stub_env, 4)
+    assert p4.returncode != 0 and b"needs 4 HIP device(s)" in p4.stderr
+    # gzip output goes through the same in-order writer (members concatenated at their offsets)
+    p3, out3, _ = run_cli(tmp_path, case, stub_env, 3, extra=["-z", "3"])
+    assert p3.returncode == 0
+
+
+def test_cli_gz_output_with_three_devices(tmp_path, stub_env):
+    case = "c3_full"
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    cmd = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq.gz"), "--failed_out", str(tmp_path / "failed.fq.gz"),
+           "-j", str(tmp_path / "o.json"), "-h", str(tmp_path / "o.html"), "--gpus", "3", "--reader_threads", "2"] + meta["flags"]
+    e = dict(stub_env, FPL_STUB_DEVICES="3", FPLH_CHUNK_BYTES="25000")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+    assert p.returncode == 0, p.stderr.decode()[-1500:]
+    assert gz(tmp_path / "out.fq.gz") == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    assert gz(tmp_path / "failed.fq.gz") == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
+
+
+def test_stub_agrees_with_the_library_on_defaults():
+    """the stand-in restates fpl_options_default: it must be the real library's (which loads without a GPU)"""
+    real = engine.load_library()
+    stub = C.CDLL(stub_build.build())
+    a, b = abi.FplOptions(), abi.FplOptions()
+    real.fpl_options_default(C.byref(a))
+    stub.fpl_options_default(C.byref(b))
+    assert bytes(a) == bytes(b)
+    assert stub.fpl_abi_version() == abi.FPL_ABI_VERSION
