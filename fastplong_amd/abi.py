@@ -4,7 +4,7 @@ Pure declarations: importing this module needs neither a GPU nor the built libra
 """
 import ctypes as C
 
-FPL_ABI_VERSION = 3
+FPL_ABI_VERSION = 4
 FPL_MAX_IN_FLIGHT = 2
 FPL_MAX_ADAPTER_LEN = 255
 FPL_END_WINDOW = 200
@@ -98,6 +98,13 @@ class FplOptions(C.Structure):
 
 class FplAdapter(C.Structure):
     _fields_ = [("seq", C.c_char_p), ("len", C.c_int32)]
+
+
+class FplAdapterPick(C.Structure):
+    """struct fpl_adapter_pick: the adapter auto-detection's verdict for one read end (fpl_pick_adapter)."""
+
+    _fields_ = [("key", C.c_int32), ("count", C.c_uint32), ("total_key", C.c_uint32), ("len", C.c_int32), ("total", C.c_uint64),
+                ("seq", C.c_char * 72)]
 
 
 class FplReadResult(C.Structure):

@@ -741,45 +741,95 @@ extern "C" int fpl_debug_prof(unsigned long long* out, int n) {
 }
 #endif
 
-int fpl_count_end_kmers(int32_t device, const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int32_t side, int32_t shift_tail,
-                        uint32_t* counts, uint64_t* position_acc, uint64_t* total) {
-    if (!off || !counts || !position_acc || !total || (n_reads && !seq) || side < 0 || side > 1 || shift_tail < 0) return FPL_ERR_ARG;
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) return FPL_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return FPL_ERR_NO_DEVICE;
-    const size_t n_keys = (size_t)1 << 20;
-    const uint64_t n_bytes = n_reads ? off[n_reads] : 0;
+/* the counting of the detection: tables in device memory (the caller frees what `bufs` lists) */
+struct KmerTables {
     u8* d_seq = nullptr;
     uint64_t* d_off = nullptr;
     u32* d_counts = nullptr;
     unsigned long long *d_pos = nullptr, *d_total = nullptr;
+    void release() {
+        void* ptrs[] = {d_seq, d_off, d_counts, d_pos, d_total};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+    }
+};
+static int count_end_kmers_device(int32_t device, const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int32_t side,
+                                  int32_t shift_tail, KmerTables& t) {
+    if (!off || (n_reads && !seq) || side < 0 || side > 1 || shift_tail < 0) return FPL_ERR_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) return FPL_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FPL_ERR_NO_DEVICE;
+    const size_t n_keys = (size_t)pick::NKEYS;
+    const uint64_t n_bytes = n_reads ? off[n_reads] : 0;
     int rc = FPL_OK;
     auto ok = [&](hipError_t e) {
         if (e != hipSuccess && rc == FPL_OK) rc = FPL_ERR_HIP;
         return e == hipSuccess;
     };
-    if (ok(hipMalloc((void**)&d_seq, n_bytes ? n_bytes : 1)) && ok(hipMalloc((void**)&d_off, sizeof(uint64_t) * ((size_t)n_reads + 1))) &&
-        ok(hipMalloc((void**)&d_counts, sizeof(u32) * n_keys)) && ok(hipMalloc((void**)&d_pos, sizeof(unsigned long long) * n_keys)) &&
-        ok(hipMalloc((void**)&d_total, sizeof(unsigned long long)))) {
-        ok(hipMemcpy(d_seq, seq, n_bytes, hipMemcpyHostToDevice));
-        ok(hipMemcpy(d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice));
-        ok(hipMemset(d_counts, 0, sizeof(u32) * n_keys));
-        ok(hipMemset(d_pos, 0, sizeof(unsigned long long) * n_keys));
-        ok(hipMemset(d_total, 0, sizeof(unsigned long long)));
+    if (ok(hipMalloc((void**)&t.d_seq, n_bytes ? n_bytes : 1)) && ok(hipMalloc((void**)&t.d_off, sizeof(uint64_t) * ((size_t)n_reads + 1))) &&
+        ok(hipMalloc((void**)&t.d_counts, sizeof(u32) * n_keys)) && ok(hipMalloc((void**)&t.d_pos, sizeof(unsigned long long) * n_keys)) &&
+        ok(hipMalloc((void**)&t.d_total, sizeof(unsigned long long)))) {
+        ok(hipMemcpy(t.d_seq, seq, n_bytes, hipMemcpyHostToDevice));
+        ok(hipMemcpy(t.d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice));
+        ok(hipMemset(t.d_counts, 0, sizeof(u32) * n_keys));
+        ok(hipMemset(t.d_pos, 0, sizeof(unsigned long long) * n_keys));
+        ok(hipMemset(t.d_total, 0, sizeof(unsigned long long)));
         if (rc == FPL_OK && n_reads) {
             u32 blocks = (n_reads + 3) / 4;
             if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL(k_count_end_kmers, dim3(blocks), dim3(256), 0, 0, (const u8*)d_seq, (const uint64_t*)d_off, n_reads, (int)side,
-                               (int)shift_tail, d_counts, d_pos, d_total);
+            hipLaunchKernelGGL(k_count_end_kmers, dim3(blocks), dim3(256), 0, 0, (const u8*)t.d_seq, (const uint64_t*)t.d_off, n_reads,
+                               (int)side, (int)shift_tail, t.d_counts, t.d_pos, t.d_total);
             ok(hipGetLastError());
         }
-        ok(hipMemcpy(counts, d_counts, sizeof(u32) * n_keys, hipMemcpyDeviceToHost));
-        ok(hipMemcpy(position_acc, d_pos, sizeof(unsigned long long) * n_keys, hipMemcpyDeviceToHost));
-        ok(hipMemcpy(total, d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
-    void* ptrs[] = {d_seq, d_off, d_counts, d_pos, d_total};
-    for (void* q : ptrs)
-        if (q) (void)hipFree(q);
+    return rc;
+}
+
+int fpl_count_end_kmers(int32_t device, const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int32_t side, int32_t shift_tail,
+                        uint32_t* counts, uint64_t* position_acc, uint64_t* total) {
+    if (!counts || !position_acc || !total) return FPL_ERR_ARG;
+    KmerTables t;
+    int rc = count_end_kmers_device(device, seq, off, n_reads, side, shift_tail, t);
+    if (rc == FPL_OK) {
+        const size_t n_keys = (size_t)pick::NKEYS;
+        if (hipMemcpy(counts, t.d_counts, sizeof(u32) * n_keys, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(position_acc, t.d_pos, sizeof(unsigned long long) * n_keys, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(total, t.d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = FPL_ERR_HIP;
+    }
+    t.release();
+    return rc;
+}
+
+static_assert(sizeof(fpl_adapter_pick) >= sizeof(pick::Pick) && sizeof(((fpl_adapter_pick*)0)->seq) >= sizeof(((pick::Pick*)0)->seq),
+              "the ABI record holds what the kernel writes");
+int fpl_pick_adapter(int32_t device, const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int32_t side, int32_t shift_tail,
+                     int32_t is_rna, fpl_adapter_pick* out) {
+    if (!out) return FPL_ERR_ARG;
+    KmerTables t;
+    pick::Pick* d_pick = nullptr;
+    int rc = count_end_kmers_device(device, seq, off, n_reads, side, shift_tail, t);
+    if (rc == FPL_OK && hipMalloc((void**)&d_pick, sizeof(pick::Pick)) != hipSuccess) rc = FPL_ERR_HIP;
+    if (rc == FPL_OK) {
+        hipLaunchKernelGGL(k_pick_adapter, dim3(1), dim3(1024), 0, 0, (const u32*)t.d_counts, (const unsigned long long*)t.d_pos,
+                           (int)(is_rna != 0), d_pick);
+        pick::Pick p;
+        unsigned long long total = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpy(&p, d_pick, sizeof(p), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&total, t.d_total, sizeof(total), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = FPL_ERR_HIP;
+        else {
+            memset(out, 0, sizeof(*out));
+            out->key = p.key;
+            out->count = p.count;
+            out->total_key = p.total_key;
+            out->len = p.len;
+            out->total = total;
+            memcpy(out->seq, p.seq, sizeof(p.seq));
+        }
+    }
+    if (d_pick) (void)hipFree(d_pick);
+    t.release();
     return rc;
 }
 

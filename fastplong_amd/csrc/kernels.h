@@ -17,6 +17,7 @@
 #ifndef FPL_KERNELS_H
 #define FPL_KERNELS_H
 
+#include "adapter_pick.h"
 #include "dev_prims.h"
 #include "dev_types.h"
 
@@ -4213,6 +4214,50 @@ k_count_end_kmers(const u8* __restrict__ seq, const uint64_t* __restrict__ off, 
     }
     const u32 t = wave_sum_u32(mine);
     if (lane == 0 && t) atomicAdd(total, (unsigned long long)t);
+}
+
+/* =========================================================================================
+ * k_pick_adapter: what the detection does with the counters (adapter_pick.h), on the device, so that the 12 MB of tables
+ * stay where they were counted: ONE block; every thread walks a stride of the 2^20 keys for the masked arg-max (the seed:
+ * the admissible key with the largest count, the smallest key among equals) and the number of keys seen at all; thread 0
+ * then grows the seed in both directions (a chain of <= 54 dependent look-ups of four counters each).
+ * ======================================================================================= */
+__global__ void __launch_bounds__(1024)
+k_pick_adapter(const u32* __restrict__ counts, const unsigned long long* __restrict__ position_acc, int is_rna,
+               pick::Pick* __restrict__ out) {
+    __shared__ u64 best[1024];
+    __shared__ u32 seen[1024];
+    u64 mine = 0;
+    u32 nseen = 0;
+    for (u32 k = threadIdx.x; k < pick::NKEYS; k += blockDim.x) {
+        const u32 val = counts[k];
+        nseen += val > 0 ? 1u : 0u;
+        if (val > 0 && pick::key_admissible(k) && pick::count_digits_vary(val)) {
+            const u64 r = pick::seed_rank(val, k);
+            mine = r > mine ? r : mine;
+        }
+    }
+    best[threadIdx.x] = mine;
+    seen[threadIdx.x] = nseen;
+    __syncthreads();
+    for (u32 d = blockDim.x / 2; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            if (best[threadIdx.x + d] > best[threadIdx.x]) best[threadIdx.x] = best[threadIdx.x + d];
+            seen[threadIdx.x] += seen[threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pick::Pick p;
+        p.key = best[0] ? (int32_t)~(u32)best[0] : -1;
+        p.count = (u32)(best[0] >> 32);
+        p.total_key = seen[0];
+        p.len = 0;
+        p.seq[0] = 0;
+        if (p.key >= 0)
+            pick::grow(p, is_rna != 0, [&](u32 k) { return k ? counts[k] : 0u; }, [&](u32 k) { return (u64)position_acc[k]; });
+        *out = p;
+    }
 }
 
 /* =========================================================================================

@@ -18,7 +18,7 @@ EXPORTS = [
     "fpl_reserve_cycles", "fpl_counters_device_ptr", "fpl_get_counters", "fpl_reset_counters", "fpl_synchronize",
     "fpl_enable_timing", "fpl_get_kernel_times", "fpl_fragment_counts", "fpl_get_fragments",
     "fpl_process_batch_async", "fpl_wait", "fpl_in_flight", "fpl_host_alloc", "fpl_host_free", "fpl_allreduce_counters",
-    "fpl_count_end_kmers",
+    "fpl_count_end_kmers", "fpl_pick_adapter",
 ]
 
 
@@ -104,6 +104,9 @@ def load_library(path=None):
     L.fpl_count_end_kmers.restype = C.c_int
     L.fpl_count_end_kmers.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_uint64)]
+    L.fpl_pick_adapter.restype = C.c_int
+    L.fpl_pick_adapter.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.POINTER(abi.FplAdapterPick)]
     if L.fpl_abi_version() != abi.FPL_ABI_VERSION:
         raise FplError("ABI version mismatch")
     if path is None:

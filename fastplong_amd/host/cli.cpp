@@ -464,12 +464,19 @@ int main(int argc, char* argv[]) {
     if (o.adapter_enabled && (startAd == "auto" || endAd == "auto")) {
         if (fromStdin || in == "/dev/stdin") cerr << "Adapter auto-detection is disabled for STDIN mode" << endl;
         else {
-            /* the 10-mer counting of the detection runs on the first device (fpl_count_end_kmers); what the reference does
-               with the counters stays on the host.  (FPLH_HOST_KMERS: count on the host -- test / measurement hook) */
+            /* counting, seed and growth of the detection run on the first device (fpl_pick_adapter; device 0: the first of
+               --gpus); the host keeps the verdict.  (FPLH_HOST_KMERS: everything on the host -- test / measurement hook) */
             if (!getenv("FPLH_HOST_KMERS"))
-                fplh::set_kmer_counter([&](const uint8_t* sq, const uint64_t* of, uint32_t n, int side, int shift, uint32_t* cnt,
-                                           uint64_t* pos, uint64_t* tot) {
-                    return fpl_count_end_kmers(0, sq, of, n, side, shift, cnt, pos, tot) == FPL_OK; /* (device 0: the first of --gpus) */
+                fplh::set_adapter_picker([&](const uint8_t* sq, const uint64_t* of, uint32_t n, int side, int shift, bool rna,
+                                             fplh::AdapterVerdict& v) {
+                    fpl_adapter_pick p;
+                    if (fpl_pick_adapter(0, sq, of, n, side, shift, rna ? 1 : 0, &p) != FPL_OK) return false;
+                    v.key = p.key;
+                    v.count = p.count;
+                    v.total_key = p.total_key;
+                    v.total = p.total;
+                    v.adapter.assign(p.seq, (size_t)(p.len > 0 ? p.len : 0));
+                    return true;
                 });
             fplh::detect_adapters(in, o.trim_tail, isRNA, startAd, endAd, &readNum);
             cerr << endl;

@@ -9,6 +9,7 @@
 #include <utility>
 #include <vector>
 
+#include "../csrc/adapter_pick.h"
 #include "fastq.h"
 
 using namespace std;
@@ -56,89 +57,31 @@ int seq2int(const char* seq, int rlen, int pos, int keylen, int last_val) {
     return key;
 }
 
-/* Evaluator::getTopKey, src/evaluator.cpp:268-326, restated literally (its diff test reads the COUNT's bits) */
-static int get_top_key(const unsigned int* counts, int keylen) {
-    const int size = 1 << (keylen * 2);
-    int topkey = -1;
-    unsigned int top_count = 0;
-    for (int k = 0; k < size; k++) {
-        const unsigned int val = counts[k];
-        int atcg[4] = {0, 0, 0, 0};
-        for (int i = 0; i < keylen; i++) atcg[(k >> (i * 2)) & 0x03]++;
-        bool low_complexity = false;
-        int zero_num = 0;
-        for (int b = 0; b < 4; b++) {
-            if (atcg[b] >= keylen - 4) low_complexity = true;
-            if (atcg[b] == 0) zero_num++;
-        }
-        if (zero_num >= 2) low_complexity = true;
-        if ((k >> keylen) == (k & ((0x01 << keylen) - 1))) low_complexity = true; /* repetitive */
-        int diff = 0;
-        for (int s = 0; s < keylen - 1; s++) {
-            const int cur = (val >> ((keylen - s) * 2)) & 0x03;
-            const int last = (val >> ((keylen - s - 1) * 2)) & 0x03;
-            if (cur != last) diff++;
-        }
-        if (diff < 3) continue;
-        if (low_complexity) continue;
-        if (atcg[2] + atcg[3] >= keylen - 2) continue; /* too many GC */
-        if ((k >> 12) == 0xff) continue;               /* starts with GGGG */
-        if (k == 0) continue;
-        if (val > top_count) {
-            top_count = val;
-            topkey = k;
-        }
+/* The seed and the adapter grown from it out of the counters (csrc/adapter_pick.h: the masked arg-max and the two walks the
+   device runs in k_pick_adapter, here over host tables).  poly-A (key 0) reads as never seen, src/evaluator.cpp:191. */
+fpl::pick::Pick pick_adapter_host(const uint32_t* counts, const uint64_t* position_acc, bool is_rna) {
+    namespace pk = fpl::pick;
+    pk::Pick p;
+    p.key = -1;
+    p.count = 0;
+    p.total_key = 0;
+    p.len = 0;
+    p.seq[0] = 0;
+    uint64_t best = 0;
+    for (uint32_t k = 0; k < pk::NKEYS; k++) {
+        const uint32_t val = counts[k];
+        if (val == 0) continue;
+        p.total_key++;
+        if (!pk::key_admissible(k) || !pk::count_digits_vary(val)) continue;
+        const uint64_t r = pk::seed_rank(val, k);
+        if (r > best) best = r;
     }
-    return topkey;
-}
-
-/* Evaluator::extendKeyToAdapter, src/evaluator.cpp:328-404 */
-static string extend_key(int key, const unsigned int* counts, const unsigned long* position_acc, int keylen, bool is_rna,
-                         bool left_first) {
-    string adapter = int2seq((unsigned)key, keylen, is_rna);
-    const int mask = (1 << (keylen * 2)) - 1;
-    const int MAX_LEN = 64;
-    char bases[4] = {'A', 'T', 'C', 'G'};
-    if (is_rna) bases[1] = 'U';
-    bool left_finished = false, right_finished = false;
-    bool extending_left = left_first;
-    while (true) {
-        int curkey = key;
-        while ((int)adapter.length() < MAX_LEN) {
-            int total_count = 0;
-            bool extended = false;
-            for (int b = 0; b < 4; b++) {
-                const int newkey = extending_left ? ((b << ((keylen - 1) * 2)) | (curkey >> 2)) : (b | (mask & (curkey << 2)));
-                total_count += counts[newkey];
-            }
-            for (int b = 0; b < 4; b++) {
-                const int newkey = extending_left ? ((b << ((keylen - 1) * 2)) | (curkey >> 2)) : (b | (mask & (curkey << 2)));
-                if (counts[newkey] == 0) continue;
-                const double offset = (double)position_acc[newkey] / counts[newkey] - (double)position_acc[curkey] / counts[curkey];
-                if ((double)counts[newkey] / (double)total_count < 0.7) continue;
-                if ((double)counts[newkey] / (double)counts[key] < 0.5) continue;
-                if (offset > 2 || offset < -4) continue; /* offset should be near -1.0 */
-                curkey = newkey;
-                extended = true;
-                if (extending_left) adapter.insert(adapter.begin(), bases[b]);
-                else adapter.insert(adapter.end(), bases[b]);
-                break;
-            }
-            if (!extended) {
-                if (extending_left) left_finished = true;
-                else right_finished = true;
-                break;
-            }
-            if ((int)adapter.length() == MAX_LEN) {
-                left_finished = true;
-                right_finished = true;
-                break;
-            }
-        }
-        extending_left = !extending_left; /* finished one side, go to the other */
-        if (left_finished && right_finished) break;
+    if (best) {
+        p.key = (int32_t)~(uint32_t)best;
+        p.count = (uint32_t)(best >> 32);
+        pk::grow(p, is_rna, [&](uint32_t k) { return k ? counts[k] : 0u; }, [&](uint32_t k) { return position_acc[k]; });
     }
-    return adapter;
+    return p;
 }
 
 namespace {
@@ -241,6 +184,8 @@ long evaluate_read_num(const string& path) {
 /* Evaluator::evalAdapterAndReadNum, src/evaluator.cpp:105-266 */
 static KmerCounter g_kmer_counter;
 void set_kmer_counter(KmerCounter f) { g_kmer_counter = std::move(f); }
+static AdapterPicker g_adapter_picker;
+void set_adapter_picker(AdapterPicker f) { g_adapter_picker = std::move(f); }
 
 /* Evaluator::evalAdapterAndReadNum's counting loops, src/evaluator.cpp:300-345 */
 void count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail, uint32_t* counts,
@@ -291,34 +236,33 @@ void detect_adapters(const string& path, int trim_tail, bool is_rna, string& sta
     if (records < 100) return; /* we need at least 100 valid records to evaluate */
     const int shift_tail = max(1, trim_tail);
     const double FOLD_THRESHOLD = 100.0;
-    const int keylen = 10;
-    const int size = 1 << (keylen * 2);
-    vector<unsigned int> counts(size);
-    vector<unsigned long> position_acc(size);
     for (int side = 0; side < 2; side++) {
         string& target = side == 0 ? start : end;
         if (target != "auto") continue;
         cerr << (side == 0 ? "Trying to detect adapter sequence at read start" : "Trying to detect adapter sequence at read end") << endl;
-        long total = 0;
-        int total_key = 0;
-        {
-            /* the counting loops: on the device when the caller has plugged one in (fpl_count_end_kmers), else here */
+        /* counting, seed and growth: on the device when the caller has plugged it in (fpl_pick_adapter), else here.
+           (the start adapter is spelled in DNA letters whatever the input, src/evaluator.cpp:205,246) */
+        const bool rna = side == 0 ? false : is_rna;
+        AdapterVerdict v;
+        bool have = g_adapter_picker && g_adapter_picker(b.seq.data(), b.off.data(), (uint32_t)records, side, shift_tail, rna, v);
+        if (!have) {
+            vector<uint32_t> counts(fpl::pick::NKEYS);
+            vector<uint64_t> position_acc(fpl::pick::NKEYS);
             uint64_t t = 0;
-            static_assert(sizeof(unsigned long) == sizeof(uint64_t), "position_acc is handed over as uint64_t");
             if (!(g_kmer_counter && g_kmer_counter(b.seq.data(), b.off.data(), (uint32_t)records, side, shift_tail, counts.data(),
-                                                   (uint64_t*)position_acc.data(), &t)))
+                                                   position_acc.data(), &t)))
                 count_end_kmers_host(b.seq.data(), b.off.data(), (uint32_t)records, side, shift_tail, counts.data(),
-                                     (uint64_t*)position_acc.data(), &t);
-            total = (long)t;
+                                     position_acc.data(), &t);
+            const fpl::pick::Pick p = pick_adapter_host(counts.data(), position_acc.data(), rna);
+            v.key = p.key;
+            v.count = p.count;
+            v.total_key = p.total_key;
+            v.total = t;
+            v.adapter.assign(p.seq, (size_t)p.len);
         }
-        for (int k = 0; k < size; k++)
-            if (counts[k] > 0) total_key++;
-        counts[0] = 0; /* AAAAAAAAAA */
-        const int key = get_top_key(counts.data(), keylen);
-        const long count = key >= 0 ? counts[key] : 0; /* (the reference indexes counts[-1] when nothing qualifies) */
-        if (key >= 0 && count > 10 && count * total_key > total * FOLD_THRESHOLD) {
-            const string adapter = side == 0 ? extend_key(key, counts.data(), position_acc.data(), keylen, false, true)
-                                             : extend_key(key, counts.data(), position_acc.data(), keylen, is_rna, true);
+        const long count = v.key >= 0 ? (long)v.count : 0; /* (the reference indexes counts[-1] when nothing qualifies) */
+        if (v.key >= 0 && count > 10 && (double)(count * (long)v.total_key) > (double)(long)v.total * FOLD_THRESHOLD) {
+            const string& adapter = v.adapter;
             if (adapter.length() > 16) {
                 cerr << "Detected: " << adapter << endl;
                 target = adapter;
@@ -346,6 +290,14 @@ long fplh_evaluate_read_num(const char* path) { return fplh::evaluate_read_num(p
 void fplh_count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail, uint32_t* counts,
                                uint64_t* position_acc, uint64_t* total) {
     fplh::count_end_kmers_host(seq, off, n_reads, side, shift_tail, counts, position_acc, total);
+}
+/* test hook: seed + grown adapter from host tables (out: >= 72 bytes); returns the seed key */
+int fplh_pick_adapter(const uint32_t* counts, const uint64_t* position_acc, int is_rna, uint32_t* count, uint32_t* total_key, char* out) {
+    const fpl::pick::Pick p = fplh::pick_adapter_host(counts, position_acc, is_rna != 0);
+    if (count) *count = p.count;
+    if (total_key) *total_key = p.total_key;
+    memcpy(out, p.seq, (size_t)p.len + 1);
+    return p.key;
 }
 long fplh_detect_read_num(const char* path) {
     std::string s = "auto", e = "auto";

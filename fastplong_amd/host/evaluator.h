@@ -1,6 +1,7 @@
 /*
- * evaluator.h -- adapter auto-detection of the reference's Evaluator (src/evaluator.cpp:105-266,
- * getTopKey :268-326, extendKeyToAdapter :328-404, int2seq / seq2int :485-560), restated for the host.
+ * evaluator.h -- adapter auto-detection, the host side of the reference's Evaluator (src/evaluator.cpp:105-266; int2seq /
+ * seq2int :485-560).  The seed choice and the growth of the adapter (getTopKey :268-326, extendKeyToAdapter :328-404) are
+ * csrc/adapter_pick.h, shared with the device kernel that runs them for the CLI.
  * It runs once before the batches flow, on the first 64 Ki reads / 512 Mbases of the input, when
  * --start_adapter / --end_adapter are left at "auto" (src/main.cpp:270-277).
  *
@@ -25,6 +26,17 @@ void count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_re
                           uint64_t* position_acc, uint64_t* total);
 using KmerCounter = std::function<bool(const uint8_t*, const uint64_t*, uint32_t, int, int, uint32_t*, uint64_t*, uint64_t*)>;
 void set_kmer_counter(KmerCounter f);
+/* ... or the whole decision for one read end -- counting, seed, growth -- in one call (the CLI: the C-ABI's fpl_pick_adapter):
+ * what Evaluator::evalAdapterAndReadNum (src/evaluator.cpp:191-222) bases its verdict on */
+struct AdapterVerdict {
+    int32_t key = -1;       /* the seed key, -1: none */
+    uint32_t count = 0;     /* its count */
+    uint32_t total_key = 0; /* keys seen at all */
+    uint64_t total = 0;     /* keys counted */
+    std::string adapter;    /* the seed grown in both directions */
+};
+using AdapterPicker = std::function<bool(const uint8_t*, const uint64_t*, uint32_t, int side, int shift_tail, bool is_rna, AdapterVerdict&)>;
+void set_adapter_picker(AdapterPicker f);
 
 std::string int2seq(unsigned int val, int seqlen, bool is_rna = false);
 int seq2int(const char* seq, int rlen, int pos, int keylen, int last_val = -1);
@@ -54,5 +66,6 @@ long fplh_evaluate_read_num(const char* path);
 void fplh_count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail, uint32_t* counts,
                                uint64_t* position_acc, uint64_t* total);
 long fplh_detect_read_num(const char* path); /* the estimate detect_adapters gives */
+int fplh_pick_adapter(const uint32_t* counts, const uint64_t* position_acc, int is_rna, uint32_t* count, uint32_t* total_key, char* out);
 }
 #endif

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 3
+#define FPL_ABI_VERSION 4
 
 /* limits */
 #define FPL_MAX_ADAPTER_LEN 255 /* longest adapter the device path accepts            */
@@ -335,6 +335,21 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n);
  * detection runs before the adapters -- and with them the contexts -- exist (src/main.cpp:270-277). */
 int fpl_count_end_kmers(int32_t device, const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int32_t side, int32_t shift_tail,
                         uint32_t* counts, uint64_t* position_acc, uint64_t* total);
+/* ... and the whole decision on the device (fastplong_amd/csrc/adapter_pick.h): the counters stay in HBM, one more launch
+ * picks the seed -- the admissible key with the largest count, Evaluator::getTopKey (src/evaluator.cpp:268-326) -- and grows it
+ * into an adapter (Evaluator::extendKeyToAdapter, :328-404).  What comes back is what Evaluator::evalAdapterAndReadNum
+ * (:191-222) needs for its verdict: the seed and its count, the number of keys seen, the keys counted, the grown sequence.
+ * key = -1 (len 0) when no key qualifies.  is_rna: T is spelled U. */
+typedef struct fpl_adapter_pick {
+    int32_t key;
+    uint32_t count;
+    uint32_t total_key;
+    int32_t len;
+    uint64_t total;
+    char seq[72]; /* NUL-terminated, <= 64 bases */
+} fpl_adapter_pick;
+int fpl_pick_adapter(int32_t device, const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int32_t side, int32_t shift_tail,
+                     int32_t is_rna, fpl_adapter_pick* out);
 int fpl_reset_counters(fpl_ctx* ctx);
 int fpl_synchronize(fpl_ctx* ctx);
 

@@ -1,0 +1,103 @@
+/*
+ * evaluator_oracle.c -- TEST INFRASTRUCTURE ONLY (part of oracle/liboracle.so).
+ *
+ * Literal restatement, loop by loop, of the two functions of the reference's adapter auto-detection that decide on the
+ * counters: Evaluator::getTopKey (src/evaluator.cpp:268-326) and Evaluator::extendKeyToAdapter (src/evaluator.cpp:328-404).
+ * The product computes the same thing in another form (fastplong_amd/csrc/adapter_pick.h: a masked arg-max and two
+ * directional walks, on the device); tests/test_host_evaluator.py compares the two on seeded counter tables.
+ *
+ * Parity status: UNPINNED.  src/evaluator.cpp includes the FASTQ reader and through it ISA-L headers this image lacks, so the
+ * real object cannot be compiled here; the reference's only known-answer test for this file (test/evaluator_test.cpp) covers
+ * int2seq / seq2int, not these two functions.  What this file gives is an independent SECOND reading of the reference.
+ */
+#include <stdint.h>
+#include <string.h>
+
+/* Evaluator::getTopKey, src/evaluator.cpp:268-326 (its diff test reads the COUNT's bits, `val`, not the key) */
+int orc_eval_top_key(const uint32_t* counts, int keylen) {
+    const int size = 1 << (keylen * 2);
+    int topkey = -1;
+    unsigned int top_count = 0;
+    for (int k = 0; k < size; k++) {
+        const unsigned int val = counts[k];
+        int atcg[4] = {0, 0, 0, 0};
+        for (int i = 0; i < keylen; i++) atcg[(k >> (i * 2)) & 0x03]++;
+        int low_complexity = 0;
+        int zero_num = 0;
+        for (int b = 0; b < 4; b++) {
+            if (atcg[b] >= keylen - 4) low_complexity = 1;
+            if (atcg[b] == 0) zero_num++;
+        }
+        if (zero_num >= 2) low_complexity = 1;
+        if ((k >> keylen) == (k & ((0x01 << keylen) - 1))) low_complexity = 1; /* :287 repetitive */
+        int diff = 0;
+        for (int s = 0; s < keylen - 1; s++) { /* :293-299 */
+            const int cur = (val >> ((keylen - s) * 2)) & 0x03;
+            const int last = (val >> ((keylen - s - 1) * 2)) & 0x03;
+            if (cur != last) diff++;
+        }
+        if (diff < 3) continue;
+        if (low_complexity) continue;
+        if (atcg[2] + atcg[3] >= keylen - 2) continue; /* :305 */
+        if ((k >> 12) == 0xff) continue;               /* :309 */
+        if (k == 0) continue;
+        if (val > top_count) {
+            top_count = val;
+            topkey = k;
+        }
+    }
+    return topkey;
+}
+
+/* Evaluator::extendKeyToAdapter, src/evaluator.cpp:328-404.  out: >= 65 bytes.  Returns the length. */
+int orc_eval_extend_key(int key, const uint32_t* counts, const uint64_t* position_acc, int keylen, int is_rna, int left_first,
+                        char* out) {
+    char buf[160];
+    int lo = 80, hi = 80; /* the adapter is buf[lo, hi) */
+    char bases[4] = {'A', 'T', 'C', 'G'};
+    if (is_rna) bases[1] = 'U';
+    for (int i = 0; i < keylen; i++) buf[hi++] = bases[(key >> (2 * (keylen - 1 - i))) & 3]; /* int2seq, :485-497 */
+    const int mask = (1 << (keylen * 2)) - 1;
+    const int MAX_LEN = 64;
+    int left_finished = 0, right_finished = 0;
+    int extending_left = left_first;
+    while (1) {
+        int curkey = key;
+        while (hi - lo < MAX_LEN) {
+            int total_count = 0;
+            int extended = 0;
+            for (int b = 0; b < 4; b++) {
+                const int newkey = extending_left ? ((b << ((keylen - 1) * 2)) | (curkey >> 2)) : (b | (mask & (curkey << 2)));
+                total_count += (int)counts[newkey];
+            }
+            for (int b = 0; b < 4; b++) {
+                const int newkey = extending_left ? ((b << ((keylen - 1) * 2)) | (curkey >> 2)) : (b | (mask & (curkey << 2)));
+                if (counts[newkey] == 0) continue;
+                const double offset = (double)position_acc[newkey] / counts[newkey] - (double)position_acc[curkey] / counts[curkey];
+                if ((double)counts[newkey] / (double)total_count < 0.7) continue;
+                if ((double)counts[newkey] / (double)counts[key] < 0.5) continue;
+                if (offset > 2 || offset < -4) continue; /* :371 */
+                curkey = newkey;
+                extended = 1;
+                if (extending_left) buf[--lo] = bases[b];
+                else buf[hi++] = bases[b];
+                break;
+            }
+            if (!extended) {
+                if (extending_left) left_finished = 1;
+                else right_finished = 1;
+                break;
+            }
+            if (hi - lo == MAX_LEN) {
+                left_finished = 1;
+                right_finished = 1;
+                break;
+            }
+        }
+        extending_left = !extending_left;
+        if (left_finished && right_finished) break;
+    }
+    memcpy(out, buf + lo, (size_t)(hi - lo));
+    out[hi - lo] = 0;
+    return hi - lo;
+}

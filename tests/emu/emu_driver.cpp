@@ -162,3 +162,14 @@ extern "C" int emu_lev_bp32_end(const char* adapter, int alen, const char* text,
     build_adapter(&ad, adapter, alen);
     return lev_bp32(ad.peq16_end, ad.plen, (const u8*)text, n);
 }
+
+/* k_pick_adapter on the emulator: seed + grown adapter from host tables (out: >= 72 bytes); returns the seed key */
+extern "C" int emu_pick_adapter(const uint32_t* counts, const uint64_t* position_acc, int is_rna, uint32_t* count, uint32_t* total_key,
+                                char* out) {
+    pick::Pick p;
+    emu_launch(k_pick_adapter, dim3(1), dim3(128), counts, (const unsigned long long*)position_acc, is_rna, &p);
+    if (count) *count = p.count;
+    if (total_key) *total_key = p.total_key;
+    memcpy(out, p.seq, (size_t)p.len + 1);
+    return p.key;
+}

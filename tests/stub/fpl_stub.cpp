@@ -224,6 +224,9 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
 int fpl_count_end_kmers(int32_t, const uint8_t*, const uint64_t*, uint32_t, int32_t, int32_t, uint32_t*, uint64_t*, uint64_t*) {
     return FPL_ERR_NO_DEVICE; /* (the tests give -s / -e, or set FPLH_HOST_KMERS) */
 }
+int fpl_pick_adapter(int32_t, const uint8_t*, const uint64_t*, uint32_t, int32_t, int32_t, int32_t, fpl_adapter_pick*) {
+    return FPL_ERR_NO_DEVICE;
+}
 int fpl_reset_counters(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
     std::fill(ctx->counters.begin(), ctx->counters.end(), 0);

@@ -202,3 +202,147 @@ def test_device_kmer_counting_equals_host(side, shift):
     rc = L.fpl_count_end_kmers(0, seq.ctypes.data, off.ctypes.data, len(off) - 1, side, shift, cnt.ctypes.data, pos.ctypes.data, C.byref(tot))
     assert rc == 0 and tot.value == want[2] > 0
     assert np.array_equal(cnt, want[0]) and np.array_equal(pos, want[1])
+
+
+# ---- seed choice and growth (csrc/adapter_pick.h) against the literal restatement of Evaluator::getTopKey /
+# ---- extendKeyToAdapter kept with the checker (oracle/evaluator_oracle.c); parity with the reference itself: unpinned
+
+
+def _pick_tables(seed):
+    """counter tables as the detection sees them: reads with one adapter planted at the start of most of them (noisy copies),
+    plus -- for odd seeds -- random sparse counts sprinkled over the table so that inadmissible keys with large counts, ties and
+    broken chains occur"""
+    import numpy as np
+    from fastplong_amd import build, synth
+    import ctypes as C
+    rng = np.random.default_rng(seed)
+    ad = synth._ACGT[rng.integers(0, 4, int(rng.integers(18, 70)))].astype(np.uint8)
+    reads = []
+    for i in range(int(rng.integers(150, 500))):
+        n = int(rng.integers(150, 500))
+        s_ = synth._ACGT[rng.integers(0, 4, n)].astype(np.uint8)
+        if rng.random() < 0.8:
+            a = ad.copy()
+            for _ in range(int(rng.integers(0, 3))):
+                a[int(rng.integers(0, len(a)))] = synth._ACGT[int(rng.integers(0, 4))]
+            lead = int(rng.integers(0, 3))
+            s_[lead:lead + len(a)] = a[:n - lead]
+        reads.append((s_, np.full(n, 40, np.uint8)))
+    seq, _, off = synth.pack(reads)
+    build.build_host()
+    H = C.CDLL(build.HOST_LIB)
+    cnt, pos, tot = _host_counts(H, np.concatenate([seq, np.zeros(16, np.uint8)]), np.ascontiguousarray(off.astype(np.uint64)), 0, 1)
+    if seed % 2:
+        k = rng.integers(0, 1 << 20, 3000)
+        cnt[k] += rng.integers(1, 400, 3000).astype(np.uint32)
+        pos[k] += (cnt[k].astype(np.uint64) * rng.integers(0, 120, 3000).astype(np.uint64))
+        cnt[0] += 5000  # poly-A: counted as seen, never a seed
+    return cnt, pos, H
+
+
+def _oracle_pick(cnt, pos, is_rna):
+    import ctypes as C
+    from oracle import oracle
+    L = oracle.lib()
+    L.orc_eval_top_key.restype = C.c_int
+    L.orc_eval_top_key.argtypes = [C.c_void_p, C.c_int]
+    L.orc_eval_extend_key.restype = C.c_int
+    L.orc_eval_extend_key.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    c0 = cnt.copy()
+    total_key = int((c0 > 0).sum())
+    c0[0] = 0  # src/evaluator.cpp:191
+    key = L.orc_eval_top_key(c0.ctypes.data, 10)
+    if key < 0:
+        return key, 0, total_key, b""
+    out = C.create_string_buffer(80)
+    L.orc_eval_extend_key(key, c0.ctypes.data, pos.ctypes.data, 10, int(is_rna), 1, out)
+    return key, int(c0[key]), total_key, out.value
+
+
+def _run_pick(fn, cnt, pos, is_rna):
+    import ctypes as C
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_char_p]
+    c, tk = C.c_uint32(0), C.c_uint32(0)
+    out = C.create_string_buffer(80)
+    key = fn(cnt.ctypes.data, pos.ctypes.data, int(is_rna), C.byref(c), C.byref(tk), out)
+    return key, int(c.value), int(tk.value), out.value
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_host_seed_and_growth_equal_the_literal_restatement(orc, seed):
+    cnt, pos, H = _pick_tables(seed)
+    want = _oracle_pick(cnt, pos, seed % 3 == 0)
+    got = _run_pick(H.fplh_pick_adapter, cnt, pos, seed % 3 == 0)
+    assert got == want, (got, want)
+    assert want[0] >= 0
+    if seed % 2 == 0:
+        assert len(want[3]) > 10  # the planted adapter is found and grown (the noise of the odd seeds may stop the walk)
+
+
+def test_pick_rules_on_single_keys(orc):
+    """every rule that bars a key from being the seed, one table each: the rule's key holds the largest count, a plain key the
+    second largest"""
+    import numpy as np
+    import ctypes as C
+    from fastplong_amd import build
+    build.build_host()
+    H = C.CDLL(build.HOST_LIB)
+    code = {"A": 0, "T": 1, "C": 2, "G": 3}
+    enc = lambda s_: sum(code[c] << (2 * (9 - i)) for i, c in enumerate(s_))  # noqa: E731
+    plain = enc("ACGTTGCAAC")
+    for barred in ["AAAAAAAAAA", "AAAAAACGTC", "ACACACACAC", "ACGTCACGTC", "GGCCGGCCAT", "GGGGACTAGC", "ATATATATCG"]:
+        for val in (1000, 0x15555, 3, 0b111001):  # the count's own digits decide too (count_digits_vary)
+            cnt = np.zeros(1 << 20, np.uint32)
+            pos = np.zeros(1 << 20, np.uint64)
+            cnt[enc(barred)] = val + 7
+            cnt[plain] = val
+            want = _oracle_pick(cnt, pos, False)
+            got = _run_pick(H.fplh_pick_adapter, cnt, pos, False)
+            assert got == want, (barred, val, got, want)
+
+
+@pytest.mark.parametrize("seed", [1, 4, 7])
+def test_emulated_pick_kernel_equals_host(seed):
+    """k_pick_adapter (what fpl_pick_adapter runs behind the counting) on the CPU emulator against the host form"""
+    from tests.emu import emu
+    cnt, pos, H = _pick_tables(seed)
+    want = _run_pick(H.fplh_pick_adapter, cnt, pos, seed == 4)
+    got = _run_pick(emu.lib().emu_pick_adapter, cnt, pos, seed == 4)
+    assert got == want and want[0] >= 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,rna", [(0, 0), (1, 0), (1, 1)])
+def test_device_pick_adapter_equals_host(side, rna):
+    """fpl_pick_adapter through the C-ABI on the GPU (counting + seed + growth in HBM) against the host path on the same reads"""
+    import ctypes as C
+    import numpy as np
+    from fastplong_amd import abi, build, engine, synth
+    build.build_host()
+    H = C.CDLL(build.HOST_LIB)
+    L = engine.load_library()
+    rng = np.random.default_rng(31 + side)
+    ad = synth._ACGT[rng.integers(0, 4, 34)].astype(np.uint8)
+    if rna:
+        ad[ad == ord("T")] = ord("U")
+    reads = []
+    for i in range(400):
+        n = int(rng.integers(200, 700))
+        s_ = synth._ACGT[rng.integers(0, 4, n)].astype(np.uint8)
+        if rna:
+            s_[s_ == ord("T")] = ord("U")
+        if rng.random() < 0.85:
+            if side == 0:
+                s_[:34] = ad
+            else:
+                s_[n - 35:n - 1] = ad
+        reads.append((s_, np.full(n, 40, np.uint8)))
+    seq, _, off = synth.pack(reads)
+    off = np.ascontiguousarray(off.astype(np.uint64))
+    cnt, pos, tot = _host_counts(H, np.concatenate([seq, np.zeros(16, np.uint8)]), off, side, 1)
+    want = _run_pick(H.fplh_pick_adapter, cnt, pos, rna)
+    p = abi.FplAdapterPick()
+    rc = L.fpl_pick_adapter(0, np.ascontiguousarray(seq).ctypes.data, off.ctypes.data, len(off) - 1, side, 1, rna, C.byref(p))
+    assert rc == 0
+    assert (p.key, p.count, p.total_key, p.seq) == want and p.total == tot and p.len == len(want[3]) > 20
