@@ -628,21 +628,33 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qua
     int r = ensure_slot(ctx, sl, n_reads, n_bytes);
     if (r != FPL_OK) return r;
     /* (the slot's previous batch has been waited for -- FPL_MAX_IN_FLIGHT slots, FIFO -- so its buffers are free) */
-    if (n_bytes) {
-        FPL_HIP(hipMemcpyAsync(sl.d_seq, seq, n_bytes, hipMemcpyHostToDevice, ctx->s_h2d));
-        FPL_HIP(hipMemcpyAsync(sl.d_qual, qual, n_bytes, hipMemcpyHostToDevice, ctx->s_h2d));
+    auto enqueue = [&]() -> int {
+        if (n_bytes) {
+            FPL_HIP(hipMemcpyAsync(sl.d_seq, seq, n_bytes, hipMemcpyHostToDevice, ctx->s_h2d));
+            FPL_HIP(hipMemcpyAsync(sl.d_qual, qual, n_bytes, hipMemcpyHostToDevice, ctx->s_h2d));
+        }
+        FPL_HIP(hipMemcpyAsync(sl.d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, ctx->s_h2d));
+        FPL_HIP(hipEventRecord(sl.ev_h2d, ctx->s_h2d));
+        FPL_HIP(hipStreamWaitEvent(ctx->stream, sl.ev_h2d, 0));
+        const int rd = fpl_process_batch_device(ctx, sl.d_seq, sl.d_qual, sl.d_off, n_reads, n_bytes, max_len, sl.d_results, ctx->stream);
+        if (rd != FPL_OK) return rd;
+        /* the records leave on their own stream, so that they do not queue behind the next batch's input copies */
+        FPL_HIP(hipEventRecord(sl.ev_kern, ctx->stream));
+        FPL_HIP(hipStreamWaitEvent(ctx->s_d2h, sl.ev_kern, 0));
+        FPL_HIP(hipMemcpyAsync(sl.h_results, sl.d_results, sizeof(fpl_read_result) * (size_t)n_reads, hipMemcpyDeviceToHost,
+                               ctx->s_d2h));
+        FPL_HIP(hipEventRecord(sl.ev_done, ctx->s_d2h));
+        return FPL_OK;
+    };
+    r = enqueue();
+    if (r != FPL_OK) {
+        /* "nothing is in flight" is what the caller reads into an error here: it recycles the host arrays at once.  Copies or
+           kernels that did get enqueued before the failing call may still read them (and the slot): wait them out first. */
+        (void)hipStreamSynchronize(ctx->s_h2d);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->s_d2h);
+        return r;
     }
-    FPL_HIP(hipMemcpyAsync(sl.d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, ctx->s_h2d));
-    FPL_HIP(hipEventRecord(sl.ev_h2d, ctx->s_h2d));
-    FPL_HIP(hipStreamWaitEvent(ctx->stream, sl.ev_h2d, 0));
-    r = fpl_process_batch_device(ctx, sl.d_seq, sl.d_qual, sl.d_off, n_reads, n_bytes, max_len, sl.d_results, ctx->stream);
-    if (r != FPL_OK) return r;
-    /* the records leave on their own stream, so that they do not queue behind the next batch's input copies */
-    FPL_HIP(hipEventRecord(sl.ev_kern, ctx->stream));
-    FPL_HIP(hipStreamWaitEvent(ctx->s_d2h, sl.ev_kern, 0));
-    FPL_HIP(hipMemcpyAsync(sl.h_results, sl.d_results, sizeof(fpl_read_result) * (size_t)n_reads, hipMemcpyDeviceToHost,
-                           ctx->s_d2h));
-    FPL_HIP(hipEventRecord(sl.ev_done, ctx->s_d2h));
     ctx->submitted++;
     return FPL_OK;
 }

@@ -78,7 +78,7 @@ static const Flag FLAGS[] = {
     {"report_title", 'R', true, "fastplong report"}, {"thread", 'w', true, "3"}, {"split", 0, true, "0"},
     {"split_by_lines", 0, true, "0"}, {"split_prefix_digits", 0, true, "4"},
     {"gpus", 0, true, "1"}, {"batch_mbases", 0, true, "256"}, {"batch_reads", 0, true, "0"},
-    {"reader_threads", 0, true, "0"}, {"chunk_mb", 0, true, "32"},
+    {"reader_threads", 0, true, "0"}, {"chunk_mb", 0, true, "32"}, {"gz_stream", 0, false, ""},
 };
 
 struct Args {
@@ -559,11 +559,16 @@ int main(int argc, char* argv[]) {
                write): the members are inflated side by side into anonymous memory, which the chunk parsers then take like
                a mapped file.  One deflate stream, or more text than a third of the machine's memory: the sequential
                reader and its stream.  (FPLH_NO_GZ_EXPAND: measurement / test hook) */
-            if (gz_file && !getenv("FPLH_NO_GZ_EXPAND") && (uint64_t)st.st_size > chunkBytes / 8) { /* (small inputs: the stream) */
+            /* The whole text sits in memory until the parsers have passed it: it may take what the process can still get --
+               MemAvailable and the cgroup's limit, whichever is smaller -- less the page-locked arena and the batches in
+               flight (2 GiB), and of that no more than half; anything larger is streamed.  --gz_stream (or FPLH_NO_GZ_EXPAND)
+               forces the stream. */
+            if (gz_file && !cmd.exist("gz_stream") && !getenv("FPLH_NO_GZ_EXPAND") && (uint64_t)st.st_size > chunkBytes / 8) { /* (small inputs: the stream) */
                 const double t0 = clk();
-                const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
+                const uint64_t budget = fplh::memory_budget(), hold = 2ull << 30;
+                const uint64_t cap = budget > hold ? (budget - hold) / 2 : 0;
                 uint64_t sz = 0, reserved = 0;
-                chunkMem = fplh::gunzip_members_to_memory(in, max(4, min(64, hw)), phys / 3, &sz, &reserved);
+                chunkMem = cap ? fplh::gunzip_members_to_memory(in, max(4, min(64, hw)), cap, &sz, &reserved) : nullptr;
                 if (chunkMem && sz <= chunkBytes) { /* one chunk of text: not worth the parsers */
                     munmap((void*)chunkMem, (size_t)reserved);
                     chunkMem = nullptr;
@@ -577,8 +582,15 @@ int main(int argc, char* argv[]) {
         }
     }
     int readerThreads = cmd.i("reader_threads");
-    if (readerThreads <= 0) readerThreads = max(2, min(16, hw / 2)); /* (half of the CPUs parse, the rest formats, copies and writes) */
+    /* (half of the CPUs parse, the rest formats, copies and writes; sixteen parsers feed one device's PCIe link with room to
+       spare -- 4.7 GB/s of text each -- so several devices get sixteen each, as far as the CPUs go) */
+    if (readerThreads <= 0) readerThreads = max(2, min(16 * nGpus, hw / 2));
     const bool chunked = (chunkFd >= 0 || chunkMem) && chunkFileSize > chunkBytes;
+    /* the chunk parsers cut the batches: one per --chunk_mb of text; --batch_mbases / --batch_reads only size the batches
+       of the sequential reader (pipes, streamed gzip, --reads_to_process) */
+    if (chunked && (cmd.exist("batch_mbases") || cmd.exist("batch_reads")))
+        cerr << "WARNING: --batch_mbases / --batch_reads do not apply to this input: its batches are the chunks of --chunk_mb ("
+             << (chunkBytes >> 20) << " MB of text each); lower --chunk_mb for smaller batches" << endl;
     fplh::FastqReader* reader = nullptr;
     /* Work objects bound what is in flight: one per parser, FPL_MAX_IN_FLIGHT per device in the copy / kernel stage,
        one per device being formatted, two waiting for the writer */

@@ -62,6 +62,39 @@ int effective_cpus() {
     return cached;
 }
 
+/* Bytes of memory this process may still take: the smaller of what the machine has available (MemAvailable) and what its
+   cgroup leaves (memory.max - memory.current, v2; limit_in_bytes - usage_in_bytes, v1) -- a container's limit is usually far
+   below the node's RAM, and going over it is a kill, not an error.  FPLH_MEM_BYTES overrides (tests). */
+uint64_t memory_budget() {
+    if (const char* e = getenv("FPLH_MEM_BYTES"))
+        if (atoll(e) > 0) return (uint64_t)atoll(e);
+    auto number = [](const char* path, uint64_t& v) -> bool {
+        FILE* f = fopen(path, "r");
+        if (!f) return false;
+        char a[64] = {0};
+        const bool got = fscanf(f, "%63s", a) == 1;
+        fclose(f);
+        if (!got || a[0] < '0' || a[0] > '9') return false; /* "max": no limit */
+        v = strtoull(a, nullptr, 10);
+        return true;
+    };
+    uint64_t best = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
+    if (FILE* f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof(line), f)) {
+            unsigned long long kb = 0;
+            if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) best = min<uint64_t>(best, (uint64_t)kb << 10);
+        }
+        fclose(f);
+    }
+    uint64_t lim = 0, use = 0;
+    if (number("/sys/fs/cgroup/memory.max", lim) || number("/sys/fs/cgroup/memory/memory.limit_in_bytes", lim)) {
+        if (!number("/sys/fs/cgroup/memory.current", use)) number("/sys/fs/cgroup/memory/memory.usage_in_bytes", use);
+        if (lim < (1ull << 60)) best = min<uint64_t>(best, lim > use ? lim - use : 0);
+    }
+    return best;
+}
+
 namespace {
 class Pool {
    public:
@@ -367,17 +400,33 @@ static char* gunzip_single_to_memory(const string& path, uint64_t max_bytes, uin
     if (in == (const unsigned char*)MAP_FAILED) return nullptr;
     char* result = nullptr;
     if (in[0] == 0x1f && in[1] == 0x8b && in[2] == 8) {
-        size_t tail = fsize; /* zlib ignores zero padding behind the last member: so does this */
-        while (tail > 18 && in[tail - 1] == 0 && tail > fsize - 4096) tail--;
-        for (int pad = 0; pad < 4 && !result; pad++) { /* (the size field itself may end in zero bytes) */
-            const size_t end = min(fsize, tail + (size_t)pad);
-            if (end < 18) break;
+        /* where the member ends: at the end of the file -- or, when zero bytes trail it (zlib ignores padding behind the last
+           member: so does this), 0..3 bytes behind the last non-zero byte (the size field itself may end in zero bytes).  The
+           likeliest end is tried first -- the file's own when fewer than four zero bytes trail it, else the last non-zero
+           byte's (a size field whose top byte is zero means a text within 16 MiB of a multiple of 4 GiB) -- and a member that
+           is followed by another one ends the attempt */
+        size_t tail = fsize;
+        while (tail > 18 && in[tail - 1] == 0 && (fsize < 4096 || tail > fsize - 4096)) tail--;
+        size_t ends[5];
+        int n_ends = 0;
+        const bool padded = fsize - tail >= 4; /* four zero bytes at the very end: padding, or a text of k * 4 GiB */
+        if (!padded) ends[n_ends++] = fsize;
+        for (int pad = 0; pad < 4 && tail < fsize; pad++)
+            if (tail + (size_t)pad < fsize) ends[n_ends++] = tail + (size_t)pad;
+        if (padded) ends[n_ends++] = fsize;
+        bool give_up = false;
+        for (int e = 0; e < n_ends && !result && !give_up; e++) {
+            const size_t end = ends[e];
+            if (end < 18) continue;
             const uint64_t isize = (uint64_t)in[end - 4] | ((uint64_t)in[end - 3] << 8) | ((uint64_t)in[end - 2] << 16) | ((uint64_t)in[end - 1] << 24);
             for (uint64_t want = isize; want <= max_bytes && !result; want += 1ull << 32) {
                 if (want == 0) continue;
                 const uint64_t span = want + (4u << 20);
                 char* base = (char*)mmap(nullptr, (size_t)span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-                if (base == (char*)MAP_FAILED) break;
+                if (base == (char*)MAP_FAILED) {
+                    give_up = true;
+                    break;
+                }
                 madvise(base, (size_t)span, MADV_HUGEPAGE); /* (one fault per 2 MiB instead of per 4 KiB as the text arrives) */
                 size_t used = 0, made = 0;
                 const int rc = gunzip_member_into(in, end, base, (size_t)want, &used, &made);
@@ -388,7 +437,16 @@ static char* gunzip_single_to_memory(const string& path, uint64_t max_bytes, uin
                     break;
                 }
                 munmap(base, (size_t)span);
-                if (rc != 2) break; /* damaged, several members, no libdeflate: not for this lane */
+                if (rc == 2) continue; /* more text than this candidate size: the next one */
+                /* a whole member that stops in front of this end with something other than padding behind it: several
+                   members, not for this lane.  Anything else (a trailer cut short by a wrong guess of the padding, a size that
+                   does not match): the next guess of where the member ends */
+                if (rc == 1 && used < end) {
+                    size_t z = used;
+                    while (z < end && in[z] == 0) z++;
+                    if (z < end) give_up = true;
+                }
+                break;
             }
         }
     }
@@ -499,13 +557,13 @@ void ByteBuf::set_arena(size_t block_bytes, size_t n_blocks) {
 void ByteBuf::release_arena() {
     lock_guard<mutex> g(g_arena.mu);
     if (g_arena.base && g_free && !g_arena.released) g_free(g_arena.base);
-    g_arena.released = true; /* (owns() stays true for stale pointers: their release is then a no-op push) */
+    g_arena.released = true; /* (owns() stays true: a buffer of the arena that is destroyed later is simply dropped) */
     g_arena.free_blocks.clear();
 }
 static void buf_release(uint8_t* p) {
     if (g_arena.owns(p)) {
         lock_guard<mutex> g(g_arena.mu);
-        g_arena.free_blocks.push_back(p);
+        if (!g_arena.released) g_arena.free_blocks.push_back(p); /* (a released arena hands nothing out again) */
     } else if (g_free) {
         g_free(p);
     } else {
@@ -519,7 +577,7 @@ void ByteBuf::reserve(size_t c) {
     if (c <= cap_) return;
     uint8_t* np = nullptr;
     size_t nc = 0;
-    if (g_arena.base && c <= g_arena.block) {
+    if (g_arena.base && !g_arena.released && c <= g_arena.block) {
         lock_guard<mutex> g(g_arena.mu);
         if (!g_arena.free_blocks.empty()) {
             np = g_arena.free_blocks.back();

@@ -29,6 +29,7 @@ void parallel_run(int tasks, const std::function<void(int)>& fn);
    CPU bandwidth quota (cpu.max / cpu.cfs_quota_us) -- a container on a 256-thread node with a 16-CPU quota is throttled,
    not sped up, by 64 busy threads (FPLH_CPUS overrides) */
 int effective_cpus();
+uint64_t memory_budget(); /* bytes this process may still take: MemAvailable and the cgroup's limit */
 
 /* growable byte array without the zero fill of std::vector::resize (batches are hundreds of megabytes and
  * every byte is overwritten by the parser's copy threads).  The memory comes from a process-wide allocator pair the
