@@ -472,21 +472,19 @@ def main(argv=None, rig=None):
     if rank == 0:
         counters = eng.counters()
         v = abi.CountersView(counters, C, eng.n_adapters)
-        dom = max(ktimes, key=ktimes.get)
-        dom_ms = ktimes[dom] / max(1, nbatches)
-        achieved = ALGO_BYTES_PER_BASE * n_bases / (dom_ms * 1e-3) / 1e9
         ms_per_step = dt / args.steps * 1e3
         # HBM bytes and vector wave-instructions per launch: PMC counters come from separate rocprofv3 --pmc passes of
         # this same command (profiles/kernel_counters.json records them per base, HBM bytes corrected as
         # MI355X_MICROARCH.md prescribes); --hbm-traffic overrides the dominant kernel's, null when nothing is recorded
         prof = {} if (args.set or args.median_len) else profile_record(args.workload)
         hbm_pb, valu_pb = prof.get("hbm_bytes_per_base", {}), prof.get("valu_insts_per_base", {})
-        # (the HIP-event stages group kernels: k_stats = the bucket kernels + k_stats_sorted + its reduce, ...)
-        stage_of = {"k_trim_ends": ("k_trim_ends", "k_trim_ends_batched"), "k_scan": ("k_scan",),
-                    "k_resolve": ("k_resolve", "k_redo", "k_break_mask"),
-                    "k_stats": ("k_stats", "k_stats_sorted", "k_stats_reduce_sorted", "k_bucket_count", "k_bucket_scan",
-                                "k_bucket_plan", "k_bucket_scatter"),
-                    "k_stats_extra": ("k_stats_extra", "k_stats_reduce")}
+        # (HIP-event stages, csrc/pipeline.h: k_trim_ends, k_scan and k_stats are single launches -- their event times are kernel
+        # durations, and the dominant kernel is the longest of them; k_resolve, k_stats_prep, k_stats_reduce, k_stats_extra
+        # group short kernels)
+        single = {k: v for k, v in ktimes.items() if k in ("k_trim_ends", "k_scan", "k_stats")} or ktimes
+        dom = max(single, key=single.get)
+        dom_ms = ktimes[dom] / max(1, nbatches)
+        achieved = ALGO_BYTES_PER_BASE * n_bases / (dom_ms * 1e-3) / 1e9
         dom_kernel = {"k_stats": "k_stats_sorted" if "k_stats_sorted" in hbm_pb else "k_stats",
                       "k_trim_ends": "k_trim_ends_batched" if "k_trim_ends_batched" in hbm_pb else "k_trim_ends"}.get(dom, dom)
         traffic, traffic_src = args.hbm_traffic, "--hbm-traffic"

@@ -693,10 +693,11 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
                                                const PT* __restrict__ peq16,
                                                const uint64_t (*__restrict__ peqf)[PW],
                                                const DevConfig* __restrict__ cfg, int& keylen,
-                                               bool may_full = true, bool may_part = true) {
+                                               bool may_full = true, bool may_part = true, int hint_lo = 0, int hint_hi = 0x3fffffff) {
     /* may_full / may_part (wave-uniform): false when the caller has PROOF that the whole-adapter search / the partial-
        pattern search finds nothing here (fasta_may_trim32) -- the search, and the Levenshtein run on its best window, are
-       then left out */
+       then left out.  [hint_lo, hint_hi] (wave-uniform): the only positions the partial-pattern search can accept
+       (fasta_hint_range); a range of <= 64 positions is ONE round of windows instead of three */
     const int lane = lane_id();
     const int rlen = e - s;
     keylen = 0;
@@ -753,6 +754,11 @@ __device__ __forceinline__ int trim_start_wave(const Win<LDSWIN>& win, int& s, i
     u64 best = ~0ull;
     /* lim <= 184: three positions per lane, evaluated as three independent chains in one straight-line
        block (positions past lim are clamped for the loads and masked afterwards) */
+    if (MODE == 2 && lim > 0 && hint_hi - hint_lo < 64) { /* (MODE 2: plen == 16) */
+        const int p = hint_lo + lane;
+        const int ed = lev16_win<true>(win, min(p, lim - 1), peq16, 16, 16);
+        if (p <= hint_hi && p < lim && ed <= thrP) best = ((u64)(u32)ed << 32) | (u32)p;
+    } else
     for (int p0 = 0; p0 < lim && !FPL_DBG(cfg->dbg, 128); p0 += 192) {
         int pp[3], ed[3];
 #pragma unroll
@@ -797,7 +803,8 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
                                              const PT* __restrict__ peq16,
                                              const uint64_t (*__restrict__ peqf)[PW],
                                              const DevConfig* __restrict__ cfg, int& keylen,
-                                             bool may_full = true, bool may_part = true) { /* (see trim_start_wave) */
+                                             bool may_full = true, bool may_part = true, int hint_lo = 0,
+                                             int hint_hi = 0x3fffffff) { /* (see trim_start_wave) */
     const int lane = lane_id();
     const int rlen = e - s;
     keylen = 0;
@@ -856,7 +863,14 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
     int pos = -1, mined = -1;
     bool stop = false;
     int ed3[3];
-    if (MODE != 0 || plen == 16) {
+    /* (hinted: the qualifying positions all lie in [hint_lo, hint_lo + 64): one round starting there -- the walk below only
+       ever looks at qualifying positions, in ascending order) */
+    const bool one_round = MODE == 2 && lim > 0 && hint_hi - hint_lo < 64;
+    const int first = one_round ? hint_lo : 0, last = one_round ? min(lim, hint_hi + 1) : lim;
+    if (one_round) {
+        ed3[0] = lev16_win<true>(win, rlen - 16 - min(first + lane, lim - 1), peq16, 16, 16);
+        ed3[1] = ed3[2] = 0x7fffffff;
+    } else if (MODE != 0 || plen == 16) {
 #pragma unroll
         for (int u = 0; u < 3; u++) /* lim <= 184 = three rounds; independent chains, one straight-line block */
             ed3[u] = lim > 0 ? lev16_win<true>(win, rlen - 16 - min(64 * u + lane, lim - 1), peq16, 16, 16) : 0x7fffffff;
@@ -865,14 +879,14 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
         for (int u = 0; u < 3; u++)
             ed3[u] = lim > 0 ? lev16_win<false>(win, rlen - plen - min(64 * u + lane, lim - 1), peq16, plen, plen) : 0x7fffffff;
     }
-    for (int p0 = 0; p0 < lim && !stop; p0 += 64) {
+    for (int p0 = first; p0 < last && !stop; p0 += 64) {
         const int p = p0 + lane;
         /* (an adapter of fewer than 8 bases has up to 194 positions: the ones behind the three precomputed rounds
            are evaluated here; the reduced instantiations only see partial patterns of 16 columns, 184 positions) */
-        int edr = p0 == 0 ? ed3[0] : (p0 == 64 ? ed3[1] : ed3[2]);
+        int edr = p0 == first ? ed3[0] : (p0 == 64 ? ed3[1] : ed3[2]);
         if (MODE == 0 && p0 >= 192) edr = lev16_win<false>(win, rlen - plen - min(p0 + lane, lim - 1), peq16, plen, plen);
-        const int ed = p < lim ? edr : 0x7fffffff;
-        u64 q = wave_ballot(p < lim && ed <= thrP);
+        const int ed = p < last ? edr : 0x7fffffff;
+        u64 q = wave_ballot(p < last && ed <= thrP);
         while (q && !stop) {
             const int b = __ffsll(q) - 1;
             q &= q - 1;
@@ -1045,27 +1059,67 @@ __device__ __forceinline__ u32 fasta_may_trim32(const FastaPeqLds* __restrict__ 
     const int lane = lane_id();
     const int m = min(alen, 32);
     u32 Pv = m >= 32 ? ~0u : ((1u << m) - 1u), Mv = 0;
-    int scF = m, scP = 16, bestF = m, bestP = 16;
+    int scF = m, scP = 16, bestF = m;
+    u32 blocks = 0; /* bit b: the partial pattern's score got down to thrP somewhere in columns [32 b, 32 b + 32) */
     const u32 topF = (u32)(m - 1);
-    for (int j = 0; j < n; j++) {
-        const u32 c = uniform_u32((u32)win[(START ? n - 1 - j : j) + boff]); /* the same byte for every lane */
-        const u32 code = (c >> 1) & 3u;
-        const u32 row = (((0x47544341u >> (8 * code)) & 0xFFu) == c) ? code : 4u;
-        const u32 Eq = t->w[row][START ? 2 : 3][lane];
-        const u32 Xv = Eq | Mv;
-        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-        u32 Ph = Mv | ~(Xh | Pv);
-        u32 Mh = Pv & Xh;
-        scF += (int)((Ph >> topF) & 1u) - (int)((Mh >> topF) & 1u);
-        scP += (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
-        Ph <<= 1; /* (no "| 1": a match may start anywhere) */
-        Mh <<= 1;
-        Pv = Mh | ~(Xv | Ph);
-        Mv = Ph & Xv;
-        bestF = min(bestF, scF);
-        bestP = min(bestP, scP);
+    for (int j0 = 0; j0 < n; j0 += 32) { /* (n <= 200: seven blocks at most) */
+        int blkP = 16 + 32;
+        const int j1 = min(n, j0 + 32);
+        /* eight columns at a time: their window bytes (the same byte for every lane) and then their Peq words are fetched
+           together -- one byte, one word and two trips to LDS per column kept the wave waiting most of the time */
+        for (int jj = j0; jj < j1; jj += 8) {
+            u32 cb[8], Eqs[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = min(jj + u, n - 1);
+                cb[u] = (u32)win[(START ? n - 1 - j : j) + boff];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const u32 c = uniform_u32(cb[u]);
+                const u32 code = (c >> 1) & 3u;
+                const u32 row = (((0x47544341u >> (8 * code)) & 0xFFu) == c) ? code : 4u;
+                Eqs[u] = t->w[row][START ? 2 : 3][lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (jj + u < j1) { /* wave-uniform */
+                    const u32 Eq = Eqs[u];
+                    const u32 Xv = Eq | Mv;
+                    const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                    u32 Ph = Mv | ~(Xh | Pv);
+                    u32 Mh = Pv & Xh;
+                    scF += (int)((Ph >> topF) & 1u) - (int)((Mh >> topF) & 1u);
+                    scP += (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
+                    Ph <<= 1; /* (no "| 1": a match may start anywhere) */
+                    Mh <<= 1;
+                    Pv = Mh | ~(Xv | Ph);
+                    Mv = Ph & Xv;
+                    bestF = min(bestF, scF);
+                    blkP = min(blkP, scP);
+                }
+            }
+        }
+        blocks |= (blkP <= thrP ? 1u : 0u) << (j0 >> 5);
     }
-    return a_ok ? ((bestF <= thrA ? 1u : 0u) | (bestP <= thrP ? 2u : 0u)) : 0u; /* bit 0: the whole adapter may match, 1: its partial pattern */
+    /* bit 0: the whole adapter may match, bit 1: its partial pattern; bits 8..: where (blocks of 32 columns) */
+    return a_ok ? ((bestF <= thrA ? 1u : 0u) | (blocks ? 2u : 0u) | (blocks << 8)) : 0u;
+}
+/* The positions p of a partial-pattern search (window of 16 bases at p, src/adaptertrimmer.cpp:202-216 / :273-286) that the
+   filter's verdict leaves open, [lo, hi]: column j of the run is the LAST byte of the end trim's window p = n - 1 - j (its
+   windows end at byte n - 1 - p of the staged tail), and -- the start trim's run walks its window backwards -- the FIRST byte
+   of the start trim's window p = n - 1 - j.  The semi-global score at a column bounds the global distance of the 16-base
+   window that ends there from below, so every p the exact search could accept lies in the range. */
+__device__ __forceinline__ void fasta_hint_range(u32 verdict, int n, int& lo, int& hi) {
+    const u32 blocks = verdict >> 8;
+    if (!blocks) {
+        lo = 1;
+        hi = 0;
+        return;
+    }
+    const int jlo = 32 * (__ffs((int)blocks) - 1), jhi = min(n - 1, 32 * (31 - __clz((int)blocks)) + 31);
+    lo = n - 1 - jhi;
+    hi = n - 1 - jlo;
 }
 /* can this lane's adapter (length alen in 16..64, thresholds thrA / thrP) trim at this end?  win = the window bytes in
    LDS (window byte j at win[j + boff]), n of them; START: the start trim (partial pattern = the adapter's last 16 bases) */
@@ -1226,7 +1280,10 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
             /* which adapters of the current group of 64 can trim the start / the end of r1 as it is now (fasta_may_trim) */
             u64 may_s = ~0ull, may_e = ~0ull;
             u64 full_s = ~0ull, part_s = ~0ull, full_e = ~0ull, part_e = ~0ull; /* ... and which of its two searches could succeed */
+            u32 verd_s = 0, verd_e = 0; /* this lane's adapter: the filter's verdicts (fasta_may_trim32), incl. where the partial pattern may sit */
+            int fn_s = 0, fn_e = 0;     /* window bytes the verdicts were made on */
             bool masks_ok = false;
+            bool dirty_s = true, dirty_e = true; /* which end's verdicts are out of date */
             auto refresh_masks = [&](int a) {
                 const int g = a >> 6, ai = g * 64 + lane;
                 const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
@@ -1245,6 +1302,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     fasta_peq_store(fp, la, a_ok);
                     wave_sync();
                     fp_group = g;
+                    dirty_s = dirty_e = true;
                 }
                 const int alen = la->len;
                 const int thrA = cfg->thr[alen], thrP = cfg->thr[FPL_PATTERN_LEN];
@@ -1253,16 +1311,23 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     return;
                 }
 #if FPL_OPT_FASTAFILTER == 2
-                {
-                    const u32 fs_ = fasta_may_trim32<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok);
-                    const u32 fe_ = fasta_may_trim32<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok);
-                    full_s = wave_ballot((fs_ & 1u) != 0);
-                    part_s = wave_ballot((fs_ & 2u) != 0);
-                    full_e = wave_ballot((fe_ & 1u) != 0);
-                    part_e = wave_ballot((fe_ & 2u) != 0);
+                /* (a trim at one end leaves the other end's window -- and with it that end's verdicts -- as they were, unless r1
+                   has become shorter than the window) */
+                if (dirty_s) {
+                    verd_s = fasta_may_trim32<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok);
+                    fn_s = wl;
+                    full_s = wave_ballot((verd_s & 1u) != 0);
+                    part_s = wave_ballot((verd_s & 2u) != 0);
                     may_s = full_s | part_s;
+                }
+                if (dirty_e) {
+                    verd_e = fasta_may_trim32<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok);
+                    fn_e = wl;
+                    full_e = wave_ballot((verd_e & 1u) != 0);
+                    part_e = wave_ballot((verd_e & 2u) != 0);
                     may_e = full_e | part_e;
                 }
+                dirty_s = dirty_e = false;
 #else
                 may_s = wave_ballot(fasta_may_trim<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok));
                 may_e = wave_ballot(fasta_may_trim<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok));
@@ -1275,6 +1340,15 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     __atomic_fetch_add(&g_filter_stats[2], (unsigned long long)__builtin_popcountll(may_e), __ATOMIC_RELAXED);
                 }
 #endif
+            };
+            /* r1 moved from [s0, e0) to [s, e): which windows -- and verdicts -- that leaves standing */
+            auto moved = [&](int s0, int e0) {
+                const int rl = e - s;
+                stale_s = stale_s || s != s0 || rl < FPL_END_WINDOW;
+                stale_e = stale_e || e != e0 || rl < FPL_END_WINDOW;
+                dirty_s = dirty_s || s != s0 || rl < FPL_END_WINDOW;
+                dirty_e = dirty_e || e != e0 || rl < FPL_END_WINDOW;
+                masks_ok = false; /* what can trim r1 has to be asked again */
             };
             for (int a = 0; MODE != 1 && a < cfg->n_fasta; a++) {
                 const DevAdapter* ad = &ads[2 + a];
@@ -1297,13 +1371,12 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_s, 0, e - s, win4_s};
+                    int hlo = 0, hhi = 0x3fffffff;
+                    if (FILT && FPL_OPT_FASTAFILTER == 2) fasta_hint_range(readlane_u32(verd_s, a & 63), fn_s, hlo, hhi);
                     trimmed += trim_start_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl, ((full_s >> (a & 63)) & 1ull) != 0,
-                                                     ((part_s >> (a & 63)) & 1ull) != 0);
+                                                     ((part_s >> (a & 63)) & 1ull) != 0, hlo, hhi);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
-                    if (s != s0 || e != e0) {
-                        stale_s = stale_e = true;
-                        masks_ok = false; /* r1 moved: what can trim it has to be asked again */
-                    }
+                    if (s != s0 || e != e0) moved(s0, e0);
                 }
                 if (FILT && !masks_ok) refresh_masks(a);
                 if (!FILT || ((may_e >> (a & 63)) & 1ull)) {
@@ -1315,13 +1388,12 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_e, rlen - wl, rlen, win4_e};
+                    int hlo = 0, hhi = 0x3fffffff;
+                    if (FILT && FPL_OPT_FASTAFILTER == 2) fasta_hint_range(readlane_u32(verd_e, a & 63), fn_e, hlo, hhi);
                     trimmed += trim_end_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl, ((full_e >> (a & 63)) & 1ull) != 0,
-                                                   ((part_e >> (a & 63)) & 1ull) != 0);
+                                                   ((part_e >> (a & 63)) & 1ull) != 0, hlo, hhi);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
-                    if (s != s0 || e != e0) {
-                        stale_s = stale_e = true;
-                        masks_ok = false;
-                    }
+                    if (s != s0 || e != e0) moved(s0, e0);
                 }
             }
             if (trimmed > 0 && lane == 0) { /* FilterResult::addReadTrimmed */

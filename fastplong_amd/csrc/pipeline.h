@@ -102,9 +102,12 @@ struct BatchArgs {
     StatsTune tune; /* tuning / test hooks, read from the environment once by whoever builds the arguments */
 };
 
-constexpr int N_STAGES = 5;
-static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_resolve", "k_stats", "k_stats_extra"};
-/* k_resolve = k_resolve + k_redo (+ k_break_mask with --break / --mask) */
+constexpr int N_STAGES = 7;
+static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_resolve", "k_stats_prep", "k_stats", "k_stats_reduce",
+                                                  "k_stats_extra"};
+/* k_resolve = k_resolve + k_redo (+ k_break_mask with --break / --mask); k_stats_prep = the bucket kernels of the sorted pass;
+   k_stats = k_stats_sorted (or the unsorted k_stats) alone; k_stats_extra = the post-only pass and its reduce.  k_trim_ends,
+   k_scan and k_stats are single launches: their event times are kernel durations */
 
 /* capacities of the lists k_break_mask appends to: every region is at least one window long, so an output
    read or a piece costs at least window + 1 bytes of input beyond the two fragments a read starts with */
@@ -291,24 +294,28 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_LAUNCH(k_bucket_plan, dim3(1), dim3(128), stream, a.sort_ws, per, stats_min_bucket(a.tune), max_slices);
         FPL_LAUNCH(k_bucket_scatter, dim3(nblk), dim3(FS_SORT_BLK), stream, a.off, (const ReadState*)a.state, n, a.sort_ws,
                    (const u32*)blkcnt, a.st_off, a.st_len, a.st_e, a.frag_off, a.frag_len, a.work_ctr + 1);
+        mark(4);
         /* persistent blocks, two per CU (what the LDS tables allow) */
         FPL_LAUNCH((k_stats_sorted<SWAVES>), dim3(2 * a.n_cu), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
                    (const uint64_t*)a.st_off, (const u32*)a.st_len, (const u32*)a.st_e, a.sort_ws, max_slices, n_tiles, a.counters,
                    a.stats_scratch, a.stats_flags, a.C);
+        mark(5);
         FPL_LAUNCH(k_stats_reduce_sorted, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, (const u32*)a.sort_ws, max_slices, n_tiles, a.counters, a.C);
     } else {
         const u32 per = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
         const u32 n_slices = cdiv(n, per);
         FPL_MEMSET(a.stats_flags, (size_t)n_slices * n_tiles + n_tiles, stream);
+        mark(4);
         FPL_LAUNCH((k_stats<SWAVES, false>), dim3(n_slices, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
                    a.off, (const u32*)nullptr, (const u32*)nullptr, (const ReadState*)a.state, n, (const u32*)nullptr, per,
                    n_slices,
                    CS_MAX_ITEMS_PER_SLICE, a.counters, a.stats_scratch, a.stats_flags, a.C);
+        mark(5);
         FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, n_slices, n_tiles, a.counters, a.C, 1);
     }
-    mark(4);
+    mark(6);
     {
         const u32 n_items = a.defer ? a.bm.item_cap : 2 * n; /* upper bound; the kernel reads the real count */
         const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n, a.tune); /* slabs per tile */
@@ -320,7 +327,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, gx, n_tiles, a.counters, a.C, 0);
     }
-    mark(5);
+    mark(7);
 }
 
 }  // namespace fpl

@@ -101,7 +101,7 @@ class _StandInEngine:
         self.calls = 0
 
     def kernel_times(self):
-        return {"k_trim_ends": 1.0 * self.calls, "k_scan": 2.0 * self.calls, "k_resolve": 0.1 * self.calls, "k_stats": 1.5 * self.calls}, self.calls
+        return {"k_trim_ends": 1.0 * self.calls, "k_scan": 2.0 * self.calls, "k_resolve": 0.1 * self.calls, "k_stats_prep": 0.1 * self.calls, "k_stats": 1.5 * self.calls}, self.calls
 
     def counters_tensor(self):
         return self.cnt
