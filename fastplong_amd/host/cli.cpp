@@ -81,23 +81,6 @@ static const Flag FLAGS[] = {
     {"reader_threads", 0, true, "0"}, {"chunk_mb", 0, true, "32"}, {"gz_stream", 0, false, ""},
 };
 
-static volatile bool g_mapped_output = false; /* an output file is written through a mapping: SIGBUS may mean "disk full" */
-/* files are read (and regular output files written) through mappings: a file cut short under the input mapping, or a file
-   system that runs out of space under the output mapping, raises SIGBUS where read() / write() would have returned an error --
-   reported with the message and the exit code of that error */
-static void install_sigbus_report() {
-    struct sigaction sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.sa_handler = [](int) {
-        static const char in_msg[] = "ERROR: reading the input failed (file truncated while it was being read?)\n";
-        static const char out_msg[] = "ERROR: write failed (no space left for the output, or the input file was truncated while it was being read)\n";
-        ssize_t r = g_mapped_output ? write(2, out_msg, sizeof(out_msg) - 1) : write(2, in_msg, sizeof(in_msg) - 1);
-        (void)r;
-        _exit(1);
-    };
-    sigaction(SIGBUS, &sa, nullptr);
-}
-
 struct Args {
     map<string, string> val;
     map<string, bool> seen;
@@ -558,7 +541,15 @@ int main(int argc, char* argv[]) {
                     madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
                     chunkMem = (const char*)m;
                     chunkMemMapped = true;
-                    install_sigbus_report();
+                    struct sigaction sa;
+                    memset(&sa, 0, sizeof(sa));
+                    sa.sa_handler = [](int) {
+                        static const char msg[] = "ERROR: reading the input failed (file truncated while it was being read?)\n";
+                        ssize_t r = write(2, msg, sizeof(msg) - 1);
+                        (void)r;
+                        _exit(1);
+                    };
+                    sigaction(SIGBUS, &sa, nullptr);
                 }
             }
         } else if (fd >= 0) {
@@ -621,15 +612,13 @@ int main(int argc, char* argv[]) {
         FILE* f = nullptr;
         bool gz = false;
         bool wrote = false;
-        /* a regular file: the pieces of a batch are written side by side at their offsets (pwrite from the worker pool) -- one
-           thread copies into the page cache at 6 GB/s, which made file output the slowest stage of the pipeline by a factor
-           of five.  Nothing goes through the FILE's buffer then.  (FPLH_SERIAL_WRITE: measurement hook, the old path) */
+        /* FPLH_PARALLEL_WRITE (measurement hook): the pieces of a batch written side by side at their offsets (pwrite from
+           the worker pool; nothing goes through the FILE's buffer then).  Measured on the GPU box into tmpfs: no gain -- one
+           thread copies into the page cache at 5.5-6 GB/s, fifteen pwrite()s side by side, or fifteen memcpy()s into a mapped
+           window of the file, fill it at the same 5.5-6 GB/s: what bounds a single output file is the kernel's insertion of
+           fresh pages into that file's page cache, not the copy.  So the plain path stays the default. */
         bool positional = false;
         uint64_t pos = 0;
-        /* ... through a window of the file mapped into memory: buffered write()s to one file serialise on its inode lock
-           (sixteen pwrite()s side by side ran at the speed of one), page faults on a mapping do not */
-        char* win = nullptr;
-        uint64_t win_off = 0, win_len = 0, file_len = 0;
         explicit operator bool() const { return f != nullptr; }
     };
     auto open_out = [](const string& path) -> OutFile {
@@ -639,7 +628,7 @@ int main(int argc, char* argv[]) {
         o.f = fopen(path.c_str(), "wb");
         if (!o.f) error_exit("Failed to write: " + path);
         struct stat st;
-        o.positional = !getenv("FPLH_SERIAL_WRITE") && fstat(fileno(o.f), &st) == 0 && S_ISREG(st.st_mode);
+        o.positional = getenv("FPLH_PARALLEL_WRITE") && fstat(fileno(o.f), &st) == 0 && S_ISREG(st.st_mode);
         return o;
     };
     /* with --split* the reference never calls initOutput (src/seprocessor.cpp:65-67): no single --out file and no
@@ -655,44 +644,32 @@ int main(int argc, char* argv[]) {
     };
     auto write_pieces = [](OutFile& o, const vector<string>& pieces) {
         if (o.positional) { /* input order by construction: the offsets are the running sum of the pieces' sizes */
-            uint64_t total = 0;
-            for (auto& piece : pieces) total += piece.size();
-            if (total == 0) return;
+            vector<uint64_t> at(pieces.size());
+            for (size_t i = 0; i < pieces.size(); i++) {
+                at[i] = o.pos;
+                o.pos += pieces[i].size();
+                if (!pieces[i].empty()) o.wrote = true;
+            }
+            std::atomic<bool> bad{false};
             const int fd = fileno(o.f);
-            if (!o.win || o.pos + total > o.win_off + o.win_len) { /* move the window: the file grows in steps of 1 GiB */
-                if (o.win) munmap(o.win, (size_t)o.win_len);
-                o.win = nullptr;
-                const uint64_t page = (uint64_t)sysconf(_SC_PAGE_SIZE), step = 1ull << 30;
-                o.win_off = o.pos / page * page;
-                o.win_len = ((o.pos + total - o.win_off) + step - 1) / step * step;
-                void* m = MAP_FAILED;
-                if (ftruncate(fd, (off_t)(o.win_off + o.win_len)) == 0) {
-                    o.file_len = o.win_off + o.win_len;
-                    m = mmap(nullptr, (size_t)o.win_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)o.win_off);
+            fplh::parallel_run((int)pieces.size(), [&](int i) {
+                const char* p = pieces[i].data();
+                size_t left = pieces[i].size();
+                uint64_t off = at[i];
+                while (left > 0) {
+                    const ssize_t w = pwrite(fd, p, left, (off_t)off);
+                    if (w < 0 && errno == EINTR) continue;
+                    if (w <= 0) {
+                        bad = true;
+                        return;
+                    }
+                    p += w;
+                    off += (uint64_t)w;
+                    left -= (size_t)w;
                 }
-                if (m == MAP_FAILED) { /* a file system that cannot do this: the plain path from here on */
-                    if (ftruncate(fd, (off_t)o.pos) != 0 || lseek(fd, (off_t)o.pos, SEEK_SET) < 0) error_exit("write failed");
-                    o.positional = false;
-                    o.file_len = 0;
-                } else {
-                    o.win = (char*)m;
-                    if (!g_mapped_output) install_sigbus_report(); /* (a full disk shows up as SIGBUS on the mapping) */
-                    g_mapped_output = true;
-                }
-            }
-            if (o.positional) {
-                vector<uint64_t> at(pieces.size());
-                for (size_t i = 0; i < pieces.size(); i++) {
-                    at[i] = o.pos - o.win_off;
-                    o.pos += pieces[i].size();
-                }
-                o.wrote = true;
-                char* const w = o.win;
-                fplh::parallel_run((int)pieces.size(), [&](int i) {
-                    if (!pieces[i].empty()) memcpy(w + at[i], pieces[i].data(), pieces[i].size());
-                });
-                return;
-            }
+            });
+            if (bad) error_exit("write failed");
+            return;
         }
         for (auto& piece : pieces)
             if (!piece.empty()) {
@@ -984,11 +961,6 @@ int main(int argc, char* argv[]) {
                 const string e = gzip_member(string(), gzLevel);
                 if (fwrite(e.data(), 1, e.size(), o->f) != e.size()) error_exit("write failed");
             }
-            if (o->win) { /* the mapped window: back to the file, which is then cut to what was written */
-                if (munmap(o->win, (size_t)o->win_len) != 0) error_exit("write failed");
-                o->win = nullptr;
-            }
-            if (o->file_len && ftruncate(fileno(o->f), (off_t)o->pos) != 0) error_exit("write failed");
             /* the buffered tail goes out here: a full disk shows up as a failing flush / close */
             if (o->f == stdout ? (fflush(stdout) != 0 || ferror(stdout)) : (fclose(o->f) != 0)) error_exit("write failed");
         }

@@ -1,7 +1,7 @@
 """The HOST side of a multi-device run on a box without GPUs: bin/fastplong_amd --gpus N against tests/stub/libfastplong_amd.so
 (LD_LIBRARY_PATH), a stand-in for the C-ABI library whose "devices" compute with the oracle.  What is under test is the CLI's
 scheduling -- batches dealt round-robin in input order, two in flight per device thread, the formatter stage, the in-order
-writer (positional, parallel file output), the counter merge behind fpl_allreduce_counters -- against the committed golden
+writer, the counter merge behind fpl_allreduce_counters -- against the committed golden
 files, which the single-GPU CLI reproduces on hardware (tests/test_golden.py)."""
 import ctypes as C
 import gzip
@@ -46,6 +46,8 @@ def run_cli(tmp_path, case, env, gpus, extra=(), chunk=30000):
     cmd = [build.CLI, "-i", str(inp), "-o", str(out / "out.fq"), "--failed_out", str(out / "failed.fq"), "-j", str(out / "out.json"),
            "-h", str(out / "out.html"), "--gpus", str(gpus), "--reader_threads", "3", "-V"] + flags + list(extra)
     e = dict(env, FPL_STUB_DEVICES="3", FPL_STUB_LOG=str(log), FPLH_CHUNK_BYTES=str(chunk))
+    if gpus == 3:
+        e["FPLH_PARALLEL_WRITE"] = "1"  # (the positional writer: the same bytes)
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
     return p, out, log
 
