@@ -50,8 +50,11 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_REDO_PREFETCH
 #define FPL_REDO_PREFETCH 1 /* k_redo: the next tile's cache lines are touched one tile ahead */
 #endif
-#ifndef FPL_REDO_WAVES16
-#define FPL_REDO_WAVES16 1 /* k_redo: blocks of sixteen waves, one per CU (fewer blocks end with global atomics on the same lines) */
+#ifndef FPL_REDO_WAVES
+#define FPL_REDO_WAVES 8 /* k_redo: waves per block; three such blocks fit a CU (LDS: 4.5 KiB per wave, 70 VGPRs) */
+#endif
+#ifndef FPL_REDO_BLOCKS_PER_CU
+#define FPL_REDO_BLOCKS_PER_CU 3
 #endif
 #ifndef FPL_OPT_HIST
 #define FPL_OPT_HIST 2 /* histogram counter address = (bin bits) | (4 KiB-aligned slice + lane copy), hist_bump.  2: written in
@@ -3245,6 +3248,9 @@ struct alignas(16) ScanWin {
 struct alignas(16) RedoItem {
     u32 ri, gs, glen, pad;
 };
+/* the REDO list (n_reads slots) is filled from both ends: reads whose r1 is longer than this from the front (their count in
+   the word two behind the short items' count), the others from the back */
+constexpr int REDO_LONG = 16384;
 
 /* the base-quality histograms of one wave of k_scan (bins 2 * lane and 2 * lane + 1, pre- / post-filter), kept in registers and
    handed to the block's LDS accumulators when they might overflow and when the wave ends */
@@ -3485,8 +3491,11 @@ __device__ __forceinline__ void extra_append(bool want, uint64_t o, u32 len, uin
  * one piece gets its result record, its FilterResult / median counters (src/seprocessor.cpp:265-281) and its plan for the
  * statistics passes right here; a read that is split goes on the REDO list (k_redo scans its fragments), or -- with --break /
  * --mask, where k_break_mask decides the fragments' fate -- gets its record with the two fragments. */
+#ifndef FPL_RESOLVE_WPS
+#define FPL_RESOLVE_WPS 4 /* waves per SIMD the register allocation must leave room for (16-wave blocks: 4 = one block per CU) */
+#endif
 template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
+__global__ void __launch_bounds__(WAVES * 64, FPL_RESOLVE_WPS)
 k_resolve(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_reads, uint64_t n_bytes,
           const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads, ReadState* __restrict__ state,
           const ScanRec* __restrict__ recs, const ScanWin* __restrict__ wins, fpl_read_result* __restrict__ results,
@@ -3513,9 +3522,14 @@ k_resolve(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_re
     const bool pair32 = cfg->ham_fast && al0 <= 32 && al1 <= 32;
     const int ext = cfg->ext;
     const u32 n_groups = (n_reads + 63) / 64;
-    for (u32 g = blockIdx.x * WAVES + wave_in_block(); g < n_groups; g += gridDim.x * WAVES) {
+    /* Places on the three lists (EXTRA, REDO short / long) are reserved ONCE per block and round: device atomics on one word
+       run at ~80 per microsecond, and one per wave and list (31 000 of them for a million reads) were two thirds of this
+       kernel's time.  wcnt[w][k]: wave w's entries for list k, then -- after thread 0's turn -- the index of its first. */
+    __shared__ u32 wcnt[WAVES][3];
+    for (u32 g0 = blockIdx.x * WAVES; g0 < n_groups; g0 += gridDim.x * WAVES) { /* block-uniform */
+        const u32 g = g0 + (u32)wave_in_block();
         const u32 ri = g * 64 + (u32)lane;
-        const bool live = ri < n_reads;
+        const bool live = g < n_groups && ri < n_reads;
         uint64_t o0 = 0, o1 = 0;
         ReadState st = {0, 0, 1, 0};
         ScanRec rec = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3642,21 +3656,44 @@ k_resolve(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_re
             results[ri] = res;
             state[ri].pad = to_post ? PLAN_TO_POST : 0u;
         }
-        extra_append(pass && !to_post, o0 + (uint64_t)s, (u32)blen, frag_off, frag_len, frag_count);
-        /* ---- split reads: k_redo scans the fragments */
-        {
-            const bool want = live && split && !dropped && !defer;
-            const u64 wm = wave_ballot(want);
-            if (wm) {
-                u32 base = 0;
-                if (lane == 0) base = atomicAdd(redo_count, (u32)__popcll(wm));
-                base = readlane_u32(base, 0);
-                if (want) {
-                    RedoItem it = {ri, (u32)gs, (u32)glen, 0u};
-                    redo[base + (u32)__popcll(wm & ((1ull << lane) - 1ull))] = it;
-                }
+        /* ---- the lists: passing reads the single statistics pass cannot count post-filter (EXTRA); split reads, whose
+           fragments k_redo scans -- the few long ones go to the FRONT of the REDO list, the others fill it from its far end,
+           so that the long ones are started first instead of ending a wave's string of items */
+        const bool wantx = pass && !to_post;
+        const bool wants = live && split && !dropped && !defer && blen <= REDO_LONG;
+        const bool wantl = live && split && !dropped && !defer && blen > REDO_LONG;
+        const u64 mx = wave_ballot(wantx), ms = wave_ballot(wants), ml = wave_ballot(wantl);
+        if (lane == 0) {
+            wcnt[wave_in_block()][0] = (u32)__popcll(mx);
+            wcnt[wave_in_block()][1] = (u32)__popcll(ms);
+            wcnt[wave_in_block()][2] = (u32)__popcll(ml);
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const u32 k = threadIdx.x;
+            u32 tot = 0;
+            for (int w = 0; w < WAVES; w++) tot += wcnt[w][k];
+            u32 base = 0;
+            if (tot) base = atomicAdd(k == 0 ? frag_count : (k == 1 ? redo_count : redo_count + 2), tot);
+            for (int w = 0; w < WAVES; w++) {
+                const u32 c = wcnt[w][k];
+                wcnt[w][k] = base;
+                base += c;
             }
         }
+        __syncthreads();
+        const u64 below = (1ull << lane) - 1ull;
+        if (wantx) {
+            const u32 slot = wcnt[wave_in_block()][0] + (u32)__popcll(mx & below);
+            frag_off[slot] = o0 + (uint64_t)s;
+            frag_len[slot] = (u32)blen;
+        }
+        if (wants || wantl) {
+            RedoItem it = {ri, (u32)gs, (u32)glen, 0u};
+            if (wants) redo[n_reads - 1u - (wcnt[wave_in_block()][1] + (u32)__popcll(ms & below))] = it;
+            else redo[wcnt[wave_in_block()][2] + (u32)__popcll(ml & below)] = it;
+        }
+        __syncthreads(); /* (wcnt is reused by the next round) */
     }
     __syncthreads();
     scan_acc_flush(acc, counters, C);
@@ -3668,7 +3705,7 @@ k_resolve(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_re
  * read's record, counters and plan. */
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t n_bytes,
+k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads, uint64_t n_bytes,
        const DevConfig* __restrict__ cfg, ReadState* __restrict__ state, const ScanRec* __restrict__ recs,
        fpl_read_result* __restrict__ results, uint64_t* __restrict__ frag_off, u32* __restrict__ frag_len,
        u32* __restrict__ frag_count, const RedoItem* __restrict__ redo, const u32* __restrict__ redo_count,
@@ -3676,6 +3713,8 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     __shared__ alignas(4096) u32 hist_all[WAVES][128 * HIST_COPIES];
     __shared__ ScanWaveLds wlds[WAVES];
     __shared__ ScanBlockAcc acc;
+    __shared__ uint64_t fb_off[WAVES][SC_FBUF]; /* passing fragments waiting for a place on the EXTRA list, per wave */
+    __shared__ u32 fb_len[WAVES][SC_FBUF];
     const int lane = lane_id();
     ScanWaveLds* const wl = &wlds[wave_in_block()];
     u32* const h = hist_all[wave_in_block()];
@@ -3688,13 +3727,14 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
     const int qq = cfg->qualified_qual;
-    const u32 n_items = *redo_count;
+    const u32 n_long = redo_count[2], n_items = n_long + redo_count[0]; /* (long reads first) */
+    u32 nbuf = 0; /* entries in this wave's buffer of EXTRA-list entries (wave-uniform) */
     /* (items off a device counter -- `for (;;) { it = atomicAdd(..); if (it >= n_items) break; ..` -- would even the hundredfold
        spread of the items' lengths out, but that form of this loop never ended on the GPU (ROCm 7.2, gfx950; the emulator and a
        fixed stride are fine): the list is walked with a fixed stride) */
     (void)redo_next;
     for (u32 it = blockIdx.x * WAVES + wave_in_block(); it < n_items; it += gridDim.x * WAVES) {
-        const RedoItem item = redo[it];
+        const RedoItem item = redo[it < n_long ? it : n_reads - 1u - (it - n_long)];
         const u32 ri = uniform_u32(item.ri);
         const int gs = uniform_i32((int)item.gs), glen = uniform_i32((int)item.glen);
         const uint64_t o0 = uniform_u64(off[ri]);
@@ -3794,22 +3834,52 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
                 ns.e = r_fs[0] + r_fl[0];
             }
             state[ri] = ns;
-            u32 cnt = (r_pass[0] && !to_post ? 1u : 0u) + (nf > 1 && r_pass[1] ? 1u : 0u);
-            if (cnt) {
-                u32 slot = atomicAdd(frag_count, cnt);
-                if (r_pass[0] && !to_post) {
-                    frag_off[slot] = o0 + r_fs[0];
-                    frag_len[slot] = r_fl[0];
-                    slot++;
-                }
-                if (nf > 1 && r_pass[1]) {
-                    frag_off[slot] = o0 + r_fs[1];
-                    frag_len[slot] = r_fl[1];
-                }
+            /* passing fragments wait in this wave's buffer for a place on the EXTRA list */
+            u32 slot = nbuf;
+            if (r_pass[0] && !to_post) {
+                fb_off[wave_in_block()][slot] = o0 + r_fs[0];
+                fb_len[wave_in_block()][slot] = r_fl[0];
+                slot++;
             }
+            if (nf > 1 && r_pass[1]) {
+                fb_off[wave_in_block()][slot] = o0 + r_fs[1];
+                fb_len[wave_in_block()][slot] = r_fl[1];
+            }
+        }
+        nbuf += (r_pass[0] && !to_post ? 1u : 0u) + (nf > 1 && r_pass[1] ? 1u : 0u); /* (wave-uniform) */
+        if (nbuf > SC_FBUF - 2) { /* the buffer is full (a wave with more than fifteen items): one atomic for its entries */
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(frag_count, nbuf);
+            base = readlane_u32(base, 0);
+            wave_sync();
+            if ((u32)lane < nbuf) {
+                frag_off[base + lane] = fb_off[wave_in_block()][lane];
+                frag_len[base + lane] = fb_len[wave_in_block()][lane];
+            }
+            wave_sync();
+            nbuf = 0;
+        }
+    }
+    /* what is left in the waves' buffers: ONE place reservation for the block (a device atomic per item -- 25 000 on one word
+       for a million reads -- was most of this kernel's time) */
+    __shared__ u32 wbase[WAVES];
+    if (lane == 0) wbase[wave_in_block()] = nbuf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tot = 0;
+        for (int w = 0; w < WAVES; w++) tot += wbase[w];
+        u32 base = tot ? atomicAdd(frag_count, tot) : 0u;
+        for (int w = 0; w < WAVES; w++) {
+            const u32 c = wbase[w];
+            wbase[w] = base;
+            base += c;
         }
     }
     __syncthreads();
+    if ((u32)lane < nbuf) {
+        frag_off[wbase[wave_in_block()] + lane] = fb_off[wave_in_block()][lane];
+        frag_len[wbase[wave_in_block()] + lane] = fb_len[wave_in_block()][lane];
+    }
     scan_acc_flush(acc, counters, C);
 }
 

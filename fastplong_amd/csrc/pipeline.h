@@ -87,7 +87,8 @@ struct BatchArgs {
     long long* counters;
     u32 C;
     u32* work_ctr; /* WORK_CTR_WORDS words zeroed before the batch: [0] k_scan work counter, [1] EXTRA fragment count,
-                      [2] k_trim_ends_batched group counter, [3] length of the REDO list, [4] k_redo work counter */
+                      [2] k_trim_ends_batched group counter, [3] REDO list: short items (from the back), [4] unused,
+                      [5] REDO list: long items (from the front) */
     ScanRec* recs = nullptr;  /* n_reads: what k_scan leaves per read for k_resolve */
     ScanWin* wins = nullptr;  /* n_reads: ... and the bytes at the two Hamming argmins */
     RedoItem* redo = nullptr; /* n_reads: the reads a middle adapter splits (k_resolve -> k_redo) */
@@ -258,11 +259,15 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                    (const ScanRec*)a.recs, (const ScanWin*)a.wins, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, a.redo,
                    a.work_ctr + 3, a.counters, a.C);
         if (!a.defer) { /* (with --break / --mask k_break_mask scans the fragments) */
-            /* the list's length is known on the device only: waves that take items off a counter; few blocks (see above) */
-            constexpr int DW = FPL_REDO_WAVES16 ? RWAVES : KWAVES;
+            /* the list's length is known on the device only: a grid that walks it (long reads first, REDO_LONG) */
+#ifdef FPL_EMU
+            constexpr int DW = KWAVES;
+#else
+            constexpr int DW = FPL_REDO_WAVES;
+#endif
             u32 dblocks = cdiv(n, DW);
-            if (dblocks > (FPL_REDO_WAVES16 ? 1u : 4u) * a.n_cu) dblocks = (FPL_REDO_WAVES16 ? 1u : 4u) * a.n_cu;
-            FPL_LAUNCH((k_redo<DW>), dim3(dblocks), dim3(DW * 64), stream, a.seq, a.qual, a.off, a.n_bytes, a.cfg, a.state,
+            if (dblocks > FPL_REDO_BLOCKS_PER_CU * a.n_cu) dblocks = FPL_REDO_BLOCKS_PER_CU * a.n_cu;
+            FPL_LAUNCH((k_redo<DW>), dim3(dblocks), dim3(DW * 64), stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.state,
                        (const ScanRec*)a.recs, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, (const RedoItem*)a.redo,
                        (const u32*)(a.work_ctr + 3), a.work_ctr + 4, a.counters, a.C);
         }
