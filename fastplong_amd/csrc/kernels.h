@@ -4059,7 +4059,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     u64* const tbl = inc_of + 256;      /* [8][FS_T pre | FS_T not-post] */
     u32* const kpre = kmer;
     u32* const kpost = kmer + 1024;
-    __shared__ u32 any_work, cur_item;
+    __shared__ u32 any_work, cur_item, cls_mask;
     const int lane = lane_id();
     const u32 lane8 = 8u * (u32)lane;
     const u8* seq_end = seq + n_bytes;
@@ -4079,6 +4079,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     if (threadIdx.x == 0) {
         cur_item = atomicAdd(&sw[SW_WORK], 1u);
         any_work = 0;
+        cls_mask = 0;
     }
     __syncthreads();
     const u32 item = cur_item;
@@ -4234,16 +4235,27 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
         }
     }
     __syncthreads();
-    /* hand-over: the two tables as one slab (pre cells, then not-post cells, both in LDS slot order) */
+    /* hand-over: the two tables as one slab (pre cells, then not-post cells, both in LDS slot order) -- the rows of the base
+       classes that occur: a byte's class is its low three bits, so DNA fills four or five of the eight rows (A 1, C 3, T 4,
+       G 7, N 6), and the slab's flag byte says which; k_stats_reduce_sorted reads no others */
+    {
+        u32 m = 0;
+        for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x)
+            if (tbl[(i / FS_T) * FS_BSTRIDE + (i % FS_T)]) m |= 1u << (i / FS_T);
+        if (m) atomicOr(&cls_mask, m);
+    }
+    __syncthreads();
+    const u32 cmask = cls_mask;
     const size_t slab = (size_t)tile * max_slices + slice;
     u64* dst = scratch + slab * FS_SLAB;
     for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) {
+        if (!((cmask >> (i / FS_T)) & 1u)) continue;
         const u32 cell = (i / FS_T) * FS_BSTRIDE + (i % FS_T);
         dst[i] = tbl[cell];
         if (tp) dst[8 * FS_T + i] = tbl[cell + FS_T];
     }
     if (threadIdx.x == 0) {
-        flags[n_tiles + slab] = 1;
+        flags[n_tiles + slab] = (u8)cmask;
         flags[tile] = 1;
 #ifdef FPL_PROF_BLOCKS
         if (item < (1u << 17)) {
@@ -4266,44 +4278,77 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
 __global__ void __launch_bounds__(256)
 k_stats_reduce_sorted(const u64* __restrict__ scratch, const u8* __restrict__ flags, const u32* __restrict__ sw,
                       u32 max_slices, u32 n_tiles, long long* __restrict__ counters, u32 C) {
+    /* the slices that handed over a slab for this tile or the next one, gathered once per block (256 at a time): a thread
+       that asks flag byte after flag byte whether a slab exists, and only then for its cell, spends its time waiting for
+       one load after the other; from the list its loads go out four at a time */
+    __shared__ u32 a_sl[256], a_sp1[256], a_n;
+    __shared__ u8 a_fh[256], a_fn[256];
     const u32 tile = blockIdx.y;
     const u32 cell = blockIdx.x * 256 + threadIdx.x;
     const bool is_post = cell >= 8 * FS_T;
     const u8* slab_flags = flags + n_tiles;
     const bool here = flags[tile] != 0, next = tile + 1 < n_tiles && flags[tile + 1] != 0;
-    if (!here && !next) return;
+    if (!here && !next) return; /* block-uniform */
     const u32 n_slices = sw[SW_NSLICES];
     const u32 cc = is_post ? cell - 8 * FS_T : cell;
     const u32 cls = cc / FS_T, x = cc % FS_T;
+    const u32 slot_pre = (x & 7) * 64 + (x >> 3);
     u64 qsum = 0, cnt = 0, q20 = 0, q30 = 0;
-    if (!is_post) {
-        if (!here) return;
-        const u32 slot = (x & 7) * 64 + (x >> 3);
-        for (u32 sl = 0; sl < n_slices; sl++) {
-            const size_t slab = (size_t)tile * max_slices + sl;
-            if (!slab_flags[slab]) continue;
-            fs_unpack_add(scratch[slab * FS_SLAB + cls * FS_T + slot], qsum, cnt, q20, q30);
+    u64 nsum = 0, ncnt = 0, n20 = 0, n30 = 0; /* post: what lies behind the reads' ends */
+    for (u32 base = 0; base < n_slices; base += 256) { /* block-uniform */
+        __syncthreads();
+        if (threadIdx.x == 0) a_n = 0;
+        __syncthreads();
+        const u32 sl = base + threadIdx.x;
+        if (sl < n_slices) {
+            const u8 fh = here ? slab_flags[(size_t)tile * max_slices + sl] : (u8)0;
+            const u8 fn = next ? slab_flags[(size_t)(tile + 1) * max_slices + sl] : (u8)0;
+            if (fh | fn) {
+                const u32 i = atomicAdd(&a_n, 1u);
+                a_sl[i] = sl;
+                a_sp1[i] = sw[SW_SLICES + 4 * sl + 2];
+                a_fh[i] = fh;
+                a_fn[i] = fn;
+            }
         }
-    } else {
-        u64 nsum = 0, ncnt = 0, n20 = 0, n30 = 0; /* what lies behind the reads' ends */
-        for (u32 sl = 0; sl < n_slices; sl++) {
-            const u32 sp1 = sw[SW_SLICES + 4 * sl + 2];
-            if (!sp1) continue;
-            const u32 xs = x + (sp1 - 1);
-            const u32 tt = tile + (xs >= (u32)FS_T ? 1u : 0u);
-            if (tt >= n_tiles) continue;
-            const size_t slab = (size_t)tt * max_slices + sl;
-            if (!slab_flags[slab]) continue;
-            const u32 xx = xs & (u32)(FS_T - 1);
-            const u32 slot = (xx & 7) * 64 + (xx >> 3);
-            fs_unpack_add(scratch[slab * FS_SLAB + cls * FS_T + slot], qsum, cnt, q20, q30);
-            fs_unpack_add(scratch[slab * FS_SLAB + 8 * FS_T + cls * FS_T + slot], nsum, ncnt, n20, n30);
+        __syncthreads();
+        const u32 na = a_n;
+        for (u32 k0 = 0; k0 < na; k0 += 4) {
+            u64 v[4] = {0, 0, 0, 0}, nv[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (u32 u = 0; u < 4; u++) {
+                const u32 k = k0 + u;
+                if (k >= na) continue;
+                const u32 s_l = a_sl[k];
+                if (!is_post) { /* (block-uniform) */
+                    if ((a_fh[k] >> cls) & 1u) v[u] = scratch[((size_t)tile * max_slices + s_l) * FS_SLAB + cls * FS_T + slot_pre];
+                } else {
+                    /* post cycle x of this tile takes, from a slice with front trim s, cycle x + s of its slab of this tile or
+                       the next: pre minus not-post */
+                    const u32 sp1 = a_sp1[k];
+                    if (!sp1) continue;
+                    const u32 xs = x + (sp1 - 1);
+                    const bool nx = xs >= (u32)FS_T;
+                    if (!(((nx ? a_fn[k] : a_fh[k]) >> cls) & 1u)) continue;
+                    const u32 xx = xs & (u32)(FS_T - 1);
+                    const u32 slot = (xx & 7) * 64 + (xx >> 3);
+                    const u64* sb = scratch + ((size_t)(tile + (nx ? 1u : 0u)) * max_slices + s_l) * FS_SLAB;
+                    v[u] = sb[cls * FS_T + slot];
+                    nv[u] = sb[8 * FS_T + cls * FS_T + slot];
+                }
+            }
+#pragma unroll
+            for (u32 u = 0; u < 4; u++) {
+                fs_unpack_add(v[u], qsum, cnt, q20, q30);
+                fs_unpack_add(nv[u], nsum, ncnt, n20, n30);
+            }
         }
-        qsum -= nsum;
-        cnt -= ncnt;
-        q20 -= n20;
-        q30 -= n30;
     }
+    if (!is_post && !here) return;
+    qsum -= nsum;
+    cnt -= ncnt;
+    q20 -= n20;
+    q30 -= n30;
     const u32 c = tile * FS_T + x;
     if (cnt && c < C) {
         long long* st = counters + (is_post ? FPL_OFF_POST(C) : FPL_OFF_PRE(C));

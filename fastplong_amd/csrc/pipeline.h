@@ -238,7 +238,10 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         /* ~32 dequeues per wave keep the tail short, but never fewer than 4 reads per dequeue once there is
            that much work: the single work counter sustains only ~80 atomics/us */
         const u32 waves = blocks * KWAVES;
-        u32 chunk = n / (waves * 32u);
+#ifndef FPL_SCAN_CHUNK_DIV
+#define FPL_SCAN_CHUNK_DIV 32u
+#endif
+        u32 chunk = n / (waves * FPL_SCAN_CHUNK_DIV);
         if (chunk < 4) chunk = n >= 8 * waves ? 4 : (n >= 2 * waves ? 2 : 1);
         if (chunk > 64) chunk = 64;
         if (a.scan_short)

@@ -128,6 +128,8 @@ inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 template <class T>
 inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 template <class T>
+inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <class T>
 inline T atomicMin(T* p, T v) {
     T old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (v < old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
