@@ -1446,6 +1446,132 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
  *   per lane   P8  confirm, finish the end trim, write the ReadState records (:256-264, :288-299)
  * --------------------------------------------------------------------------------------- */
 
+/* ---- Filter::trimAndCut and PolyX::trimPolyX with LANE = READ (k_trim_ends_batched).
+ * Both are short sequential scans with an early exit -- a sliding window that stops at the first good window (a handful of
+ * positions in), a tail scan that stops once no base dominates (nine positions in when there is no poly-X tail).  With
+ * lanes = positions (trim_and_cut_wave, trim_polyx_wave) a wave evaluates 64 candidates to use the first few, once per read;
+ * here every lane walks the reference's own loop on its own read and the wave loops for as long as its slowest lane -- a
+ * few dozen rounds for 64 reads.  A lane whose scan outlasts LANE_SCAN_CAP rounds gives up (slow = true): the caller sends
+ * that read through the wave-per-read forms, so that one read with a long bad stretch cannot hold 63 others. */
+constexpr int LANE_SCAN_CAP = 160;
+constexpr int LANE_SCAN_WMAX = 16; /* windows beyond this take the wave-per-read form for every read (the warm-up sum is a loop) */
+
+/* Filter::trimAndCut, src/filter.cpp:130-232, one read per lane: sq / ql = this lane's read (length l).
+   Out: alive (false: the reference returns NULL), [s, e) in coordinates of the read, slow (see above). */
+__device__ __forceinline__ void trim_and_cut_lanes(const u8* __restrict__ sq, const u8* __restrict__ ql, int l, bool valid,
+                                                   const DevConfig* __restrict__ cfg, int& s_out, int& e_out, bool& alive,
+                                                   bool& slow) {
+    int front = cfg->trim_front, tail = cfg->trim_tail;
+    const bool cf = cfg->cut_front != 0, ct = cfg->cut_tail != 0;
+    s_out = 0;
+    e_out = l;
+    alive = valid;
+    slow = false;
+    if (front == 0 && tail == 0 && !cf && !ct) return; /* :133-134 (wave-uniform) */
+    int rlen = l - front - tail;
+    if (rlen < 0) alive = false; /* :137-139 */
+    if (!cf && !ct) { /* :141-151 */
+        s_out = front;
+        e_out = front + rlen;
+        return;
+    }
+    if (cf) { /* :159-189 */
+        const int w = cfg->cut_front_w, thr = cfg->cut_front_thr;
+        if (l - front - tail - w <= 0) alive = false;
+        const int lim = l - tail - w; /* the loop runs while s < lim */
+        int s = front, total = 0, it = 0;
+        if (alive)
+            for (int i = 0; i < w - 1; i++) total += ql[front + i];
+        while (alive && !slow && s < lim) {
+            total += ql[s + w - 1];
+            if (s > front) total -= ql[s - 1];
+            if (total >= thr) break; /* total / w >= 33 + q */
+            s++;
+            if (++it > LANE_SCAN_CAP) slow = true;
+        }
+        if (s > 0) s = s + w - 1;
+        it = 0;
+        while (alive && !slow && s < l && sq[s] == 'N') {
+            s++;
+            if (++it > LANE_SCAN_CAP) slow = true;
+        }
+        front = s;
+        rlen = l - front - tail;
+    }
+    if (ct) { /* :191-219 */
+        const int w = cfg->cut_tail_w, thr = cfg->cut_tail_thr;
+        if (l - front - tail - w <= 0) alive = false;
+        int t = l - tail - 1, total = 0, it = 0;
+        if (alive && !slow)
+            for (int i = 0; i < w - 1; i++) total += ql[t - i]; /* qual[t - w + 2 .. t] */
+        while (alive && !slow && t - w >= front) {
+            total += ql[t - w + 1];
+            if (t < l - tail - 1) total -= ql[t + 1];
+            if (total >= thr) break;
+            t--;
+            if (++it > LANE_SCAN_CAP) slow = true;
+        }
+        if (t < l - 1) t = t - w + 1;
+        it = 0;
+        while (alive && !slow && t >= 0 && sq[t] == 'N') {
+            t--;
+            if (++it > LANE_SCAN_CAP) slow = true;
+        }
+        rlen = t - front + 1;
+    }
+    if (rlen <= 0 || front >= l - 1) alive = false; /* :221-222 */
+    s_out = front;
+    e_out = front + rlen;
+}
+
+/* PolyX::trimPolyX, src/polyx.cpp:11-78, one read per lane: r = first base of r1 (rlen bases).  Returns the new
+   length; poly (0..3 = A, T, C, G; -1: nothing cut) and the bases cut; slow as above. */
+__device__ __forceinline__ int trim_polyx_lanes(const u8* __restrict__ r, int rlen, bool active, int compareReq, int& poly_out,
+                                                int& trimmed_out, bool& slow) {
+    poly_out = -1;
+    trimmed_out = 0;
+    int cA = 0, cT = 0, cC = 0, cG = 0;
+    int P = rlen; /* value of pos when the scan ends without a break */
+    int pos = 0, it = 0;
+    while (active && !slow && pos < rlen) {
+        const u32 c = r[rlen - pos - 1];
+        cA += (c == 'A' || c == 'N');
+        cT += (c == 'T' || c == 'N');
+        cC += (c == 'C' || c == 'N');
+        cG += (c == 'G' || c == 'N');
+        const int cmp = pos + 1, allowed = min(5, cmp / 8);
+        const bool need = (cmp - cA > allowed) && (cmp - cT > allowed) && (cmp - cC > allowed) && (cmp - cG > allowed);
+        if (need && (pos >= 8 || pos + 1 >= compareReq - 1)) {
+            P = pos;
+            break;
+        }
+        pos++;
+        if (++it > LANE_SCAN_CAP) slow = true;
+    }
+    if (!active || slow || P + 1 < compareReq) return rlen; /* :57 */
+    int poly = 0, maxc = cA; /* the first maximum in A, T, C, G order */
+    if (cT > maxc) { maxc = cT; poly = 1; }
+    if (cC > maxc) { maxc = cC; poly = 2; }
+    if (cG > maxc) { maxc = cG; poly = 3; }
+    const u32 polyBase = poly == 0 ? 'A' : (poly == 1 ? 'T' : (poly == 2 ? 'C' : 'G'));
+    /* :71  walk pos down from P until r[rlen - pos - 1] == polyBase: the first index >= max(0, rlen - P - 1) holding
+       polyBase; index -1 (P == rlen) never matches; pos = -1 when nothing matches */
+    int i = rlen - P - 1;
+    if (i < 0) i = 0;
+    it = 0;
+    while (i < rlen && r[i] != polyBase) {
+        i++;
+        if (++it > LANE_SCAN_CAP) {
+            slow = true;
+            return rlen;
+        }
+    }
+    const int p2 = i < rlen ? rlen - i - 1 : -1;
+    poly_out = poly;
+    trimmed_out = p2 + 1;
+    return rlen - p2 - 1; /* Read::resize: a no-op when pos == -1 */
+}
+
 /* Global edit distance <= thr? between the adapter slice [shift, shift + m) (m <= 32; peqf = word 0 of the adapter's Peq
  * table, in LDS) and the m text bytes at `text`, one problem per lane (need = this lane has one).  The exact distance
  * as the reference's edit_distance computes it (src/editdistance.cpp:30-61), compared per lane. */
@@ -1591,8 +1717,34 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         int v_mpos = -1; /* full match decided at this r1 position */
         int v_cand = -1; /* candidate of the window scan that still needs its edit distance */
 
-        /* ---- P1: trimAndCut, polyX, start adapter window scan */
-        for (int j = 0; j < gn; j++) {
+        /* ---- P1a: trimAndCut and polyX, lane = read */
+        bool v_slow = false;
+        {
+            bool alive = false, slow = false;
+            const bool wide = (cfg->cut_front && cfg->cut_front_w > LANE_SCAN_WMAX) || (cfg->cut_tail && cfg->cut_tail_w > LANE_SCAN_WMAX);
+            if (!wide) {
+                trim_and_cut_lanes(seq + v_o0, qual + v_o0, v_l, lane < gn, cfg, v_s, v_e, alive, slow);
+                if (cfg->polyx) { /* src/seprocessor.cpp:198-201 */
+                    int poly, tl;
+                    const int nl = trim_polyx_lanes(seq + v_o0 + v_s, v_e - v_s, alive && !slow, cfg->polyx_min_len, poly, tl, slow);
+                    if (!slow) {
+                        v_e = v_s + nl;
+                        if (poly >= 0) {
+                            atomicAdd(&acc.fr[FPL_FR_POLYX_READS + poly], (u64)1);
+                            atomicAdd(&acc.fr[FPL_FR_POLYX_BASES + poly], (u64)tl);
+                        }
+                    }
+                }
+            } else {
+                slow = lane < gn;
+            }
+            v_alive = alive ? 1 : 0;
+            v_slow = slow;
+        }
+        /* ---- P1b: the reads whose scans ran long (and every read when a cut window is wide), lanes = positions */
+        for (u64 todo = wave_ballot(v_slow); todo;) {
+            const int j = __ffsll(todo) - 1;
+            todo &= todo - 1;
             const uint64_t o0 = readlane_u64(v_o0, j);
             const int l = lane_get(v_l, j);
             const u8* sq = seq + o0;
@@ -1603,7 +1755,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             const EndsView vq = {ql, (const u8*)win_hq, (const u8*)win_tq, tail0};
             int s, e;
             const bool alive = trim_and_cut_wave(vs, vq, l, cfg, s, e);
-            if (alive && cfg->polyx) { /* src/seprocessor.cpp:198-201 */
+            if (alive && cfg->polyx) {
                 int poly, tl;
                 const int nl = trim_polyx_wave(vs, s, e - s, cfg->polyx_min_len, poly, tl);
                 e = s + nl;
@@ -1612,24 +1764,30 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
                     atomicAdd(&acc.fr[FPL_FR_POLYX_BASES + poly], (u64)tl);
                 }
             }
-            int mpos = -1, cand = -1;
-            const int rlen = e - s;
-            if (alive && do_start && rlen >= FPL_PATTERN_LEN) { /* searchAdapter, asRightAsPossible (:109-131) */
+            lane_set(v_s, j, s);
+            lane_set(v_e, j, e);
+            lane_set(v_alive, j, alive ? 1 : 0);
+        }
+        /* ---- P1c: start adapter window scan, one read at a time (lanes = positions; searchAdapter, asRightAsPossible, :109-131) */
+        if (do_start) {
+            u64 todo = wave_ballot(v_alive && (v_e - v_s) >= FPL_PATTERN_LEN);
+            while (todo) {
+                const int j = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                const uint64_t o0 = readlane_u64(v_o0, j);
+                const int s = lane_get(v_s, j), e = lane_get(v_e, j), rlen = e - s;
+                const u8* sq = seq + o0;
+                int mpos = -1, cand = -1;
                 const int searchEnd = min(rlen, FPL_END_WINDOW);
                 if (alen0 <= rlen && searchEnd > alen0) {
-                    const int wl = searchEnd;
-                    int bias = -s;
-                    if (s + wl > TRIM_WIN) {
-                        stage_window(win_s, sq + s, wl, seq_end, win4_s);
-                        bias = 0;
-                    }
+                    stage_window(win_s, sq + s, searchEnd, seq_end, win4_s);
                     const int npos = searchEnd - alen0 + 1;
                     int hit = -1;
                     u64 best = ~0ull;
                     for (int p0 = 0; p0 < npos; p0 += 64) {
                         const int p = p0 + lane;
                         int mm = 0x7fffffff;
-                        if (p < npos) mm = hamming_onehot<4>(win4_s, p - bias, ad1h0, alen0);
+                        if (p < npos) mm = hamming_onehot<4>(win4_s, p, ad1h0, alen0);
                         const u64 m = wave_ballot(p < npos && mm <= thrA0);
                         if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
                         if (p < npos) {
@@ -1643,12 +1801,9 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
                         if (best != ~0ull) cand = (int)(u32)best;
                     }
                 }
+                lane_set(v_mpos, j, mpos);
+                lane_set(v_cand, j, cand);
             }
-            lane_set(v_s, j, s);
-            lane_set(v_e, j, e);
-            lane_set(v_alive, j, alive ? 1 : 0);
-            lane_set(v_mpos, j, mpos);
-            lane_set(v_cand, j, cand);
         }
         /* ---- P2: the candidates' edit distance, 64 reads at once */
         if (do_start) {
