@@ -1572,6 +1572,89 @@ __device__ __forceinline__ int trim_polyx_lanes(const u8* __restrict__ r, int rl
     return rlen - p2 - 1; /* Read::resize: a no-op when pos == -1 */
 }
 
+/* the four bases of a dword as one-hot nibbles (A 1, C 2, G 4, T 8; any other byte 0), base k in bits 4k..4k+3 */
+__device__ __forceinline__ u32 onehot4(u32 w) {
+    const u32 code = (w >> 1) & 0x03030303u;            /* A0 C1 T2 G3 */
+    const u32 t = perm_lo(0x47544341u, code) ^ w;       /* zero byte <=> exactly that letter */
+    const u32 ok = (~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) >> 7) & 0x01010101u;
+    const u32 nib = perm_lo(0x04080201u, code) & (ok * 15u);
+    const u32 h = (nib | (nib >> 4)) & 0x00FF00FFu;
+    return (h | (h >> 8)) & 0xFFFFu;
+}
+/* searchAdapter's window scan (src/adaptertrimmer.cpp:84-131) with LANE = READ: every lane slides a 32-base window of one-hot
+ * nibbles along its own read -- four bases enter per dword load -- and counts the adapter's matches with four AND + popcount.
+ * r1 / rlen: this lane's trimmed read.  START: asRightAsPossible over p in [0, min(rlen, 200) - alen]: hit = the LARGEST p
+ * within thr (the reference scans downwards and returns at once), else cand = the smallest p among the minima (ties: "<="
+ * in a descending scan).  END: asLeftAsPossible over p in [max(0, rlen - 200), rlen - alen): hit = the SMALLEST p within thr,
+ * else cand = the largest p among the minima.  hit / cand are -1 when there is none.  A few hundred vector instructions per
+ * 64 reads and end where the scan with lanes = positions (one read at a time) took as many per read. */
+template <bool START>
+__device__ __forceinline__ void ham_scan_lanes(const u8* __restrict__ r1, int rlen, bool active, const u32 (&ad1h)[4], int alen,
+                                               int thr, const u8* __restrict__ seq_end, int& hit, int& cand) {
+    hit = -1;
+    cand = -1;
+    int p_lo = 0, np = 0; /* first position and number of positions of this lane */
+    if (START) {
+        const int searchEnd = min(rlen, FPL_END_WINDOW);
+        if (active && alen <= rlen && searchEnd > alen) np = searchEnd - alen + 1;
+    } else {
+        const int ss = max(0, rlen - FPL_END_WINDOW);
+        if (active && ss + alen <= rlen) {
+            p_lo = ss;
+            np = rlen - alen - ss; /* the last position is never tested */
+        }
+    }
+    const int npmax = (int)wave_max_u32((u32)max(np, 0));
+    if (npmax == 0) return; /* wave-uniform */
+    const u8* base = r1 + p_lo;
+    const int navail = np > 0 ? rlen - p_lo : 0; /* bytes of the read from `base` on */
+    /* dword k of the stream: bases 4k .. 4k + 3 behind `base`; bytes past the read count as no base */
+    auto nibbles = [&](int k) -> u32 {
+        const int left = navail - 4 * k;
+        if (left <= 0) return 0u;
+        u32 w = load4_guard(base + 4 * k, seq_end);
+        if (left < 4) w &= (1u << (8 * left)) - 1u;
+        return onehot4(w);
+    };
+    u32 W[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) W[k] = nibbles(2 * k) | (nibbles(2 * k + 1) << 16);
+    int bestmm = 0x7fffffff;
+    u32 nxt = nibbles(8);
+    for (int i0 = 0; i0 < npmax; i0 += 4) { /* wave-uniform trip count */
+        const u32 cur = nxt;
+        nxt = nibbles(i0 / 4 + 9); /* (requested one step ahead of its use) */
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u;
+            u32 matches = popc32(W[0] & ad1h[0]);
+            matches = popc_acc(W[1] & ad1h[1], matches);
+            matches = popc_acc(W[2] & ad1h[2], matches);
+            matches = popc_acc(W[3] & ad1h[3], matches);
+            const int mm = alen - (int)matches;
+            const bool in = i < np;
+            const int p = p_lo + i;
+            if (START) {
+                hit = (in && mm <= thr) ? p : hit;         /* ascending: the last one stands */
+                const bool better = in && mm < bestmm;     /* the first of the minima */
+                cand = better ? p : cand;
+                bestmm = better ? mm : bestmm;
+            } else {
+                hit = (in && hit < 0 && mm <= thr) ? p : hit; /* the first one stands */
+                const bool better = in && mm <= bestmm;       /* the last of the minima */
+                cand = better ? p : cand;
+                bestmm = better ? mm : bestmm;
+            }
+            /* slide by one base: the next nibble of the stream enters at the top */
+            W[0] = alignbit(W[1], W[0], 4);
+            W[1] = alignbit(W[2], W[1], 4);
+            W[2] = alignbit(W[3], W[2], 4);
+            W[3] = (W[3] >> 4) | (((cur >> (4 * u)) & 15u) << 28);
+        }
+    }
+    if (hit >= 0) cand = -1;
+}
+
 /* Global edit distance <= thr? between the adapter slice [shift, shift + m) (m <= 32; peqf = word 0 of the adapter's Peq
  * table, in LDS) and the m text bytes at `text`, one problem per lane (need = this lane has one).  The exact distance
  * as the reference's edit_distance computes it (src/editdistance.cpp:30-61), compared per lane. */
@@ -1656,8 +1739,12 @@ __device__ __forceinline__ bool partial16_possible(const u8* __restrict__ text, 
 __device__ __forceinline__ int lane_get(int v, int j) { return readlane_i32(v, j); }
 __device__ __forceinline__ void lane_set(int& v, int j, int x) { v = lane_id() == j ? x : v; }
 
+#ifndef FPL_TRIM_WAVES_PER_SIMD_BATCHED
+#define FPL_TRIM_WAVES_PER_SIMD_BATCHED 5 /* (the lane-per-read phases hold a read's state and a sliding window per lane: 72 registers
+                                             spilled 51 of them -- 1.80 ms per million reads at 7 waves per SIMD, 1.55 at 6, 1.48 at 5) */
+#endif
 template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, FPL_TRIM_WAVES_PER_SIMD_SHORT)
+__global__ void __launch_bounds__(WAVES * 64, FPL_TRIM_WAVES_PER_SIMD_BATCHED)
 k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
                     uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
                     ReadState* __restrict__ state, long long* __restrict__ counters, u32 C, u32* __restrict__ group_ctr) {
@@ -1768,42 +1855,10 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             lane_set(v_e, j, e);
             lane_set(v_alive, j, alive ? 1 : 0);
         }
-        /* ---- P1c: start adapter window scan, one read at a time (lanes = positions; searchAdapter, asRightAsPossible, :109-131) */
+        /* ---- P1c: start adapter window scan, lane = read (searchAdapter, asRightAsPossible, :109-131) */
         if (do_start) {
-            u64 todo = wave_ballot(v_alive && (v_e - v_s) >= FPL_PATTERN_LEN);
-            while (todo) {
-                const int j = __ffsll(todo) - 1;
-                todo &= todo - 1;
-                const uint64_t o0 = readlane_u64(v_o0, j);
-                const int s = lane_get(v_s, j), e = lane_get(v_e, j), rlen = e - s;
-                const u8* sq = seq + o0;
-                int mpos = -1, cand = -1;
-                const int searchEnd = min(rlen, FPL_END_WINDOW);
-                if (alen0 <= rlen && searchEnd > alen0) {
-                    stage_window(win_s, sq + s, searchEnd, seq_end, win4_s);
-                    const int npos = searchEnd - alen0 + 1;
-                    int hit = -1;
-                    u64 best = ~0ull;
-                    for (int p0 = 0; p0 < npos; p0 += 64) {
-                        const int p = p0 + lane;
-                        int mm = 0x7fffffff;
-                        if (p < npos) mm = hamming_onehot<4>(win4_s, p, ad1h0, alen0);
-                        const u64 m = wave_ballot(p < npos && mm <= thrA0);
-                        if (m) hit = p0 + 63 - __clzll(m); /* rightmost hit so far */
-                        if (p < npos) {
-                            const u64 k = ((u64)(u32)mm << 32) | (u32)p; /* ties: leftmost (descending scan, <=) */
-                            best = k < best ? k : best;
-                        }
-                    }
-                    if (hit >= 0) mpos = hit;
-                    else {
-                        best = wave_min_u64(best);
-                        if (best != ~0ull) cand = (int)(u32)best;
-                    }
-                }
-                lane_set(v_mpos, j, mpos);
-                lane_set(v_cand, j, cand);
-            }
+            const bool act = v_alive && (v_e - v_s) >= FPL_PATTERN_LEN;
+            ham_scan_lanes<true>(seq + v_o0 + v_s, v_e - v_s, act, ad1h0, alen0, thrA0, seq_end, v_mpos, v_cand);
         }
         /* ---- P2: the candidates' edit distance, 64 reads at once */
         if (do_start) {
@@ -1876,49 +1931,12 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             v_trim += got;
             if (kl > 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
         }
-        /* ---- P5: end adapter window scan (searchAdapter, asLeftAsPossible, :84-107) */
+        /* ---- P5: end adapter window scan, lane = read (searchAdapter, asLeftAsPossible, :84-107) */
         v_mpos = -1;
         v_cand = -1;
         if (do_end) {
-            u64 todo = wave_ballot(v_alive && (v_e - v_s) >= FPL_PATTERN_LEN);
-            while (todo) {
-                const int j = __ffsll(todo) - 1;
-                todo &= todo - 1;
-                const uint64_t o0 = readlane_u64(v_o0, j);
-                const int s = lane_get(v_s, j), e = lane_get(v_e, j), rlen = e - s;
-                const u8* sq = seq + o0;
-                int mpos = -1, cand = -1;
-                const int ss = max(0, rlen - FPL_END_WINDOW);
-                if (ss + alen1 <= rlen) {
-                    const int wl = min(rlen, FPL_END_WINDOW);
-                    stage_window(win_e, sq + e - wl, wl, seq_end, win4_e);
-                    const int bias = rlen - wl;
-                    const int pend = rlen - alen1; /* p in [ss, pend) : the last position is never tested */
-                    int hit = -1;
-                    u64 best = ~0ull;
-                    for (int p0 = ss; p0 < pend; p0 += 64) {
-                        const int p = p0 + lane;
-                        int mm = 0x7fffffff;
-                        if (p < pend) mm = hamming_onehot<4>(win4_e, p - bias, ad1h1, alen1);
-                        const u64 m = wave_ballot(p < pend && mm <= thrA1);
-                        if (m) {
-                            hit = p0 + __ffsll(m) - 1; /* leftmost hit, returned at once (:98-101) */
-                            break;
-                        }
-                        if (p < pend) {
-                            const u64 k = ((u64)(u32)mm << 32) | (u32)(0xFFFFFFFFu - (u32)p); /* ties: rightmost (<=) */
-                            best = k < best ? k : best;
-                        }
-                    }
-                    if (hit >= 0) mpos = hit;
-                    else {
-                        best = wave_min_u64(best);
-                        if (best != ~0ull) cand = (int)(0xFFFFFFFFu - (u32)best);
-                    }
-                }
-                lane_set(v_mpos, j, mpos);
-                lane_set(v_cand, j, cand);
-            }
+            const bool act = v_alive && (v_e - v_s) >= FPL_PATTERN_LEN;
+            ham_scan_lanes<false>(seq + v_o0 + v_s, v_e - v_s, act, ad1h1, alen1, thrA1, seq_end, v_mpos, v_cand);
         }
         /* ---- P6 */
         if (do_end) {

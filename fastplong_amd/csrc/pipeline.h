@@ -216,7 +216,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         if (a.trim_mode == 1 && FPL_OPT_BATCH && n >= batch_min) {
             /* a wave takes 64 reads per round: enough waves to fill the chip, few enough to keep every wave a few rounds long */
             u32 gblocks = cdiv(cdiv(n, 64u), KWAVES);
-            const u32 gcap = FPL_TRIM_WAVES_PER_SIMD_SHORT * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
+            const u32 gcap = FPL_TRIM_WAVES_PER_SIMD_BATCHED * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
             if (gblocks > gcap) gblocks = gcap;
             FPL_LAUNCH((k_trim_ends_batched<KWAVES>), dim3(gblocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                        a.ads, a.state, a.counters, a.C, a.work_ctr + 2);

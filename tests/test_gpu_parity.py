@@ -73,7 +73,7 @@ def test_adversarial_reads_bit_exact(orc, engine_mod, name):
 
 
 @pytest.mark.parametrize("la,lb", [(64, 65), (65, 64), (100, 150), (250, 33), (8, 12), (15, 16), (4, 32), (16, 0), (0, 31), (24, 7), (7, 6), (5, 4),
-                                   (40, 50), (33, 64), (64, 20), (45, 45)])
+                                   (40, 50), (33, 64), (64, 20), (45, 45), (32, 16), (17, 31), (29, 32)])
 def test_odd_command_line_adapter_lengths_bit_exact(orc, engine_mod, la, lb):
     """-s / -e adapters beyond 64 bases leave the LDS tables of k_trim_ends (one 64-column Peq word per byte value) and
     take the global-memory path; beyond 200 bases they are longer than the end window; below 16 bases (partial

@@ -157,6 +157,22 @@ def test_emulated_kernels_byte_scan_fallback(orc):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
+@pytest.mark.parametrize("la,lb", [(32, 17), (16, 31)])
+def test_emulated_batched_trim_kernel_adapter_lengths(orc, la, lb):
+    """the lane-per-read window scans of k_trim_ends_batched (ham_scan_lanes) slide 32 one-hot nibbles: adapters at both ends of
+    the 16..32 range, planted near both read ends by the adversarial generator"""
+    rng = np.random.default_rng(la * 100 + lb)
+    start = "".join("ACGT"[i] for i in rng.integers(0, 4, la))
+    end = "".join("ACGT"[i] for i in rng.integers(0, 4, lb))
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1), start, end)
+    seq, qual, off = synth.adversarial(150, seed=la + lb, start_adapter=start, end_adapter=end)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
 def test_emulated_kernels_adapters_of_33_to_64_bases(orc):
     """A / C / G / T adapters beyond 32 bases: the bit-sliced scan with seven count planes in k_scan, and k_resolve's edit
     distances on 64-bit columns, one window per lane (lev_lanes64_acgt)"""
