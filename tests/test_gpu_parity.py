@@ -568,3 +568,23 @@ def test_every_bench_workload_bit_exact(orc, engine_mod, monkeypatch, workload, 
     opt = abi.FplOptions.default(**wl["opt"])
     verdict, n, nb = bench.parity_sample(rig, opt, (ad_start, ad_end, ad_fasta), seq_t, qual_t, off_t, 0, 700)
     assert verdict == "ok" and n == 700, verdict
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_long_trim_scans_fall_back_bit_exact(orc, engine_mod, seed):
+    """k_trim_ends_batched: lanes whose trimAndCut / polyX scans outlast the iteration cap are redone by the wave-per-read forms"""
+    from tests.test_kernels_emu import _reads_with_long_scans
+
+    seq, qual, off = _reads_with_long_scans(seed, n=600)
+    cfgd = dict(opt=dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=4, polyx=1, n_base_percent_limit=60),
+                start=synth.START_ADAPTER, end=synth.END_ADAPTER)
+    res, _ = _run_both(orc, engine_mod, cfgd, seq, qual, off)
+    assert (res["dropped"] != 0).any()
+
+
+def test_long_reads_split_by_middle_adapters_bit_exact(orc, engine_mod):
+    """k_resolve -> k_redo: split reads beyond 16 kb (front of the REDO list) and below (its far end), many per block"""
+    seq, qual, off = synth.ont_like(500, seed=8, median_len=17000, sigma_len=0.3, p_middle=0.6)
+    res, _ = _run_both(orc, engine_mod, CASES["full_pipeline"], seq, qual, off, via="device")
+    split = res["n_frag"] == 2
+    assert (split & (res["r1_len"] > 16384)).sum() > 50 and (split & (res["r1_len"] <= 16384)).sum() > 50

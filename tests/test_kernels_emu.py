@@ -173,6 +173,67 @@ def test_emulated_batched_trim_kernel_adapter_lengths(orc, la, lb):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
+def _reads_with_long_scans(seed, n=40):
+    """reads whose trimAndCut / polyX scans run long: low-quality heads and tails of 100..500 bases (a sliding window finds
+    nothing good for hundreds of positions), poly-A tails and N runs beyond the lane-per-read forms' iteration cap, and a few
+    reads that are ALL low quality or all one base"""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for i in range(n):
+        L = int(rng.integers(700, 2500))
+        sq = synth._ACGT[rng.integers(0, 4, L)].astype(np.uint8)
+        ql = (np.clip(np.round(rng.normal(24, 5, L)), 2, 50) + 33).astype(np.uint8)
+        k = i % 8
+        if k == 0:
+            ql[:int(rng.integers(100, 500))] = 35  # Q2 head
+        elif k == 1:
+            ql[-int(rng.integers(100, 500)):] = 35  # Q2 tail
+        elif k == 2:
+            sq[-int(rng.integers(170, 400)):] = ord("A")  # poly-A beyond the cap
+        elif k == 3:
+            a = int(rng.integers(170, 300))
+            ql[:a] = 35
+            sq[a - 3:a + int(rng.integers(165, 260))] = ord("N")  # a long N run behind the cut point
+        elif k == 4:
+            ql[:] = 36  # nothing good anywhere
+        elif k == 5:
+            sq[:] = ord("G")
+        elif k == 6:
+            b = int(rng.integers(170, 300))
+            ql[-b:] = 35
+            sq[-(b + int(rng.integers(165, 240))):-(b - 3)] = ord("N")
+        reads.append((sq, ql))
+    return synth.pack(reads)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_emulated_batched_trim_kernel_long_scans_fall_back(orc, seed):
+    """the lane-per-read trimAndCut / polyX of k_trim_ends_batched give up after LANE_SCAN_CAP rounds and hand the read to the
+    wave-per-read forms: same results either way"""
+    seq, qual, off = _reads_with_long_scans(seed)
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=4, polyx=1,
+                                            n_base_percent_limit=60), synth.START_ADAPTER, synth.END_ADAPTER)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    assert (want_res["dropped"] != 0).any() and (want_res["r1_len"][want_res["dropped"] == 0] < 600).any()
+
+
+def test_emulated_long_reads_split_by_middle_adapters(orc):
+    """reads beyond REDO_LONG (16 kb) with a middle adapter go to the FRONT of the REDO list, the others to its far end"""
+    seq, qual, off = synth.ont_like(14, seed=3, median_len=19000, sigma_len=0.25, p_middle=0.9)
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1, complexity_filter=1), synth.START_ADAPTER, synth.END_ADAPTER)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    split = want_res["n_frag"] == 2
+    assert (split & (want_res["r1_len"] > 16384)).any() and (split & (want_res["r1_len"] <= 16384)).any()
+
+
 def test_emulated_kernels_adapters_of_33_to_64_bases(orc):
     """A / C / G / T adapters beyond 32 bases: the bit-sliced scan with seven count planes in k_scan, and k_resolve's edit
     distances on 64-bit columns, one window per lane (lev_lanes64_acgt)"""
