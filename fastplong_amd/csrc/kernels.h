@@ -947,8 +947,12 @@ struct TrimLds {
 
 /* copy bytes [from, from + n) of a read (n <= TRIM_WIN) into this wave's window, 4 bytes per lane */
 /* ... and, when dst4 is given, the same bytes as one-hot nibbles (A 1, C 2, G 4, T 8, anything else 0), 16 bits per lane */
+/* dstr (with dst4): per byte the row of the adapter filter's Peq table it selects -- its code when it is exactly A / C / T / G,
+   else 4, the all-zero row (fasta_may_trim32 would otherwise work that out on the scalar unit, column by column, for every
+   group of adapters and every refresh) */
 __device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __restrict__ src, int n,
-                                             const u8* __restrict__ seq_end, u32* __restrict__ dst4 = nullptr) {
+                                             const u8* __restrict__ seq_end, u32* __restrict__ dst4 = nullptr,
+                                             u32* __restrict__ dstr = nullptr) {
     const int lane = lane_id();
     wave_sync();
     if (lane < TRIM_WIN / 4) {
@@ -962,6 +966,7 @@ __device__ __forceinline__ void stage_window(u32* __restrict__ dst, const u8* __
             const u32 nib = perm_lo(0x04080201u, code) & (ok * 15u);
             const u32 h = (nib | (nib >> 4)) & 0x00FF00FFu;
             ((uint16_t*)dst4)[lane] = (uint16_t)((h | (h >> 8)) & 0xFFFFu);
+            if (dstr) dstr[lane] = (code & (ok * 3u)) | ((ok ^ 0x01010101u) << 2);
         }
     }
     if (dst4 && lane < 16) dst4[TRIM_WIN / 8 + (lane & 7)] = 0u; /* (what a shifted read of the last positions touches) */
@@ -1057,8 +1062,8 @@ __device__ __forceinline__ void fasta_peq_store(FastaPeqLds* __restrict__ t, con
    last 16 bases -- is again the first 16 columns.  18 vector instructions per window byte instead of 49; what it lets
    through that the two-run form would have stopped only costs an exact trim that finds nothing. */
 template <bool START>
-__device__ __forceinline__ u32 fasta_may_trim32(const FastaPeqLds* __restrict__ t, const u8* __restrict__ win, int boff, int n,
-                                                 int alen, int thrA, int thrP, bool a_ok) {
+__device__ __forceinline__ u32 fasta_may_trim32(const FastaPeqLds* __restrict__ t, const u8* __restrict__ rowc, int boff, int n,
+                                                 int alen, int thrA, int thrP, bool a_ok) { /* rowc: stage_window's dstr */
     const int lane = lane_id();
     const int m = min(alen, 32);
     u32 Pv = m >= 32 ? ~0u : ((1u << m) - 1u), Mv = 0;
@@ -1075,15 +1080,10 @@ __device__ __forceinline__ u32 fasta_may_trim32(const FastaPeqLds* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int j = min(jj + u, n - 1);
-                cb[u] = (u32)win[(START ? n - 1 - j : j) + boff];
+                cb[u] = (u32)rowc[(START ? n - 1 - j : j) + boff];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const u32 c = uniform_u32(cb[u]);
-                const u32 code = (c >> 1) & 3u;
-                const u32 row = (((0x47544341u >> (8 * code)) & 0xFFu) == c) ? code : 4u;
-                Eqs[u] = t->w[row][START ? 2 : 3][lane];
-            }
+            for (int u = 0; u < 8; u++) Eqs[u] = t->w[uniform_u32(cb[u])][START ? 2 : 3][lane];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 if (jj + u < j1) { /* wave-uniform */
@@ -1209,6 +1209,9 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     u32* const win_tq = lds.win[wave_in_block()][3];
     u32* const win4_s = MODE != 0 ? lds.win4[wave_in_block()][0] : nullptr; /* (only the reduced instantiations scan nibbles) */
     u32* const win4_e = MODE != 0 ? lds.win4[wave_in_block()][1] : nullptr;
+    __shared__ u32 winr[FILT ? WAVES : 1][2][TRIM_WIN / 4 + 8]; /* the two windows as Peq-table rows (stage_window's dstr) */
+    u32* const winr_s = FILT ? winr[wave_in_block()][0] : nullptr;
+    u32* const winr_e = FILT ? winr[wave_in_block()][1] : nullptr;
 
     const u32 wave_global = blockIdx.x * WAVES + wave_in_block();
     const u32 n_waves = gridDim.x * WAVES;
@@ -1295,8 +1298,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     may_s = may_e = 0;
                     return;
                 }
-                if (stale_s) stage_window(win_s, sq + s, wl, seq_end, win4_s);
-                if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end, win4_e);
+                if (stale_s) stage_window(win_s, sq + s, wl, seq_end, win4_s, winr_s);
+                if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end, win4_e, winr_e);
                 stale_s = stale_e = false;
                 const bool a_ok = ai < cfg->n_fasta;
                 const DevAdapter* la = &ads[2 + (a_ok ? ai : a)];
@@ -1317,14 +1320,14 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 /* (a trim at one end leaves the other end's window -- and with it that end's verdicts -- as they were, unless r1
                    has become shorter than the window) */
                 if (dirty_s) {
-                    verd_s = fasta_may_trim32<true>(fp, (const u8*)win_s, 0, wl, alen, thrA, thrP, a_ok);
+                    verd_s = fasta_may_trim32<true>(fp, (const u8*)winr_s, 0, wl, alen, thrA, thrP, a_ok);
                     fn_s = wl;
                     full_s = wave_ballot((verd_s & 1u) != 0);
                     part_s = wave_ballot((verd_s & 2u) != 0);
                     may_s = full_s | part_s;
                 }
                 if (dirty_e) {
-                    verd_e = fasta_may_trim32<false>(fp, (const u8*)win_e, 0, wl, alen, thrA, thrP, a_ok);
+                    verd_e = fasta_may_trim32<false>(fp, (const u8*)winr_e, 0, wl, alen, thrA, thrP, a_ok);
                     fn_e = wl;
                     full_e = wave_ballot((verd_e & 1u) != 0);
                     part_e = wave_ballot((verd_e & 2u) != 0);
@@ -1367,7 +1370,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 }
                 if (FILT && (!masks_ok || (a >> 6) != fp_group)) refresh_masks(a);
                 if (!FILT || ((may_s >> (a & 63)) & 1ull)) {
-                    if (stale_s) stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end, win4_s);
+                    if (stale_s) stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end, win4_s, winr_s);
                     stale_s = false;
                     wave_sync();
                     for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_start[i];
@@ -1384,7 +1387,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 if (FILT && !masks_ok) refresh_masks(a);
                 if (!FILT || ((may_e >> (a & 63)) & 1ull)) {
                     const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
-                    if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end, win4_e);
+                    if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end, win4_e, winr_e);
                     stale_e = false;
                     wave_sync();
                     for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_end[i];
