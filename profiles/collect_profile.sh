@@ -15,7 +15,8 @@ W=$OUT/work_$WL
 rm -rf "$W"; mkdir -p "$W"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --workload $WL --cpu-bases 0 --e2e-reads 0 --parity-reads 0 $*"
-$BENCH --steps 10 --warmup 2 > "$OUT/bench_$WL.json" 2> "$W/bench.err"
+# (the bench line that is kept carries the parity sample; the profiled repeats leave it out)
+python $ROOT/bench.py --workload $WL --cpu-bases 0 --e2e-reads 0 $* --steps 10 --warmup 2 > "$OUT/bench_$WL.json" 2> "$W/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/stats" -- $BENCH --steps 5 --warmup 1 > "$W/stats.log" 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --output-format csv -d "$W/pmc_$ctr" -- $BENCH --steps 2 --warmup 1 > "$W/pmc_$ctr.log" 2>&1
