@@ -220,6 +220,19 @@ __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 n) {
 #endif
 }
 
+/* the bits of x in reverse order (v_bfrev_b32) */
+__device__ __forceinline__ u32 brev32(u32 x) {
+#ifdef FPL_EMU
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+#else
+    return __builtin_bitreverse32(x);
+#endif
+}
+
 /* any three-input bitwise function in one VALU op (v_bitop3_b32); TT = f(0xF0, 0xCC, 0xAA) */
 template <int TT>
 __device__ __forceinline__ u32 bitop3(u32 a, u32 b, u32 c) {

@@ -97,6 +97,11 @@ __device__ unsigned long long g_fpl_prof[64];
                                  and a 16-column run for the partial pattern (fasta_may_trim); 2: one 32-column run with two
                                  score taps (fasta_may_trim32) */
 #endif
+#ifndef FPL_OPT_PARTLANES
+#define FPL_OPT_PARTLANES 1 /* k_trim_ends_batched: the partial-pattern searches with lane = read on the columns the search
+                               pass leaves open (partial16_candidates / partial16_resolve_lanes) instead of a wave and 184
+                               windows per flagged read */
+#endif
 #ifndef FPL_OPT_SGFILTER
 #define FPL_OPT_SGFILTER 1 /* k_trim_ends_batched: a lane-parallel Myers search pass decides which reads need the
                               partial-pattern search at all (partial16_possible) */
@@ -1738,6 +1743,160 @@ __device__ __forceinline__ bool partial16_possible(const u8* __restrict__ text, 
     return need && best <= thr;
 }
 
+#ifdef FPL_EMU_TRIM_STATS
+static unsigned long long g_trim_stats[10]; /* emulator only: groups, lanes handed to P1b, P2 / P3 wants / P3 may, P6 / P7 wants / P7 may, lane-parallel partial searches / their rounds */
+#define FPL_TRIM_STAT(i, n) (g_trim_stats[i] += (unsigned long long)(n))
+#else
+#define FPL_TRIM_STAT(i, n) ((void)0)
+#endif
+/* partial16_possible that also says WHERE (FPL_OPT_PARTLANES): bit (j & 31) of cand[j >> 5][lane] = the search variant's score
+ * at text column j is <= thr -- the only columns a window accepted by the exact search can END at (its global distance is
+ * no smaller than that score).  Returns, per lane, which of the seven words hold a bit (0: the search finds nothing).
+ * The running value is score - thr - 1, so "reached thr" is its sign bit and one v_alignbit per column collects the bits:
+ * the same instruction count as the minimum that partial16_possible keeps. */
+constexpr int PART_WORDS = 7; /* ceil(FPL_END_WINDOW / 32) */
+__device__ __forceinline__ u32 partial16_candidates(const u8* __restrict__ text, int n, int thr, bool need,
+                                                    const uint16_t* __restrict__ peq16, const u8* __restrict__ seq_end,
+                                                    u32 (*__restrict__ cand)[64]) {
+    const int lane = lane_id();
+    const int nn = need ? n : 0;
+    const int nmax = (int)wave_max_u32((u32)nn);
+    u32 Pv = 0xFFFFu, Mv = 0;
+    int x = 16 - (thr + 1);
+    u32 nz = 0, lo = 0;
+    for (int c0 = 0; c0 < nmax; c0 += 16) { /* wave-uniform */
+        u32 w[4] = {0, 0, 0, 0};
+        if (c0 < nn) {
+            const u32x4 a = load16_guard(text + c0, seq_end);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        }
+        u32 bits = 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const u32 c = (w[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+            const u32 Eq = peq16[c];
+            const u32 Xv = Eq | Mv;
+            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u32 Ph = Mv | ~(Xh | Pv);
+            u32 Mh = Pv & Xh;
+            const int sc = x + (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
+            Ph <<= 1;
+            Mh <<= 1;
+            const bool act = c0 + t < nn;
+            const u32 nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
+            x = act ? sc : x;
+            Pv = act ? nPv : Pv;
+            Mv = act ? nMv : Mv;
+            bits = alignbit(bits, (u32)x, 31); /* (bits << 1) | sign(x): column c0 + t ends up at bit 15 - t */
+        }
+        const int nv = nn - c0; /* columns of this block that exist in this lane's text */
+        const u32 h = (brev32(bits) >> 16) & (nv >= 16 ? 0xFFFFu : (nv <= 0 ? 0u : ((1u << nv) - 1u)));
+        if (c0 & 16) { /* wave-uniform */
+            const u32 word = lo | (h << 16);
+            cand[c0 >> 5][lane] = word;
+            nz |= (word ? 1u : 0u) << (c0 >> 5);
+        } else {
+            lo = h;
+        }
+    }
+    if (nmax > 0 && !((nmax - 1) & 16)) { /* the last block was the low half of its word */
+        const int k = (nmax - 1) >> 5;
+        cand[k][lane] = lo;
+        nz |= (lo ? 1u : 0u) << k;
+    }
+    return need ? nz : 0u; /* (only the words flagged in nz are ever read) */
+}
+
+/* the global edit distance between the 16-base pattern (peq16, in LDS) and the 16 text bytes at `text`, one problem per lane:
+ * lev16_win<true> with lane = read */
+__device__ __forceinline__ int lev16_lanes(const u8* __restrict__ text, bool need, const uint16_t* __restrict__ peq16,
+                                           const u8* __restrict__ seq_end) {
+    u32 w[4] = {0, 0, 0, 0};
+    if (need) {
+        const u32x4 a = load16_guard(text, seq_end);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    }
+    u32 eq[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) eq[t] = peq16[(w[t >> 2] >> (8 * (t & 3))) & 0xFFu];
+    u32 Pv = ~0u, Mv = 0;
+    int score = 16;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const u32 Eq = eq[t];
+        const u32 Xv = Eq | Mv;
+        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        u32 Ph = Mv | ~(Xh | Pv);
+        u32 Mh = Pv & Xh;
+        score += (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
+        Ph = (Ph << 1) | 1u;
+        Mh <<= 1;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+    }
+    return score;
+}
+
+/* The partial-pattern searches of trimBySequenceStart / End (src/adaptertrimmer.cpp:202-216, :273-286) with lane = read:
+ * every lane walks ITS candidate columns (partial16_candidates) in the order the reference walks the windows and takes
+ * the exact 16 x 16 distance of each -- usually one to three per flagged read instead of 184 windows.  START: windows
+ * r1[p, p + 16), p = column - 15, ascending, the smallest distance wins and the smallest p among equals.  !START: windows
+ * r1[rlen - 16 - p, rlen - p), p = n - 1 - column ascending (columns descending), the reference's "stop at the first
+ * increase" walk over the qualifying windows.  A lane that still has candidates after PART_CAND_CAP rounds reports over =
+ * true and takes the wave-per-read search instead.  r1w = the first byte of window p = 0's text row: r1 (START) / the byte
+ * 16 before the end of r1 (!START), so window p starts at r1w + p / r1w - p. */
+constexpr int PART_CAND_CAP = 10;
+template <bool START>
+__device__ __forceinline__ int partial16_resolve_lanes(const u8* __restrict__ r1w, int n, int lim, int thrP, u32 nz,
+                                                       const uint16_t* __restrict__ peq16, const u8* __restrict__ seq_end,
+                                                       u32 (*__restrict__ cand)[64], bool& over) {
+    const int lane = lane_id();
+    u32 cur = 0;
+    int k = 0;
+    int pos = -1, mined = 0x7fffffff;
+    bool stop = false;
+    over = false;
+    FPL_TRIM_STAT(8, 1);
+    for (int it = 0;; it++) { /* wave-uniform */
+        if (cur == 0 && nz != 0) { /* this lane's next non-empty word */
+            k = START ? (int)__ffs((int)nz) - 1 : 31 - (int)__clz((int)nz);
+            nz &= ~(1u << k);
+            cur = cand[k][lane];
+        }
+        const bool has = cur != 0;
+        if (!wave_ballot(has)) break;
+        FPL_TRIM_STAT(9, 1);
+        if (it == PART_CAND_CAP) {
+            over = has;
+            break;
+        }
+        const int b = has ? (START ? (int)__ffs((int)cur) - 1 : 31 - (int)__clz((int)cur)) : 0;
+        cur &= ~(1u << b);
+        const int j = 32 * k + b;
+        const int p = START ? j - 15 : n - 1 - j;
+        const bool ok = has && p >= 0 && p < lim;
+        const int ed = lev16_lanes(START ? r1w + p : r1w - p, ok, peq16, seq_end);
+        if (ok && ed <= thrP) {
+            if (START) {
+                if (ed < mined) { /* (ascending p: the first of equals stays) */
+                    mined = ed;
+                    pos = p;
+                }
+            } else if (pos < 0 || ed <= mined) {
+                pos = p;
+                mined = ed;
+            } else {
+                stop = true;
+            }
+        }
+        if (stop) {
+            cur = 0;
+            nz = 0;
+        }
+    }
+    return pos;
+}
+
 /* the value lane j holds, as a wave-uniform value / set lane j's value */
 __device__ __forceinline__ int lane_get(int v, int j) { return readlane_i32(v, j); }
 __device__ __forceinline__ void lane_set(int& v, int j, int x) { v = lane_id() == j ? x : v; }
@@ -1754,7 +1913,9 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
     __shared__ TrimBlockAcc acc;
     __shared__ TrimLds<WAVES> lds;
     __shared__ int thr_lds[40]; /* DevConfig::thr[0..32] */
+    __shared__ u32 cand_lds[FPL_OPT_PARTLANES ? WAVES : 1][PART_WORDS][64]; /* per lane: the columns its partial-pattern search may end at */
     const int lane = lane_id();
+    u32(*const cand)[64] = cand_lds[FPL_OPT_PARTLANES ? wave_in_block() : 0];
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x) acc.fr[i] = 0;
     for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x) acc.key[i] = 0;
     for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
@@ -1796,6 +1957,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         if (grp >= n_groups) break;
         const u32 g0 = grp * 64;
         const int gn = (int)min(64u, n_reads - g0);
+        FPL_TRIM_STAT(0, 1);
         /* lane j = read g0 + j */
         uint64_t v_o0 = 0;
         int v_l = 0;
@@ -1835,6 +1997,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         for (u64 todo = wave_ballot(v_slow); todo;) {
             const int j = __ffsll(todo) - 1;
             todo &= todo - 1;
+            FPL_TRIM_STAT(1, 1);
             const uint64_t o0 = readlane_u64(v_o0, j);
             const int l = lane_get(v_l, j);
             const u8* sq = seq + o0;
@@ -1866,6 +2029,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         /* ---- P2: the candidates' edit distance, 64 reads at once */
         if (do_start) {
             const bool need = v_cand >= 0;
+            FPL_TRIM_STAT(2, __popcll(wave_ballot(need)));
             if (wave_ballot(need)) {
                 const bool ok = lev_lanes32(seq + v_o0 + v_s + v_cand, alen0, 0, thrA0, need, lds.peqf[0], seq_end);
                 v_mpos = ok ? v_cand : v_mpos;
@@ -1878,9 +2042,20 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             const int rl = v_e - v_s;
             const bool wants = v_alive && v_mpos < 0 && rl >= FPL_PATTERN_LEN;
             bool may = wants;
-            if (FPL_OPT_SGFILTER && wave_ballot(wants))
+            if (FPL_OPT_PARTLANES) {
+                may = false;
+                if (wave_ballot(wants)) {
+                    const int n = min(rl, FPL_END_WINDOW);
+                    const u32 nzc = partial16_candidates(seq + v_o0 + v_s, n, thrP, wants, lds.peq16[0], seq_end, cand);
+                    if (wave_ballot(nzc != 0))
+                        v_ppos = partial16_resolve_lanes<true>(seq + v_o0 + v_s, n, min(rl - plen, FPL_END_WINDOW - plen), thrP, nzc,
+                                                               lds.peq16[0], seq_end, cand, may);
+                }
+            } else if (FPL_OPT_SGFILTER && wave_ballot(wants))
                 may = partial16_possible(seq + v_o0 + v_s, min(rl, FPL_END_WINDOW), thrP, wants, lds.peq16[0], seq_end);
             u64 todo = wave_ballot(may);
+            FPL_TRIM_STAT(3, __popcll(wave_ballot(wants)));
+            FPL_TRIM_STAT(4, __popcll(todo));
             while (todo) {
                 const int j = __ffsll(todo) - 1;
                 todo &= todo - 1;
@@ -1944,6 +2119,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         /* ---- P6 */
         if (do_end) {
             const bool need = v_cand >= 0;
+            FPL_TRIM_STAT(5, __popcll(wave_ballot(need)));
             if (wave_ballot(need)) {
                 const bool ok = lev_lanes32(seq + v_o0 + v_s + v_cand, alen1, 0, thrA1, need, lds.peqf[1], seq_end);
                 v_mpos = ok ? v_cand : v_mpos;
@@ -1956,9 +2132,21 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             const int rl = v_e - v_s, wlf = min(rl, FPL_END_WINDOW);
             const bool wants = v_alive && v_mpos < 0 && rl >= FPL_PATTERN_LEN;
             bool may = wants;
-            if (FPL_OPT_SGFILTER && wave_ballot(wants))
+            if (FPL_OPT_PARTLANES) {
+                may = false;
+                if (wave_ballot(wants)) {
+                    const u32 nzc = partial16_candidates(seq + v_o0 + v_e - wlf, wlf, thrP, wants, lds.peq16[1], seq_end, cand);
+                    if (wave_ballot(nzc != 0)) {
+                        const int pos = partial16_resolve_lanes<false>(seq + v_o0 + v_e - 16, wlf, min(rl - plen, FPL_END_WINDOW - plen), thrP,
+                                                                       nzc, lds.peq16[1], seq_end, cand, may);
+                        v_ppos = pos > 0 ? pos : -1; /* :288 strict */
+                    }
+                }
+            } else if (FPL_OPT_SGFILTER && wave_ballot(wants))
                 may = partial16_possible(seq + v_o0 + v_e - wlf, wlf, thrP, wants, lds.peq16[1], seq_end);
             u64 todo = wave_ballot(may);
+            FPL_TRIM_STAT(6, __popcll(wave_ballot(wants)));
+            FPL_TRIM_STAT(7, __popcll(todo));
             while (todo) {
                 const int j = __ffsll(todo) - 1;
                 todo &= todo - 1;

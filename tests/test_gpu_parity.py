@@ -236,7 +236,8 @@ def random_case(seed):
 
 
 # 13107: a --mask'ed read whose unmasked piece starts three bases in front of a cycle-tile boundary (found by a 20 000-seed soak)
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_FUZZ_SEEDS", "32")))) + [13107])
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_FUZZ_FROM", "0")),
+                                            int(os.environ.get("FPL_FUZZ_FROM", "0")) + int(os.environ.get("FPL_FUZZ_SEEDS", "32")))) + [13107])
 def test_random_option_sets_bit_exact(orc, engine_mod, seed):
     """seeded random corners of the option space (including --break / --mask) on adversarial + ONT-like reads"""
     okw, start, end, seq, qual, off = random_case(seed)
@@ -580,6 +581,19 @@ def test_long_trim_scans_fall_back_bit_exact(orc, engine_mod, seed):
                 start=synth.START_ADAPTER, end=synth.END_ADAPTER)
     res, _ = _run_both(orc, engine_mod, cfgd, seq, qual, off)
     assert (res["dropped"] != 0).any()
+
+
+@pytest.mark.parametrize("seed,kind", [(1, "default"), (2, "repeat"), (3, "mixed"), (4, "repeat"), (5, "default")])
+def test_partial_pattern_searches_lane_per_read_bit_exact(orc, engine_mod, seed, kind):
+    """k_trim_ends_batched: the partial-pattern searches walk each lane's candidate columns; reads with more candidates than the
+    cap (adapters with repeats, patterns with insertions) are redone by the wave-per-read search"""
+    from tests.test_kernels_emu import REPEAT_END, REPEAT_START, _reads_with_partial_adapters
+
+    start = synth.START_ADAPTER if kind == "default" else REPEAT_START
+    end = REPEAT_END if kind == "repeat" else synth.END_ADAPTER
+    seq, qual, off = _reads_with_partial_adapters(seed, start, end, n=1400)
+    res, _ = _run_both(orc, engine_mod, dict(opt=dict(), start=start, end=end), seq, qual, off)
+    assert (res["r1_start"] > 0).sum() > 100
 
 
 def test_long_reads_split_by_middle_adapters_bit_exact(orc, engine_mod):

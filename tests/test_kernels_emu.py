@@ -221,6 +221,79 @@ def test_emulated_batched_trim_kernel_long_scans_fall_back(orc, seed):
     assert (want_res["dropped"] != 0).any() and (want_res["r1_len"][want_res["dropped"] == 0] < 600).any()
 
 
+REPEAT_START = "GTCAGTTACGTATTGC" + "AC" * 8  # (the start trim's partial pattern = the LAST 16 bases)
+REPEAT_END = "TG" * 8 + "AGCAATACGTAACTGA"   # (the end trim's = the FIRST 16)
+
+
+def _reads_with_partial_adapters(seed, start, end, n=96):
+    """reads for the partial-pattern searches of the end trims: noisy truncated copies of the adapters at the very ends (the last
+    10..25 bases of the start adapter in front, the first 10..25 of the end adapter behind), several copies in a row, runs of
+    the adapters' 16-base patterns' repeat unit (dozens of candidate windows per read), reads shorter than the 200-base
+    windows, and plain reads"""
+    rng = np.random.default_rng(seed)
+    sa = np.frombuffer(start.encode(), dtype=np.uint8)
+    ea = np.frombuffer(end.encode(), dtype=np.uint8)
+
+    def noisy(x, err):
+        x = x.copy()
+        hit = rng.random(len(x)) < err
+        x[hit] = synth._ACGT[rng.integers(0, 4, int(hit.sum()))]
+        return x
+
+    reads = []
+    for i in range(n):
+        L = int(rng.integers(40, 260)) if i % 6 == 5 else int(rng.integers(300, 1500))
+        sq = synth._ACGT[rng.integers(0, 4, L)].astype(np.uint8)
+        ql = (np.clip(np.round(rng.normal(24, 5, L)), 2, 50) + 33).astype(np.uint8)
+        k = i % 8
+        if k in (0, 1, 4):  # truncated start adapter(s) at the head
+            at = int(rng.integers(0, 30))
+            for _ in range(1 + (k == 4) * int(rng.integers(1, 4))):
+                t = noisy(sa[-int(rng.integers(10, 26)):], float(rng.choice([0.0, 0.08, 0.2])))
+                if at + len(t) < L:
+                    sq[at:at + len(t)] = t
+                at += len(t) + int(rng.integers(0, 12))
+        if k in (1, 2, 4):  # truncated end adapter(s) at the tail
+            at = L - int(rng.integers(0, 30))
+            for _ in range(1 + (k == 4) * int(rng.integers(1, 4))):
+                t = noisy(ea[:int(rng.integers(10, 26))], float(rng.choice([0.0, 0.08, 0.2])))
+                if at - len(t) > 0:
+                    sq[at - len(t):at] = t
+                at -= len(t) + int(rng.integers(0, 12))
+        if k == 3:  # runs of the patterns' repeat units at both ends
+            a, b = int(rng.integers(30, 190)), int(rng.integers(30, 190))
+            if a + b < L:
+                sq[:a] = noisy(np.resize(sa[-16:], a), 0.06)
+                sq[L - b:] = noisy(np.resize(ea[:16], b), 0.06)
+        if k == 7 and L >= 300:  # the patterns with three bases inserted in the middle, several times over: columns the search
+            # variant cannot rule out (score 3) whose exact windows do not qualify -- more candidates than the lanes' cap
+            for side in (0, 1):
+                pat = sa[-16:] if side == 0 else ea[:16]
+                blocks = np.concatenate([np.concatenate([pat[:8], synth._ACGT[rng.integers(0, 4, 3)], pat[8:]]) for _ in range(7)])
+                if side == 0:
+                    sq[2:2 + len(blocks)] = blocks
+                else:
+                    sq[L - 2 - len(blocks):L - 2] = blocks
+        reads.append((sq, ql))
+    return synth.pack(reads)
+
+
+@pytest.mark.parametrize("seed,start,end", [(1, synth.START_ADAPTER, synth.END_ADAPTER), (2, REPEAT_START, REPEAT_END),
+                                            (3, REPEAT_START, synth.END_ADAPTER)])
+def test_emulated_batched_trim_kernel_partial_pattern_searches(orc, seed, start, end):
+    """k_trim_ends_batched's partial-pattern searches with lane = read (partial16_candidates / partial16_resolve_lanes): a few
+    candidate columns per read as a rule; reads with more than PART_CAND_CAP of them (repeats) fall back to the wave-per-read
+    search -- same results either way"""
+    seq, qual, off = _reads_with_partial_adapters(seed, start, end)
+    cfg = orc.Config(abi.FplOptions.default(), start, end)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    assert (want_res["r1_start"] > 0).sum() > 10 and (want_res["r1_start"] + want_res["r1_len"] < np.diff(off.astype(np.int64))).sum() > 10
+
+
 def test_emulated_long_reads_split_by_middle_adapters(orc):
     """reads beyond REDO_LONG (16 kb) with a middle adapter go to the FRONT of the REDO list, the others to its far end"""
     seq, qual, off = synth.ont_like(14, seed=3, median_len=19000, sigma_len=0.25, p_middle=0.9)
