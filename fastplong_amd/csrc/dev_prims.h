@@ -131,6 +131,15 @@ __device__ __forceinline__ u32 wave_next_u32(u32 v) {
     return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
 #endif
 }
+/* the value of the previous lane (lane 0 gets `first`): DPP wave_shr:1, no LDS */
+__device__ __forceinline__ u32 wave_prev_u32(u32 v, u32 first) {
+#ifdef FPL_EMU
+    const u32 o = shfl_up_u32(v, 1);
+    return lane_id() == 0 ? first : o;
+#else
+    return (u32)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+#endif
+}
 /* inclusive prefix sum across lanes */
 __device__ __forceinline__ u32 wave_scan_incl_u32(u32 v) {
 #ifdef FPL_EMU

@@ -97,6 +97,21 @@ __device__ unsigned long long g_fpl_prof[64];
                                  and a 16-column run for the partial pattern (fasta_may_trim); 2: one 32-column run with two
                                  score taps (fasta_may_trim32) */
 #endif
+#ifndef FPL_OPT_DPPPREV
+#define FPL_OPT_DPPPREV 1 /* "the dword of the lane in front" (k_scan's predecessor byte, the 5-mer halo of the statistics kernels) through DPP
+                             wave_shr:1 instead of ds_bpermute: one vector op, no trip through the LDS crossbar */
+#endif
+#ifndef FPL_OPT_VALADDC
+#define FPL_OPT_VALADDC 1 /* sliced_max: the value bit by bit through add-with-carry */
+#endif
+#ifndef FPL_OPT_PADSCALAR
+#define FPL_OPT_PADSCALAR 1 /* k_scan: the ragged last tile of a range is padded with wave-uniform byte masks (one lane is cut by
+                               the end of the range, and which one is a scalar) instead of per-lane ones: 25 instead of 97 vector
+                               instructions per read */
+#endif
+#ifndef FPL_OPT_VMFULL
+#define FPL_OPT_VMFULL 1 /* k_scan: the mask of testable window positions is worked out only in the tiles where it is not all ones */
+#endif
 #ifndef FPL_OPT_PARTLANES
 #define FPL_OPT_PARTLANES 1 /* k_trim_ends_batched: the partial-pattern searches with lane = read on the columns the search
                                pass leaves open (partial16_candidates / partial16_resolve_lanes) instead of a wave and 184
@@ -2501,7 +2516,7 @@ k_stats(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_byte
                 const int s = (int)uniform_u32(SG[g]), e = (int)uniform_u32(EG[g]);
                 const int nvalid = itemL > c0 ? (int)min(8u, itemL - c0) : 0; /* bytes of the item in this lane */
                 /* the four bases in front of this lane's chunk: previous lane's last dword */
-                const u32 up = shfl_up_u32(sw[1], 1);
+                const u32 up = FPL_OPT_DPPPREV ? wave_prev_u32(sw[1], 0u) : shfl_up_u32(sw[1], 1);
                 const bool have_halo = lane > 0 || tile_start >= 4;
                 const u32 halo = allN ? 0x4E4E4E4Eu : (lane > 0 ? up : haloG[g]);
                 /* 5-mers, twelve bases at once: 2-bit codes (Stats::base2val: A0 T1 C2 G3) packed earliest base
@@ -3086,7 +3101,17 @@ __device__ __forceinline__ void sliced_max(const u32 (&B)[NB], u32 cand, int& va
         const u32 t = cand & B[b];
         const bool nz = t != 0;
         cand = nz ? t : cand;
+#if FPL_OPT_VALADDC && !defined(FPL_EMU)
+        { /* val = 2 val + nz in one op: the compare's lane mask is the carry of an add-with-carry */
+            u64 c = wave_ballot(nz);
+            /* (s_nop: the mask comes from a vector compare, and nothing tells the scheduler that this instruction reads it) */
+            asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(val), "+s"(c));
+        }
+#elif FPL_OPT_VALADDC
+        val = val + val + (nz ? 1 : 0);
+#else
         val |= nz ? (1 << b) : 0;
+#endif
     }
     first = __ffs(cand) - 1;
 }
@@ -3201,11 +3226,16 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
     const HistLane hl = hist_lane(h);
     u32 lowq = 0, nn = 0, totq = 0, diff = 0;
     int bm0 = -1, bp0 = 0, bm1 = -1, bp1 = 0; /* best match count / its position, per lane */
+    const u32 act_mask = lane < ACTIVE ? 0xFFFFFFFFu : 0u;
+    (void)act_mask;
     const int npos0 = (HAM && do_ham) ? blen - ad0->len : 0, npos1 = (HAM && do_ham) ? blen - ad1->len : 0;
     const int dbg = qualified_qual >> 8; /* ablation switches ride in the high bits */
     qualified_qual &= 0xFF;
     const u32 qqrep = 0x01010101u * (u32)(qualified_qual & 0x7F);
     u32 prev_tile_last = 0;
+    /* the last byte of the range (the same in every lane; the ragged last tile pads with it) */
+    u32 last_v = 0; /* (left in its vector register until the last tile: nothing waits for this load up front) */
+    if (FPL_OPT_PADSCALAR && !LEAN && blen > 0) last_v = (u32)rb[a + blen - 1];
     for (int t0 = 0; t0 < blen; t0 += ADV) {
         /* A wave consumes its tile as soon as the loads are back, so it sits out one trip to HBM per tile.  One byte
            of every 128-byte line of the NEXT tile (lanes 0..31 the bases, 32..63 the qualities), requested before this
@@ -3251,7 +3281,31 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
            the histogram), and what a padding N adds to the N count is taken out of this lane's partial sum right here.  No
            tested window reaches a padding base (positions p < length - alen).  A lane without any byte of the range pads
            with 'A'. */
-        if (!LEAN && wave_ballot(navail < SC_CHUNK) != 0) { /* wave-uniform */
+        if (!LEAN && t0 + 64 * SC_CHUNK > blen) { /* wave-uniform: some lane holds fewer than 32 bytes of the range */
+#if FPL_OPT_PADSCALAR
+            /* only ONE lane is cut by the end of the range -- lane lb, which keeps its first nb bytes -- and both numbers are
+               wave-uniform: the eight byte masks are scalar values, the lanes in front of lb stay as they are, lane lb takes
+               one v_bfi / v_and per dword, the lanes behind it (no byte of the range: nothing was loaded) become 'A's */
+            const int rem = blen - t0; /* 1 .. 64 * 32 - 1 */
+            const int lb = rem >> 5, nb = rem & 31;
+            const u32 last_byte = uniform_u32(last_v);
+            const u32 rep = 0x01010101u * last_byte;
+            if (lane >= lb) {
+                if (lane == lb && nb != 0) {
+#pragma unroll
+                    for (int d = 0; d < 8; d++) {
+                        const int c = nb - 4 * d; /* (wave-uniform) */
+                        const u32 bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
+                        s[d] = (s[d] & bm) | (rep & ~bm);
+                        q[d] &= bm;
+                    }
+                    if (SUMS && lane < ACTIVE && last_byte == (u32)'N') nn -= (u32)(SC_CHUNK - nb);
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 8; d++) s[d] = 0x41414141u;
+                }
+            }
+#else
             if (navail < SC_CHUNK) {
                 const int li = navail > 0 ? navail - 1 : 0;
                 u32 lw = s[0];
@@ -3268,10 +3322,11 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
                 }
                 if (SUMS && nstat > 0 && last == (u32)'N') nn -= (u32)(SC_CHUNK - nstat);
             }
+#endif
         }
         /* predecessor of this chunk's first byte: last dword of the previous lane / previous tile */
-        u32 prevd = shfl_up_u32(s[7], 1);
-        if (lane == 0) prevd = prev_tile_last;
+        u32 prevd = FPL_OPT_DPPPREV ? wave_prev_u32(s[7], prev_tile_last) : shfl_up_u32(s[7], 1);
+        if (!FPL_OPT_DPPPREV && lane == 0) prevd = prev_tile_last;
         prev_tile_last = readlane_u32(s[7], ACTIVE - 1);
         if (j0 == 0) prevd = s[0] << 24; /* the first byte of the range has no predecessor */
         /* a tile whose bytes are all exactly A, C, G, T or N -- nearly every tile -- is scanned on three code bit-planes:
@@ -3319,8 +3374,11 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
                 u32 B[NB];
                 if (npos0 > t0 && !FPL_DBG(dbg, 8)) {
                     match_counts(plane_lane, ad0, B);
-                    const int nv = npos0 - j0;
-                    const u32 vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+                    u32 vm = act_mask; /* every position of every active lane is a window start ... */
+                    if (!FPL_OPT_VMFULL || npos0 - t0 < ACTIVE * SC_CHUNK) { /* ... except in the last tile(s) (wave-uniform) */
+                        const int nv = npos0 - j0;
+                        vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+                    }
                     if (vm) {
                         int val, first;
                         sliced_max(B, vm, val, first);
@@ -3332,8 +3390,11 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
                 }
                 if (npos1 > t0 && !FPL_DBG(dbg, 8)) {
                     match_counts(plane_lane, ad1, B);
-                    const int nv = npos1 - j0;
-                    const u32 vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+                    u32 vm = act_mask; /* every position of every active lane is a window start ... */
+                    if (!FPL_OPT_VMFULL || npos1 - t0 < ACTIVE * SC_CHUNK) { /* ... except in the last tile(s) (wave-uniform) */
+                        const int nv = npos1 - j0;
+                        vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+                    }
                     if (vm) {
                         int val, first;
                         sliced_max(B, vm, val, first);
@@ -4516,7 +4577,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                 const u32 qw[2] = {qvG[g].x, qvG[g].y};
                 const int e = (int)uniform_u32(EG[g]);
                 const int nvalid = itemL > c0 ? (int)min(8u, itemL - c0) : 0;
-                const u32 up = shfl_up_u32(sw2[1], 1);
+                const u32 up = FPL_OPT_DPPPREV ? wave_prev_u32(sw2[1], 0u) : shfl_up_u32(sw2[1], 1);
                 const bool have_halo = lane > 0 || tile_start >= 4;
                 const u32 halo = lane > 0 ? up : haloG[g];
                 const u32 vh = kmer_codes(halo), v0 = kmer_codes(sw2[0]), v1 = kmer_codes(sw2[1]);

@@ -596,6 +596,17 @@ def test_partial_pattern_searches_lane_per_read_bit_exact(orc, engine_mod, seed,
     assert (res["r1_start"] > 0).sum() > 100
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(complexity_filter=1, n_base_percent_limit=60), dict(adapter_enabled=0, complexity_filter=1)])
+def test_scan_ragged_last_tiles_bit_exact(orc, engine_mod, opts):
+    """k_scan: reads that end at every offset of a 32-byte chunk / a 1984-byte tile, in N, in one base, in lower-case letters"""
+    from tests.test_kernels_emu import _reads_ending_anywhere
+
+    on = opts.get("adapter_enabled", 1)
+    for seed in (5, 6):
+        seq, qual, off = _reads_ending_anywhere(seed)
+        _run_both(orc, engine_mod, dict(opt=opts, start=synth.START_ADAPTER if on else "", end=synth.END_ADAPTER if on else ""), seq, qual, off)
+
+
 def test_long_reads_split_by_middle_adapters_bit_exact(orc, engine_mod):
     """k_resolve -> k_redo: split reads beyond 16 kb (front of the REDO list) and below (its far end), many per block"""
     seq, qual, off = synth.ont_like(500, seed=8, median_len=17000, sigma_len=0.3, p_middle=0.6)

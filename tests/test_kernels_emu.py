@@ -221,6 +221,41 @@ def test_emulated_batched_trim_kernel_long_scans_fall_back(orc, seed):
     assert (want_res["dropped"] != 0).any() and (want_res["r1_len"][want_res["dropped"] == 0] < 600).any()
 
 
+def _reads_ending_anywhere(seed):
+    """every length modulo the scan's 32-byte chunks and 1984-byte tiles, tails of N / of one base / of lower-case letters: the
+    ragged last tile of k_scan pads itself with the read's last byte"""
+    rng = np.random.default_rng(seed)
+    lens = list(range(1, 140)) + [1984 + d for d in range(-34, 35)] + [2 * 1984 + d for d in (-33, -32, -31, -1, 0, 1, 31, 32, 33)] + [2048, 4031, 4032]
+    reads = []
+    for i, L in enumerate(lens):
+        sq = synth._ACGT[rng.integers(0, 4, L)].astype(np.uint8)
+        ql = (np.clip(np.round(rng.normal(26, 6, L)), 2, 50) + 33).astype(np.uint8)
+        r = int(rng.integers(0, min(L, 45) + 1))
+        k = i % 5
+        if k == 0 and r:
+            sq[L - r:] = ord("N")
+        elif k == 1 and r:
+            sq[L - r:] = ord("G")
+        elif k == 2 and r:
+            sq[L - r:] = np.frombuffer(b"acgtn", dtype=np.uint8)[rng.integers(0, 5, r)]
+        elif k == 3:
+            sq[L - 1] = ord("N")
+        reads.append((sq, ql))
+    return synth.pack(reads)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(complexity_filter=1, n_base_percent_limit=60), dict(adapter_enabled=0, complexity_filter=1)])
+def test_emulated_scan_ragged_last_tiles(orc, opts):
+    seq, qual, off = _reads_ending_anywhere(5)
+    cfg = orc.Config(abi.FplOptions.default(**opts), synth.START_ADAPTER if opts.get("adapter_enabled", 1) else "",
+                     synth.END_ADAPTER if opts.get("adapter_enabled", 1) else "")
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
 REPEAT_START = "GTCAGTTACGTATTGC" + "AC" * 8  # (the start trim's partial pattern = the LAST 16 bases)
 REPEAT_END = "TG" * 8 + "AGCAATACGTAACTGA"   # (the end trim's = the FIRST 16)
 
