@@ -28,10 +28,17 @@ res_t = torch.empty(n * 36, dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream(dev).cuda_stream
 engs = []
 for spec in a.libs:  # lib.so or lib.so@FLAGS (FPL_DEBUG_FLAGS for a build with -DFPL_ABLATE: wrong results, timing only)
-    p, _, flags = spec.partition("@")
+    # ... or lib.so%NAME=VALUE[,NAME=VALUE]: tuning variables the library reads when a context is created
+    spec0, _, envs = spec.partition("%")
+    p, _, flags = spec0.partition("@")
     L = engine.load_library(os.path.abspath(p))
     os.environ["FPL_DEBUG_FLAGS"] = flags or "0"
+    kv = [x.split("=", 1) for x in envs.split(",") if x]
+    for k, v in kv:
+        os.environ[k] = v
     engs.append((spec, engine.Engine(opt, s_ad, e_ad, fasta, device=0, max_cycles=max_len, lib=L)))
+    for k, _v in kv:
+        os.environ.pop(k, None)
 os.environ.pop("FPL_DEBUG_FLAGS", None)
 ref_cnt = None
 tot = {p: {} for p, _ in engs}
@@ -48,7 +55,7 @@ for r in range(a.rounds + 1):
             c = e.counters()
             if ref_cnt is None:
                 ref_cnt = c
-            elif "@" not in p and not (c == ref_cnt).all():
+            elif "@" not in p.split("%")[0] and not (c == ref_cnt).all():
                 print("!! %s: counters differ from %s" % (p, engs[0][0]))
             continue
         for k, v in kt.items():
