@@ -104,6 +104,11 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_OPT_VALADDC
 #define FPL_OPT_VALADDC 1 /* sliced_max: the value bit by bit through add-with-carry */
 #endif
+#ifndef FPL_OPT_PFNEXT
+#define FPL_OPT_PFNEXT 0 /* k_scan: the last tile of a read touches the lines of the next read's head (L2 prefetch across the read
+                            boundary).  Measured SLOWER: 5.47 -> 5.69 ms at 8 kb reads, 2.18 -> 2.41 ms at 2 kb -- a read's first tile is not
+                            what its wave waits for */
+#endif
 #ifndef FPL_OPT_PADSCALAR
 #define FPL_OPT_PADSCALAR 1 /* k_scan: the ragged last tile of a range is padded with wave-uniform byte masks (one lane is cut by
                                the end of the range, and which one is a scalar) instead of per-lane ones: 25 instead of 97 vector
@@ -3245,6 +3250,14 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
             const int line = 128 * (lane & 31), nx = t0 + ADV + line;
             if (line < ADV + 128 && nx < blen) pf = (u32)(lane < 32 ? rb : qb)[a + nx];
         }
+        /* ... and in the last tile of a range the 4 KB behind it: the reads of a wave's chunk lie one behind the other, so that
+           is what is left of this read and the head of the NEXT one -- whose first tile otherwise costs a whole trip to HBM
+           with nothing to overlap it (short reads: a third of k_scan's time per read) */
+        if (FPL_OPT_PFNEXT && NB < 7 && !PREFETCH && !LEAN && SUMS && t0 + ADV >= blen) { /* wave-uniform; (NB < 7: the instance of the usual
+                                                                                              configuration -- the general one has no register to spare) */
+            const u8* const pp = (lane < 32 ? rb : qb) + b + 128 * (lane & 31);
+            if (pp < (lane < 32 ? seq_end : qual_end)) pf = (u32)*pp;
+        }
         const int j0 = t0 + SC_CHUNK * lane;
         const int navail = blen > j0 ? min(SC_CHUNK, blen - j0) : 0; /* bytes of the range in this chunk */
         const int nstat = lane < ACTIVE ? navail : 0;                 /* bytes this lane accounts for */
@@ -3407,7 +3420,7 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
             }
         }
 #if !defined(FPL_EMU)
-        if (PREFETCH && !LEAN) asm volatile("" ::"v"(pf)); /* (keeps the touch load alive; it has long returned) */
+        if ((PREFETCH || (FPL_OPT_PFNEXT && NB < 7 && SUMS)) && !LEAN) asm volatile("" ::"v"(pf)); /* (keeps the touch load alive; it has long returned) */
 #else
         (void)pf;
 #endif

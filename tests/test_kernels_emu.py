@@ -221,11 +221,13 @@ def test_emulated_batched_trim_kernel_long_scans_fall_back(orc, seed):
     assert (want_res["dropped"] != 0).any() and (want_res["r1_len"][want_res["dropped"] == 0] < 600).any()
 
 
-def _reads_ending_anywhere(seed):
+def _reads_ending_anywhere(seed, small=False):
     """every length modulo the scan's 32-byte chunks and 1984-byte tiles, tails of N / of one base / of lower-case letters: the
     ragged last tile of k_scan pads itself with the read's last byte"""
     rng = np.random.default_rng(seed)
     lens = list(range(1, 140)) + [1984 + d for d in range(-34, 35)] + [2 * 1984 + d for d in (-33, -32, -31, -1, 0, 1, 31, 32, 33)] + [2048, 4031, 4032]
+    if small:  # (the emulator's share: every offset of a chunk once, the tile boundaries)
+        lens = list(range(1, 67)) + [1984 + d for d in (-33, -32, -31, -2, -1, 0, 1, 2, 31, 32, 33)] + [2 * 1984 - 1, 2 * 1984 + 1, 2048]
     reads = []
     for i, L in enumerate(lens):
         sq = synth._ACGT[rng.integers(0, 4, L)].astype(np.uint8)
@@ -246,7 +248,7 @@ def _reads_ending_anywhere(seed):
 
 @pytest.mark.parametrize("opts", [dict(), dict(complexity_filter=1, n_base_percent_limit=60), dict(adapter_enabled=0, complexity_filter=1)])
 def test_emulated_scan_ragged_last_tiles(orc, opts):
-    seq, qual, off = _reads_ending_anywhere(5)
+    seq, qual, off = _reads_ending_anywhere(5, small=True)
     cfg = orc.Config(abi.FplOptions.default(**opts), synth.START_ADAPTER if opts.get("adapter_enabled", 1) else "",
                      synth.END_ADAPTER if opts.get("adapter_enabled", 1) else "")
     C = int(np.diff(off.astype(np.int64)).max()) + 1
@@ -331,7 +333,7 @@ def test_emulated_batched_trim_kernel_partial_pattern_searches(orc, seed, start,
 
 def test_emulated_long_reads_split_by_middle_adapters(orc):
     """reads beyond REDO_LONG (16 kb) with a middle adapter go to the FRONT of the REDO list, the others to its far end"""
-    seq, qual, off = synth.ont_like(14, seed=3, median_len=19000, sigma_len=0.25, p_middle=0.9)
+    seq, qual, off = synth.ont_like(7, seed=3, median_len=19000, sigma_len=0.25, p_middle=0.9)
     cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1, complexity_filter=1), synth.START_ADAPTER, synth.END_ADAPTER)
     C = int(np.diff(off.astype(np.int64)).max()) + 1
     want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
