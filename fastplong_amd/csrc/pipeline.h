@@ -175,7 +175,7 @@ inline bool stats_use_sorted(u32 n_reads, const StatsTune& tune) {
     return n_reads >= FS_SORT_MIN_READS;
 }
 inline size_t sort_ws_words(u32 max_slices, u32 n_reads) {
-    return (size_t)SW_SLICES + 4 * (size_t)max_slices + (size_t)FS_NB * cdiv(n_reads ? n_reads : 1, FS_SORT_BLK);
+    return (size_t)SW_SLICES + 4 * (size_t)max_slices + (size_t)FS_NB * cdiv(n_reads ? n_reads : 1, FS_SORT_READS);
 }
 /* slabs (tiles x slices) the scratch buffer must hold for a batch */
 inline size_t stats_scratch_slabs(u32 n_reads, uint64_t n_bytes, u32 max_read_len, u32 n_cu, const StatsTune& tune) {
@@ -295,7 +295,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         const u32 max_slices = stats_sorted_max_slices(n, per, a.tune);
         FPL_MEMSET(a.sort_ws, (size_t)SW_SLICES * sizeof(u32), stream);
         FPL_MEMSET(a.stats_flags, (size_t)max_slices * n_tiles + n_tiles, stream);
-        const u32 nblk = cdiv(n, FS_SORT_BLK);
+        const u32 nblk = cdiv(n, FS_SORT_READS);
         u32* const blkcnt = a.sort_ws + SW_SLICES + 4 * (size_t)max_slices;
         FPL_LAUNCH(k_bucket_count, dim3(nblk), dim3(FS_SORT_BLK), stream, (const ReadState*)a.state, n, blkcnt);
         FPL_LAUNCH(k_bucket_scan, dim3(FS_NB), dim3(256), stream, blkcnt, nblk, a.sort_ws);
