@@ -179,6 +179,7 @@ CLI_FLAGS = {
 }
 
 
+E2E_TIMEOUT_S = 180  # one CLI run of the end-to-end leg (seconds)
 E2E_RUNS = (("to_dev_null_first_pass", "/dev/null"), ("to_dev_null", "/dev/null"), ("to_file", None))
 
 
@@ -293,8 +294,14 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
                 continue
             target = target or outp
             t0 = time.perf_counter()
-            p = subprocess.run(cmd + ["-o", target], capture_output=True, text=True,
-                               env=dict(os.environ, FPLH_T0=repr(time.time()), FPLH_TIMING="1"))
+            try:  # (a run that does not come back must not take the bench line with it)
+                p = subprocess.run(cmd + ["-o", target], capture_output=True, text=True, timeout=E2E_TIMEOUT_S,
+                                   env=dict(os.environ, FPLH_T0=repr(time.time()), FPLH_TIMING="1"))
+            except subprocess.TimeoutExpired as e:
+                runs[name] = {"rc": -1, "process_seconds": time.perf_counter() - t0, "value": 0.0, "pipeline_seconds": None,
+                              "pipeline_value": None, "stages": [], "stderr_tail": "timed out after %d s: %s" % (
+                                  E2E_TIMEOUT_S, ((e.stderr or b"")[-300:].decode("utf-8", "replace") if isinstance(e.stderr, bytes) else str(e.stderr)[-300:]))}
+                break
             dt = time.perf_counter() - t0
             pipe = None
             keep = []
@@ -312,7 +319,7 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
             except OSError:
                 pass
         res["cli"] = runs
-        if runs["to_dev_null"]["rc"] == 0:
+        if runs.get("to_dev_null", {}).get("rc") == 0:
             res["value"] = runs["to_dev_null"]["value"]
             res["what"] = ("bin/fastplong_amd%s -i <FASTQ in tmpfs> -o /dev/null + JSON + HTML: input bases / wall time of the "
                            "whole process; cli.to_file = the same with the trimmed FASTQ written to tmpfs; "
