@@ -35,7 +35,7 @@ def stub_env():
     return env
 
 
-def run_cli(tmp_path, case, env, gpus, extra=(), chunk=30000):
+def run_cli(tmp_path, case, env, gpus, extra=(), chunk=30000, devices=3):
     meta = json.load(open(os.path.join(GOLD, case, "case.json")))
     inp = tmp_path / "in.fq"
     inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
@@ -45,7 +45,7 @@ def run_cli(tmp_path, case, env, gpus, extra=(), chunk=30000):
     log = out / "stub.log"
     cmd = [build.CLI, "-i", str(inp), "-o", str(out / "out.fq"), "--failed_out", str(out / "failed.fq"), "-j", str(out / "out.json"),
            "-h", str(out / "out.html"), "--gpus", str(gpus), "--reader_threads", "3", "-V"] + flags + list(extra)
-    e = dict(env, FPL_STUB_DEVICES="3", FPL_STUB_LOG=str(log), FPLH_CHUNK_BYTES=str(chunk))
+    e = dict(env, FPL_STUB_DEVICES=str(devices), FPL_STUB_LOG=str(log), FPLH_CHUNK_BYTES=str(chunk))
     if gpus == 3:
         e["FPLH_PARALLEL_WRITE"] = "1"  # (the positional writer: the same bytes)
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
@@ -99,6 +99,18 @@ def test_cli_device_count_is_partition_invariant_and_checked(tmp_path, stub_env)
     # gzip output goes through the same in-order writer (members concatenated at their offsets)
     p3, out3, _ = run_cli(tmp_path, case, stub_env, 3, extra=["-z", "3"])
     assert p3.returncode == 0
+
+
+def test_cli_eight_stub_devices(tmp_path, stub_env):
+    """the node's full width: eight device threads, sixteen batches in flight, one writer; default reader threads"""
+    case = "c3_full"
+    p, out, log = run_cli(tmp_path, case, stub_env, 8, chunk=12000, devices=8)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert (out / "out.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    assert (out / "failed.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
+    got = [l for l in (out / "out.json").read_bytes().split(b"\n") if not l.startswith(b'\t"command":')]
+    assert got == gz(os.path.join(GOLD, case, "expected.json.gz")).split(b"\n")
+    assert sorted(set(int(l.split()[0]) for l in open(log))) == list(range(8))
 
 
 def test_cli_gz_output_with_three_devices(tmp_path, stub_env):
