@@ -68,73 +68,121 @@ def make_batch(wl, n_reads, rank, dev):
     return seq_t, qual_t, off_t, max_len, synth.START_ADAPTER, synth.END_ADAPTER, []
 
 
-def cpu_baseline(opt, adapters, seq_t, qual_t, off_t, target_bases, max_threads=16):
-    """Time the oracle (C restatement of the reference path, kind="port") on the host cores over
-    the first reads of the same batch.  Outside the timed region; the oracle is only the thing
-    measured here, never part of the GPU path."""
+def oracle_prefix(opt, adapters, seq, qual, off, C, threads):
+    """The oracle (C restatement of the reference path; the checker) over a CSR batch held in numpy arrays, on `threads` host
+    threads: contiguous shards, one per thread (the reference round-robins packs of 16 reads over <= 16 workers).
+    -> (records of every read in input order, counter buffers summed over the shards, seconds)"""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
-    from fastplong_amd import abi, synth
     from oracle import oracle
 
-    off = off_t.cpu().numpy().astype(np.int64)
-    n = int(np.searchsorted(off, target_bases))
-    n = max(16, min(n, len(off) - 1))
-    nb = int(off[n])
-    seq = seq_t[:nb].cpu().numpy()
-    qual = qual_t[:nb].cpu().numpy()
-    threads = max(1, min(os.cpu_count() or 1, max_threads))
+    n = len(off) - 1
     cfg = oracle.Config(opt, adapters[0], adapters[1], adapters[2])
     oracle.lib()
-    C = int(np.diff(off[:n + 1]).max())
-    # contiguous shards, one per thread (the reference round-robins packs of 16 reads over <= 16 workers)
+    threads = max(1, min(threads, n))
     cuts = [int(i * n / threads) for i in range(threads + 1)]
 
     def work(t):
         a, b = cuts[t], cuts[t + 1]
-        if b <= a:
-            return
         o = (off[a:b + 1] - off[a]).astype(np.uint64)
-        oracle.process_batch(cfg, seq[off[a]:off[b]], qual[off[a]:off[b]], o, max_cycles=C)
+        return oracle.process_batch(cfg, seq[int(off[a]):int(off[b])], qual[int(off[a]):int(off[b])], o, max_cycles=C)
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(work, range(threads)))
+        parts = list(ex.map(work, range(threads)))
     dt = time.perf_counter() - t0
-    return {"value": nb / dt / 1e9, "unit": "Gbases/s", "cores": threads, "kind": "port",
-            "sample": "first %d reads (%d bases) of the same batch, oracle/liboracle.so, %d threads, %.1f s" % (
-                n, nb, threads, dt)}
+    res = np.concatenate([p[0] for p in parts])
+    cnt = parts[0][1].copy()
+    for p in parts[1:]:
+        cnt += p[1]
+    return res, cnt, dt
 
 
-def parity_sample(rig, opt, adapters, seq_t, qual_t, off_t, local_rank, n_sample=2000):
-    """Outside the timed region: the first reads of the bench batch through a fresh context of the HIP library,
-    records AND counters compared bit for bit with the oracle (the checker; never the thing measured)."""
+def parity_of_timed_batch(rig, opt, adapters, seq_t, qual_t, off_t, res_t, C, local_rank, n_prefix_bases, n_prefix_reads,
+                          n_strided, threads):
+    """Outside the timed region, the oracle as the checker (never the thing measured on the GPU side):
+      (1) the RECORDS the timed step left in res_t -- the very batch, the very kernels that were timed -- for the first
+          `n` reads of the batch and for `n_strided` reads spread evenly over the rest of it, against the oracle's records;
+      (2) every COUNTER (Stats pre / post, FilterResult, adapter histogram) of the first `n` reads through a fresh context
+          of the HIP library, against the oracle's counter buffer for those reads.  The prefix is large enough for the library
+          to take the kernels of the timed batch by itself (k_trim_ends_batched from 65 536 reads, k_stats_sorted from
+          150 000); when it is not (small --reads), the library's size hooks are set so that it takes them anyway.
+    -> (verdict string, description, the oracle's seconds on the prefix, reads, bases of the prefix)"""
     import numpy as np
-    from oracle import oracle
+    from fastplong_amd import abi
     from tests import parity
 
-    n = min(n_sample, off_t.numel() - 1)
-    off = off_t[:n + 1].cpu().numpy().astype(np.uint64)
+    n_all = off_t.numel() - 1
+    off_all = off_t.cpu().numpy().astype(np.int64)
+    n = int(np.searchsorted(off_all, n_prefix_bases)) if n_prefix_bases > 0 else 0
+    n = min(n_all, max(n, n_prefix_reads, min(n_all, 16)))
+    off = off_all[:n + 1].astype(np.uint64)
     nb = int(off[-1])
     seq, qual = seq_t[:nb].cpu().numpy(), qual_t[:nb].cpu().numpy()
-    C = int(np.diff(off.astype(np.int64)).max())
-    cfg = oracle.Config(opt, adapters[0], adapters[1], adapters[2])
-    want_res, want_cnt = oracle.process_batch(cfg, seq, qual, off, max_cycles=C)
-    eng = rig.engine(opt, adapters[0], adapters[1], adapters[2], local_rank, C)
+    want_res, want_cnt, dt = oracle_prefix(opt, adapters, seq, qual, off, C, threads)
+    got_all = np.ascontiguousarray(res_t.cpu().numpy()).view(abi.RESULT_DTYPE)[:n_all]
+    what = []
     try:
-        rt = eng.process_device(seq_t[:nb], qual_t[:nb], off_t[:n + 1], C)
-        rig.synchronize(seq_t.device)
-        got_res = eng.results_to_numpy(rt, n)
-        got_cnt = eng.counters()
-        nad = eng.n_adapters
-    finally:
-        eng.close()
-    try:
+        # (1a) records of the timed batch, prefix
+        parity.assert_results_equal(got_all[:n], want_res, seq, off)
+        what.append("records of the TIMED batch (res_t of the last timed step): reads 0..%d" % (n - 1))
+        # (1b) ... and a strided sample of the rest
+        if n_strided > 0 and n_all > n:
+            idx = np.unique(np.linspace(n, n_all - 1, min(n_strided, n_all - n)).astype(np.int64))
+            lens = off_all[idx + 1] - off_all[idx]
+            soff = np.zeros(len(idx) + 1, np.uint64)
+            soff[1:] = np.cumsum(lens)
+            it = torch_gather_reads(seq_t, qual_t, off_all, idx, soff)
+            sres, _, _ = oracle_prefix(opt, adapters, it[0], it[1], soff, C, threads)
+            parity.assert_results_equal(got_all[idx], sres, it[0], soff)
+            what.append("+ %d reads spread evenly over reads %d..%d" % (len(idx), n, n_all - 1))
+        # (2) counters of the prefix through a fresh context
+        hooks = {}
+        if n_all >= 65536 > n:
+            hooks["FPL_TRIM_BATCH_MIN"] = "1"
+        if n_all >= 150000 > n:
+            hooks["FPL_STATS_SORT_MIN"] = "1"
+        saved = {k: os.environ.get(k) for k in hooks}
+        os.environ.update(hooks)  # (read once, in fpl_create)
+        try:
+            eng = rig.engine(opt, adapters[0], adapters[1], adapters[2], local_rank, C)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        try:
+            rt = eng.process_device(seq_t[:nb], qual_t[:nb], off_t[:n + 1], C)
+            rig.synchronize(seq_t.device)
+            got_res = eng.results_to_numpy(rt, n)
+            got_cnt = eng.counters()
+            nad = eng.n_adapters
+        finally:
+            eng.close()
         parity.assert_results_equal(got_res, want_res, seq, off)
         parity.assert_counters_equal(got_cnt, want_cnt, C, nad)
+        what.append("every counter (and the records again) of reads 0..%d (%d bases) through a fresh context%s" % (
+            n - 1, nb, (" with " + " ".join("%s=%s" % kv for kv in sorted(hooks.items())) + " so that it takes the timed batch's kernels")
+            if hooks else " (same kernels as the timed batch by the library's own size rules: no hook set)"))
+        verdict = "ok"
     except AssertionError as e:
-        return "MISMATCH: " + str(e)[:300], n, nb
-    return "ok", n, nb
+        verdict = "MISMATCH: " + str(e)[:300]
+    return verdict, "; ".join(what) + "; bit for bit against oracle/liboracle.so, outside the timed region", dt, n, nb
+
+
+def torch_gather_reads(seq_t, qual_t, off_all, idx, soff):
+    """the reads `idx` of the resident batch as one small CSR batch in host memory"""
+    import numpy as np
+
+    total = int(soff[-1])
+    seq = np.empty(total, np.uint8)
+    qual = np.empty(total, np.uint8)
+    for k, i in enumerate(idx):
+        a, b = int(off_all[i]), int(off_all[i + 1])
+        seq[int(soff[k]):int(soff[k + 1])] = seq_t[a:b].cpu().numpy()
+        qual[int(soff[k]):int(soff[k + 1])] = qual_t[a:b].cpu().numpy()
+    return seq, qual
 
 
 def profile_record(workload):
@@ -321,6 +369,9 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
         res["cli"] = runs
         if runs.get("to_dev_null", {}).get("rc") == 0:
             res["value"] = runs["to_dev_null"]["value"]
+            # what `value` wrote where -- a reader of the N-GPU line must not take it for a file sink
+            res["sink"] = "/dev/null (the trimmed FASTQ goes to /dev/null as gather lists over the batches' arrays; JSON + HTML reports are written)"
+            res["command"] = "bin/fastplong_amd --gpus %d -i <%d x %d reads in tmpfs> -o /dev/null" % (n_gpus, copies, n_reads)
             res["what"] = ("bin/fastplong_amd%s -i <FASTQ in tmpfs> -o /dev/null + JSON + HTML: input bases / wall time of the "
                            "whole process; cli.to_file = the same with the trimmed FASTQ written to tmpfs; "
                            "pipeline_value = without process start-up (HIP context) and the report writers" % (
@@ -384,7 +435,11 @@ def main(argv=None, rig=None):
     ap.add_argument("--e2e-copies", type=int, default=4,
                     help="N = 1: a second end-to-end run over this many copies of the reads, so that the process's fixed cost "
                          "(HIP context, reports, exit) weighs less (0 or 1 = skip)")
-    ap.add_argument("--parity-reads", type=int, default=2000, help="reads of the batch checked against the oracle outside the timed region (0 = skip)")
+    ap.add_argument("--parity-reads", type=int, default=200_000,
+                    help="outside the timed region: the first reads of the timed batch (at N = 1 at least the CPU baseline's sample) whose "
+                         "records and counters are checked against the oracle (0 = skip)")
+    ap.add_argument("--parity-strided", type=int, default=2000,
+                    help="... and this many reads spread evenly over the rest of the timed batch (records only)")
     ap.add_argument("--workload", default="c3_full_pipeline", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-bases", type=float, default=6e9, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--set", default="", help="ablation only: comma separated fpl_options overrides, e.g. adapter_enabled=0")
@@ -553,12 +608,30 @@ def main(argv=None, rig=None):
                                "expected_bases_in": args.steps * total_bases, "ok": bool(reads_ok)},
         }
         if args.parity_reads > 0:
-            verdict, pn, pb = parity_sample(rig, opt, adapters, seq_t, qual_t, off_t, local_rank, args.parity_reads)
+            # ONE run of the oracle serves both: the checker of the timed batch's records / counters and -- at N = 1 -- the CPU
+            # baseline (its seconds over the same reads; rank 0 at N = 1 only: the other ranks would sit in the barrier meanwhile)
+            threads = max(1, min(os.cpu_count() or 1, 16))
+            with_cpu = args.cpu_bases > 0 and world == 1
+            verdict, pwhat, odt, pn, pb = parity_of_timed_batch(rig, opt, adapters, seq_t, qual_t, off_t, res_t, C, local_rank,
+                                                                args.cpu_bases if with_cpu else 0, min(n, args.parity_reads),
+                                                                args.parity_strided, threads)
             out["parity_sample"] = verdict
-            out["parity_sample_what"] = ("first %d reads (%d bases) of the bench batch: result records and every counter of a fresh "
-                                         "context, bit for bit against oracle/liboracle.so, outside the timed region" % (pn, pb))
-        if args.cpu_bases > 0 and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in the barrier meanwhile)
-            out["cpu_baseline"] = cpu_baseline(opt, adapters, seq_t, qual_t, off_t, args.cpu_bases)
+            out["parity_sample_what"] = pwhat
+            if with_cpu:
+                out["cpu_baseline"] = {"value": pb / odt / 1e9, "unit": "Gbases/s", "cores": min(threads, pn), "kind": "port",
+                                       "sample": "first %d reads (%d bases) of the same batch, oracle/liboracle.so, %d threads, %.1f s "
+                                                 "(the run whose records and counters parity_sample compares)" % (pn, pb, min(threads, pn), odt)}
+        elif args.cpu_bases > 0 and world == 1:
+            import numpy as _np
+            offc = off_t.cpu().numpy().astype(_np.int64)
+            pn = max(16, min(int(_np.searchsorted(offc, args.cpu_bases)), n))
+            pb = int(offc[pn])
+            threads = max(1, min(os.cpu_count() or 1, 16))
+            _, _, odt = oracle_prefix(opt, adapters, seq_t[:pb].cpu().numpy(), qual_t[:pb].cpu().numpy(), offc[:pn + 1].astype(_np.uint64),
+                                      C, threads)
+            out["cpu_baseline"] = {"value": pb / odt / 1e9, "unit": "Gbases/s", "cores": min(threads, pn), "kind": "port",
+                                   "sample": "first %d reads (%d bases) of the same batch, oracle/liboracle.so, %d threads, %.1f s" % (
+                                       pn, pb, min(threads, pn), odt)}
     eng.close()  # (idempotent)
     run_e2e = args.e2e_reads > 0 and not args.set and dev.type == "cuda"
     if run_e2e and world > 1:

@@ -27,7 +27,7 @@ def _hipcc():
 
 
 def hip_sources():
-    return [os.path.join(CSRC, f) for f in ("fpl_hip.hip", "kernels.h", "pipeline.h", "dev_prims.h", "dev_types.h")] + [
+    return [os.path.join(CSRC, f) for f in ("fpl_hip.hip", "kernels.h", "pipeline.h", "dev_prims.h", "dev_types.h", "adapter_pick.h")] + [
         os.path.join(ROOT, "include", "fastplong_amd.h")]
 
 

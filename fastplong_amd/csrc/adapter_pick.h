@@ -40,6 +40,29 @@ FPL_HD inline int popc(uint32_t x) {
     return __builtin_popcount(x);
 #endif
 }
+/* The window of key positions the detection looks at in a read of rlen bases (src/evaluator.cpp:166-183, :207-225): the first
+   128 positions (side 0) or the last 129 in front of the skipped tail (side 1), a key never reaching into the last shift_tail
+   bases.  false: the read is too short to hold a key. */
+FPL_HD inline bool key_window(long long rlen, int side, int shift_tail, long long& first, long long& last) {
+    last = rlen - KEYLEN - shift_tail;
+    if (last < 0) return false;
+    first = side == 0 ? 0 : (last - 128 > 0 ? last - 128 : 0);
+    if (side == 0 && last > 127) last = 127;
+    return true;
+}
+/* the key of the ten bases at data[0..10): false when one of them is not A, T/U, C, G (the reference rolls its key and starts
+   over behind such a base: the same set of (position, key) pairs) */
+FPL_HD inline bool key_at(const uint8_t* data, uint32_t& key) {
+    uint32_t k = 0, bad = 0;
+    for (int i = 0; i < KEYLEN; i++) {
+        const uint32_t c = data[i];
+        const uint32_t code = c == 'A' ? 0u : ((c == 'T' || c == 'U') ? 1u : (c == 'C' ? 2u : (c == 'G' ? 3u : 4u)));
+        bad |= code;
+        k = (k << 2) | (code & 3u);
+    }
+    key = k;
+    return bad < 4u;
+}
 /* how many of the ten digits of k equal d */
 FPL_HD inline int digits_equal(uint32_t k, uint32_t d) {
     const uint32_t x = k ^ (DIGITS * d); /* 00 where the digit is d */

@@ -284,6 +284,7 @@ int fpl_get_counters(fpl_ctx* ctx, int64_t* host_buf, size_t n) {
 namespace {
 struct Rccl {
     void* lib = nullptr;
+    std::string path; /* what dlopen took */
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -292,9 +293,38 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load(std::string& err) {
         if (lib) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (lib) break;
+        /* a librccl the process has mapped already (PyTorch-ROCm carries its own under torch/lib, beside its HIP runtime) is THE
+           one to use: a second copy would bring a second set of communicator state.  Else the loader's search path, ROCm's
+           directory, and the directory of the HIP runtime this library itself resolved to. */
+        std::vector<std::string> names;
+        if (FILE* maps = fopen("/proc/self/maps", "r")) {
+            char line[4096];
+            while (fgets(line, sizeof line, maps)) {
+                const char* path = strchr(line, '/');
+                if (!path || !strstr(path, "librccl.so")) continue;
+                std::string s(path);
+                while (!s.empty() && (s.back() == '\n' || s.back() == ' ')) s.pop_back();
+                names.push_back(s);
+                break;
+            }
+            fclose(maps);
+        }
+        names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
+        Dl_info hip_at;
+        if (dladdr((void*)&hipGetDeviceCount, &hip_at) && hip_at.dli_fname) {
+            std::string dir(hip_at.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                names.push_back(dir.substr(0, slash) + "/librccl.so.1");
+                names.push_back(dir.substr(0, slash) + "/librccl.so");
+            }
+        }
+        for (const std::string& name : names) {
+            lib = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (lib) {
+                path = name;
+                break;
+            }
         }
         if (!lib) {
             err = std::string("dlopen(librccl): ") + dlerror();
@@ -336,7 +366,11 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
         FPL_HIP(hipSetDevice(ctxs[i]->device));
         FPL_HIP(hipDeviceSynchronize());
     }
-    if (n == 1) return FPL_OK;
+    /* one context: nothing to merge.  FPL_RCCL_FORCE=1 (a test hook) runs the collective all the same -- a one-rank communicator,
+       the in-place sum on the context's stream -- so that the loader, the communicator set-up and the call are exercised on a
+       box with a single GPU; the buffer must come out unchanged. */
+    const char* force = getenv("FPL_RCCL_FORCE");
+    if (n == 1 && !(force && atoi(force) > 0)) return FPL_OK;
     if (!g_rccl.load(ctx->err)) return FPL_ERR_STATE;
 #define FPL_NCCL(call)                                                                                   \
     do {                                                                                                 \
@@ -374,6 +408,8 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
 #undef FPL_NCCL
     return rc;
 }
+
+const char* fpl_rccl_library(void) { return g_rccl.path.c_str(); }
 
 int fpl_reset_counters(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;

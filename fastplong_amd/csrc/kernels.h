@@ -4827,30 +4827,19 @@ k_stats_reduce_sorted(const u64* __restrict__ scratch, const u8* __restrict__ fl
 __global__ void __launch_bounds__(256)
 k_count_end_kmers(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_reads, int side, int shift_tail,
                   u32* __restrict__ counts, unsigned long long* __restrict__ position_acc, unsigned long long* __restrict__ total) {
-    constexpr int KEYLEN = 10;
     const int lane = lane_id();
     u32 mine = 0;
     for (u32 ri = blockIdx.x * (blockDim.x / 64) + wave_in_block(); ri < n_reads; ri += gridDim.x * (blockDim.x / 64)) {
         const uint64_t o = off[ri];
         const long long rlen = (long long)(off[ri + 1] - o);
-        const long long last = rlen - KEYLEN - shift_tail; /* the last position that is looked at */
-        if (last < 0) continue;
-        const long long first = side == 0 ? 0 : (last - 128 > 0 ? last - 128 : 0);
-        const long long end = side == 0 ? (last < 127 ? last : 127) : last;
+        long long first, end;
+        if (!pick::key_window(rlen, side, shift_tail, first, end)) continue;
         const u8* data = seq + o;
         for (long long p0 = first; p0 <= end; p0 += 64) {
             const long long pos = p0 + lane;
             if (pos > end) continue;
-            u32 key = 0;
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < KEYLEN; i++) {
-                const u32 c = data[pos + i];
-                const u32 code = c == 'A' ? 0u : ((c == 'T' || c == 'U') ? 1u : (c == 'C' ? 2u : (c == 'G' ? 3u : 4u)));
-                ok = ok && code < 4u;
-                key = (key << 2) | (code & 3u);
-            }
-            if (!ok) continue;
+            u32 key;
+            if (!pick::key_at(data + pos, key)) continue;
             atomicAdd(&counts[key], 1u);
             atomicAdd(&position_acc[key], (unsigned long long)(side == 0 ? pos : rlen - pos));
             mine++;

@@ -971,6 +971,8 @@ int main(int argc, char* argv[]) {
         for (auto& D : dev) ctxs.push_back(D.ctx);
         const int rc = fpl_allreduce_counters(ctxs.data(), (int32_t)ctxs.size());
         if (rc != FPL_OK) error_exit(string("fpl_allreduce_counters: ") + fpl_strerror(rc) + " " + fpl_last_error(ctxs[0]));
+        if (cmd.exist("verbose") && fpl_rccl_library()[0])
+            cerr << "counter merge: one all-reduce over " << ctxs.size() << " device(s), RCCL from " << fpl_rccl_library() << endl;
     }
     const uint32_t C = fpl_max_cycles(dev[0].ctx);
     const size_t ncnt = fpl_counters_len(dev[0].ctx);

@@ -187,40 +187,28 @@ void set_kmer_counter(KmerCounter f) { g_kmer_counter = std::move(f); }
 static AdapterPicker g_adapter_picker;
 void set_adapter_picker(AdapterPicker f) { g_adapter_picker = std::move(f); }
 
-/* Evaluator::evalAdapterAndReadNum's counting loops, src/evaluator.cpp:300-345 */
+/* The end-k-mer counters of the evaluation prefix on the host, for when no device call is plugged in (tests, FPLH_HOST_KMERS):
+   the windows and the key coder are the ones k_count_end_kmers uses (csrc/adapter_pick.h), one independent key per position. */
 void count_end_kmers_host(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail, uint32_t* counts,
                           uint64_t* position_acc, uint64_t* total) {
-    const int keylen = 10;
-    const size_t size = (size_t)1 << (keylen * 2);
-    fill(counts, counts + size, 0u);
-    fill(position_acc, position_acc + size, (uint64_t)0);
-    uint64_t t = 0;
-    for (uint32_t i = 0; i < n_reads; i++) {
-        const char* data = (const char*)seq + off[i];
-        const int rlen = (int)(off[i + 1] - off[i]);
-        int key = -1;
-        if (side == 0) {
-            for (int pos = 0; pos <= rlen - keylen - shift_tail && pos < 128; pos++) {
-                key = seq2int(data, rlen, pos, keylen, key);
-                if (key >= 0) {
-                    counts[key]++;
-                    position_acc[key] += (uint64_t)pos;
-                    t++;
-                }
-            }
-        } else {
-            const int startpos = max(0, rlen - keylen - shift_tail - 128);
-            for (int pos = startpos; pos <= rlen - keylen - shift_tail; pos++) {
-                key = seq2int(data, rlen, pos, keylen, key);
-                if (key >= 0) {
-                    counts[key]++;
-                    position_acc[key] += (uint64_t)(rlen - pos);
-                    t++;
-                }
-            }
+    namespace pk = fpl::pick;
+    fill(counts, counts + pk::NKEYS, 0u);
+    fill(position_acc, position_acc + pk::NKEYS, (uint64_t)0);
+    uint64_t seen = 0;
+    for (uint32_t r = 0; r < n_reads; r++) {
+        const long long rlen = (long long)(off[r + 1] - off[r]);
+        long long first, last;
+        if (!pk::key_window(rlen, side, shift_tail, first, last)) continue;
+        const uint8_t* data = seq + off[r];
+        for (long long pos = first; pos <= last; pos++) {
+            uint32_t key;
+            if (!pk::key_at(data + pos, key)) continue;
+            counts[key]++;
+            position_acc[key] += (uint64_t)(side == 0 ? pos : rlen - pos);
+            seen++;
         }
     }
-    *total = t;
+    *total = seen;
 }
 
 void detect_adapters(const string& path, int trim_tail, bool is_rna, string& start, string& end, long* read_num) {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 4
+#define FPL_ABI_VERSION 5
 
 /* limits */
 #define FPL_MAX_ADAPTER_LEN 255 /* longest adapter the device path accepts            */
@@ -326,6 +326,11 @@ int fpl_get_counters(fpl_ctx* ctx, int64_t* host_buf, size_t n);
  * fpl_counters_device_ptr() themselves (bench.py does, through torch.distributed) after agreeing on C.
  */
 int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n);
+/* (ABI v5) Path of the RCCL library fpl_allreduce_counters runs on: "" until a merge has needed it.  A librccl the process has
+ * mapped already is taken first (PyTorch-ROCm's own), then the loader's search path, ROCm's directory and the directory of the
+ * HIP runtime in use.  With FPL_RCCL_FORCE=1 in the environment a merge of ONE context goes through RCCL as well (a one-rank
+ * communicator; the buffer comes out unchanged) -- the way to exercise the collective on a box with a single GPU. */
+const char* fpl_rccl_library(void);
 
 /* The counting loops of the adapter auto-detection, Evaluator::evalAdapterAndReadNum (src/evaluator.cpp:300-345), on the
  * device: for the reads of the evaluation prefix (host CSR arrays; the reference looks at <= 64 Ki reads / 512 Mbases) count

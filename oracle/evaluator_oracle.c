@@ -6,6 +6,10 @@
  * The product computes the same thing in another form (fastplong_amd/csrc/adapter_pick.h: a masked arg-max and two
  * directional walks, on the device); tests/test_host_evaluator.py compares the two on seeded counter tables.
  *
+ * Also here: the counting loops in front of them (evalAdapterAndReadNum, src/evaluator.cpp:166-183 and :207-225) with the
+ * rolling key coder they call (Evaluator::seq2int, src/evaluator.cpp:503-560) -- what fpl_count_end_kmers / fpl_pick_adapter are
+ * checked against on the GPU.
+ *
  * Parity status: UNPINNED.  src/evaluator.cpp includes the FASTQ reader and through it ISA-L headers this image lacks, so the
  * real object cannot be compiled here; the reference's only known-answer test for this file (test/evaluator_test.cpp) covers
  * int2seq / seq2int, not these two functions.  What this file gives is an independent SECOND reading of the reference.
@@ -100,4 +104,73 @@ int orc_eval_extend_key(int key, const uint32_t* counts, const uint64_t* positio
     memcpy(out, buf + lo, (size_t)(hi - lo));
     out[hi - lo] = 0;
     return hi - lo;
+}
+
+/* Evaluator::seq2int, src/evaluator.cpp:503-560: rolls the previous key when there is one, else codes keylen bases afresh;
+   -1 on anything but A, T/U, C, G (this is the coder the reference's KAT test/evaluator_test.cpp round-trips) */
+int orc_eval_seq2int(const char* seq, int pos, int keylen, int last_val) {
+    if (last_val >= 0) {
+        const int mask = (1 << (keylen * 2)) - 1;
+        int key = (last_val << 2) & mask;
+        switch (seq[pos + keylen - 1]) {
+            case 'A': key += 0; break;
+            case 'T':
+            case 'U': key += 1; break;
+            case 'C': key += 2; break;
+            case 'G': key += 3; break;
+            default: return -1;
+        }
+        return key;
+    }
+    int key = 0;
+    for (int i = pos; i < keylen + pos; i++) {
+        key <<= 2;
+        switch (seq[i]) {
+            case 'A': key += 0; break;
+            case 'T':
+            case 'U': key += 1; break;
+            case 'C': key += 2; break;
+            case 'G': key += 3; break;
+            default: return -1;
+        }
+    }
+    return key;
+}
+
+/* the two counting loops of Evaluator::evalAdapterAndReadNum: side 0 = read start (src/evaluator.cpp:166-183), side 1 = read
+   end (src/evaluator.cpp:207-225); reads as one CSR batch.  counts / position_acc: 4^10 entries, zeroed here (:163-164). */
+void orc_eval_count_end_kmers(const uint8_t* seq, const uint64_t* off, uint32_t n_reads, int side, int shift_tail,
+                              uint32_t* counts, uint64_t* position_acc, uint64_t* total_out) {
+    const int keylen = 10;
+    const int size = 1 << (keylen * 2);
+    long total = 0;
+    memset(counts, 0, sizeof(uint32_t) * (size_t)size);
+    memset(position_acc, 0, sizeof(uint64_t) * (size_t)size);
+    for (uint32_t i = 0; i < n_reads; i++) {
+        const char* data = (const char*)seq + off[i];
+        const int length = (int)(off[i + 1] - off[i]);
+        int key = -1;
+        if (side == 0) {
+            for (int pos = 0; pos <= length - keylen - shift_tail && pos < 128; pos++) {
+                key = orc_eval_seq2int(data, pos, keylen, key);
+                if (key >= 0) {
+                    counts[key]++;
+                    position_acc[key] += (uint64_t)pos;
+                    total++;
+                }
+            }
+        } else {
+            int startpos = length - keylen - shift_tail - 128;
+            if (startpos < 0) startpos = 0;
+            for (int pos = startpos; pos <= length - keylen - shift_tail; pos++) {
+                key = orc_eval_seq2int(data, pos, keylen, key);
+                if (key >= 0) {
+                    counts[key]++;
+                    position_acc[key] += (uint64_t)(length - pos);
+                    total++;
+                }
+            }
+        }
+    }
+    *total_out = (uint64_t)total;
 }

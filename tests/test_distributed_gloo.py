@@ -88,7 +88,11 @@ class _StandInEngine:
         r, c = self.orc.process_batch(self.cfg, seq_t.numpy(), qual_t.numpy(), off_t.numpy().astype(np.uint64), max_cycles=self.C)
         self.cnt += torch.from_numpy(c)
         self.calls += 1
-        return torch.from_numpy(np.ascontiguousarray(r).view(np.uint8).copy())
+        out = torch.from_numpy(np.ascontiguousarray(r).view(np.uint8).copy())
+        if res_t is not None:  # (the caller's record buffer, as the C-ABI fills it)
+            res_t[:out.numel()].copy_(out)
+            return res_t
+        return out
 
     @staticmethod
     def results_to_numpy(results_t, n):

@@ -156,6 +156,26 @@ def test_cli_gather_output_reproduces_golden_on_gpu(tmp_path, case, how):
 
 
 @pytest.mark.gpu
+def test_cli_counter_merge_through_rccl_on_gpu(tmp_path):
+    """bin/fastplong_amd ends every run with fpl_allreduce_counters over its devices' contexts; FPL_RCCL_FORCE=1 makes the
+    one-device run take the RCCL path too (a process WITHOUT torch: librccl comes from the loader's own search).  Reports
+    and output must not change."""
+    build.build_all()
+    case = "c3_full"
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    cmd = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"),
+           "-V"] + list(meta["flags"])
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, FPL_RCCL_FORCE="1"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"counter merge: one all-reduce over 1 device(s), RCCL from " in p.stderr and b"librccl" in p.stderr
+    assert (tmp_path / "out.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    got = [l for l in (tmp_path / "out.json").read_bytes().split(b"\n") if not l.startswith(b'\t"command":')]
+    assert got == gz(os.path.join(GOLD, case, "expected.json.gz")).split(b"\n")
+
+
+@pytest.mark.gpu
 def test_cli_gzip_outputs_on_gpu(tmp_path):
     """names ending in .gz are written as concatenated gzip members (one per formatted slice, deflated in parallel)"""
     case = "c3_full"

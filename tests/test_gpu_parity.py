@@ -469,6 +469,37 @@ def test_async_pipeline_two_deep_bit_exact(orc, engine_mod):
     eng.close()
 
 
+def test_allreduce_counters_runs_rccl_on_one_gpu(orc, engine_mod, monkeypatch):
+    """fpl_allreduce_counters with FPL_RCCL_FORCE=1: the merge of ONE context goes through the whole RCCL path of the C-ABI --
+    finding and dlopen-ing librccl, ncclCommInitAll over the context's device, the grouped in-place int64 ncclAllReduce on the
+    context's stream, ncclCommDestroy -- which N > 1 contexts take in bin/fastplong_amd --gpus N.  One rank: the buffer must
+    come out as it went in, and the capacity agreement still happens."""
+    import ctypes as Ct
+
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, polyx=1), synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = synth.adversarial(800, seed=77)
+    C = int(np.diff(off.astype(np.int64)).max())
+    _, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    eng = engine_mod.Engine(cfg.opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=C)
+    eng.process_host(seq, qual, off)
+    arr = (Ct.c_void_p * 1)(eng.h)
+    monkeypatch.setenv("FPL_RCCL_FORCE", "1")
+    for _ in range(2):  # (a second merge builds a second communicator)
+        rc = eng.L.fpl_allreduce_counters(arr, 1)
+        assert rc == 0, (eng.L.fpl_strerror(rc), eng.L.fpl_last_error(eng.h))
+        assert (eng.L.fpl_last_error(eng.h) or b"") == b""
+        parity.assert_counters_equal(eng.counters(), want_cnt, C, 2)
+    used = eng.L.fpl_rccl_library().decode()
+    assert "librccl" in used, used
+    # the process has ONE librccl mapped: the loader took the copy torch brought along rather than a second one
+    mapped = {line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line}
+    assert len(mapped) == 1, mapped
+    # the batch path still works on the context afterwards (streams / device state untouched)
+    eng.process_host(seq, qual, off)
+    parity.assert_counters_equal(eng.counters(), 2 * want_cnt, C, 2)
+    eng.close()
+
+
 def test_offsets_beyond_4_gib_bit_exact(orc, engine_mod):
     """A batch whose byte offsets pass 2^32 (the bench batch is 9 GB per array): the records of the LAST reads --
     the ones whose addresses need more than 32 bits in every kernel -- equal the oracle's on the same reads taken
@@ -539,8 +570,8 @@ def test_offsets_beyond_4_gib_bit_exact(orc, engine_mod):
 @pytest.mark.parametrize("forced", [False, True])
 def test_every_bench_workload_bit_exact(orc, engine_mod, monkeypatch, workload, forced):
     """What bench.py runs, as bench.py builds it (its generators, its option sets, its adapters -- c5 with -s / -e set to the
-    first FASTA adapter and its reverse complement), at a size the oracle checks in full: bench.parity_sample is the very
-    function behind the `parity_sample` field of the bench line.  forced: with the kernels that only batches of bench size
+    first FASTA adapter and its reverse complement), at a size the oracle checks in full: bench.parity_of_timed_batch is the very
+    function behind the `parity_sample` field of the bench line (records of the step's own buffer + counters of a fresh context).  forced: with the kernels that only batches of bench size
     take (k_trim_ends_batched, k_stats_sorted) forced on the small batch."""
     import torch
 
@@ -567,8 +598,50 @@ def test_every_bench_workload_bit_exact(orc, engine_mod, monkeypatch, workload, 
     if workload == "c5_hifi64":
         assert ad_start and ad_end == synth.revcomp(ad_start) and len(ad_fasta) == 64
     opt = abi.FplOptions.default(**wl["opt"])
-    verdict, n, nb = bench.parity_sample(rig, opt, (ad_start, ad_end, ad_fasta), seq_t, qual_t, off_t, 0, 700)
-    assert verdict == "ok" and n == 700, verdict
+    verdict, what, n = _bench_parity(bench, rig, opt, (ad_start, ad_end, ad_fasta), seq_t, qual_t, off_t, max_len, 500, 200)
+    assert verdict == "ok" and n == 500, verdict
+    assert "200 reads spread evenly over reads 500..699" in what
+
+
+def _bench_parity(bench, rig, opt, adapters, seq_t, qual_t, off_t, max_len, n_prefix, n_strided):
+    """one step of the batch into a record buffer, as bench.py's timed loop does, then bench.py's own check of that buffer"""
+    import torch
+
+    n = off_t.numel() - 1
+    eng = rig.engine(opt, adapters[0], adapters[1], adapters[2], 0, max_len)
+    res_t = torch.empty(n * 36, dtype=torch.uint8, device=seq_t.device)
+    eng.process_device(seq_t, qual_t, off_t, max_len, res_t, rig.stream(seq_t.device))
+    torch.cuda.synchronize()
+    eng.close()
+    verdict, what, _, pn, _ = bench.parity_of_timed_batch(rig, opt, adapters, seq_t, qual_t, off_t, res_t, max_len, 0, 0, n_prefix,
+                                                          n_strided, 16)
+    return verdict, what, pn
+
+
+@pytest.mark.parametrize("workload,n_reads,median", [("c3_full_pipeline", 160_000, 3000), ("c4_mixed", 155_000, 2500)])
+def test_bench_sized_batch_no_hooks_bit_exact(orc, engine_mod, monkeypatch, workload, n_reads, median):
+    """A batch large enough for the library to pick, BY ITS OWN SIZE RULES, the kernels bench.py times (k_trim_ends_batched from
+    65 536 reads, k_stats_sorted + bucket kernels from 150 000): no FPL_* hook in the environment.  Every record and every
+    counter of the whole batch against the oracle (16 host threads), through bench.py's own checker."""
+    import torch
+
+    import bench
+
+    for k in ("FPL_TRIM_BATCH_MIN", "FPL_STATS_SORT_MIN", "FPL_STATS_MIN_BUCKET", "FPL_STATS_PER"):
+        monkeypatch.delenv(k, raising=False)
+    wl = dict(bench.WORKLOADS[workload])
+    g = dict(wl["gen"], median_len=median)
+    if "max_len" in g:
+        g.update(max_len=60000)
+    wl["gen"] = g
+    rig = bench.Rig()
+    seq_t, qual_t, off_t, max_len, ad_start, ad_end, ad_fasta = rig.make_batch(wl, n_reads, 0, torch.device("cuda", 0))
+    n = off_t.numel() - 1
+    assert n >= 150_000
+    opt = abi.FplOptions.default(**wl["opt"])
+    verdict, what, pn = _bench_parity(bench, rig, opt, (ad_start, ad_end, ad_fasta), seq_t, qual_t, off_t, max_len, n, 0)
+    assert verdict == "ok" and pn == n, verdict
+    assert "no hook set" in what
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
