@@ -50,6 +50,9 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_REDO_PREFETCH
 #define FPL_REDO_PREFETCH 1 /* k_redo: the next tile's cache lines are touched one tile ahead */
 #endif
+#ifndef FPL_OPT_REDO_DYN
+#define FPL_OPT_REDO_DYN 0 /* k_redo takes its items off a device counter (work_ctr[4]) instead of walking the list with a fixed stride */
+#endif
 #ifndef FPL_REDO_WAVES
 #define FPL_REDO_WAVES 8 /* k_redo: waves per block; three such blocks fit a CU (LDS: 4.5 KiB per wave, 70 VGPRs) */
 #endif
@@ -4167,11 +4170,23 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     const int qq = cfg->qualified_qual;
     const u32 n_long = redo_count[2], n_items = n_long + redo_count[0]; /* (long reads first) */
     u32 nbuf = 0; /* entries in this wave's buffer of EXTRA-list entries (wave-uniform) */
-    /* (items off a device counter -- `for (;;) { it = atomicAdd(..); if (it >= n_items) break; ..` -- would even the hundredfold
-       spread of the items' lengths out, but that form of this loop never ended on the GPU (ROCm 7.2, gfx950; the emulator and a
-       fixed stride are fine): the list is walked with a fixed stride) */
+    /* The list is walked with a fixed stride, long reads first (REDO_LONG).  Taking the items off a device counter
+       (FPL_OPT_REDO_DYN: the dequeue k_scan uses, one item at a time) evens the hundredfold spread of the items' lengths out no
+       better than the ordering does and costs one same-address atomic per wave and item: 6 144 waves + 14 000 items on one word
+       are 0.24 ms of a 0.16 ms kernel (c3, measured side by side in round 4).  Round 3 saw a build of that loop that never
+       ended on the GPU; its code had a second loop header BEHIND the dequeue that tested the stale lane-0 value again.  Today's
+       build of either form has the atomic in the loop header (tools/dequeue_isa.py checks that for every work-counter loop of
+       the library, tests/test_isa_dequeue.py runs it). */
+#if FPL_OPT_REDO_DYN
+    for (;;) {
+        u32 it = 0;
+        if (lane == 0) it = atomicAdd(redo_next, 1u);
+        it = readlane_u32(it, 0);
+        if (it >= n_items) break;
+#else
     (void)redo_next;
     for (u32 it = blockIdx.x * WAVES + wave_in_block(); it < n_items; it += gridDim.x * WAVES) {
+#endif
         const RedoItem item = redo[it < n_long ? it : n_reads - 1u - (it - n_long)];
         const u32 ri = uniform_u32(item.ri);
         const int gs = uniform_i32((int)item.gs), glen = uniform_i32((int)item.glen);
