@@ -228,7 +228,8 @@ CLI_FLAGS = {
 
 
 E2E_TIMEOUT_S = 180  # one CLI run of the end-to-end leg (seconds)
-E2E_RUNS = (("to_dev_null_first_pass", "/dev/null"), ("to_dev_null", "/dev/null"), ("to_file", None))
+E2E_SPLIT = 16  # files (and per-worker writer threads) of the to_split_files run: --split 16 -w 16
+E2E_RUNS = (("to_dev_null_first_pass", "/dev/null"), ("to_dev_null", "/dev/null"), ("to_file", None), ("to_split_files", None))
 
 
 def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1, copies=None, with_pcie=True, run_names=None):
@@ -239,7 +240,9 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
           H2D / kernels / D2H two batches deep per device -> trimmed FASTQ + fastplong.json / .html; wall time of the
           whole process (HIP start-up, reports and exit included) and of its host pipeline alone;
       (2) n_gpus == 1: the PCIe-inclusive C-ABI call, fpl_process_batch_async / fpl_wait from page-locked arrays, two deep."""
+    import glob
     import shutil
+    import signal
     import subprocess
 
     import ctypes as C
@@ -301,10 +304,11 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
             continue
         if d == "/dev/shm" and head is not None:
             free = min(free, head // 2)  # (tmpfs pages count against the container's memory; the run itself needs room too)
-        while copies > 1 and free < 2.3 * per_copy * copies:
-            copies -= 1  # what fits
-        if free > 2.3 * per_copy * copies:
-            tmp = d
+        fit = copies  # (per directory: what /dev/shm could not hold must not shrink the run that /tmp can)
+        while fit > 1 and free < 2.3 * per_copy * fit:
+            fit -= 1
+        if free > 2.3 * per_copy * fit:
+            tmp, copies = d, fit
             break
     if tmp is None:
         res["cli"] = None
@@ -341,15 +345,30 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
             if run_names and name not in run_names:
                 continue
             target = target or outp
+            # one file on tmpfs takes 6-9 GB/s whoever writes it (page-cache insertion of ONE inode serialises in the kernel);
+            # --split N gives every worker's writer thread a file of its own
+            split = ["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)] if name == "to_split_files" else []
             t0 = time.perf_counter()
-            try:  # (a run that does not come back must not take the bench line with it)
-                p = subprocess.run(cmd + ["-o", target], capture_output=True, text=True, timeout=E2E_TIMEOUT_S,
-                                   env=dict(os.environ, FPLH_T0=repr(time.time()), FPLH_TIMING="1"))
-            except subprocess.TimeoutExpired as e:
+            # (a run that does not come back must not take the bench line with it: its own session, so that the whole process
+            # group can be killed, and a bounded wait for its pipes afterwards -- a process stuck in the driver may never close them)
+            proc = subprocess.Popen(cmd + split + ["-o", target], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                    start_new_session=True, env=dict(os.environ, FPLH_T0=repr(time.time()), FPLH_TIMING="1"))
+            try:
+                so, se = proc.communicate(timeout=E2E_TIMEOUT_S)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                try:
+                    so, se = proc.communicate(timeout=10)
+                except subprocess.TimeoutExpired:
+                    so, se = "", "(the process did not go away within 10 s of SIGKILL)"
                 runs[name] = {"rc": -1, "process_seconds": time.perf_counter() - t0, "value": 0.0, "pipeline_seconds": None,
-                              "pipeline_value": None, "stages": [], "stderr_tail": "timed out after %d s: %s" % (
-                                  E2E_TIMEOUT_S, ((e.stderr or b"")[-300:].decode("utf-8", "replace") if isinstance(e.stderr, bytes) else str(e.stderr)[-300:]))}
+                              "pipeline_value": None, "stages": [], "stderr_tail": "timed out after %d s: %s" % (E2E_TIMEOUT_S, (se or "")[-300:])}
                 break
+            import types
+            p = types.SimpleNamespace(returncode=proc.returncode, stderr=se or "")
             dt = time.perf_counter() - t0
             pipe = None
             keep = []
@@ -362,6 +381,19 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
                           "pipeline_seconds": pipe, "pipeline_value": (nb * copies / pipe / 1e9) if pipe else None, "stages": keep}
             if p.returncode != 0:
                 runs[name]["stderr_tail"] = p.stderr[-500:]
+            if split:
+                parts = sorted(glob.glob(os.path.join(tmp, "*." + os.path.basename(outp))))
+                runs[name]["files"] = len(parts)
+                runs[name]["bytes_written"] = sum(os.path.getsize(f) for f in parts)
+                runs[name]["what"] = "--split %d -w %d: %d files, one writer thread per worker (writev gather lists)" % (
+                    E2E_SPLIT, E2E_SPLIT, len(parts))
+                for f in parts:
+                    try:
+                        os.remove(f)
+                    except OSError:
+                        pass
+            elif target == outp and os.path.exists(outp):
+                runs[name]["bytes_written"] = os.path.getsize(outp)
             try:
                 os.remove(outp)
             except OSError:
@@ -381,7 +413,7 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
                                  "reads_out": jr["summary"]["after_filtering"]["total_reads"],
                                  "ok": jr["summary"]["before_filtering"]["total_reads"] == n_reads * copies}
     finally:
-        for f in (fq, outp, js, html, fa):
+        for f in [fq, outp, js, html, fa] + glob.glob(os.path.join(tmp, "*." + os.path.basename(outp))):
             try:
                 os.remove(f)
             except OSError:
@@ -659,7 +691,7 @@ def main(argv=None, rig=None):
         if args.e2e_copies > 1:
             try:
                 big = end_to_end(args.workload, opt, adapters, seq_t, qual_t, off_t, ne, copies=args.e2e_copies,
-                                 with_pcie=False, run_names=("to_dev_null", "to_file"))
+                                 with_pcie=False, run_names=("to_dev_null", "to_file", "to_split_files"))
                 out["e2e"]["large_input"] = big
             except Exception as e:
                 out["e2e"]["large_input"] = {"error": repr(e)[:300]}

@@ -163,20 +163,22 @@ struct Work {
     string gather_text;          /* the few bytes of it that exist nowhere yet: names with a split prefix */
     int rc = 0;
     string err;
+    std::atomic<int> holders{0}; /* --split*: the per-worker writer threads that still read this batch (+ the in-order thread) */
 };
 /* The passing reads of a batch as they go to --out (Read::appendToString, src/read.cpp:119-143), NOT copied together: every
  * line is a slice of what the batch already holds -- names and '+' lines in Batch::text, bases and qualities in the
  * page-locked arrays -- so the writer hands the kernel a gather list (writev) instead of a second copy of the data.
  * Formatting 18 GB of output text was 4.5 of the pipeline's 9 CPU-seconds, and the CPU quota is what bounds it.
  * (Plain --out only: gzip members, --failed_out, --split* and --break / --mask output go through format_batch_parallel.) */
-static void build_gather(const fplh::Batch& b, const fpl_read_result* res, vector<struct iovec>& iov, string& text) {
+static void build_gather(const fplh::Batch& b, const fpl_read_result* res, vector<struct iovec>& iov, string& text,
+                         uint32_t first = 0, uint32_t last = ~0u) {
     static const char* prefix[3] = {"", "split-by-adapter-left-", "split-by-adapter-right-"}; /* src/read.cpp:199,208 */
     static const char nl_byte = '\n';
-    const uint32_t n = b.n();
+    const uint32_t n = min(last, b.n());
     iov.clear();
     text.clear();
     size_t need = 0; /* bytes of prefixed names: reserved up front, the list points into the string */
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = first; i < n; i++) {
         const fpl_read_result& r = res[i];
         if (r.dropped) continue;
         for (int f = 0; f < r.n_frag; f++)
@@ -190,7 +192,7 @@ static void build_gather(const fplh::Batch& b, const fpl_read_result* res, vecto
         v.iov_len = len;
         iov.push_back(v);
     };
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = first; i < n; i++) {
         const fpl_read_result& r = res[i];
         if (r.dropped) continue;
         const char* name = b.text.data() + b.name_off[i];
@@ -876,17 +878,28 @@ int main(int argc, char* argv[]) {
         readBase += n;
     };
     long packReads = 0, packPassed = 0; /* the pack of 16 input reads under way (it may straddle two batches) */
-    string packText;
-    auto split_reads = [&](const Work& w) { /* before note_reads: readBase is the index of the batch's first read */
+    /* --split*: this thread only PLANS -- which reads of the batch go to which worker's writer, and after which of them the
+       worker's ThreadConfig::markProcessed is due (with what count); the workers' own threads (SplitOutput::start_threads)
+       put the text together and write it, every worker into its own file.  A pack of 16 reads belongs to worker
+       (index / 16) % workers (src/seprocessor.cpp:343-378); one that straddles two batches is marked with the second. */
+    struct PackRange {
+        uint32_t first, last;
+        long mark; /* -1: the pack goes on in the next batch */
+    };
+    const bool splitThreads = split && !getenv("FPLH_SPLIT_ONE_THREAD"); /* (test hook: the replay on this thread) */
+    if (splitThreads) split->start_threads();
+    auto release = [&](Work* w) {
+        if (--w->holders == 0) freeq.push(w);
+    };
+    auto split_reads = [&](Work* wp) { /* before note_reads: readBase is the index of the batch's first read */
+        const Work& w = *wp;
         const uint32_t n = w.batch.n();
         const fplh::FragmentList* fl = fragmentMode ? &w.frags : nullptr;
+        vector<vector<PackRange>> plan((size_t)workers);
         for (uint32_t i = 0; i < n;) {
             const uint64_t g = readBase + i;
             const uint32_t j = (uint32_t)min<uint64_t>(n, i + (16 - g % 16));
             const int wk = (int)((g / 16) % (uint64_t)workers);
-            packText.clear();
-            fplh::format_range(w.batch, w.res.data(), i, j, packText, nullptr, fl);
-            split->write(wk, packText);
             for (uint32_t k = i; k < j; k++) { /* `passed`, src/seprocessor.cpp:264-276: any output read of the read passes */
                 bool passed = false;
                 if (fl) {
@@ -897,11 +910,39 @@ int main(int argc, char* argv[]) {
                 packPassed += passed;
             }
             packReads += j - i;
+            long mark = -1;
             if ((readBase + j) % 16 == 0) { /* the pack is complete: ThreadConfig::markProcessed */
-                split->mark(wk, splitByLines ? packPassed : packReads);
+                mark = splitByLines ? packPassed : packReads;
                 packReads = packPassed = 0;
             }
+            plan[(size_t)wk].push_back({i, j, mark});
             i = j;
+        }
+        for (int wk = 0; wk < workers; wk++) {
+            if (plan[(size_t)wk].empty()) continue;
+            auto job = [&, wp, wk, fl, ranges = std::move(plan[(size_t)wk])]() {
+                const bool gather = !fl && !split->gzipped();
+                vector<struct iovec> iov;
+                string text;
+                for (const PackRange& r : ranges) {
+                    if (gather) { /* the worker's getWriter1()->writeString(outstr), as a gather list over the batch's arrays */
+                        build_gather(wp->batch, wp->res.data(), iov, text, r.first, r.last);
+                        split->write_gather(wk, iov.data(), iov.size());
+                    } else {
+                        text.clear();
+                        fplh::format_range(wp->batch, wp->res.data(), r.first, r.last, text, nullptr, fl);
+                        split->write(wk, text);
+                    }
+                    if (r.mark >= 0) split->mark(wk, r.mark);
+                }
+                if (splitThreads) release(wp);
+            };
+            if (splitThreads) {
+                wp->holders++;
+                split->post(wk, std::move(job));
+            } else {
+                job();
+            }
         }
     };
     { /* writer: this thread, in input order */
@@ -927,18 +968,25 @@ int main(int argc, char* argv[]) {
                     }
                 } else if (fout) write_pieces(fout, r->outs);
                 if (ffail) write_pieces(ffail, r->faileds);
-                if (split) split_reads(*r);
+                r->holders = 1; /* this thread's own hold, until note_reads is done with the batch */
+                if (split) split_reads(r);
                 note_reads(*r);
                 tWrite += now() - t0;
                 next++;
-                freeq.push(r);
+                release(r);
             }
         }
     }
     if (split) {
-        if (packReads > 0) /* the last, short pack */
-            split->mark((int)(((readBase - 1) / 16) % (uint64_t)workers), splitByLines ? packPassed : packReads);
-        split->close();
+        if (packReads > 0) { /* the last, short pack */
+            const int wk = (int)(((readBase - 1) / 16) % (uint64_t)workers);
+            const long cnt = splitByLines ? packPassed : packReads;
+            if (splitThreads) split->post(wk, [&, wk, cnt]() { split->mark(wk, cnt); });
+            else split->mark(wk, cnt);
+        }
+        const double t0 = now();
+        split->close(); /* (threaded: waits for the workers' writers) */
+        tWrite += now() - t0;
         delete split;
     }
     readerThread.join();

@@ -1,7 +1,10 @@
 #include "split.h"
 
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -198,16 +201,51 @@ string gzip_member(const string& in, int level) {
 
 SplitOutput::SplitOutput(const string& out, int digits, int workers, bool by_lines, int number, long size, int gz_level)
     : out_(out), digits_(digits), T_(workers), by_lines_(by_lines), number_(number), size_(size), level_(gz_level), w_(workers) {
+    gz_ = out_.size() > 3 && out_.compare(out_.size() - 3, 3, ".gz") == 0;
     for (int t = 0; t < T_; t++) {
         w_[t].working = t; /* mWorkingSplit = threadId */
         open(w_[t]);
     }
+}
+SplitOutput::~SplitOutput() {
+    if (!closed_) close();
 }
 void SplitOutput::write(int t, const string& text) { /* config->getWriter1()->writeString(outstr), src/seprocessor.cpp:297-301 */
     if (out_.empty()) return;
     Worker& w = w_[t];
     w.pending += text;
     if (w.pending.size() >= (4u << 20)) flush(w);
+}
+void SplitOutput::write_gather(int t, struct iovec* iov, size_t cnt) {
+    if (out_.empty() || cnt == 0) return;
+    Worker& w = w_[t];
+    if (gz_) { /* (a gzip member needs the text in one piece) */
+        for (size_t k = 0; k < cnt; k++) w.pending.append((const char*)iov[k].iov_base, iov[k].iov_len);
+        if (w.pending.size() >= (4u << 20)) flush(w);
+        return;
+    }
+    flush(w);
+    size_t k = 0;
+    while (k < cnt) { /* writev takes 1024 entries at a time and may stop short */
+        const int c = (int)min<size_t>(1024, cnt - k);
+        ssize_t n = writev(w.fd, iov + k, c);
+        if (n < 0) {
+            if (errno == EINTR) continue;
+            error_exit("write failed");
+        }
+        while (n > 0 && k < cnt) {
+            if ((size_t)n >= iov[k].iov_len) {
+                n -= (ssize_t)iov[k].iov_len;
+                k++;
+            } else {
+                iov[k].iov_base = (char*)iov[k].iov_base + n;
+                iov[k].iov_len -= (size_t)n;
+                n = 0;
+            }
+        }
+        while (k < cnt && iov[k].iov_len == 0) k++;
+    }
+    w.wrote = true;
 }
 void SplitOutput::mark(int t, long reads) { /* ThreadConfig::markProcessed, src/threadconfig.cpp:89-110 */
     Worker& w = w_[t];
@@ -218,32 +256,84 @@ void SplitOutput::mark(int t, long reads) { /* ThreadConfig::markProcessed, src/
         w.current = 0;
     }
 }
-void SplitOutput::close() { /* ThreadConfig::cleanup: files a short input never reached still have to exist */
-    for (Worker& w : w_) {
-        if (!by_lines_)
-            while (w.working + T_ < number_) {
-                w.working += T_;
-                open(w);
+void SplitOutput::finish(Worker& w) { /* ThreadConfig::cleanup: files a short input never reached still have to exist */
+    if (!by_lines_)
+        while (w.working + T_ < number_) {
+            w.working += T_;
+            open(w);
+        }
+    shut(w);
+}
+void SplitOutput::close() {
+    if (closed_) return;
+    closed_ = true;
+    if (threaded()) {
+        for (Worker& w : w_) {
+            { lock_guard<mutex> g(w.m); w.stop = true; }
+            w.cv.notify_one();
+        }
+        for (thread& th : threads_) th.join();
+        threads_.clear();
+    } else {
+        for (Worker& w : w_) finish(w);
+    }
+    for (Worker& w : w_) names.insert(names.end(), w.opened.begin(), w.opened.end());
+}
+void SplitOutput::start_threads() {
+    if (threaded() || closed_) return;
+    for (int t = 0; t < T_; t++)
+        threads_.emplace_back([this, t]() {
+            Worker& w = w_[t];
+            for (;;) {
+                function<void()> job;
+                {
+                    unique_lock<mutex> g(w.m);
+                    w.cv.wait(g, [&] { return !w.q.empty() || w.stop; });
+                    if (w.q.empty()) break; /* (stop, and nothing left) */
+                    job = std::move(w.q.front());
+                    w.q.pop_front();
+                }
+                job();
             }
-        shut(w);
+            finish(w);
+        });
+}
+void SplitOutput::post(int t, function<void()> job) {
+    Worker& w = w_[t];
+    { lock_guard<mutex> g(w.m); w.q.push_back(std::move(job)); }
+    w.cv.notify_one();
+}
+void SplitOutput::put(Worker& w, const char* p, size_t n) {
+    while (n > 0) {
+        const ssize_t k = ::write(w.fd, p, n);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            error_exit("write failed");
+        }
+        p += k;
+        n -= (size_t)k;
     }
 }
 void SplitOutput::flush(Worker& w) {
-    if (w.pending.empty() || !w.f) return;
-    const string& bytes = w.gz ? gzip_member(w.pending, level_) : w.pending;
-    if (fwrite(bytes.data(), 1, bytes.size(), w.f) != bytes.size()) error_exit("write failed");
+    if (w.pending.empty() || w.fd < 0) return;
+    if (gz_) {
+        const string bytes = gzip_member(w.pending, level_);
+        put(w, bytes.data(), bytes.size());
+    } else {
+        put(w, w.pending.data(), w.pending.size());
+    }
     w.wrote = true;
     w.pending.clear();
 }
 void SplitOutput::shut(Worker& w) {
-    if (!w.f) return;
+    if (w.fd < 0) return;
     flush(w);
-    if (w.gz && !w.wrote) {
+    if (gz_ && !w.wrote) {
         const string e = gzip_member(string(), level_);
-        if (fwrite(e.data(), 1, e.size(), w.f) != e.size()) error_exit("write failed");
+        put(w, e.data(), e.size());
     }
-    if (fclose(w.f) != 0) error_exit("write failed");
-    w.f = nullptr;
+    if (::close(w.fd) != 0) error_exit("write failed");
+    w.fd = -1;
 }
 void SplitOutput::open(Worker& w) { /* ThreadConfig::initWriterForSplit: 1-based number, zero-padded, in front of the base name */
     if (out_.empty()) return;
@@ -254,11 +344,10 @@ void SplitOutput::open(Worker& w) { /* ThreadConfig::initWriterForSplit: 1-based
     const string dir = slash == string::npos ? "./" : out_.substr(0, slash + 1);
     const string base = slash == string::npos ? out_ : out_.substr(slash + 1);
     const string path = dir + num + "." + base;
-    w.f = fopen(path.c_str(), "wb");
-    if (!w.f) error_exit("Failed to write: " + path);
-    w.gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    w.fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (w.fd < 0) error_exit("Failed to write: " + path);
     w.wrote = false;
-    names.push_back(path);
+    w.opened.push_back(path);
 }
 
 bool load_fasta_contigs(const string& path, map<string, string>& contigs, string& err) {

@@ -8,10 +8,17 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <sys/uio.h>
+
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <ostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace fplh {
@@ -82,29 +89,54 @@ int gunzip_member_into(const unsigned char* in, size_t in_len, char* out, size_t
 class SplitOutput {
    public:
     SplitOutput(const std::string& out, int digits, int workers, bool by_lines, int number, long size, int gz_level);
+    ~SplitOutput();
     void write(int t, const std::string& text);
+    /* the same bytes as a gather list (plain files only): what is pending for worker t goes out first, then the list, by
+       writev -- no copy of the text in user space */
+    void write_gather(int t, struct iovec* iov, size_t cnt);
     void mark(int t, long reads);
     void close();
-    std::vector<std::string> names;
+    bool gzipped() const { return gz_; }
+    std::vector<std::string> names; /* the files opened, in the order they were opened (threaded: per worker, then merged) */
+
+    /* One thread per worker -- the reference's writers ARE per worker (ThreadConfig owns its Writer, src/threadconfig.cpp:72-87),
+     * and one file on tmpfs takes 6-9 GB/s whoever writes it while fifteen files take 60 (tools/file_write_probe.cpp).
+     * start_threads() once; post(t, job) hands worker t's thread a job that calls write / write_gather / mark for worker t ONLY
+     * (jobs of one worker run in the order they were posted, so every file gets the bytes the one-thread replay gives it);
+     * close() drains the queues, runs the workers' clean-up and joins. */
+    void start_threads();
+    void post(int t, std::function<void()> job);
+    bool threaded() const { return !threads_.empty(); }
 
    private:
     struct Worker {
         int working = 0;
         long current = 0;
-        FILE* f = nullptr;
-        bool gz = false, wrote = false;
+        int fd = -1;
+        bool wrote = false;
         std::string pending;
+        std::vector<std::string> opened;
+        /* threaded mode */
+        std::mutex m;
+        std::condition_variable cv;
+        std::deque<std::function<void()>> q;
+        bool stop = false;
     };
     void flush(Worker& w);
     void shut(Worker& w);
     void open(Worker& w);
+    void finish(Worker& w);
+    void put(Worker& w, const char* p, size_t n);
     std::string out_;
     int digits_, T_;
     bool by_lines_;
     int number_;
     long size_;
     int level_;
+    bool gz_ = false;
     std::vector<Worker> w_;
+    std::vector<std::thread> threads_;
+    bool closed_ = false;
 };
 
 /* --adapter_fasta: FastaReader + Options::loadFastaAdapters (src/fastareader.cpp:5-101, src/options.cpp:39-66).

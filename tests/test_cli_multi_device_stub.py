@@ -136,3 +136,45 @@ def test_stub_agrees_with_the_library_on_defaults():
     stub.fpl_options_default(C.byref(b))
     assert bytes(a) == bytes(b)
     assert stub.fpl_abi_version() == abi.FPL_ABI_VERSION
+
+
+@pytest.mark.parametrize("mode", ["number_w16", "number_w2", "lines_w3", "number_gz", "one_thread"])
+def test_cli_split_outputs_per_worker_writer_threads(tmp_path, stub_env, orc, mode):
+    """--split / --split_by_lines with one writer thread per worker (SplitOutput::start_threads: the in-order thread only plans
+    which reads go to which worker, the workers' threads gather and write): every numbered file holds the bytes the reference's
+    per-worker writers put there (tests/hostio.expected_split, the replay pinned against the real ThreadConfig / Writer), whatever
+    the batch cuts -- 30 kB chunks, so packs of 16 reads straddle batches -- and on two devices."""
+    import numpy as np
+    from fastplong_amd import synth
+    from tests import hostio
+    from tests.test_golden import OPTS, _per_read_outputs
+
+    okw, start, end = OPTS["c3_full"]
+    seq, qual, off = synth.ont_like(1500, seed=21, median_len=700, max_len=2500, p_middle=0.1, p_polya=0.2)
+    text, names, strands = hostio.make_fastq(seq, qual, off)
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    cfg = orc.Config(abi.FplOptions.default(**okw), start, end)
+    res, _ = orc.process_batch(cfg, seq, qual, off)
+    texts, passed = _per_read_outputs(seq, qual, off, names, strands, res)
+    flags = json.load(open(os.path.join(GOLD, "c3_full", "case.json")))["flags"]
+    gzipped = mode == "number_gz"
+    out = str(tmp_path / ("out.fq.gz" if gzipped else "out.fq"))
+    env = dict(stub_env, FPL_STUB_DEVICES="2", FPLH_CHUNK_BYTES="30000")
+    if mode == "lines_w3":
+        extra, want = ["--split_by_lines", "1000", "-w", "3", "--split_prefix_digits", "0"], \
+            hostio.expected_split(texts, passed, out, 3, True, 0, 250, digits=0)
+    elif mode == "number_w2" or mode == "one_thread":
+        extra, want = ["--split", "7", "-w", "2"], hostio.expected_split(texts, passed, out, 2, False, 7, 1500 // 7)
+        if mode == "one_thread":
+            env["FPLH_SPLIT_ONE_THREAD"] = "1"
+    else:  # 7 files, -w 16 is capped at the file count
+        extra, want = ["--split", "7", "-w", "16"], hostio.expected_split(texts, passed, out, 7, False, 7, 1500 // 7)
+    cmd = [build.CLI, "-i", str(inp), "-o", out, "-j", str(tmp_path / "o.json"), "-h", str(tmp_path / "o.html"), "--gpus", "2",
+           "--reader_threads", "3"] + flags + extra
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = {str(f): (gz(str(f)) if gzipped else f.read_bytes()) for f in tmp_path.iterdir() if "out.fq" in f.name}
+    assert sorted(got) == sorted(want) and len(want) >= 6
+    for k in want:
+        assert got[k] == want[k], k
