@@ -414,40 +414,50 @@ static char* gunzip_single_to_memory(const string& path, uint64_t max_bytes, uin
         for (int pad = 0; pad < 4 && tail < fsize; pad++)
             if (tail + (size_t)pad < fsize) ends[n_ends++] = tail + (size_t)pad;
         if (padded) ends[n_ends++] = fsize;
-        bool give_up = false;
-        for (int e = 0; e < n_ends && !result && !give_up; e++) {
+        /* The candidate ends only say how much text to make room for (the size field in front of them).  The inflate itself
+           always gets the whole file: it stops where the member really ends (`used`, trailer checked) -- so a member with
+           padding behind it is accepted from the FIRST attempt that had room for its text, instead of being inflated again for
+           every guess of where the padding starts.  At most four attempts in all: every one is a full pass over the file. */
+        uint64_t wants[12];
+        int n_wants = 0;
+        for (int e = 0; e < n_ends; e++) {
             const size_t end = ends[e];
             if (end < 18) continue;
             const uint64_t isize = (uint64_t)in[end - 4] | ((uint64_t)in[end - 3] << 8) | ((uint64_t)in[end - 2] << 16) | ((uint64_t)in[end - 1] << 24);
-            for (uint64_t want = isize; want <= max_bytes && !result; want += 1ull << 32) {
-                if (want == 0) continue;
-                const uint64_t span = want + (4u << 20);
-                char* base = (char*)mmap(nullptr, (size_t)span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-                if (base == (char*)MAP_FAILED) {
-                    give_up = true;
-                    break;
-                }
-                madvise(base, (size_t)span, MADV_HUGEPAGE); /* (one fault per 2 MiB instead of per 4 KiB as the text arrives) */
-                size_t used = 0, made = 0;
-                const int rc = gunzip_member_into(in, end, base, (size_t)want, &used, &made);
-                if (rc == 1 && made == want && used == end) {
+            for (uint64_t want = isize; want <= max_bytes && n_wants < 12; want += 1ull << 32) {
+                bool seen = want == 0;
+                for (int k = 0; k < n_wants; k++) seen = seen || wants[k] == want;
+                if (!seen) wants[n_wants++] = want;
+                if (want - isize >= (1ull << 32)) break; /* (one wrap per candidate: a text beyond 8 GiB of a guess is the next guess's) */
+            }
+        }
+        int attempts = 0;
+        for (int k = 0; k < n_wants && !result && attempts < 4; k++) {
+            const uint64_t want = wants[k];
+            const uint64_t span = want + (4u << 20);
+            char* base = (char*)mmap(nullptr, (size_t)span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (base == (char*)MAP_FAILED) break;
+            madvise(base, (size_t)span, MADV_HUGEPAGE); /* (one fault per 2 MiB instead of per 4 KiB as the text arrives) */
+            size_t used = 0, made = 0;
+            attempts++;
+            const int rc = gunzip_member_into(in, fsize, base, (size_t)want, &used, &made);
+            if (rc == 1 && made > 0) {
+                /* a whole member.  Zero padding may follow (zlib ignores it: so does this); anything else is another member --
+                   not for this lane */
+                size_t z = used;
+                while (z < fsize && in[z] == 0) z++;
+                if (z == fsize) {
                     result = base;
-                    *size_out = want;
+                    *size_out = made;
                     *reserved = span;
                     break;
                 }
                 munmap(base, (size_t)span);
-                if (rc == 2) continue; /* more text than this candidate size: the next one */
-                /* a whole member that stops in front of this end with something other than padding behind it: several
-                   members, not for this lane.  Anything else (a trailer cut short by a wrong guess of the padding, a size that
-                   does not match): the next guess of where the member ends */
-                if (rc == 1 && used < end) {
-                    size_t z = used;
-                    while (z < end && in[z] == 0) z++;
-                    if (z < end) give_up = true;
-                }
                 break;
             }
+            munmap(base, (size_t)span);
+            if (rc != 2) break; /* damaged, or no libdeflate: the streaming reader reports it / takes over */
+            /* rc == 2: more text than this guess made room for: the next one */
         }
     }
     munmap((void*)in, fsize);
