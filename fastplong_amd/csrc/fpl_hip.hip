@@ -48,6 +48,12 @@ struct fpl_ctx {
     u32* d_st_e = nullptr;
     u64* d_stats_scratch = nullptr;
     u8* d_stats_flags = nullptr;
+    u64* d_extra_scratch = nullptr; /* the post-only pass's own slabs / flags (it runs on s_aux beside the reduce of k_stats_sorted) */
+    u8* d_extra_flags = nullptr;
+    size_t extra_slabs = 0;
+    hipStream_t s_aux = nullptr;    /* owned: the side stream of a batch (pipeline.h: FPL_FORK / FPL_JOIN) */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;            /* FPL_NO_OVERLAP=1 (read in fpl_create): everything on the one stream */
     /* staging for the host-pointer entry points: FPL_MAX_IN_FLIGHT slots, so that the copies of one batch
        overlap the kernels of the previous one */
     struct Slot {
@@ -160,6 +166,10 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         FPL_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         FPL_HIP(hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
         FPL_HIP(hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+        FPL_HIP(hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+        FPL_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        FPL_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        if (const char* e = getenv("FPL_NO_OVERLAP")) ctx->overlap = atoi(e) == 0;
         for (auto& sl : ctx->slot) {
             FPL_HIP(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
             FPL_HIP(hipEventCreateWithFlags(&sl.ev_kern, hipEventDisableTiming));
@@ -212,7 +222,7 @@ void fpl_destroy(fpl_ctx* ctx) {
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {ctx->d_cfg, ctx->d_ads, ctx->d_counters, ctx->d_state, ctx->d_frag_off, ctx->d_frag_len,
-                    ctx->d_work_ctr, ctx->d_stats_scratch,
+                    ctx->d_work_ctr, ctx->d_stats_scratch, ctx->d_extra_scratch, ctx->d_extra_flags,
                     ctx->d_stats_flags, ctx->d_frag_cyc, ctx->bm.frags, ctx->bm.regs, ctx->bm.counts,
                     ctx->d_sort_ws, ctx->d_st_off, ctx->d_st_len, ctx->d_st_e, ctx->d_recs, ctx->d_redo, ctx->d_wins};
     for (void* p : ptrs)
@@ -228,6 +238,9 @@ void fpl_destroy(fpl_ctx* ctx) {
     }
     if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
+    if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int r = 0; r < fpl_ctx::EV_RING; r++)
         for (int i = 0; i <= N_STAGES; i++)
             if (ctx->ev[r][i]) (void)hipEventDestroy(ctx->ev[r][i]);
@@ -435,6 +448,25 @@ static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_r
     return FPL_OK;
 }
 
+/* slabs of the post-only pass when it has a stream of its own: FS_EXTRA_BLOCKS per cycle tile */
+static int ensure_extra_scratch(fpl_ctx* ctx, u32 n_reads, u32 max_read_len) {
+    if (!ctx->overlap || ctx->hcfg.defer) return FPL_OK;
+    const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, FS_T);
+    const size_t slabs = (size_t)stats_extra_blocks(n_reads, ctx->tune) * n_tiles;
+    if (slabs <= ctx->extra_slabs) return FPL_OK;
+    FPL_HIP(hipDeviceSynchronize());
+    if (ctx->d_extra_scratch) (void)hipFree(ctx->d_extra_scratch);
+    if (ctx->d_extra_flags) (void)hipFree(ctx->d_extra_flags);
+    ctx->d_extra_scratch = nullptr;
+    ctx->d_extra_flags = nullptr;
+    ctx->extra_slabs = 0;
+    const size_t cap = slabs + slabs / 4;
+    FPL_HIP(hipMalloc((void**)&ctx->d_extra_scratch, cap * (size_t)FS_SLAB * sizeof(u64)));
+    FPL_HIP(hipMalloc((void**)&ctx->d_extra_flags, cap + cap / 8 + 4096));
+    ctx->extra_slabs = cap;
+    return FPL_OK;
+}
+
 static int ensure_sort_ws(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes) {
     const u32 per = stats_items_per_slice(n_reads, n_reads ? (u32)(n_bytes / n_reads) : 0, ctx->n_cu, ctx->tune);
     const size_t words = sort_ws_words(stats_sorted_max_slices(n_reads, per, ctx->tune), n_reads);
@@ -537,6 +569,8 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         if (r != FPL_OK) return r;
         r = ensure_scratch(ctx, n_reads, n_bytes, max_read_len);
         if (r != FPL_OK) return r;
+        r = ensure_extra_scratch(ctx, n_reads, max_read_len);
+        if (r != FPL_OK) return r;
         r = ensure_sort_ws(ctx, n_reads, n_bytes);
         if (r != FPL_OK) return r;
         r = ensure_break_mask(ctx, n_reads, n_bytes);
@@ -574,6 +608,13 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.st_e = ctx->d_st_e;
     a.stats_scratch = ctx->d_stats_scratch;
     a.stats_flags = ctx->d_stats_flags;
+    if (ctx->overlap && ctx->d_extra_scratch) {
+        a.extra_scratch = ctx->d_extra_scratch;
+        a.extra_flags = ctx->d_extra_flags;
+        a.aux = ctx->s_aux;
+        a.ev_fork = (void*)ctx->ev_fork;
+        a.ev_join = (void*)ctx->ev_join;
+    }
     a.n_cu = ctx->n_cu;
     a.dbg = ctx->dbg;
     a.tune = ctx->tune;

@@ -120,6 +120,13 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_OPT_VMFULL
 #define FPL_OPT_VMFULL 1 /* k_scan: the mask of testable window positions is worked out only in the tiles where it is not all ones */
 #endif
+#ifndef FPL_OPT_PAIR
+#define FPL_OPT_PAIR 1 /* k_scan (usual configuration): the head of the NEXT read of a wave's chunk rides in the lanes the last, ragged
+                          tile of a read leaves empty (range_scan_fast<.., PAIR>) */
+#endif
+#ifndef FPL_PAIR_MIN_LANES
+#define FPL_PAIR_MIN_LANES 12 /* ... when at least this many lanes are left for it (a packed tile costs ~100 instructions more) */
+#endif
 #ifndef FPL_OPT_PARTLANES
 #define FPL_OPT_PARTLANES 1 /* k_trim_ends_batched: the partial-pattern searches with lane = read on the columns the search
                                pass leaves open (partial16_candidates / partial16_resolve_lanes) instead of a wave and 184
@@ -3205,6 +3212,36 @@ __device__ __forceinline__ void hist32(const HistLane& hl, const u32 q[8], int n
    partly filled chunk */
 __device__ __forceinline__ u32 hist_dumped(int blen) { return blen > 0 ? (u32)((SC_CHUNK - (blen % SC_CHUNK)) % SC_CHUNK) : 0u; }
 
+/* Pair packing (north_star: "length-bucketed ... for coalesced loads"; what bucketing is for is that no lane idles): the reads of
+ * a wave's chunk lie one behind the other, and the last tile of a read is ragged -- on average half its lanes hold nothing.
+ * Lanes hb..61 of that tile take the first 32 * (62 - hb) bytes of the NEXT read's r1 (lanes 62 / 63: the plane words its last
+ * windows reach into), so that read starts its own tiles that much further in.  Everything in the tile loop is lane-local but
+ * four things: the predecessor byte (the head's first byte has none), the per-lane running sums and best windows (the lanes of
+ * the head still hold the first read's: set aside for the tile and handed on as PairCarry), and the quality histogram -- one per
+ * wave, so the head's 8 quality dwords per lane wait in registers until the first read's totals are taken. */
+#ifdef FPL_EMU_PAIR_STATS
+static unsigned long long g_pair_stats[2]; /* emulator only: last tiles that hosted a head, bytes of heads */
+#endif
+struct PairCarry { /* the state of a read whose head was scanned in its predecessor's last tile */
+    int t0;        /* wave-uniform: bytes of r1 that are done (0: none -- a plain scan) */
+    u32 nn, diff;  /* per lane: the head's partial N count / complexity sum */
+    int bm0, bp0, bm1, bp1; /* per lane: best match count / position so far, per adapter */
+    u32 prev_last; /* wave-uniform: the dword whose top byte is the head's last byte */
+};
+struct PairIO {
+    PairCarry in;  /* what the predecessor's last tile did of THIS range */
+    /* the next read of the chunk as its metadata loads deliver it (per-lane copies of the same values: made wave-uniform where
+       they are used -- in the last tile, so that the loads have the whole scan to come back) */
+    bool allow;    /* wave-uniform: this read may host a head at all (and there is a next read) */
+    uint64_t nx_o0;
+    u32 nx_s, nx_e, nx_dropped;
+    const u8* seq;
+    const u8* qual;
+    PairCarry out; /* out.t0 > 0: that much of the NEXT read's r1 was scanned in this range's last tile */
+    int hb;        /* ... in lanes hb .. 61; their quality bytes are still to be counted (the caller loads them again and runs hist32
+                      once the wave's histogram is free: holding them in registers through the window search costs spills) */
+};
+
 /*
  * One pass over bytes [a, b) of a read, 32 bases per lane and tile:
  *   - quality histogram into h (this wave's slice, see ScanWaveLds),
@@ -3219,12 +3256,13 @@ __device__ __forceinline__ u32 hist_dumped(int blen) { return blen > 0 ? (u32)((
 /* NB: bit-planes the match counts need (6 when both adapters have <= 32 bases, else 7).  h = this wave's histogram
  * slice.  Returns the number of bytes the masked tiles parked in bin 0 of the histogram (hist_dumped): the caller takes
  * them out of that bin's total. */
-template <bool SUMS, bool HAM, bool LEAN = false, int NB = 7, bool PREFETCH = (FPL_OPT_PREFETCH != 0)>
+template <bool SUMS, bool HAM, bool LEAN = false, int NB = 7, bool PREFETCH = (FPL_OPT_PREFETCH != 0), bool PAIR = false>
 __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
                                                const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
                                                ScanWaveLds* __restrict__ w, u32* __restrict__ h, int qualified_qual, RangeSums& sums,
                                                const DevAdapter* __restrict__ ad0, const DevAdapter* __restrict__ ad1,
-                                               u64& key0, u64& key1, bool do_ham = true) {
+                                               u64& key0, u64& key1, bool do_ham = true, PairIO* __restrict__ pio = nullptr) {
+    static_assert(!PAIR || (SUMS && HAM && !LEAN), "pair packing: the main scan only");
     /* do_ham (wave-uniform): false turns a HAM instance into a plain scan -- no window is tested, the keys come out
        as ~0 -- so that one inlined copy of the loop can serve reads with and without an adapter search */
     const int lane = lane_id();
@@ -3244,7 +3282,24 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
     /* the last byte of the range (the same in every lane; the ragged last tile pads with it) */
     u32 last_v = 0; /* (left in its vector register until the last tile: nothing waits for this load up front) */
     if (FPL_OPT_PADSCALAR && !LEAN && blen > 0) last_v = (u32)rb[a + blen - 1];
-    for (int t0 = 0; t0 < blen; t0 += ADV) {
+    /* what the lanes of a head find (they still hold THIS range's running sums and best windows: kept apart) */
+    u32 h_nn = 0, h_diff = 0;
+    int h_bm0 = -1, h_bp0 = 0, h_bm1 = -1, h_bp1 = 0;
+    int t_first = 0;
+    if (PAIR) {
+        if (pio->in.t0 > 0) { /* (wave-uniform) the head of this range is done: go on from there with what its lanes found */
+            t_first = pio->in.t0;
+            nn = pio->in.nn;
+            diff = pio->in.diff;
+            bm0 = pio->in.bm0;
+            bp0 = pio->in.bp0;
+            bm1 = pio->in.bm1;
+            bp1 = pio->in.bp1;
+            prev_tile_last = pio->in.prev_last;
+        }
+        pio->out.t0 = 0;
+    }
+    for (int t0 = t_first; t0 < blen; t0 += ADV) {
         /* A wave consumes its tile as soon as the loads are back, so it sits out one trip to HBM per tile.  One byte
            of every 128-byte line of the NEXT tile (lanes 0..31 the bases, 32..63 the qualities), requested before this
            tile's own loads, brings that tile into the XCD's L2 meanwhile. */
@@ -3261,13 +3316,45 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
             const u8* const pp = (lane < 32 ? rb : qb) + b + 128 * (lane & 31);
             if (pp < (lane < 32 ? seq_end : qual_end)) pf = (u32)*pp;
         }
-        const int j0 = t0 + SC_CHUNK * lane;
-        const int navail = blen > j0 ? min(SC_CHUNK, blen - j0) : 0; /* bytes of the range in this chunk */
+        /* pair packing: does the next read's head ride in this tile, and from which lane on (hb; 64: no) */
+        int hb = 64;
+        const u8* nrb = nullptr;
+        const u8* nqb = nullptr;
+        if (PAIR && t0 + ADV >= blen && pio->allow && do_ham) { /* wave-uniform: the last tile of a read that may host */
+            const int la = (blen - t0 + SC_CHUNK - 1) / SC_CHUNK; /* lanes this range still needs */
+            if (ACTIVE - la >= FPL_PAIR_MIN_LANES) {
+                const int ns = (int)uniform_u32(pio->nx_s), ne = (int)uniform_u32(pio->nx_e);
+                /* every lane of the head, halo lanes included, loads 32 bytes of the next read's r1, and every position of
+                   its active lanes starts a tested window (adapters of <= 32 bases here) */
+                if (uniform_u32(pio->nx_dropped) == 0 && ne - ns >= SC_CHUNK * (64 - la) + 64) {
+                    hb = la;
+                    const uint64_t no0 = uniform_u64(pio->nx_o0);
+                    nrb = pio->seq + no0 + ns;
+                    nqb = pio->qual + no0 + ns;
+                }
+            }
+        }
+        const bool packed = PAIR && hb < 64;            /* wave-uniform */
+        const bool head = PAIR && lane >= hb;           /* this lane holds bytes of the NEXT read */
+        const int j0 = head ? SC_CHUNK * (lane - hb) : t0 + SC_CHUNK * lane; /* (the head's positions count from ITS first byte) */
+        const int navail = head ? SC_CHUNK : (blen > j0 ? min(SC_CHUNK, blen - j0) : 0); /* bytes of the range in this chunk */
         const int nstat = lane < ACTIVE ? navail : 0;                 /* bytes this lane accounts for */
         u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         /* a lane loads 32 bytes wherever its chunk starts inside the range: only the chunks of the batch's very last bytes
            can reach past the buffers (wave-uniform test on the tile's last possible byte), and only those pay for guards */
-        if (LEAN || rb + a + min(blen, t0 + 64 * SC_CHUNK) + SC_CHUNK > seq_end) {
+        if (packed) {
+            /* (every lane has bytes, and the head lies in front of at least 64 more bytes of its read: no load leaves the batch) */
+            const u8* const ps = head ? nrb + j0 : rb + a + j0;
+            const u8* const pq = head ? nqb + j0 : qb + a + j0;
+            const u32x4 s0 = load16(ps), s1 = load16(ps + 16);
+            s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w;
+            s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+            if (nstat > 0) {
+                const u32x4 q0 = load16(pq), q1 = load16(pq + 16);
+                q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
+                q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+            }
+        } else if (LEAN || rb + a + min(blen, t0 + 64 * SC_CHUNK) + SC_CHUNK > seq_end) {
             if (navail > 0) {
                 const u32x4 s0 = load16_guard(rb + a + j0, seq_end), s1 = load16_guard(rb + a + j0 + 16, seq_end);
                 s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w;
@@ -3306,7 +3393,7 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
             const int lb = rem >> 5, nb = rem & 31;
             const u32 last_byte = uniform_u32(last_v);
             const u32 rep = 0x01010101u * last_byte;
-            if (lane >= lb) {
+            if (lane >= lb && !head) { /* (a head starts right behind the lane the range ends in) */
                 if (lane == lb && nb != 0) {
 #pragma unroll
                     for (int d = 0; d < 8; d++) {
@@ -3357,9 +3444,17 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         }
         if (!LEAN) {
             if (nstat > 0) {
-                if (!FPL_DBG(dbg, 1)) hist32<false>(hl, q, SC_CHUNK);
+                if (!FPL_DBG(dbg, 1) && !head) hist32<false>(hl, q, SC_CHUNK); /* (the head's bytes: PairIO::q, counted by the caller) */
                 if (SUMS && !FPL_DBG(dbg, 2)) { /* (N count and complexity sum; lowq / totq: hist_quality_sums) */
-                    if (acgt) sums32_acgtn<false, false>(s[0], q, SC_CHUNK, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
+                    if (packed) { /* (wave-uniform) the head's lanes add to sums of their own */
+                        u32 t_nn = head ? 0u : nn, t_diff = head ? 0u : diff;
+                        if (acgt) sums32_acgtn<false, false>(s[0], q, SC_CHUNK, cL, cH, cN, prevd, qqrep, lowq, t_nn, totq, t_diff);
+                        else sums32<false, false>(s, q, SC_CHUNK, prevd, qqrep, lowq, t_nn, totq, t_diff);
+                        h_nn = head ? t_nn : 0u;
+                        h_diff = head ? t_diff : 0u;
+                        nn = head ? nn : t_nn;
+                        diff = head ? diff : t_diff;
+                    } else if (acgt) sums32_acgtn<false, false>(s[0], q, SC_CHUNK, cL, cH, cN, prevd, qqrep, lowq, nn, totq, diff);
                     else sums32<false, false>(s, q, SC_CHUNK, prevd, qqrep, lowq, nn, totq, diff);
                 }
                 if (FPL_DBG(dbg, 4)) totq += s[0] + s[3] + s[4] + s[7] + q[0] + q[3] + q[4] + q[7]; /* keep the loads alive */
@@ -3369,7 +3464,7 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
             if (SUMS) sums32<true>(s, q, nstat, prevd, qqrep, lowq, nn, totq, diff);
         }
         if (HAM) {
-            if ((npos0 > t0 || npos1 > t0) && !FPL_DBG(dbg, 16)) { /* wave-uniform: some window of this tile is tested */
+            if ((npos0 > t0 || npos1 > t0 || packed) && !FPL_DBG(dbg, 16)) { /* wave-uniform: some window of this tile is tested */
                 u32 PA, PC, PT, PG;
                 if (acgt) {
                     PA = ~(cH | cL); /* (an N has both bits set) */
@@ -3388,33 +3483,41 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
                 /* lanes 62/63 hold halo words only; their (clamped) plane reads are never used */
                 const u32* plane_lane = &w->planes[0][lane < ACTIVE ? lane : 0];
                 u32 B[NB];
-                if (npos0 > t0 && !FPL_DBG(dbg, 8)) {
+                if ((npos0 > t0 || packed) && !FPL_DBG(dbg, 8)) {
                     match_counts(plane_lane, ad0, B);
                     u32 vm = act_mask; /* every position of every active lane is a window start ... */
                     if (!FPL_OPT_VMFULL || npos0 - t0 < ACTIVE * SC_CHUNK) { /* ... except in the last tile(s) (wave-uniform) */
                         const int nv = npos0 - j0;
                         vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
                     }
+                    if (head) vm = act_mask; /* (a head is followed by more of its read than any window is long) */
                     if (vm) {
                         int val, first;
                         sliced_max(B, vm, val, first);
-                        if (val > bm0) {
+                        if (packed && head) { /* (its first and only tile so far) */
+                            h_bm0 = val;
+                            h_bp0 = j0 + first;
+                        } else if (val > bm0) {
                             bm0 = val;
                             bp0 = j0 + first;
                         }
                     }
                 }
-                if (npos1 > t0 && !FPL_DBG(dbg, 8)) {
+                if ((npos1 > t0 || packed) && !FPL_DBG(dbg, 8)) {
                     match_counts(plane_lane, ad1, B);
                     u32 vm = act_mask; /* every position of every active lane is a window start ... */
                     if (!FPL_OPT_VMFULL || npos1 - t0 < ACTIVE * SC_CHUNK) { /* ... except in the last tile(s) (wave-uniform) */
                         const int nv = npos1 - j0;
                         vm = (lane >= ACTIVE || nv <= 0) ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
                     }
+                    if (head) vm = act_mask; /* (a head is followed by more of its read than any window is long) */
                     if (vm) {
                         int val, first;
                         sliced_max(B, vm, val, first);
-                        if (val > bm1) {
+                        if (packed && head) { /* (its first and only tile so far) */
+                            h_bm1 = val;
+                            h_bp1 = j0 + first;
+                        } else if (val > bm1) {
                             bm1 = val;
                             bp1 = j0 + first;
                         }
@@ -3427,6 +3530,23 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
 #else
         (void)pf;
 #endif
+        if (packed) { /* (wave-uniform; the last tile) what the head's lanes found goes to the next read */
+            pio->out.t0 = SC_CHUNK * (ACTIVE - hb);
+            pio->out.nn = h_nn;
+            pio->out.diff = h_diff;
+            pio->out.bm0 = h_bm0;
+            pio->out.bp0 = h_bp0;
+            pio->out.bm1 = h_bm1;
+            pio->out.bp1 = h_bp1;
+            pio->out.prev_last = prev_tile_last; /* (lane 61's last dword: the head's last byte on top) */
+            pio->hb = hb;
+#ifdef FPL_EMU_PAIR_STATS
+            if (lane == 0) {
+                __atomic_fetch_add(&g_pair_stats[0], 1ull, __ATOMIC_RELAXED);
+                __atomic_fetch_add(&g_pair_stats[1], (unsigned long long)pio->out.t0, __ATOMIC_RELAXED);
+            }
+#endif
+        }
     }
     if (SUMS) {
         /* (the main scan leaves lowq / totq to its caller: hist_quality_sums on the histogram totals) */
@@ -3750,6 +3870,13 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
        hot counter sustains only ~80 atomics/us, which a per-read dequeue would saturate) */
     u32 chunk_next = 0, chunk_end = 0;
     bool have_next = false;
+    constexpr bool PAIR = SHORT && FPL_OPT_PAIR != 0;
+    PairIO pio;
+    pio.in.t0 = 0;
+    pio.out.t0 = 0;
+    pio.allow = false;
+    pio.seq = seq;
+    pio.qual = qual;
     PROF_INIT();
     uint64_t nx_o0 = 0, nx_o1 = 0;
     ReadState nx_st = {0, 0, 0, 0};
@@ -3789,6 +3916,12 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             nx_o1 = off[ri + 2];
             nx_st = state[ri + 1];
         }
+        if (PAIR) {
+            pio.nx_o0 = nx_o0;
+            pio.nx_s = nx_st.s;
+            pio.nx_e = nx_st.e;
+            pio.nx_dropped = nx_st.dropped;
+        }
         const int l = (int)(o1 - o0);
         const u8* rb = seq + o0;
         const u8* qb = qual + o0;
@@ -3806,7 +3939,13 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         const bool ham = !dropped && cfg->adapter_enabled;
         u32 dumped = 0; /* bytes the padded last tile of the body scan parked in bin 0 (hist_dumped) */
         bool qsums = true; /* lowq / totq still to come (from the histogram) */
-        if (SHORT || (ham && cfg->ham_fast)) /* (SHORT: also the reads without an adapter search, through do_ham) */
+        if (PAIR) {
+            /* the next read's head may ride in this read's last tile when the histogram is not needed again before this
+               read's totals are taken: no trimmed end so long that it takes a scan of its own (below) */
+            pio.allow = have_next && ham && !defer && s <= SC_END_PF && l - e <= SC_END_PF;
+            dumped = range_scan_fast<true, true, false, NB, (FPL_OPT_PREFETCH != 0), true>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, &ads[0],
+                                                                                          &ads[1], key0, key1, ham, &pio);
+        } else if (SHORT || (ham && cfg->ham_fast)) /* (SHORT: also the reads without an adapter search, through do_ham) */
             dumped = range_scan_fast<true, true, false, NB>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, &ads[0], &ads[1], key0, key1, ham);
         else if (ham) { /* adapters with bytes outside ACGT or longer than 64: byte-wise SWAR scan */
             range_scan_bytes<true, true>(rb, qb, s, e, seq_end, qual_end, h, qq, sm, &ads[0], &ads[1], key0, key1);
@@ -3821,9 +3960,25 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             if (k != ~0ull) wv = load4_guard(rb + s + (int)(u32)k + 4 * (lane & 7), seq_end);
         }
         PROF(2) /* body scan */
+        /* (pair packing) the qualities of the next read's head, lanes hb .. 61: fetched again -- they are in the cache -- rather
+           than carried through the window search in registers; counted once this read's totals are out of the histogram */
+        u32 hq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool head_q = PAIR && pio.out.t0 > 0 && lane >= pio.hb && lane < SC_LANES_HAM;
+        if (PAIR && pio.out.t0 > 0 && !(FPL_ABL & 128)) { /* wave-uniform */
+            if (head_q) {
+                const u8* const pq = qual + uniform_u64(pio.nx_o0) + uniform_u32(pio.nx_s) + SC_CHUNK * (lane - pio.hb);
+                const u32x4 q0 = load16(pq), q1 = load16(pq + 16);
+                hq[0] = q0.x; hq[1] = q0.y; hq[2] = q0.z; hq[3] = q0.w;
+                hq[4] = q1.x; hq[5] = q1.y; hq[6] = q1.z; hq[7] = q1.w;
+            }
+        }
         u32 hb0, hb1;
         hist_totals(h, hb0, hb1);
         if (lane == 0) hb0 -= dumped;
+        if (PAIR) {
+            if (pio.out.t0 > 0 && head_q && !(FPL_ABL & 128)) hist32<false>(hist_lane(h), hq, SC_CHUNK); /* (128: timing experiment) */
+            pio.in = pio.out; /* what the next read starts from (t0 == 0: from scratch) */
+        }
         if (qsums && !dropped && !defer) hist_quality_sums(hb0, hb1, qq & 0x7F, sm.lowq, sm.totq); /* (wave-uniform) */
         PROF(3)
         /* ---- the ends: their first SC_END_PF bytes from the prefetched registers into the small histogram,
@@ -4824,10 +4979,20 @@ k_stats_reduce_sorted(const u64* __restrict__ scratch, const u8* __restrict__ fl
     const u32 c = tile * FS_T + x;
     if (cnt && c < C) {
         long long* st = counters + (is_post ? FPL_OFF_POST(C) : FPL_OFF_PRE(C));
-        st[FPL_ST_CYC(c, 0, cls)] += (long long)cnt;
-        st[FPL_ST_CYC(c, 1, cls)] += (long long)qsum - 33ll * (long long)cnt;
-        st[FPL_ST_CYC(c, 2, cls)] += (long long)q20;
-        st[FPL_ST_CYC(c, 3, cls)] += (long long)q30;
+        if (is_post) {
+            /* (the post-only pass may run beside this kernel on the side stream, and a block of it whose packed fields fill up
+               empties its table into these very counters with atomics: so does this kernel -- one owner per cell here, the
+               atomic costs no more than the store) */
+            atomicAdd((u64*)&st[FPL_ST_CYC(c, 0, cls)], cnt);
+            atomicAdd((u64*)&st[FPL_ST_CYC(c, 1, cls)], qsum - 33ull * cnt);
+            atomicAdd((u64*)&st[FPL_ST_CYC(c, 2, cls)], q20);
+            atomicAdd((u64*)&st[FPL_ST_CYC(c, 3, cls)], q30);
+        } else {
+            st[FPL_ST_CYC(c, 0, cls)] += (long long)cnt;
+            st[FPL_ST_CYC(c, 1, cls)] += (long long)qsum - 33ll * (long long)cnt;
+            st[FPL_ST_CYC(c, 2, cls)] += (long long)q20;
+            st[FPL_ST_CYC(c, 3, cls)] += (long long)q30;
+        }
     }
 }
 

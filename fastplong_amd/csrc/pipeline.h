@@ -27,6 +27,9 @@ constexpr int RWAVES = 2;
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
 #define FPL_MEMSET(ptr, bytes, stream) memset(ptr, 0, bytes)
 typedef void* fpl_stream_t;
+#define FPL_FORK_MARK(a, stream) (void)0
+#define FPL_FORK(a, stream) (stream)
+#define FPL_JOIN(a, stream) (void)0
 #else
 constexpr int KWAVES = 4;
 constexpr int RWAVES = 16; /* k_resolve */
@@ -37,15 +40,21 @@ constexpr int SWAVES = FPL_SWAVES; /* k_stats: 16 waves share one 80 KiB LDS tab
 #define FPL_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #define FPL_MEMSET(ptr, bytes, stream) (void)hipMemsetAsync(ptr, 0, bytes, stream)
 typedef hipStream_t fpl_stream_t;
+/* a side stream for work that does not depend on what the main stream does next (BatchArgs::aux; none: everything in order) */
+#define FPL_FORK_MARK(a, stream) pipeline_fork_mark(a, stream)
+#define FPL_FORK(a, stream) pipeline_fork(a, stream)
+#define FPL_JOIN(a, stream) pipeline_join(a, stream)
 #endif
 
 /* Tuning / test hooks of the statistics passes (FPL_STATS_PER, FPL_STATS_EXTRA_PER, FPL_STATS_EXTRA_BLOCKS,
- * FPL_STATS_EXTRA_ACC, FPL_STATS_MIN_BUCKET, FPL_STATS_SORT_MIN, FPL_TRIM_BATCH_MIN in the environment; 0 = built-in choice).  The library reads them ONCE, in fpl_create(); the
+ * FPL_STATS_EXTRA_ACC, FPL_STATS_MIN_BUCKET, FPL_STATS_SORT_MIN, FPL_TRIM_BATCH_MIN, FPL_SCAN_CHUNK in the environment; 0 = built-in choice).  The library reads them ONCE, in fpl_create(); the
  * per-batch path only sees this struct. */
 struct StatsTune {
     u32 per = 0, extra_per = 0, extra_blocks = 0, extra_acc = 0;
     u32 min_bucket = 0; /* FPL_STATS_MIN_BUCKET: reads that must share a front trim to get slices of their own (k_stats_sorted) */
     u32 sort_min = 0;   /* FPL_STATS_SORT_MIN: batches of fewer reads take the unsorted statistics pass */
+    u32 scan_chunk = 0;     /* FPL_SCAN_CHUNK: reads a k_scan wave takes per dequeue, whatever the batch size (the built-in rule gives small
+                               batches chunks of one read: no wave then has a NEXT read whose head could ride in a last tile) */
     u32 trim_batch_min = 0; /* FPL_TRIM_BATCH_MIN: batches of fewer reads take k_trim_ends<1> (a wave per read) instead of
                                k_trim_ends_batched (64 reads per wave) */
 };
@@ -62,6 +71,7 @@ inline StatsTune stats_tune_from_env() {
     t.min_bucket = get("FPL_STATS_MIN_BUCKET");
     t.sort_min = get("FPL_STATS_SORT_MIN");
     t.trim_batch_min = get("FPL_TRIM_BATCH_MIN");
+    t.scan_chunk = get("FPL_SCAN_CHUNK");
     return t;
 }
 
@@ -98,10 +108,35 @@ struct BatchArgs {
     u32* st_e = nullptr;
     u64* stats_scratch;   /* stats_scratch_slabs() x FS_SLAB u64 */
     u8* stats_flags;      /* n_tiles tile flags + one byte per slab, zeroed before each statistics pass */
+    u64* extra_scratch = nullptr; /* the post-only (EXTRA) pass's own slabs and flags: it runs beside k_stats_sorted's reduce */
+    u8* extra_flags = nullptr;
+    fpl_stream_t aux = nullptr;   /* side stream + the two events that tie it to the main stream (device build only) */
+    void* ev_fork = nullptr;
+    void* ev_join = nullptr;
     u32 n_cu;      /* compute units of the device (grid sizing) */
     int dbg = 0;   /* FPL_DEBUG_FLAGS ablation switches (profiling only) */
     StatsTune tune; /* tuning / test hooks, read from the environment once by whoever builds the arguments */
 };
+
+#ifndef FPL_EMU
+/* FORK_MARK: the point of the main stream the side stream's work depends on; FORK: the side stream, which waits for that point.
+   What is enqueued on `stream` between the two is AHEAD of the side stream's work in the device's queues -- a kernel that fills
+   the chip is resident before the side work asks for room -- but the side work does not wait for it. */
+inline void pipeline_fork_mark(const BatchArgs& a, hipStream_t stream) {
+    if (a.aux) (void)hipEventRecord((hipEvent_t)a.ev_fork, stream);
+}
+inline hipStream_t pipeline_fork(const BatchArgs& a, hipStream_t stream) {
+    if (!a.aux) return stream;
+    (void)hipStreamWaitEvent(a.aux, (hipEvent_t)a.ev_fork, 0);
+    return a.aux;
+}
+/* `stream` goes on when the side stream's work is done */
+inline void pipeline_join(const BatchArgs& a, hipStream_t stream) {
+    if (!a.aux) return;
+    (void)hipEventRecord((hipEvent_t)a.ev_join, a.aux);
+    (void)hipStreamWaitEvent(stream, (hipEvent_t)a.ev_join, 0);
+}
+#endif
 
 constexpr int N_STAGES = 7;
 static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_resolve", "k_stats_prep", "k_stats", "k_stats_reduce",
@@ -244,6 +279,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         u32 chunk = n / (waves * FPL_SCAN_CHUNK_DIV);
         if (chunk < 4) chunk = n >= 8 * waves ? 4 : (n >= 2 * waves ? 2 : 1);
         if (chunk > 64) chunk = 64;
+        if (a.tune.scan_chunk) chunk = a.tune.scan_chunk < 64 ? a.tune.scan_chunk : 64;
         if (a.scan_short)
             FPL_LAUNCH((k_scan<KWAVES, true>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.ads,
                        (const ReadState*)a.state, a.recs, a.wins, a.counters, a.C, a.work_ctr, chunk);
@@ -285,6 +321,22 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     }
     mark(3);
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
+    /* the post-only pass over the EXTRA list (fragments of split reads, far-trimmed reads): the statistics kernel, then its reduce */
+    bool extra_forked = false;
+    auto launch_extra = [&](fpl_stream_t st, u64* scratch, u8* flags, bool reduce) {
+        const u32 n_items = a.defer ? a.bm.item_cap : 2 * n; /* upper bound; the kernel reads the real count */
+        const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n, a.tune); /* slabs per tile */
+        if (!reduce) {
+            FPL_MEMSET(flags, (size_t)gx * n_tiles + n_tiles, st);
+            FPL_LAUNCH((k_stats<SWAVES, true>), dim3(gx, n_tiles), dim3(SWAVES * 64), st, a.seq, a.qual, a.n_bytes,
+                       (const uint64_t*)a.frag_off, (const u32*)a.frag_len, (const u32*)a.frag_cyc, (const ReadState*)nullptr, n_items,
+                       (const u32*)(a.work_ctr + 1), stats_extra_per(a.tune), gx, stats_extra_max_acc(a.tune), a.counters, scratch,
+                       flags, a.C);
+        } else {
+            FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), st, (const u64*)scratch, (const u8*)flags, gx,
+                       n_tiles, a.counters, a.C, 0);
+        }
+    };
     const u32 per_sorted = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
     /* (the persistent blocks number their (tile, slice) items with 32 bits; a batch beyond that -- hundreds of millions of
        reads next to a read of hundreds of megabases -- takes the plain walk) */
@@ -303,10 +355,15 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_LAUNCH(k_bucket_scatter, dim3(nblk), dim3(FS_SORT_BLK), stream, a.off, (const ReadState*)a.state, n, a.sort_ws,
                    (const u32*)blkcnt, a.st_off, a.st_len, a.st_e, a.frag_off, a.frag_len, a.work_ctr + 1);
         mark(4);
+        /* the post-only (EXTRA) pass needs nothing of what follows: on the side stream its blocks fill the slots the persistent
+           blocks of k_stats_sorted leave as they run out of items, and run on beside the reduce kernel (a bandwidth kernel) */
+        extra_forked = a.aux != nullptr && a.extra_scratch != nullptr;
+        if (extra_forked) FPL_FORK_MARK(a, stream);
         /* persistent blocks, two per CU (what the LDS tables allow) */
         FPL_LAUNCH((k_stats_sorted<SWAVES>), dim3(2 * a.n_cu), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
                    (const uint64_t*)a.st_off, (const u32*)a.st_len, (const u32*)a.st_e, a.sort_ws, max_slices, n_tiles, a.counters,
                    a.stats_scratch, a.stats_flags, a.C);
+        if (extra_forked) launch_extra(FPL_FORK(a, stream), a.extra_scratch, a.extra_flags, false);
         mark(5);
         FPL_LAUNCH(k_stats_reduce_sorted, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, (const u32*)a.sort_ws, max_slices, n_tiles, a.counters, a.C);
@@ -324,16 +381,12 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                    (const u8*)a.stats_flags, n_slices, n_tiles, a.counters, a.C, 1);
     }
     mark(6);
-    {
-        const u32 n_items = a.defer ? a.bm.item_cap : 2 * n; /* upper bound; the kernel reads the real count */
-        const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n, a.tune); /* slabs per tile */
-        FPL_MEMSET(a.stats_flags, (size_t)gx * n_tiles + n_tiles, stream);
-        FPL_LAUNCH((k_stats<SWAVES, true>), dim3(gx, n_tiles), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
-                   (const uint64_t*)a.frag_off, (const u32*)a.frag_len, (const u32*)a.frag_cyc, (const ReadState*)nullptr, n_items,
-                   (const u32*)(a.work_ctr + 1), stats_extra_per(a.tune), gx, stats_extra_max_acc(a.tune), a.counters, a.stats_scratch,
-                   a.stats_flags, a.C);
-        FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
-                   (const u8*)a.stats_flags, gx, n_tiles, a.counters, a.C, 0);
+    if (extra_forked) {
+        FPL_JOIN(a, stream);
+        launch_extra(stream, a.extra_scratch, a.extra_flags, true); /* (the reduce: it adds to the counters the reduce above owns) */
+    } else {
+        launch_extra(stream, a.stats_scratch, a.stats_flags, false);
+        launch_extra(stream, a.stats_scratch, a.stats_flags, true);
     }
     mark(7);
 }

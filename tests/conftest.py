@@ -14,6 +14,10 @@ def pytest_configure(config):
     # below that.  The test batches are small: by default they go through the batched kernel -- the one the bench and any
     # large batch take -- and the tests named *_wave_per_read_* clear the hook to cover the other one.
     os.environ.setdefault("FPL_TRIM_BATCH_MIN", "1")
+    # Likewise k_scan: a wave of a large batch takes its reads in chunks, and the head of a chunk's next read rides in the lanes a
+    # read's last tile leaves empty (pair packing).  Small batches would get chunks of one read; the suite asks for chunks of four,
+    # and the tests named *_plain_scan_* clear the hook.
+    os.environ.setdefault("FPL_SCAN_CHUNK", "4")
 
 
 @pytest.fixture(scope="session")

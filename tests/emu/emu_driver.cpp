@@ -107,6 +107,10 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     fprintf(stderr, "emu: filter refreshes %llu, flagged start %llu, end %llu (reads %u)\n", fpl::g_filter_stats[0], fpl::g_filter_stats[1],
             fpl::g_filter_stats[2], n_reads);
 #endif
+#ifdef FPL_EMU_PAIR_STATS
+    fprintf(stderr, "emu: k_scan pair packing: %llu last tiles hosted a head, %llu head bytes (reads %u)\n", fpl::g_pair_stats[0],
+            fpl::g_pair_stats[1], n_reads);
+#endif
 #ifdef FPL_EMU_TRIM_STATS
     fprintf(stderr, "emu: k_trim_ends_batched groups %llu, P1b lanes %llu, P2 %llu, P3 wants %llu may %llu, P6 %llu, P7 wants %llu may %llu, lane searches %llu rounds %llu (all x 64 lanes; reads %u)\n",
             fpl::g_trim_stats[0], fpl::g_trim_stats[1], fpl::g_trim_stats[2], fpl::g_trim_stats[3], fpl::g_trim_stats[4], fpl::g_trim_stats[5],

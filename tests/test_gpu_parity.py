@@ -680,6 +680,30 @@ def test_scan_ragged_last_tiles_bit_exact(orc, engine_mod, opts):
         _run_both(orc, engine_mod, dict(opt=opts, start=synth.START_ADAPTER if on else "", end=synth.END_ADAPTER if on else ""), seq, qual, off)
 
 
+@pytest.mark.parametrize("opts,chunk", [(dict(), "4"), (dict(cut_front=1, cut_tail=1, complexity_filter=1, n_base_percent_limit=60), "3"),
+                                        (dict(cut_front=1, cut_tail=1, polyx=1), "64"), (dict(), "2")])
+def test_scan_pair_packing_bit_exact(orc, engine_mod, monkeypatch, opts, chunk):
+    """k_scan: the head of a chunk's next read in the free lanes of a read's last tile -- every split of the 62 lanes, next reads
+    on both sides of the length a head needs, N / lower case / middle adapters in and across the head, dropped next reads, reads
+    whose trimmed end is too long to host (tests/test_kernels_emu.py::_reads_for_pair_packing)"""
+    from tests.test_kernels_emu import _reads_for_pair_packing
+
+    monkeypatch.setenv("FPL_SCAN_CHUNK", chunk)
+    for seed in (7, 8):
+        seq, qual, off = _reads_for_pair_packing(seed)
+        res, _ = _run_both(orc, engine_mod, dict(opt=opts, start=synth.START_ADAPTER, end=synth.END_ADAPTER), seq, qual, off, via="device")
+        assert (res["n_frag"] == 2).any()
+
+
+def test_plain_scan_without_chunks_bit_exact(orc, engine_mod, monkeypatch):
+    """the built-in chunk rule (no FPL_SCAN_CHUNK): a batch this small is dealt one read per dequeue, no read has a next one"""
+    from tests.test_kernels_emu import _reads_for_pair_packing
+
+    monkeypatch.delenv("FPL_SCAN_CHUNK", raising=False)
+    seq, qual, off = _reads_for_pair_packing(9)
+    _run_both(orc, engine_mod, CASES["full_pipeline"], seq, qual, off, via="device")
+
+
 def test_long_reads_split_by_middle_adapters_bit_exact(orc, engine_mod):
     """k_resolve -> k_redo: split reads beyond 16 kb (front of the REDO list) and below (its far end), many per block"""
     seq, qual, off = synth.ont_like(500, seed=8, median_len=17000, sigma_len=0.3, p_middle=0.6)

@@ -258,6 +258,80 @@ def test_emulated_scan_ragged_last_tiles(orc, opts):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
+def _reads_for_pair_packing(seed, small=False):
+    """k_scan's pair packing: the head of a chunk's NEXT read rides in the lanes a read's ragged last tile leaves empty.  Pairs
+    (A, B) back to back: A's last tile needs 1 .. 62 lanes (a head takes what is left when >= 12 lanes are), B is just short of /
+    just long enough for / far beyond what the head needs, B's head holds N runs, lower-case letters (the byte-wise tile), the
+    middle adapters at its start, across the lane the head ends in and just behind it, B is dropped by trimAndCut, A has a long
+    trimmed end (no hosting), reads of several tiles whose own tiles then start 32 * (62 - hb) bytes in."""
+    rng = np.random.default_rng(seed)
+    sa = np.frombuffer(synth.START_ADAPTER.encode(), np.uint8)
+    ea = np.frombuffer(synth.END_ADAPTER.encode(), np.uint8)
+
+    def read(L, mu=26.0):
+        sq = synth._ACGT[rng.integers(0, 4, L)].astype(np.uint8)
+        ql = (np.clip(np.round(rng.normal(mu, 6, L)), 2, 50) + 33).astype(np.uint8)
+        return sq, ql
+
+    rems = [1, 31, 32, 33, 500, 1023, 1024, 1025, 1599, 1600, 1601, 1983] if small else \
+        [1, 2, 31, 32, 33, 63, 64, 65, 300, 500, 777, 1000, 1023, 1024, 1025, 1300, 1567, 1568, 1569, 1599, 1600, 1601, 1602, 1900, 1983, 1984]
+    reads = []
+    k = 0
+    for rem in rems:
+        la = (rem + 31) // 32
+        need = 32 * (64 - la) + 64  # the shortest r1 of B that gets a head
+        for dB in ((-1, 0, 1, 700, 2500) if not small else (-1, 0, 2500)):
+            LA = rem + (1984 if (k % 3 == 0) else 0)
+            a_s, a_q = read(LA)
+            LB = max(40, need + dB)
+            b_s, b_q = read(LB)
+            hb_bytes = 32 * (62 - la)
+            v = k % 8
+            if v == 1 and hb_bytes > 40:
+                b_s[5:5 + 20] = ord("N")
+                b_s[hb_bytes - 3:hb_bytes + 3] = ord("N")
+            elif v == 2 and hb_bytes > 40:
+                b_s[hb_bytes // 2] = ord("a")  # one lower-case letter in the head: the whole tile takes the byte-wise sums
+            elif v == 3 and hb_bytes > 100 and LB > hb_bytes + 100:
+                p = hb_bytes - 15  # a middle adapter across the boundary between the head and B's own first tile
+                b_s[p:p + len(sa)] = sa
+            elif v == 4 and LB > 200:
+                b_s[60:60 + len(ea)] = ea  # ... and one inside the head
+            elif v == 5 and hb_bytes > 100 and LB > hb_bytes + 100:
+                p = hb_bytes + 1
+                b_s[p:p + len(ea)] = ea  # ... and one that starts right behind it
+            elif v == 6:
+                b_q[:] = 33 + 2  # everything below the cut threshold: with cut_front / cut_tail B is dropped
+            elif v == 7 and LA > 400:
+                a_q[:200] = 33 + 2  # A loses 200 bases at the front with cut_front: a trimmed end beyond the prefetch -> no hosting
+            reads += [(a_s, a_q), (b_s, b_q)]
+            k += 1
+    # a run of reads that all host and are hosted (every read's tiles start inside it)
+    for L in ([2100, 3100, 2500, 5000, 2048, 2300] if small else [2100, 3100, 2500, 5000, 2048, 2300, 4100, 6100, 2200, 9000, 2400]):
+        reads.append(read(L))
+    return synth.pack(reads)
+
+
+@pytest.mark.parametrize("opts,chunk", [(dict(), "4"), (dict(cut_front=1, cut_tail=1, complexity_filter=1, n_base_percent_limit=60), "3"),
+                                        (dict(cut_front=1, cut_tail=1), "64"), (dict(), "")])
+def test_emulated_scan_pair_packing(orc, monkeypatch, opts, chunk):
+    """(chunk "": the built-in chunk rule -- one read per dequeue for a batch this small, the plain scan)"""
+    if chunk:
+        monkeypatch.setenv("FPL_SCAN_CHUNK", chunk)
+    else:
+        monkeypatch.delenv("FPL_SCAN_CHUNK", raising=False)
+    seq, qual, off = _reads_for_pair_packing(7, small=True)
+    cfg = orc.Config(abi.FplOptions.default(**opts), synth.START_ADAPTER, synth.END_ADAPTER)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    if opts.get("cut_front"):
+        assert (want_res["dropped"] != 0).any()
+    assert (want_res["n_frag"] == 2).any()  # (the planted middle adapters split their reads)
+
+
 REPEAT_START = "GTCAGTTACGTATTGC" + "AC" * 8  # (the start trim's partial pattern = the LAST 16 bases)
 REPEAT_END = "TG" * 8 + "AGCAATACGTAACTGA"   # (the end trim's = the FIRST 16)
 
