@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -360,13 +361,67 @@ struct Rccl {
 Rccl g_rccl;
 }  // namespace
 
-int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
+/* communicators made ahead of the merge (fpl_comm_init), kept for the devices they were made for */
+namespace {
+struct CommCache {
+    std::mutex m;
+    std::vector<int> devs;
+    std::vector<ncclComm_t> comms;
+    bool matches(fpl_ctx** ctxs, int n) const {
+        if ((int)devs.size() != n || n == 0) return false;
+        for (int i = 0; i < n; i++)
+            if (devs[(size_t)i] != ctxs[i]->device) return false;
+        return true;
+    }
+    void drop() { /* (caller holds m) */
+        for (ncclComm_t c : comms)
+            if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
+        comms.clear();
+        devs.clear();
+    }
+};
+CommCache g_comms;
+bool rccl_forced() {
+    const char* force = getenv("FPL_RCCL_FORCE");
+    return force && atoi(force) > 0;
+}
+int check_merge_args(fpl_ctx** ctxs, int32_t n) {
     if (!ctxs || n < 1) return FPL_ERR_ARG;
     for (int i = 0; i < n; i++) {
         if (!ctxs[i] || ctxs[i]->n_adapters != ctxs[0]->n_adapters) return FPL_ERR_ARG;
         for (int j = 0; j < i; j++)
             if (ctxs[j]->device == ctxs[i]->device) return FPL_ERR_ARG; /* one context per device */
     }
+    return FPL_OK;
+}
+}  // namespace
+
+int fpl_comm_init(fpl_ctx** ctxs, int32_t n) {
+    if (!ctxs && n == 0) { /* give the kept communicators back */
+        std::lock_guard<std::mutex> g(g_comms.m);
+        g_comms.drop();
+        return FPL_OK;
+    }
+    const int rc0 = check_merge_args(ctxs, n);
+    if (rc0 != FPL_OK) return rc0;
+    if (n == 1 && !rccl_forced()) return FPL_OK; /* (one context: the merge needs no communicator) */
+    std::lock_guard<std::mutex> g(g_comms.m);
+    if (g_comms.matches(ctxs, n)) return FPL_OK;
+    std::string err;
+    if (!g_rccl.load(err)) return FPL_ERR_STATE; /* (fpl_allreduce_counters will say why) */
+    g_comms.drop();
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; i++) devs[(size_t)i] = ctxs[i]->device;
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    if (g_rccl.CommInitAll(comms.data(), n, devs.data()) != ncclSuccess) return FPL_ERR_HIP;
+    g_comms.devs = devs;
+    g_comms.comms = comms;
+    return FPL_OK;
+}
+
+int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
+    const int rc0 = check_merge_args(ctxs, n);
+    if (rc0 != FPL_OK) return rc0;
     fpl_ctx* ctx = ctxs[0]; /* (FPL_HIP reports through this one) */
     u32 C = 0;
     for (int i = 0; i < n; i++) {
@@ -382,8 +437,7 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
     /* one context: nothing to merge.  FPL_RCCL_FORCE=1 (a test hook) runs the collective all the same -- a one-rank communicator,
        the in-place sum on the context's stream -- so that the loader, the communicator set-up and the call are exercised on a
        box with a single GPU; the buffer must come out unchanged. */
-    const char* force = getenv("FPL_RCCL_FORCE");
-    if (n == 1 && !(force && atoi(force) > 0)) return FPL_OK;
+    if (n == 1 && !rccl_forced()) return FPL_OK;
     if (!g_rccl.load(ctx->err)) return FPL_ERR_STATE;
 #define FPL_NCCL(call)                                                                                   \
     do {                                                                                                 \
@@ -394,11 +448,18 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
         }                                                                                                \
     } while (0)
     int rc = FPL_OK;
-    std::vector<ncclComm_t> comms((size_t)n, nullptr);
-    std::vector<int> devs((size_t)n);
-    for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
-    FPL_NCCL(g_rccl.CommInitAll(comms.data(), n, devs.data()));
-    if (rc != FPL_OK) return rc;
+    /* the communicators fpl_comm_init made for exactly these devices, else a set of this call's own */
+    std::lock_guard<std::mutex> keep(g_comms.m);
+    const bool kept = g_comms.matches(ctxs, n);
+    std::vector<ncclComm_t> own;
+    if (!kept) {
+        own.assign((size_t)n, nullptr);
+        std::vector<int> devs((size_t)n);
+        for (int i = 0; i < n; i++) devs[(size_t)i] = ctxs[i]->device;
+        FPL_NCCL(g_rccl.CommInitAll(own.data(), n, devs.data()));
+        if (rc != FPL_OK) return rc;
+    }
+    const std::vector<ncclComm_t>& comms = kept ? g_comms.comms : own;
     const size_t len = FPL_COUNTERS_LEN(C, ctx->n_adapters);
     FPL_NCCL(g_rccl.GroupStart());
     for (int i = 0; i < n && rc == FPL_OK; i++) {
@@ -407,7 +468,7 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
             rc = FPL_ERR_HIP;
             break;
         }
-        FPL_NCCL(g_rccl.AllReduce(ctxs[i]->d_counters, ctxs[i]->d_counters, len, ncclInt64, ncclSum, comms[i], ctxs[i]->stream));
+        FPL_NCCL(g_rccl.AllReduce(ctxs[i]->d_counters, ctxs[i]->d_counters, len, ncclInt64, ncclSum, comms[(size_t)i], ctxs[i]->stream));
     }
     FPL_NCCL(g_rccl.GroupEnd());
     for (int i = 0; i < n; i++) {
@@ -416,8 +477,8 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
             rc = FPL_ERR_HIP;
         }
     }
-    for (int i = 0; i < n; i++)
-        if (comms[i]) FPL_NCCL(g_rccl.CommDestroy(comms[i]));
+    for (ncclComm_t c : own)
+        if (c) FPL_NCCL(g_rccl.CommDestroy(c));
 #undef FPL_NCCL
     return rc;
 }

@@ -18,7 +18,7 @@ EXPORTS = [
     "fpl_reserve_cycles", "fpl_counters_device_ptr", "fpl_get_counters", "fpl_reset_counters", "fpl_synchronize",
     "fpl_enable_timing", "fpl_get_kernel_times", "fpl_fragment_counts", "fpl_get_fragments",
     "fpl_process_batch_async", "fpl_wait", "fpl_in_flight", "fpl_host_alloc", "fpl_host_free", "fpl_allreduce_counters",
-    "fpl_count_end_kmers", "fpl_pick_adapter", "fpl_rccl_library",
+    "fpl_count_end_kmers", "fpl_pick_adapter", "fpl_rccl_library", "fpl_comm_init",
 ]
 
 
@@ -101,6 +101,8 @@ def load_library(path=None):
     L.fpl_host_free.argtypes = [C.c_void_p]
     L.fpl_allreduce_counters.restype = C.c_int
     L.fpl_allreduce_counters.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
+    L.fpl_comm_init.restype = C.c_int
+    L.fpl_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
     L.fpl_rccl_library.restype = C.c_char_p
     L.fpl_rccl_library.argtypes = []
     L.fpl_count_end_kmers.restype = C.c_int

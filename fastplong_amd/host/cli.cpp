@@ -498,14 +498,33 @@ int main(int argc, char* argv[]) {
     vector<fpl_adapter> fa(fasta.size());
     for (size_t i = 0; i < fasta.size(); i++) fa[i] = fpl_adapter{fasta[i].data(), (int32_t)fasta[i].size()};
     vector<Device> dev(nGpus);
-    for (int d = 0; d < nGpus; d++) {
-        int rc = fpl_create(&dev[d].ctx, &o, startAd.data(), (int32_t)startAd.size(), endAd.data(), (int32_t)endAd.size(),
-                            fa.data(), (int32_t)fa.size(), d, 65536);
-        if (rc == FPL_ERR_NO_DEVICE)
-            error_exit("fastplong_amd needs " + to_string(nGpus) + " HIP device(s); there is no CPU path");
-        if (rc != FPL_OK) error_exit(string("fpl_create: ") + fpl_strerror(rc));
+    {
+        /* (a context costs a tenth of a second -- streams, events, tables, the device's first allocations: the devices' contexts
+           are made side by side, a node's eight in the time of one) */
+        vector<int> rcs((size_t)nGpus, FPL_OK);
+        auto make = [&](int d) {
+            rcs[(size_t)d] = fpl_create(&dev[(size_t)d].ctx, &o, startAd.data(), (int32_t)startAd.size(), endAd.data(), (int32_t)endAd.size(),
+                                        fa.data(), (int32_t)fa.size(), d, 65536);
+        };
+        vector<thread> makers;
+        for (int d = 1; d < nGpus; d++) makers.emplace_back(make, d);
+        make(0);
+        for (auto& t : makers) t.join();
+        for (int d = 0; d < nGpus; d++) {
+            if (rcs[(size_t)d] == FPL_ERR_NO_DEVICE)
+                error_exit("fastplong_amd needs " + to_string(nGpus) + " HIP device(s); there is no CPU path");
+            if (rcs[(size_t)d] != FPL_OK) error_exit(string("fpl_create: ") + fpl_strerror(rcs[(size_t)d]));
+        }
     }
 
+    /* the communicators of the closing merge, made while the batches run (a thread of its own: ncclCommInitAll over several devices
+       takes longer than many a run's whole pipeline; a failure here is not one yet -- the merge then makes its own and reports) */
+    thread commMaker;
+    {
+        vector<fpl_ctx*> ctxs;
+        for (auto& D : dev) ctxs.push_back(D.ctx);
+        if (nGpus > 1 || getenv("FPL_RCCL_FORCE")) commMaker = thread([ctxs]() mutable { (void)fpl_comm_init(ctxs.data(), (int32_t)ctxs.size()); });
+    }
     const double tCreate = clk();
     if (cmd.exist("verbose"))
         cerr << "start-up: input evaluation " << tEval - tMain << " s, device contexts " << tCreate - tEval << " s" << endl;
@@ -1017,7 +1036,10 @@ int main(int argc, char* argv[]) {
     {
         vector<fpl_ctx*> ctxs;
         for (auto& D : dev) ctxs.push_back(D.ctx);
+        if (commMaker.joinable()) commMaker.join();
+        const double tM0 = now();
         const int rc = fpl_allreduce_counters(ctxs.data(), (int32_t)ctxs.size());
+        if (cmd.exist("verbose") && fpl_rccl_library()[0]) cerr << "counter merge: " << now() - tM0 << " s" << endl;
         if (rc != FPL_OK) error_exit(string("fpl_allreduce_counters: ") + fpl_strerror(rc) + " " + fpl_last_error(ctxs[0]));
         if (cmd.exist("verbose") && fpl_rccl_library()[0])
             cerr << "counter merge: one all-reduce over " << ctxs.size() << " device(s), RCCL from " << fpl_rccl_library() << endl;

@@ -331,6 +331,12 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n);
  * HIP runtime in use.  With FPL_RCCL_FORCE=1 in the environment a merge of ONE context goes through RCCL as well (a one-rank
  * communicator; the buffer comes out unchanged) -- the way to exercise the collective on a box with a single GPU. */
 const char* fpl_rccl_library(void);
+/* (ABI v5) Optional: make the RCCL communicators of these contexts' devices AHEAD of the merge and keep them -- ncclCommInitAll over
+ * a node's eight devices takes far longer than the all-reduce of a few megabytes that follows, and a host can pay for it on a thread
+ * of its own while its batches run (bin/fastplong_amd does).  fpl_allreduce_counters uses kept communicators when they were made
+ * for exactly its devices (same order) and makes its own otherwise.  fpl_comm_init(NULL, 0) gives them back.  Thread-safe; may run
+ * beside fpl_process_batch* on the same contexts. */
+int fpl_comm_init(fpl_ctx** ctxs, int32_t n);
 
 /* The counting loops of the adapter auto-detection, Evaluator::evalAdapterAndReadNum (src/evaluator.cpp:300-345), on the
  * device: for the reads of the evaluation prefix (host CSR arrays; the reference looks at <= 64 Ki reads / 512 Mbases) count

@@ -222,6 +222,7 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
     return FPL_OK;
 }
 const char* fpl_rccl_library(void) { return ""; }
+int fpl_comm_init(fpl_ctx**, int32_t) { return FPL_OK; }
 int fpl_count_end_kmers(int32_t, const uint8_t*, const uint64_t*, uint32_t, int32_t, int32_t, uint32_t*, uint64_t*, uint64_t*) {
     return FPL_ERR_NO_DEVICE; /* (the tests give -s / -e, or set FPLH_HOST_KMERS) */
 }

@@ -170,6 +170,7 @@ def test_cli_counter_merge_through_rccl_on_gpu(tmp_path):
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, FPL_RCCL_FORCE="1"))
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert b"counter merge: one all-reduce over 1 device(s), RCCL from " in p.stderr and b"librccl" in p.stderr
+    assert re.search(rb"counter merge: [0-9.e-]+ s", p.stderr)  # (the communicator was made on its own thread beside the batches)
     assert (tmp_path / "out.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
     got = [l for l in (tmp_path / "out.json").read_bytes().split(b"\n") if not l.startswith(b'\t"command":')]
     assert got == gz(os.path.join(GOLD, case, "expected.json.gz")).split(b"\n")

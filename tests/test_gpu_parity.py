@@ -491,6 +491,14 @@ def test_allreduce_counters_runs_rccl_on_one_gpu(orc, engine_mod, monkeypatch):
         parity.assert_counters_equal(eng.counters(), want_cnt, C, 2)
     used = eng.L.fpl_rccl_library().decode()
     assert "librccl" in used, used
+    # communicators made ahead of the merge (what bin/fastplong_amd does on a thread of its own while its batches run) are the
+    # ones the merge then uses; made twice for the same devices they are made once; handed back with (NULL, 0)
+    assert eng.L.fpl_comm_init(arr, 1) == 0 and eng.L.fpl_comm_init(arr, 1) == 0
+    rc = eng.L.fpl_allreduce_counters(arr, 1)
+    assert rc == 0, (eng.L.fpl_strerror(rc), eng.L.fpl_last_error(eng.h))
+    parity.assert_counters_equal(eng.counters(), want_cnt, C, 2)
+    assert eng.L.fpl_comm_init(None, 0) == 0
+    assert eng.L.fpl_comm_init(arr, 0) == abi.FPL_ERR_ARG
     # the process has ONE librccl mapped: the loader took the copy torch brought along rather than a second one
     mapped = {line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line}
     assert len(mapped) == 1, mapped
