@@ -120,6 +120,11 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_OPT_VMFULL
 #define FPL_OPT_VMFULL 1 /* k_scan: the mask of testable window positions is worked out only in the tiles where it is not all ones */
 #endif
+#ifndef FPL_OPT_TRIMPF
+#define FPL_OPT_TRIMPF 0 /* k_trim_ends_batched: the cache lines of the NEXT group of 64 reads requested a group ahead -- SLOWER (1.24 -> 1.42 ms
+                            per million reads, round 4): loads return in order, so whatever the group at hand loads next waits for the
+                            touches of the group after it; there is no prefetch instruction on gfx950 that leaves vmcnt alone */
+#endif
 #ifndef FPL_OPT_PAIR
 #define FPL_OPT_PAIR 1 /* k_scan (usual configuration): the head of the NEXT read of a wave's chunk rides in the lanes the last, ragged
                           tile of a read leaves empty (range_scan_fast<.., PAIR>) */
@@ -1980,11 +1985,41 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
     /* groups of 64 reads are handed out through one counter (zeroed before the batch): the grid is what the chip holds
        at once, and no wave idles while another still has rounds to go */
     const u32 n_groups = (n_reads + 63) / 64;
+#if FPL_OPT_TRIMPF
+    /* this kernel is the first to touch a read: every phase's first byte of a lane is a trip to HBM, one behind the other.  A wave
+       therefore holds TWO groups -- the one it works on and the next one, whose reads' first and last lines (bases and
+       qualities) it requests now, a whole group's work ahead of their use */
+    u32 grp_next = 0;
+    if (lane == 0) grp_next = atomicAdd(group_ctr, 1u);
+    grp_next = readlane_u32(grp_next, 0);
+#endif
     for (;;) {
+#if FPL_OPT_TRIMPF
+        const u32 grp = grp_next;
+        if (grp >= n_groups) break;
+        {
+            u32 nx = 0;
+            if (lane == 0) nx = atomicAdd(group_ctr, 1u);
+            grp_next = readlane_u32(nx, 0);
+        }
+        u32 pf_keep = 0;
+        if (grp_next < n_groups && (u32)lane < min(64u, n_reads - grp_next * 64)) {
+            const uint64_t po0 = off[grp_next * 64 + lane], po1 = off[grp_next * 64 + lane + 1];
+            if (po1 > po0) {
+                const uint64_t hl = po1 - po0 < 384 ? po1 - 1 : po0 + 383, tl = po1 - po0 < 384 ? po0 : po1 - 384;
+                /* the first / last 384 bytes of the bases (cut, polyX, the 200-base windows of both adapter searches), the first /
+                   last 128 of the qualities (cut): one byte per 128-byte line */
+                pf_keep = (u32)seq[po0] + seq[min(po0 + 128, hl)] + seq[min(po0 + 256, hl)] + seq[hl] + (u32)seq[po1 - 1] +
+                          seq[max(po1 - 129, tl)] + seq[max(po1 - 257, tl)] + seq[tl] + (u32)qual[po0] + qual[min(po0 + 127, po1 - 1)] +
+                          (u32)qual[po1 - 1] + qual[max(po1 - 128, po0)];
+            }
+        }
+#else
         u32 grp = 0;
         if (lane == 0) grp = atomicAdd(group_ctr, 1u);
         grp = readlane_u32(grp, 0);
         if (grp >= n_groups) break;
+#endif
         const u32 g0 = grp * 64;
         const int gn = (int)min(64u, n_reads - g0);
         FPL_TRIM_STAT(0, 1);
@@ -2256,6 +2291,11 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             st.pad = 0;
             state[g0 + lane] = st;
         }
+#if FPL_OPT_TRIMPF && !defined(FPL_EMU)
+        asm volatile("" ::"v"(pf_keep)); /* (keeps the touch loads alive; they have long returned) */
+#elif FPL_OPT_TRIMPF
+        (void)pf_keep;
+#endif
     }
     __syncthreads();
     long long* fr = counters + FPL_OFF_FR(C);
