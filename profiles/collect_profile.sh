@@ -22,5 +22,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --output-format csv -d "$W/pmc_$ctr" -- $BENCH --steps 2 --warmup 1 > "$W/pmc_$ctr.log" 2>&1
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$W/pmc_SQ" -- $BENCH --steps 2 --warmup 1 > "$W/pmc_SQ.log" 2>&1
+# LDS: cycles the pipe is busy and cycles lost to bank conflicts (a pass of their own: the SQ block has few counter slots)
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d "$W/pmc_LDS" -- $BENCH --steps 2 --warmup 1 > "$W/pmc_LDS.log" 2>&1
 python "$ROOT/profiles/summarize_profile.py" "$OUT" "$WL"
 rm -rf "$W/stats" "$W"/pmc_*/ 2>/dev/null  # (the raw traces are large; the summaries stay)

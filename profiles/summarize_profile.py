@@ -16,6 +16,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SQ = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_BUSY_CYCLES")
+LDS = ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS")
 
 
 def short(name):
@@ -61,6 +62,8 @@ def main(out, wl):
             per.setdefault(kn, {})[ctr + "_KB"] = d[ctr]
     for kn, d in per_kernel(os.path.join(work, "pmc_SQ", "**", "*counter_collection.csv"), SQ).items():
         per.setdefault(kn, {}).update(d)
+    for kn, d in per_kernel(os.path.join(work, "pmc_LDS", "**", "*counter_collection.csv"), LDS).items():
+        per.setdefault(kn, {}).update(d)
     kernels = {}
     for kn, d in per.items():
         if not kn.startswith("k_"):
@@ -71,11 +74,14 @@ def main(out, wl):
             d["hbm_bytes_per_base"] = b / n_bases
             if "SQ_INSTS_VALU" in d:
                 d["valu_insts_per_base"] = d["SQ_INSTS_VALU"] / n_bases
+        if d.get("SQ_LDS_IDX_ACTIVE"):
+            d["lds_bank_conflict_frac"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
         kernels[kn] = d
     rec = {
         "workload": wl,
         "bench_line": bench.get("config", {}).get("workload", "?"),
-        "note": "separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_*), averaged over launches. gfx950: "
+        "note": "separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_*; SQ_LDS_*), averaged over launches. "
+                "lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles). gfx950: "
                 "FETCH_SIZE / WRITE_SIZE are in KB and FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads "
                 "(MI355X_MICROARCH.md, HBM), so hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; SQ_INSTS_* are wave-instructions",
         "bases_per_launch": n_bases,
