@@ -4558,9 +4558,20 @@ constexpr int SW_CNT = 0;                /* [FS_NB] reads per bucket */
 constexpr int SW_CUR = FS_NB;            /* [FS_NB] next free position of the range of bucket b */
 constexpr int SW_MAP = 2 * FS_NB;        /* [FS_NB] the bucket that bucket b is filed under: b, or FS_B_NOPOST when too small */
 constexpr int SW_NSLICES = 3 * FS_NB;    /* slices in the table */
-constexpr int SW_WORK = 3 * FS_NB + 1;   /* k_stats_sorted: the next (tile, slice) item */
-constexpr int SW_SLICES = 3 * FS_NB + 2; /* [slices][4]: begin, end (positions of the sorted order), front trim + 1 (0: not
-                                            post-filter), unused */
+constexpr int SW_WORK = 3 * FS_NB + 1;   /* k_stats_sorted: the next (tile, slice) / (tile, group) item */
+constexpr int SW_NGROUPS = 3 * FS_NB + 2; /* groups in the table behind the slices */
+constexpr int SW_SLICES = 3 * FS_NB + 3; /* [slices][4]: begin, end (positions of the sorted order), front trim + 1 (0: not
+                                            post-filter), unused; behind them [groups][2]: first slice, one past the last */
+/* Beyond the typical read length a (tile, slice) item holds a handful of rows -- the few reads of the slice that are that long --
+   but still costs its block the zeroing of 80 KB of tables and a slab for the reduce kernel to read (configs[3], 300 b ... 200 kb:
+   1 % of the rows, most of the slabs).  From cycle tile `hi_tile` on the items are therefore (tile, GROUP of up to FS_GROUP
+   consecutive slices of one front trim): one table set, one slab -- filed under the group's first slice that has rows -- for as
+   long as the rows counted so far fit the 14-bit fields (counted, not assumed: a group whose rows would not fit is handed over in
+   pieces). */
+#ifndef FPL_STATS_GROUP
+#define FPL_STATS_GROUP 16
+#endif
+constexpr int FS_GROUP = FPL_STATS_GROUP;
 constexpr int FS_BSTRIDE = 2 * FS_T;     /* LDS cells per base class: [FS_T pre | FS_T not-post] */
 
 __device__ __forceinline__ u32 plan_bucket(const ReadState& st) {
@@ -4616,7 +4627,7 @@ k_bucket_scan(u32* __restrict__ blkcnt, u32 nblk, u32* __restrict__ sw) {
 
 /* one thread: 98 buckets */
 __global__ void __launch_bounds__(128)
-k_bucket_plan(u32* __restrict__ sw, u32 per, u32 min_bucket, u32 max_slices) {
+k_bucket_plan(u32* __restrict__ sw, u32 per, u32 min_bucket, u32 max_slices, u32 group) {
     __shared__ u32 cnt[FS_NB];
     for (u32 b = threadIdx.x; b < (u32)FS_NB; b += blockDim.x) cnt[b] = sw[SW_CNT + b];
     __syncthreads();
@@ -4633,13 +4644,15 @@ k_bucket_plan(u32* __restrict__ sw, u32 per, u32 min_bucket, u32 max_slices) {
     }
     sw[SW_MAP + FS_B_NOPOST] = FS_B_NOPOST;
     cnt[FS_B_NOPOST] = nopost;
-    u32 pos = 0, ns = 0;
+    u32 pos = 0, ns = 0, ng = 0;
+    u32* const gt = sw + SW_SLICES + 4 * (size_t)max_slices; /* groups: runs of <= group consecutive slices of one bucket */
     for (int b = 0; b < FS_NB; b++) {
         const u32 c = cnt[b];
         sw[SW_CUR + b] = pos;
         if (c) {
             const u32 k = (c + per - 1) / per;
             const u32 pb = (((c + k - 1) / k) + 63u) / 64u * 64u; /* <= per: per is a multiple of 64 */
+            const u32 ns0 = ns;
             for (u32 i = 0; i < k; i++) {
                 const u32 begin = pos + i * pb, end = min(pos + c, begin + pb);
                 if (begin < end && ns < max_slices) {
@@ -4650,10 +4663,16 @@ k_bucket_plan(u32* __restrict__ sw, u32 per, u32 min_bucket, u32 max_slices) {
                     e[3] = 0;
                 }
             }
+            for (u32 g0 = ns0; g0 < ns; g0 += group) {
+                gt[2 * ng] = g0;
+                gt[2 * ng + 1] = min(ns, g0 + group);
+                ng++;
+            }
         }
         pos += c;
     }
     sw[SW_NSLICES] = ns;
+    sw[SW_NGROUPS] = ng;
 }
 
 __global__ void __launch_bounds__(FS_SORT_BLK)
@@ -4717,7 +4736,7 @@ __global__ void __launch_bounds__(WAVES * 64, (2 * WAVES + 3) / 4)
 k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t n_bytes,
                const uint64_t* __restrict__ st_off, const u32* __restrict__ st_len, const u32* __restrict__ st_e,
                u32* __restrict__ sw, u32 max_slices, u32 n_tiles, long long* __restrict__ counters,
-               u64* __restrict__ scratch, u8* __restrict__ flags, u32 C) {
+               u64* __restrict__ scratch, u8* __restrict__ flags, u32 C, u32 hi_tile, u32 max_rows) {
     (void)C;
     __shared__ u64 lds_all[1024 + 256 + 8 * FS_BSTRIDE];
     static_assert(sizeof(u64) * (1024 + 256 + 8 * FS_BSTRIDE) <= 81920, "two blocks per CU");
@@ -4736,41 +4755,112 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     for (u32 q = threadIdx.x; q < 256; q += blockDim.x)
         inc_of[q] = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);
     const u32 n_slices = uniform_u32(sw[SW_NSLICES]);
-    const u32 n_items = n_slices * n_tiles;
-    /* The blocks are persistent (two per CU) and take (tile, slice) items off one counter, tile by tile -- the heavy low
-       tiles first.  A grid of one block per item leaves a fifth of the chip idle: the hardware hands blocks to the XCDs
-       in turn and in order, so every XCD waits for the one whose slots are all taken by long blocks (block timeline in
-       profiles/r02_ab) */
+    const u32 n_groups = uniform_u32(sw[SW_NGROUPS]);
+    const u32* const gtab = sw + SW_SLICES + 4 * (size_t)max_slices;
+    const u32 lo_tiles = min(hi_tile, n_tiles);                 /* tiles whose items are single slices */
+    const u32 lo_items = lo_tiles * n_slices;
+    const u32 n_items = lo_items + (n_tiles - lo_tiles) * n_groups;
+    /* The blocks are persistent (two per CU) and take (tile, slice) items -- (tile, group of slices) from tile hi_tile on -- off
+       one counter, tile by tile -- the heavy low tiles first.  A grid of one block per item leaves a fifth of the chip idle: the
+       hardware hands blocks to the XCDs in turn and in order, so every XCD waits for the one whose slots are all taken by long
+       blocks (block timeline in profiles/r02_ab) */
     for (;;) {
     __syncthreads(); /* (everybody is done with the previous item's tables and cur_item) */
-    if (threadIdx.x == 0) {
-        cur_item = atomicAdd(&sw[SW_WORK], 1u);
-        any_work = 0;
-        cls_mask = 0;
-    }
+    if (threadIdx.x == 0) cur_item = atomicAdd(&sw[SW_WORK], 1u);
     __syncthreads();
     const u32 item = cur_item;
     if (item >= n_items) break; /* block-uniform */
-    const u32 tile = item / n_slices, slice = item - tile * n_slices;
+    u32 tile, sl0, sl1;
+    if (item < lo_items) {
+        tile = item / n_slices;
+        sl0 = item - tile * n_slices;
+        sl1 = sl0 + 1;
+    } else {
+        const u32 j = item - lo_items;
+        tile = lo_tiles + j / n_groups;
+        const u32 g = j - (tile - lo_tiles) * n_groups;
+        sl0 = uniform_u32(gtab[2 * g]);
+        sl1 = uniform_u32(gtab[2 * g + 1]);
+    }
 #ifdef FPL_PROF_BLOCKS
     const unsigned long long prof_t0 = wall_clock64();
 #endif
-    const u32 i_begin = uniform_u32(sw[SW_SLICES + 4 * slice]), i_end = uniform_u32(sw[SW_SLICES + 4 * slice + 1]);
-    const u32 sp1 = uniform_u32(sw[SW_SLICES + 4 * slice + 2]);
+    const u32 sp1 = uniform_u32(sw[SW_SLICES + 4 * sl0 + 2]); /* (one front trim per group) */
     const bool tp = sp1 != 0;            /* the slice's reads pass unsplit, all with ... */
     const int s = tp ? (int)sp1 - 1 : 0; /* ... this front trim */
     const u32 tile_start = tile * FS_T;
     const u32 c0 = tile_start + 8 * lane;
+    /* hand-over: the two tables as one slab (pre cells, then not-post cells, both in LDS slot order) -- the rows of the base
+       classes that occur: a byte's class is its low three bits, so DNA fills four or five of the eight rows (A 1, C 3, T 4,
+       G 7, N 6), and the slab's flag byte says which; k_stats_reduce_sorted reads no others.  Filed under slice `leader`. */
+    auto hand_over = [&](u32 leader) {
+        __syncthreads(); /* (every wave is done with its rows) */
+        if (threadIdx.x == 0) cls_mask = 0;
+        __syncthreads();
+        {
+            u32 m = 0;
+            for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x)
+                if (tbl[(i / FS_T) * FS_BSTRIDE + (i % FS_T)]) m |= 1u << (i / FS_T);
+            if (m) atomicOr(&cls_mask, m);
+        }
+        __syncthreads();
+        const u32 cmask = cls_mask;
+        const size_t slab = (size_t)tile * max_slices + leader;
+        u64* dst = scratch + slab * FS_SLAB;
+        for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) {
+            if (!((cmask >> (i / FS_T)) & 1u)) continue;
+            const u32 cell = (i / FS_T) * FS_BSTRIDE + (i % FS_T);
+            dst[i] = tbl[cell];
+            if (tp) dst[8 * FS_T + i] = tbl[cell + FS_T];
+        }
+        if (threadIdx.x == 0) {
+            flags[n_tiles + slab] = (u8)cmask;
+            flags[tile] = 1;
+#ifdef FPL_PROF_BLOCKS
+            if (item < (1u << 17)) {
+                g_blockprof[item][0] = prof_t0;
+                g_blockprof[item][1] = (wall_clock64() << 8) | (__builtin_amdgcn_s_getreg(6164) & 0xF);
+            }
+#endif
+        }
+        for (u32 i = threadIdx.x; i < 1024 && !(FPL_ABL & 64); i += blockDim.x) {
+            const u32 both = kpost[i], pre_only = kpre[i];
+            if (both + pre_only) atomicAdd((u64*)&kg0[i], (u64)both + pre_only);
+            if (both) atomicAdd((u64*)&kg1[i], (u64)both);
+        }
+        __syncthreads(); /* (the tables may be zeroed again) */
+    };
+    bool open = false; /* block-uniform: the tables are zeroed and may hold rows */
+    u32 held = 0, leader = 0;
+    for (u32 slice = sl0; slice < sl1; slice++) { /* block-uniform */
+    const u32 i_begin = uniform_u32(sw[SW_SLICES + 4 * slice]), i_end = uniform_u32(sw[SW_SLICES + 4 * slice + 1]);
+    /* the rows of this slice in this tile (most (tile, slice) pairs beyond the typical read length have none: find out before
+       paying for the tables) */
+    __syncthreads();
+    if (threadIdx.x == 0) any_work = 0;
+    __syncthreads();
     {
-        bool mine = false;
-        for (u32 it = i_begin + threadIdx.x; it < i_end; it += blockDim.x) mine = mine || (st_len[it] > tile_start);
-        if (wave_ballot(mine) && lane == 0) any_work = 1;
+        u32 mine = 0;
+        for (u32 it = i_begin + threadIdx.x; it < i_end; it += blockDim.x) mine += st_len[it] > tile_start ? 1u : 0u;
+        const u32 w = wave_sum_u32(mine);
+        if (w && lane == 0) atomicAdd(&any_work, w);
     }
     __syncthreads();
-    if (!any_work) continue; /* block-uniform */
-    for (u32 i = threadIdx.x; i < 8 * FS_BSTRIDE; i += blockDim.x) tbl[i] = 0;
-    for (u32 i = threadIdx.x; i < 2048; i += blockDim.x) kmer[i] = 0;
-    __syncthreads();
+    const u32 rows = any_work;
+    if (!rows) continue; /* block-uniform */
+    if (open && held + rows > max_rows) { /* the packed 14-bit fields hold max_rows rows: what is there goes out first */
+        hand_over(leader);
+        open = false;
+    }
+    if (!open) {
+        for (u32 i = threadIdx.x; i < 8 * FS_BSTRIDE; i += blockDim.x) tbl[i] = 0;
+        for (u32 i = threadIdx.x; i < 2048; i += blockDim.x) kmer[i] = 0;
+        __syncthreads();
+        open = true;
+        held = 0;
+        leader = slice;
+    }
+    held += rows;
 
     for (u32 ib = i_begin + 64 * wave_in_block(); ib < i_end; ib += 64 * WAVES) {
         const u32 it = ib + lane;
@@ -4901,41 +4991,8 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
             }
         }
     }
-    __syncthreads();
-    /* hand-over: the two tables as one slab (pre cells, then not-post cells, both in LDS slot order) -- the rows of the base
-       classes that occur: a byte's class is its low three bits, so DNA fills four or five of the eight rows (A 1, C 3, T 4,
-       G 7, N 6), and the slab's flag byte says which; k_stats_reduce_sorted reads no others */
-    {
-        u32 m = 0;
-        for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x)
-            if (tbl[(i / FS_T) * FS_BSTRIDE + (i % FS_T)]) m |= 1u << (i / FS_T);
-        if (m) atomicOr(&cls_mask, m);
-    }
-    __syncthreads();
-    const u32 cmask = cls_mask;
-    const size_t slab = (size_t)tile * max_slices + slice;
-    u64* dst = scratch + slab * FS_SLAB;
-    for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x) {
-        if (!((cmask >> (i / FS_T)) & 1u)) continue;
-        const u32 cell = (i / FS_T) * FS_BSTRIDE + (i % FS_T);
-        dst[i] = tbl[cell];
-        if (tp) dst[8 * FS_T + i] = tbl[cell + FS_T];
-    }
-    if (threadIdx.x == 0) {
-        flags[n_tiles + slab] = (u8)cmask;
-        flags[tile] = 1;
-#ifdef FPL_PROF_BLOCKS
-        if (item < (1u << 17)) {
-            g_blockprof[item][0] = prof_t0;
-            g_blockprof[item][1] = (wall_clock64() << 8) | (__builtin_amdgcn_s_getreg(6164) & 0xF);
-        }
-#endif
-    }
-    for (u32 i = threadIdx.x; i < 1024 && !(FPL_ABL & 64); i += blockDim.x) {
-        const u32 both = kpost[i], pre_only = kpre[i];
-        if (both + pre_only) atomicAdd((u64*)&kg0[i], (u64)both + pre_only);
-        if (both) atomicAdd((u64*)&kg1[i], (u64)both);
-    }
+    } /* slices of the item */
+    if (open) hand_over(leader);
     }
 }
 

@@ -53,6 +53,9 @@ struct StatsTune {
     u32 per = 0, extra_per = 0, extra_blocks = 0, extra_acc = 0;
     u32 min_bucket = 0; /* FPL_STATS_MIN_BUCKET: reads that must share a front trim to get slices of their own (k_stats_sorted) */
     u32 sort_min = 0;   /* FPL_STATS_SORT_MIN: batches of fewer reads take the unsorted statistics pass */
+    u32 hi_tile = 0;        /* FPL_STATS_HI_TILE: (value - 1) = the first cycle tile whose k_stats_sorted items are groups of slices */
+    u32 group = 0;          /* FPL_STATS_GROUP: slices per group */
+    u32 group_rows = 0;     /* FPL_STATS_GROUP_ROWS: rows a group's slab may take before it is handed over (test hook: small) */
     u32 scan_chunk = 0;     /* FPL_SCAN_CHUNK: reads a k_scan wave takes per dequeue, whatever the batch size (the built-in rule gives small
                                batches chunks of one read: no wave then has a NEXT read whose head could ride in a last tile) */
     u32 trim_batch_min = 0; /* FPL_TRIM_BATCH_MIN: batches of fewer reads take k_trim_ends<1> (a wave per read) instead of
@@ -72,6 +75,9 @@ inline StatsTune stats_tune_from_env() {
     t.sort_min = get("FPL_STATS_SORT_MIN");
     t.trim_batch_min = get("FPL_TRIM_BATCH_MIN");
     t.scan_chunk = get("FPL_SCAN_CHUNK");
+    t.hi_tile = get("FPL_STATS_HI_TILE");
+    t.group = get("FPL_STATS_GROUP");
+    t.group_rows = get("FPL_STATS_GROUP_ROWS");
     return t;
 }
 
@@ -210,7 +216,7 @@ inline bool stats_use_sorted(u32 n_reads, const StatsTune& tune) {
     return n_reads >= FS_SORT_MIN_READS;
 }
 inline size_t sort_ws_words(u32 max_slices, u32 n_reads) {
-    return (size_t)SW_SLICES + 4 * (size_t)max_slices + (size_t)FS_NB * cdiv(n_reads ? n_reads : 1, FS_SORT_READS);
+    return (size_t)SW_SLICES + 6 * (size_t)max_slices + (size_t)FS_NB * cdiv(n_reads ? n_reads : 1, FS_SORT_READS); /* slices, groups, block counts */
 }
 /* slabs (tiles x slices) the scratch buffer must hold for a batch */
 inline size_t stats_scratch_slabs(u32 n_reads, uint64_t n_bytes, u32 max_read_len, u32 n_cu, const StatsTune& tune) {
@@ -348,10 +354,18 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_MEMSET(a.sort_ws, (size_t)SW_SLICES * sizeof(u32), stream);
         FPL_MEMSET(a.stats_flags, (size_t)max_slices * n_tiles + n_tiles, stream);
         const u32 nblk = cdiv(n, FS_SORT_READS);
-        u32* const blkcnt = a.sort_ws + SW_SLICES + 4 * (size_t)max_slices;
+        u32* const blkcnt = a.sort_ws + SW_SLICES + 6 * (size_t)max_slices;
         FPL_LAUNCH(k_bucket_count, dim3(nblk), dim3(FS_SORT_BLK), stream, (const ReadState*)a.state, n, blkcnt);
         FPL_LAUNCH(k_bucket_scan, dim3(FS_NB), dim3(256), stream, blkcnt, nblk, a.sort_ws);
-        FPL_LAUNCH(k_bucket_plan, dim3(1), dim3(128), stream, a.sort_ws, per, stats_min_bucket(a.tune), max_slices);
+        FPL_LAUNCH(k_bucket_plan, dim3(1), dim3(128), stream, a.sort_ws, per, stats_min_bucket(a.tune), max_slices,
+                   a.tune.group ? a.tune.group : (u32)FS_GROUP);
+        /* from this cycle tile on the items are groups of slices: two and a half times the mean read length -- beyond it a slice
+           holds a few rows per tile (any value is correct: a group's rows are counted before they share a slab; measured flat
+           between 1.5 and 3 times the mean, worse below: groups of full slices are items too heavy to balance) */
+        const u32 hi_tile = a.tune.hi_tile ? a.tune.hi_tile - 1 : 5 * ((u32)(a.n_bytes / n) / FS_T) / 2 + 2;
+        u32 max_rows = a.tune.group_rows ? a.tune.group_rows : CS_MAX_ITEMS_PER_SLICE;
+        if (max_rows < per) max_rows = per; /* (one slice always fits) */
+        if (max_rows > CS_MAX_ITEMS_PER_SLICE) max_rows = CS_MAX_ITEMS_PER_SLICE;
         FPL_LAUNCH(k_bucket_scatter, dim3(nblk), dim3(FS_SORT_BLK), stream, a.off, (const ReadState*)a.state, n, a.sort_ws,
                    (const u32*)blkcnt, a.st_off, a.st_len, a.st_e, a.frag_off, a.frag_len, a.work_ctr + 1);
         mark(4);
@@ -362,7 +376,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         /* persistent blocks, two per CU (what the LDS tables allow) */
         FPL_LAUNCH((k_stats_sorted<SWAVES>), dim3(2 * a.n_cu), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
                    (const uint64_t*)a.st_off, (const u32*)a.st_len, (const u32*)a.st_e, a.sort_ws, max_slices, n_tiles, a.counters,
-                   a.stats_scratch, a.stats_flags, a.C);
+                   a.stats_scratch, a.stats_flags, a.C, hi_tile, max_rows);
         if (extra_forked) launch_extra(FPL_FORK(a, stream), a.extra_scratch, a.extra_flags, false);
         mark(5);
         FPL_LAUNCH(k_stats_reduce_sorted, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,

@@ -127,6 +127,26 @@ def test_sorted_statistics_pass_bit_exact(orc, engine_mod, monkeypatch, min_buck
     _run_both(orc, engine_mod, CASES["full_pipeline"], seq, qual, off, via="device")
 
 
+@pytest.mark.parametrize("hi_tile,group,rows,per", [(1, 3, 0, 64), (1, 16, 70, 64), (2, 2, 0, 128), (3, 5, 64, 64), (4, 16, 0, 0)])
+def test_sorted_statistics_pass_slice_groups_bit_exact(orc, engine_mod, monkeypatch, hi_tile, group, rows, per):
+    """k_stats_sorted: from cycle tile hi_tile - 1 on an item is a group of consecutive slices of one front trim -- one table set,
+    one slab, for as long as the rows counted so far fit (FPL_STATS_GROUP_ROWS: a small limit hands groups over in pieces)"""
+    monkeypatch.setenv("FPL_STATS_MIN_BUCKET", "2")
+    if per:
+        monkeypatch.setenv("FPL_STATS_PER", str(per))
+    monkeypatch.setenv("FPL_STATS_HI_TILE", str(hi_tile))
+    monkeypatch.setenv("FPL_STATS_GROUP", str(group))
+    if rows:
+        monkeypatch.setenv("FPL_STATS_GROUP_ROWS", str(rows))
+    a = synth.ont_like(2500, seed=43, median_len=1500, sigma_len=0.8, min_len=300, max_len=20000, p_middle=0.05)
+    b = synth.adversarial(1000, seed=44)
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
+    _run_both(orc, engine_mod, CASES["full_pipeline"], seq, qual, off, via="device")
+
+
 def test_multi_adapter_fasta_bit_exact(orc, engine_mod):
     fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA",
              "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG",

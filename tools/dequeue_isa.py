@@ -82,16 +82,15 @@ def dequeues(code):
                 break  # overwritten
         if j_cmp is None:
             continue  # (a place reservation: base = readlane(atomicAdd(..)) used as an address, no exit test)
-        # the guard `if (lane == 0)` in front of the atomic belongs to the sequence: an s_cbranch_execz a few instructions ahead of
-        # it that lands on the instruction behind it (the join)
-        join = code[i + 1][0]
+        # the guard `if (lane == 0)` / `if (threadIdx.x == 0)` in front of the atomic belongs to the sequence: an s_cbranch_execz a
+        # few instructions ahead of it that lands behind it, in front of the readlane (the join)
         a_lo, a_hi = addr, code[j_cmp][0]
         bad = []
         for k, (s_addr, o, _a, t) in enumerate(code):
             if t is None or not (a_lo < t <= a_hi) or a_lo <= s_addr <= a_hi:
                 continue
-            if o == "s_cbranch_execz" and t == join and i - 10 <= k < i:
-                continue
+            if o == "s_cbranch_execz" and i - 12 <= k < i and t <= code[j_rl][0]:
+                continue  # (the guard: it skips the atomic -- and, in a block-wide dequeue, the LDS store behind it -- for the other lanes)
             bad.append((s_addr, t))
         if bad:
             out.append((addr, a_hi, False, "a branch at 0x%x lands inside the dequeue (0x%x): a path to the exit test that skips the atomic" % bad[0]))
