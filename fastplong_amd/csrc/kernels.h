@@ -120,6 +120,9 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_OPT_VMFULL
 #define FPL_OPT_VMFULL 1 /* k_scan: the mask of testable window positions is worked out only in the tiles where it is not all ones */
 #endif
+#ifndef FPL_RED_UNROLL
+#define FPL_RED_UNROLL 4 /* k_stats_reduce_sorted: slabs whose cells a thread has in flight at a time */
+#endif
 #ifndef FPL_OPT_TRIMPF
 #define FPL_OPT_TRIMPF 0 /* k_trim_ends_batched: the cache lines of the NEXT group of 64 reads requested a group ahead -- SLOWER (1.24 -> 1.42 ms
                             per million reads, round 4): loads return in order, so whatever the group at hand loads next waits for the
@@ -5037,10 +5040,10 @@ k_stats_reduce_sorted(const u64* __restrict__ scratch, const u8* __restrict__ fl
         }
         __syncthreads();
         const u32 na = a_n;
-        for (u32 k0 = 0; k0 < na; k0 += 4) {
-            u64 v[4] = {0, 0, 0, 0}, nv[4] = {0, 0, 0, 0};
+        for (u32 k0 = 0; k0 < na; k0 += FPL_RED_UNROLL) {
+            u64 v[FPL_RED_UNROLL] = {}, nv[FPL_RED_UNROLL] = {};
 #pragma unroll
-            for (u32 u = 0; u < 4; u++) {
+            for (u32 u = 0; u < FPL_RED_UNROLL; u++) {
                 const u32 k = k0 + u;
                 if (k >= na) continue;
                 const u32 s_l = a_sl[k];
@@ -5062,7 +5065,7 @@ k_stats_reduce_sorted(const u64* __restrict__ scratch, const u8* __restrict__ fl
                 }
             }
 #pragma unroll
-            for (u32 u = 0; u < 4; u++) {
+            for (u32 u = 0; u < FPL_RED_UNROLL; u++) {
                 fs_unpack_add(v[u], qsum, cnt, q20, q30);
                 fs_unpack_add(nv[u], nsum, ncnt, n20, n30);
             }

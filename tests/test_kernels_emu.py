@@ -127,11 +127,11 @@ def test_emulated_sorted_statistics_pass(orc, monkeypatch, min_bucket, per):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
-@pytest.mark.parametrize("hi_tile,group,rows,per", [(1, 3, 0, 64), (2, 16, 70, 64)])
+@pytest.mark.parametrize("hi_tile,group,rows,per", [(2, 4, 70, 64)])
 def test_emulated_sorted_statistics_pass_slice_groups(orc, monkeypatch, hi_tile, group, rows, per):
     """k_stats_sorted: from cycle tile hi_tile - 1 on an item is a GROUP of consecutive slices of one front trim that share a
     table set and a slab while their rows fit (FPL_STATS_GROUP_ROWS: a small limit, so that groups are handed over in pieces);
-    reads of 300 .. 3000 bases in slices of 64: several tiles, several slices per front trim, leaders that differ from tile to tile"""
+    reads of 300 .. 2500 bases in slices of 64: several tiles, several slices per front trim, leaders that differ from tile to tile"""
     monkeypatch.setenv("FPL_STATS_MIN_BUCKET", "2")
     monkeypatch.setenv("FPL_STATS_PER", str(per))
     monkeypatch.setenv("FPL_STATS_HI_TILE", str(hi_tile))
@@ -140,7 +140,7 @@ def test_emulated_sorted_statistics_pass_slice_groups(orc, monkeypatch, hi_tile,
         monkeypatch.setenv("FPL_STATS_GROUP_ROWS", str(rows))
     cfg = orc.Config(abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1,
                                             complexity_filter=1), synth.START_ADAPTER, synth.END_ADAPTER)
-    a = synth.ont_like(200, seed=22, median_len=800, sigma_len=0.7, min_len=300, max_len=3000, p_middle=0.05)
+    a = synth.ont_like(150, seed=22, median_len=700, sigma_len=0.7, min_len=300, max_len=2500, p_middle=0.05)
     b = synth.adversarial(30, seed=23)
     reads = []
     for (s_, q_, o_) in (a, b):
@@ -338,8 +338,7 @@ def _reads_for_pair_packing(seed, small=False):
     return synth.pack(reads)
 
 
-@pytest.mark.parametrize("opts,chunk", [(dict(), "4"), (dict(cut_front=1, cut_tail=1, complexity_filter=1, n_base_percent_limit=60), "3"),
-                                        (dict(cut_front=1, cut_tail=1), "64"), (dict(), "")])
+@pytest.mark.parametrize("opts,chunk", [(dict(cut_front=1, cut_tail=1, complexity_filter=1, n_base_percent_limit=60), "3"), (dict(), "")])
 def test_emulated_scan_pair_packing(orc, monkeypatch, opts, chunk):
     """(chunk "": the built-in chunk rule -- one read per dequeue for a batch this small, the plain scan)"""
     if chunk:
