@@ -1,15 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- Gbases/s of the per-read hot path (trim + cut + filter + stats) on MI355X.
 
-One "step" = one pass of the whole hot path (k_trim_ends, k_cycle_stats pre, k_scan,
-k_cycle_stats post) over one resident batch of synthetic ONT-like reads.  Inputs are in HBM when
-the timed region starts.  One process per GPU; for N > 1 launch with torch.distributed.run: every
+One "step" = one pass of the whole hot path (csrc/pipeline.h: k_trim_ends, k_scan, k_resolve + k_redo, the bucket
+kernels, k_stats_sorted + its reduce, the post-only pass) over one resident batch of synthetic reads.  Inputs are in
+HBM when the timed region starts.  One process per GPU; for N > 1 launch with torch.distributed.run: every
 rank owns its own shard of reads (weak scaling, no data-path collective) and the additive counter
 buffer is all-reduced over RCCL once at the end of the timed region.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
-HIP-event timed inside the timed region) and `cpu_baseline` (the oracle on the host cores, on a
-bounded sample of the same workload, outside the timed region).
+HIP-event timed inside the timed region), `cpu_baseline` (the oracle on the host cores, on a
+bounded sample of the same workload, outside the timed region), `parity_sample` (the records the
+timed step left behind and the counters of the same reads against that oracle run) and `e2e`
+(bin/fastplong_amd on the same reads as FASTQ text: /dev/null, one file, 16 --split files).
 """
 import argparse
 import json
