@@ -205,8 +205,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         ctx->C = max_cycles ? max_cycles : 1;
         int r = alloc_counters(ctx, ctx->C, &ctx->d_counters);
         if (r != FPL_OK) return r;
-        for (int r = 0; r < fpl_ctx::EV_RING; r++)
-            for (int i = 0; i <= N_STAGES; i++) FPL_HIP(hipEventCreate(&ctx->ev[r][i]));
+        /* (the ring of timing events -- a thousand of them -- is made when timing is first asked for: a command-line run never does) */
         return FPL_OK;
     }();
     if (rc != FPL_OK) {
@@ -818,6 +817,11 @@ void fpl_host_free(void* p) {
 
 int fpl_enable_timing(fpl_ctx* ctx, int enable) {
     if (!ctx) return FPL_ERR_ARG;
+    if (enable && !ctx->ev[0][0]) {
+        FPL_HIP(hipSetDevice(ctx->device));
+        for (int r = 0; r < fpl_ctx::EV_RING; r++)
+            for (int i = 0; i <= N_STAGES; i++) FPL_HIP(hipEventCreate(&ctx->ev[r][i]));
+    }
     ctx->timing = enable ? 1 : 0;
     ctx->ev_calls = 0;
     return FPL_OK;
