@@ -100,6 +100,9 @@ __device__ unsigned long long g_fpl_prof[64];
                                  and a 16-column run for the partial pattern (fasta_may_trim); 2: one 32-column run with two
                                  score taps (fasta_may_trim32) */
 #endif
+#ifndef FPL_OPT_FASTANEAR
+#define FPL_OPT_FASTANEAR 1 /* k_trim_ends<2>: without a whole-adapter flag, partial-pattern hits only count next to the read's end */
+#endif
 #ifndef FPL_OPT_DPPPREV
 #define FPL_OPT_DPPPREV 1 /* "the dword of the lane in front" (k_scan's predecessor byte, the 5-mer halo of the statistics kernels) through DPP
                              wave_shr:1 instead of ds_bpermute: one vector op, no trip through the LDS crossbar */
@@ -1070,7 +1073,7 @@ __device__ __forceinline__ void stage_ends(u32* __restrict__ hs, u32* __restrict
  * thresholds cannot trim this end, and the chain skips it.  Anything else gets the exact code, unchanged.
  * FastaPeqLds: the Peq words of a group of 64 adapters, [letter code | 4 = any other byte: zero][field][lane]. */
 #ifdef FPL_EMU_FILTER_STATS
-static unsigned long long g_filter_stats[4]; /* emulator only: mask refreshes, adapters flagged at the start / at the end */
+static unsigned long long g_filter_stats[8]; /* emulator only: mask refreshes, adapters flagged at the start / at the end, of those: whole-adapter flags, exact trims called, trims that moved r1 */
 #endif
 struct FastaPeqLds {
     u32 w[5][4][64]; /* field 0 / 1: whole adapter, low / high word; 2: last 16 bases; 3: first 16 bases */
@@ -1148,8 +1151,23 @@ __device__ __forceinline__ u32 fasta_may_trim32(const FastaPeqLds* __restrict__ 
         }
         blocks |= (blkP <= thrP ? 1u : 0u) << (j0 >> 5);
     }
+    /* A partial-pattern hit only trims when its confirmation passes (src/adaptertrimmer.cpp:218-233 / :288-299): the adapter's
+       last / first cmplen = min(p + 16, alen) bases against the read around the hit, within thr[cmplen].  For a hit at p >= alen - 16
+       that is the WHOLE adapter within thrA -- which the other tap of this very run would have seen (a whole adapter within thrA
+       has its first / last 32 columns within thrA of some substring).  So without that flag only the hits next to the read's end
+       count: p < alen - 16, i.e. columns j = n - 1 - p >= n - alen + 16, i.e. the blocks from (n - alen + 16) / 32 on (the few
+       columns of that block in front of the bound ride along).  Random 16-mers within 4 edits of SOME stretch of 200 bases are
+       what 8 of the 10 flags per read were (emulator, c5-like reads); nearly all of them sit further in. */
+    const bool fullF = bestF <= thrA;
+    bool partF = blocks != 0;
+    if (FPL_OPT_FASTANEAR && !fullF) {
+        /* (only WHETHER the search runs is decided here: when it does it must see every hit -- the walk over the hits picks its
+           position among all of them, and one further in can take the place of one next to the end) */
+        const int jn = n - alen + 16;
+        partF = (jn <= 0 ? blocks : (blocks & (~0u << (jn >> 5)))) != 0;
+    }
     /* bit 0: the whole adapter may match, bit 1: its partial pattern; bits 8..: where (blocks of 32 columns) */
-    return a_ok ? ((bestF <= thrA ? 1u : 0u) | (blocks ? 2u : 0u) | (blocks << 8)) : 0u;
+    return a_ok ? ((fullF ? 1u : 0u) | (partF ? 2u : 0u) | ((partF ? blocks : 0u) << 8)) : 0u;
 }
 /* The positions p of a partial-pattern search (window of 16 bases at p, src/adaptertrimmer.cpp:202-216 / :273-286) that the
    filter's verdict leaves open, [lo, hi]: column j of the run is the LAST byte of the end trim's window p = n - 1 - j (its
@@ -1387,6 +1405,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     __atomic_fetch_add(&g_filter_stats[0], 1ull, __ATOMIC_RELAXED);
                     __atomic_fetch_add(&g_filter_stats[1], (unsigned long long)__builtin_popcountll(may_s), __ATOMIC_RELAXED);
                     __atomic_fetch_add(&g_filter_stats[2], (unsigned long long)__builtin_popcountll(may_e), __ATOMIC_RELAXED);
+                    __atomic_fetch_add(&g_filter_stats[3], (unsigned long long)(__builtin_popcountll(full_s) + __builtin_popcountll(full_e)), __ATOMIC_RELAXED);
                 }
 #endif
             };
@@ -1425,6 +1444,12 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     trimmed += trim_start_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl, ((full_s >> (a & 63)) & 1ull) != 0,
                                                      ((part_s >> (a & 63)) & 1ull) != 0, hlo, hhi);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 0) * FPL_KEY_STRIDE + kl], (u64)1);
+#ifdef FPL_EMU_FILTER_STATS
+                    if (lane == 0) {
+                        __atomic_fetch_add(&g_filter_stats[4], 1ull, __ATOMIC_RELAXED);
+                        if (s != s0 || e != e0) __atomic_fetch_add(&g_filter_stats[5], 1ull, __ATOMIC_RELAXED);
+                    }
+#endif
                     if (s != s0 || e != e0) moved(s0, e0);
                 }
                 if (FILT && !masks_ok) refresh_masks(a);
@@ -1442,6 +1467,12 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     trimmed += trim_end_wave<MODE>(wn, s, e, ad, pq, ad->peq_full, cfg, kl, ((full_e >> (a & 63)) & 1ull) != 0,
                                                    ((part_e >> (a & 63)) & 1ull) != 0, hlo, hhi);
                     if (kl > 0 && lane == 0) atomicAdd((u64*)&keyh[((2 + a) * 2 + 1) * FPL_KEY_STRIDE + kl], (u64)1);
+#ifdef FPL_EMU_FILTER_STATS
+                    if (lane == 0) {
+                        __atomic_fetch_add(&g_filter_stats[4], 1ull, __ATOMIC_RELAXED);
+                        if (s != s0 || e != e0) __atomic_fetch_add(&g_filter_stats[5], 1ull, __ATOMIC_RELAXED);
+                    }
+#endif
                     if (s != s0 || e != e0) moved(s0, e0);
                 }
             }

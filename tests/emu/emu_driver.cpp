@@ -104,8 +104,9 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.stats_flags = sflags.data();
     enqueue_batch(a, nullptr, [](int) {});
 #ifdef FPL_EMU_FILTER_STATS
-    fprintf(stderr, "emu: filter refreshes %llu, flagged start %llu, end %llu (reads %u)\n", fpl::g_filter_stats[0], fpl::g_filter_stats[1],
-            fpl::g_filter_stats[2], n_reads);
+    fprintf(stderr, "emu: filter refreshes %llu, flagged start %llu, end %llu, whole-adapter flags %llu, exact trims run %llu, of which moved r1 %llu (reads %u)\n",
+            fpl::g_filter_stats[0], fpl::g_filter_stats[1], fpl::g_filter_stats[2], fpl::g_filter_stats[3], fpl::g_filter_stats[4],
+            fpl::g_filter_stats[5], n_reads);
 #endif
 #ifdef FPL_EMU_PAIR_STATS
     fprintf(stderr, "emu: k_scan pair packing: %llu last tiles hosted a head, %llu head bytes (reads %u)\n", fpl::g_pair_stats[0],
