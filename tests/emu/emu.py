@@ -18,8 +18,12 @@ SRCS = [os.path.join(HERE, "emu_driver.cpp"), os.path.join(HERE, "hip_emu.h")] +
 
 def build():
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in SRCS):
+        # (into a file of this process's own, then renamed: several pytest-xdist workers may find the library stale at once, and
+        # none of them must load another one's half-written file)
+        tmp = "%s.tmp.%d" % (LIB, os.getpid())
         subprocess.check_call(["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-I" + HERE,
-                               "-o", LIB, SRCS[0]])
+                               "-o", tmp, SRCS[0]])
+        os.replace(tmp, LIB)
 
 
 _lib = None
