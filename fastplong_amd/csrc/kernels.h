@@ -3291,8 +3291,9 @@ __device__ __forceinline__ u32 hist_dumped(int blen) { return blen > 0 ? (u32)((
  * Lanes hb..61 of that tile take the first 32 * (62 - hb) bytes of the NEXT read's r1 (lanes 62 / 63: the plane words its last
  * windows reach into), so that read starts its own tiles that much further in.  Everything in the tile loop is lane-local but
  * four things: the predecessor byte (the head's first byte has none), the per-lane running sums and best windows (the lanes of
- * the head still hold the first read's: set aside for the tile and handed on as PairCarry), and the quality histogram -- one per
- * wave, so the head's 8 quality dwords per lane wait in registers until the first read's totals are taken. */
+ * the head still hold the first read's: the head gets accumulators of its own, handed on as PairCarry), the masks of testable
+ * windows (all ones in a head), and the quality histogram -- one per wave, so the head's quality bytes are counted once the first
+ * read's totals are out of it (k_scan fetches them again for that: they are in the cache). */
 #ifdef FPL_EMU_PAIR_STATS
 static unsigned long long g_pair_stats[2]; /* emulator only: last tiles that hosted a head, bytes of heads */
 #endif
@@ -3518,7 +3519,7 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         }
         if (!LEAN) {
             if (nstat > 0) {
-                if (!FPL_DBG(dbg, 1) && !head) hist32<false>(hl, q, SC_CHUNK); /* (the head's bytes: PairIO::q, counted by the caller) */
+                if (!FPL_DBG(dbg, 1) && !head) hist32<false>(hl, q, SC_CHUNK); /* (the head's bytes are counted by the caller, later) */
                 if (SUMS && !FPL_DBG(dbg, 2)) { /* (N count and complexity sum; lowq / totq: hist_quality_sums) */
                     if (packed) { /* (wave-uniform) the head's lanes add to sums of their own */
                         u32 t_nn = head ? 0u : nn, t_diff = head ? 0u : diff;
@@ -4038,7 +4039,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
            than carried through the window search in registers; counted once this read's totals are out of the histogram */
         u32 hq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const bool head_q = PAIR && pio.out.t0 > 0 && lane >= pio.hb && lane < SC_LANES_HAM;
-        if (PAIR && pio.out.t0 > 0 && !(FPL_ABL & 128)) { /* wave-uniform */
+        if (PAIR && pio.out.t0 > 0) { /* wave-uniform */
             if (head_q) {
                 const u8* const pq = qual + uniform_u64(pio.nx_o0) + uniform_u32(pio.nx_s) + SC_CHUNK * (lane - pio.hb);
                 const u32x4 q0 = load16(pq), q1 = load16(pq + 16);
@@ -4050,7 +4051,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         hist_totals(h, hb0, hb1);
         if (lane == 0) hb0 -= dumped;
         if (PAIR) {
-            if (pio.out.t0 > 0 && head_q && !(FPL_ABL & 128)) hist32<false>(hist_lane(h), hq, SC_CHUNK); /* (128: timing experiment) */
+            if (pio.out.t0 > 0 && head_q) hist32<false>(hist_lane(h), hq, SC_CHUNK);
             pio.in = pio.out; /* what the next read starts from (t0 == 0: from scratch) */
         }
         if (qsums && !dropped && !defer) hist_quality_sums(hb0, hb1, qq & 0x7F, sm.lowq, sm.totq); /* (wave-uniform) */
