@@ -297,6 +297,9 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
     host.fplh_write_fastq_ex.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_int]
     copies = copies or n_gpus
     per_copy = 2.0 * nb + 16.0 * n_reads
+    # room per copy of the input in the scratch directory: the text itself, and as much again (+ slack) when a run writes its output there
+    writes = any(t is None and (not run_names or nm in run_names) for nm, t in E2E_RUNS)
+    room = 2.3 if writes else 1.2
     tmp = None
     head = mem_headroom()
     for d in ("/dev/shm", "/tmp"):
@@ -307,14 +310,14 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
         if d == "/dev/shm" and head is not None:
             free = min(free, head // 2)  # (tmpfs pages count against the container's memory; the run itself needs room too)
         fit = copies  # (per directory: what /dev/shm could not hold must not shrink the run that /tmp can)
-        while fit > 1 and free < 2.3 * per_copy * fit:
+        while fit > 1 and free < room * per_copy * fit:
             fit -= 1
-        if free > 2.3 * per_copy * fit:
+        if free > room * per_copy * fit:
             tmp, copies = d, fit
             break
     if tmp is None:
         res["cli"] = None
-        res["note"] = "no scratch directory with %.0f GB free" % (2.3 * per_copy / 1e9)
+        res["note"] = "no scratch directory with %.0f GB free" % (room * per_copy / 1e9)
         return res
     res["copies"] = copies
     res["bases"] = nb * copies
