@@ -161,7 +161,8 @@ def test_hifi_like_64_adapters_bit_exact(orc, engine_mod):
     _run_both(orc, engine_mod, cfgd, seq, qual, off, fasta=sorted(ads))
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_FUZZ_FASTA", "8")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_FUZZ_FASTA_FROM", "0")),
+                                            int(os.environ.get("FPL_FUZZ_FASTA_FROM", "0")) + int(os.environ.get("FPL_FUZZ_FASTA", "8")))))
 def test_random_fasta_sets_of_16_to_64_mers_bit_exact(orc, engine_mod, seed):
     """adapter sets made of 16..64-base ACGT adapters only (k_trim_ends<2>: the lane-per-adapter filter in front of the exact
     trims, fasta_may_trim) -- 1, 3, 64, 65 and 130 FASTA adapters (one, two and three groups of 64 lanes), mutated /
