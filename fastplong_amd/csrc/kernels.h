@@ -126,6 +126,9 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_RED_UNROLL
 #define FPL_RED_UNROLL 4 /* k_stats_reduce_sorted: slabs whose cells a thread has in flight at a time */
 #endif
+#ifndef FPL_OPT_PACKRED
+#define FPL_OPT_PACKRED 1 /* k_scan / k_redo: the wave reductions behind a range scan take two values each where the range's length allows */
+#endif
 #ifndef FPL_OPT_TRIMPF
 #define FPL_OPT_TRIMPF 0 /* k_trim_ends_batched: the cache lines of the NEXT group of 64 reads requested a group ahead -- SLOWER (1.24 -> 1.42 ms
                             per million reads, round 4): loads return in order, so whatever the group at hand loads next waits for the
@@ -3626,15 +3629,29 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
     if (SUMS) {
         /* (the main scan leaves lowq / totq to its caller: hist_quality_sums on the histogram totals) */
         sums.lowq = LEAN ? wave_sum_u32(lowq) : 0u;
-        sums.nn = wave_sum_u32(nn);
         sums.totq = LEAN ? wave_sum_u32(totq) : 0u;
-        sums.diff = wave_sum_u32(diff);
+        if (FPL_OPT_PACKRED && !LEAN && blen < 65536) { /* (wave-uniform) neither sum exceeds the range's length: one reduction for the two */
+            const u32 x = wave_sum_u32(nn | (diff << 16));
+            sums.nn = x & 0xFFFFu;
+            sums.diff = x >> 16;
+        } else {
+            sums.nn = wave_sum_u32(nn);
+            sums.diff = wave_sum_u32(diff);
+        }
     }
     if (HAM) {
         /* the first position with the fewest mismatches = the largest match count, then the smallest position holding it:
            two 32-bit reductions per adapter (the (mismatches, position) pair as one 64-bit key costs three times that) */
         key0 = key1 = ~0ull;
-        if (do_ham) { /* wave-uniform */
+        if (do_ham && FPL_OPT_PACKRED && blen < (1 << 24)) { /* wave-uniform */
+            /* (match count + 1) above the position counted down from 2^24 - 1: ONE maximum per adapter gives the largest count and,
+               among the lanes holding it, the smallest position (a lane that tested nothing holds 0 above 2^24 - 1: below any real key) */
+            const u32 k0 = wave_max_u32(((u32)(bm0 + 1) << 24) | (0xFFFFFFu - (u32)bp0));
+            const u32 k1 = wave_max_u32(((u32)(bm1 + 1) << 24) | (0xFFFFFFu - (u32)bp1));
+            const u32 m0 = k0 >> 24, m1 = k1 >> 24;
+            if (m0) key0 = ((u64)(u32)(ad0->len - (int)(m0 - 1)) << 32) | (0xFFFFFFu - (k0 & 0xFFFFFFu));
+            if (m1) key1 = ((u64)(u32)(ad1->len - (int)(m1 - 1)) << 32) | (0xFFFFFFu - (k1 & 0xFFFFFFu));
+        } else if (do_ham) { /* wave-uniform */
             const u32 m0 = wave_max_u32((u32)(bm0 + 1)), m1 = wave_max_u32((u32)(bm1 + 1)); /* 0: no window was tested */
             const u32 p0 = wave_min_u32((u32)(bm0 + 1) == m0 ? (u32)bp0 : ~0u);
             const u32 p1 = wave_min_u32((u32)(bm1 + 1) == m1 ? (u32)bp1 : ~0u);
