@@ -43,6 +43,18 @@ struct fpl_ctx {
 };
 
 static std::mutex g_log_m;
+/* FPL_STUB_COMM_LOG=<file>: one line per call of the two merge entry points, in the order the host made them */
+static void comm_log(const char* what, fpl_ctx** ctxs, int32_t n) {
+    const char* lf = getenv("FPL_STUB_COMM_LOG");
+    if (!lf) return;
+    std::lock_guard<std::mutex> g(g_log_m);
+    if (FILE* f = fopen(lf, "a")) {
+        fprintf(f, "%s %d", what, n);
+        for (int i = 0; ctxs && i < n; i++) fprintf(f, " %d", ctxs[i] ? ctxs[i]->device : -1);
+        fputc('\n', f);
+        fclose(f);
+    }
+}
 static int stub_devices() {
     const char* e = getenv("FPL_STUB_DEVICES");
     return e && atoi(e) > 0 ? atoi(e) : 1;
@@ -209,6 +221,7 @@ int fpl_get_counters(fpl_ctx* ctx, int64_t* buf, size_t n) {
 /* Stats::merge / FilterResult::merge: agree on the capacity, then every context holds the sums */
 int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
     if (!ctxs || n < 1) return FPL_ERR_ARG;
+    comm_log("allreduce", ctxs, n);
     uint32_t C = 0;
     for (int i = 0; i < n; i++) {
         if (!ctxs[i] || !ctxs[i]->q.empty()) return FPL_ERR_STATE;
@@ -222,7 +235,10 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
     return FPL_OK;
 }
 const char* fpl_rccl_library(void) { return ""; }
-int fpl_comm_init(fpl_ctx**, int32_t) { return FPL_OK; }
+int fpl_comm_init(fpl_ctx** ctxs, int32_t n) {
+    comm_log("comm_init", ctxs, n);
+    return FPL_OK;
+}
 int fpl_count_end_kmers(int32_t, const uint8_t*, const uint64_t*, uint32_t, int32_t, int32_t, uint32_t*, uint64_t*, uint64_t*) {
     return FPL_ERR_NO_DEVICE; /* (the tests give -s / -e, or set FPLH_HOST_KMERS) */
 }

@@ -35,6 +35,20 @@ def stub_env():
     return env
 
 
+def test_cli_makes_the_communicators_ahead_of_the_merge(tmp_path, stub_env):
+    """--gpus N: fpl_comm_init over the N contexts (device order 0 .. N-1) is called once, on a thread of its own while the
+    batches run, and the one fpl_allreduce_counters over the same contexts comes after it; a one-device run calls neither
+    fpl_comm_init nor needs a communicator"""
+    clog = tmp_path / "comm.log"
+    p, out, _ = run_cli(tmp_path, CASES[0], dict(stub_env, FPL_STUB_COMM_LOG=str(clog)), 3)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert open(clog).read().splitlines() == ["comm_init 3 0 1 2", "allreduce 3 0 1 2"]
+    clog.unlink()
+    p, out, _ = run_cli(tmp_path, CASES[0], dict(stub_env, FPL_STUB_COMM_LOG=str(clog)), 1, devices=1)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert open(clog).read().splitlines() == ["allreduce 1 0"]
+
+
 def run_cli(tmp_path, case, env, gpus, extra=(), chunk=30000, devices=3):
     meta = json.load(open(os.path.join(GOLD, case, "case.json")))
     inp = tmp_path / "in.fq"
