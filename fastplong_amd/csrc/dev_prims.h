@@ -44,6 +44,15 @@ __device__ __forceinline__ int wave_in_block() {
 
 __device__ __forceinline__ u64 wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
 
+/* hide where a value came from (no instruction): keeps the optimiser from rewriting an expression around it */
+__device__ __forceinline__ void opaque_u32(u32& v) {
+#ifndef FPL_EMU
+    asm volatile("" : "+v"(v));
+#else
+    (void)v;
+#endif
+}
+
 /* order this wave's LDS traffic across lanes (zero -> atomics -> reads of a per-wave table) */
 __device__ __forceinline__ void wave_sync() {
 #ifdef FPL_EMU
@@ -271,6 +280,19 @@ __device__ __forceinline__ u32 udot4(u32 a, u32 b, u32 c) {
     return r;
 #else
     return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+/* Wait states behind dot products whose results the NEXT instructions use.  Measured on the MI355X (round 4): a vector
+   instruction that reads a v_dot4 result one instruction behind the dot gets the register's old value -- the rule LLVM's
+   hazard recogniser has for gfx90a (a different instruction reads a dot's destination: 3 wait states, overwrites it: 4) holds
+   on gfx950 too, and this hipcc does not insert the nops.  A dot that feeds the next dot's accumulator is forwarded and needs
+   none.  tools/dot_hazard_isa.py checks every v_dot4 of the built library (tests/test_isa_dequeue.py). */
+__device__ __forceinline__ void dot_settle(u32& a, u32& b) {
+#ifndef FPL_EMU
+    asm volatile("s_nop 3" : "+v"(a), "+v"(b));
+#else
+    (void)a;
+    (void)b;
 #endif
 }
 /* sum of the 4 bytes of a, plus c (v_sad_u8 against 0) */

@@ -134,6 +134,10 @@ __device__ unsigned long long g_fpl_prof[64];
                             per million reads, round 4): loads return in order, so whatever the group at hand loads next waits for the
                             touches of the group after it; there is no prefetch instruction on gfx950 that leaves vmcnt alone */
 #endif
+#ifndef FPL_OPT_STATSETUP
+#define FPL_OPT_STATSETUP 1 /* k_stats_sorted: a row's 5-mer stream from v_dot4 packs and the NEIGHBOUR's finished pack (one DPP move), lane 0's
+                               halo once per group of four rows -- instead of packing the neighbour's bytes a second time in every lane */
+#endif
 #ifndef FPL_OPT_PAIR
 #define FPL_OPT_PAIR 1 /* k_scan (usual configuration): the head of the NEXT read of a wave's chunk rides in the lanes the last, ragged
                           tile of a read leaves empty (range_scan_fast<.., PAIR>) */
@@ -2387,6 +2391,18 @@ __device__ __forceinline__ u32 kmer_codes(u32 d) { return (d & 0x02020202u) | ((
 __device__ __forceinline__ u32 kmer_pack(u32 v) {
     const u32 x = lshl_or<10>(v, v);
     return lshl_or<20>(x, x);
+}
+/* the same four codes packed into the LOW byte, by one v_dot4 (weights 64, 16, 4, 1) */
+__device__ __forceinline__ u32 kmer_pack_dot(u32 v) { return udot4(v, 0x01041040u, 0u); }
+/* A lane's 5-mer stream: the packed codes of the four bases in front of its eight (bits 16..23), of its first four (8..15) and
+   of its last four (0..7); the window that ends at byte k is the 10-bit field at bit 2 * (7 - k).  The four bases in front are
+   the previous lane's last four: its finished pack comes over with one DPP move (lane 0: pack_h0, wave-uniform).  Bits 24..31
+   hold the previous lane's first pack, which no window reads. */
+__device__ __forceinline__ u32 kmer_stream(u32 v0, u32 v1, u32 pack_h0) {
+    u32 p0 = kmer_pack_dot(v0), p1 = kmer_pack_dot(v1);
+    dot_settle(p0, p1);
+    const u32 W01 = lshl_or<8>(p0, p1);
+    return lshl_or<16>(wave_prev_u32(W01, pack_h0), W01);
 }
 /* d = four bases, mapped = the letters their 2-bit codes stand for (A T C G): bit i of the result is set when base i is
    not one of A, T, U, C, G.  A mapped T also admits U (0x54 ^ 0x55 = 1; T is the only mapped letter with bit 4). */
@@ -4927,9 +4943,12 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
         while (m) {
             u32x2 svG[CS_GROUP], qvG[CS_GROUP];
             u32 haloG[CS_GROUP], LG[CS_GROUP], EG[CS_GROUP];
+            u32 haloAll = 0; /* lane g: the four bases in front of row g's tile */
 #pragma unroll
             for (int g = 0; g < CS_GROUP; g++) {
-                svG[g] = {0, 0};
+                /* (lanes behind the end of the read load nothing: with the set-up below they hold 'A's, so that they do not
+                   send the row's validity test down the exact path; none of their bytes is counted either way) */
+                svG[g] = FPL_OPT_STATSETUP ? u32x2{0x41414141u, 0x41414141u} : u32x2{0, 0};
                 qvG[g] = {0, 0};
                 haloG[g] = 0;
                 LG[g] = EG[g] = 0;
@@ -4950,8 +4969,20 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                             qvG[g] = load8_guard(qual + start + c0, qual_end);
                         }
                     }
-                    if (lane == 0 && tile_start >= 4) haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
+                    if (FPL_OPT_STATSETUP) {
+                        if (lane == g && tile_start >= 4) haloAll = load4_guard(seq + start + tile_start - 4, seq_end);
+                    } else if (lane == 0 && tile_start >= 4) {
+                        haloG[g] = load4_guard(seq + start + tile_start - 4, seq_end);
+                    }
                 }
+            }
+            /* the four bases in front of the tile, of all rows of the group at once (lane g: row g): their packed codes and
+               which of them are no bases -- once per group instead of once per row */
+            u32 packAll = 0, invAll = 0;
+            if (FPL_OPT_STATSETUP) {
+                const u32 vA = kmer_codes(haloAll);
+                packAll = kmer_pack_dot(vA);
+                invAll = invalid_nibble(perm_lo(0x47435441u, vA), haloAll);
             }
 #pragma unroll
             for (int g = 0; g < CS_GROUP; g++) {
@@ -4960,14 +4991,46 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                 const u32 sw2[2] = {svG[g].x, svG[g].y};
                 const u32 qw[2] = {qvG[g].x, qvG[g].y};
                 const int e = (int)uniform_u32(EG[g]);
+#if FPL_OPT_STATSETUP
+                /* (bytes of the row in this lane: only the rows that hold an end of the read or of r1 ask -- FPL_FB_ROW(.., false)) */
+#define FPL_FS_NVALID (itemL > c0 ? (int)min(8u, itemL - c0) : 0)
+#else
                 const int nvalid = itemL > c0 ? (int)min(8u, itemL - c0) : 0;
-                const u32 up = FPL_OPT_DPPPREV ? wave_prev_u32(sw2[1], 0u) : shfl_up_u32(sw2[1], 1);
+#define FPL_FS_NVALID nvalid
+#endif
                 const bool have_halo = lane > 0 || tile_start >= 4;
+                u32 W, okmask;
+                bool allok = false; /* wave-uniform */
+#if FPL_OPT_STATSETUP
+                {
+                    /* 5-mers: the 2-bit codes of a dword packed by one v_dot4 (weights 64, 16, 4, 1); the twelve bases a lane
+                       needs are its own two packs and the previous lane's -- the neighbour's finished packs through one DPP move
+                       (lane 0: the group's halo register), not the neighbour's bytes packed again.  Bits 24.. of W hold the
+                       neighbour's first pack, which no window reads */
+                    const u32 v0 = kmer_codes(sw2[0]), v1 = kmer_codes(sw2[1]);
+                    W = kmer_stream(v0, v1, readlane_u32(packAll, g));
+                    const u32 m0 = perm_lo(0x47435441u, v0), m1 = perm_lo(0x47435441u, v1);
+                    u32 bad = (m0 ^ sw2[0]) | (m1 ^ sw2[1]);
+                    opaque_u32(bad); /* (one compare for the ballot: the compiler would test the two halves apart and merge the masks) */
+                    /* (a lane's halo is its neighbour's second dword, which that lane tests itself: only lane 0's is extra) */
+                    const u32 inv_h0 = tile_start >= 4 ? readlane_u32(invAll, g) : 0xFu; /* wave-uniform */
+                    if (!wave_ballot(bad != 0) && !(tile_start >= 4 && inv_h0 != 0)) {
+                        okmask = have_halo ? 0xFFu : 0xF0u;
+                        allok = tile_start >= 4; /* every window of every lane counts: the 5-mer updates add a constant */
+                    } else {
+                        const u32 i1 = invalid_nibble(m1, sw2[1]);
+                        const u32 ih = wave_prev_u32(i1, inv_h0);
+                        const u32 inv = lshl_or<8>(i1, lshl_or<4>(invalid_nibble(m0, sw2[0]), ih));
+                        const u32 r = inv | (inv >> 1) | (inv >> 2) | (inv >> 3) | (inv >> 4);
+                        okmask = ~r & 0xFFu;
+                    }
+                    /* (no mask of the row's bytes on top: a window is only looked at for a byte of the row) */
+                }
+#else
+                const u32 up = FPL_OPT_DPPPREV ? wave_prev_u32(sw2[1], 0u) : shfl_up_u32(sw2[1], 1);
                 const u32 halo = lane > 0 ? up : haloG[g];
                 const u32 vh = kmer_codes(halo), v0 = kmer_codes(sw2[0]), v1 = kmer_codes(sw2[1]);
-                const u32 W = perm_b32(kmer_pack(vh), perm_b32(kmer_pack(v0), kmer_pack(v1), 0x0c0c0703u), 0x0c070100u);
-                u32 okmask;
-                bool allok = false; /* wave-uniform */
+                W = perm_b32(kmer_pack(vh), perm_b32(kmer_pack(v0), kmer_pack(v1), 0x0c0c0703u), 0x0c070100u);
                 {
                     const u32 m0 = perm_lo(0x47435441u, v0), m1 = perm_lo(0x47435441u, v1), mh = perm_lo(0x47435441u, vh);
                     u32 bad = (m0 ^ sw2[0]) | (m1 ^ sw2[1]);
@@ -4983,6 +5046,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                     }
                     okmask &= (1u << nvalid) - 1u;
                 }
+#endif
                 const int p0 = (int)c0;
                 /* one byte.  NPM: bit k of npmask says whether byte k lies behind the end of r1 (it then also goes to the
                    not-post table); KM: the byte's 5-mer window is counted 0 pre-filter only, 1 pre- and post-filter, 2 as
@@ -4994,7 +5058,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
 #define FPL_FS_Q(k) ((qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF)
                 u64 inc_n = inc_of[FPL_FS_Q(0)];
 #define FPL_FB_BYTE(k, NPM, KM, FULL)                                                                             \
-    if (FULL || (k) < nvalid) {                                                                                   \
+    if (FULL || (k) < nv_row) {                                                                                   \
         const u32 bb = (sw2[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                   \
         u64* const cellp = (u64*)((char*)tbl + mad_u24(bb & 7u, 8 * FS_BSTRIDE, lane8)); /* (byte offset: one op) */ \
         atomicAdd(&cellp[(k)*64], inc);                                                                           \
@@ -5009,10 +5073,14 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
             atomicAdd(&kmer[(((kbodymask >> (k)) & 1u) << 10) + kidx], kval);                                     \
     }
 #define FPL_FB_ROW(NPM, KM, FULL)                                                                                 \
-    _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                               \
-        const u64 inc = inc_n;                                                                                    \
-        if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];                                                               \
-        FPL_FB_BYTE(k, NPM, KM, FULL)                                                                             \
+    {                                                                                                             \
+        const int nv_row = FULL ? 8 : FPL_FS_NVALID;                                                              \
+        (void)nv_row;                                                                                             \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                           \
+            const u64 inc = inc_n;                                                                                \
+            if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];                                                           \
+            FPL_FB_BYTE(k, NPM, KM, FULL)                                                                         \
+        }                                                                                                         \
     }
                 if (tp && (int)tile_start >= s + 4 && (int)(tile_start + FS_T) <= e) {
                     /* wave-uniform: the whole tile lies inside r1 (and inside the read) */
@@ -5040,6 +5108,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
 #undef FPL_FB_ROW
 #undef FPL_FB_BYTE
 #undef FPL_FS_Q
+#undef FPL_FS_NVALID
             }
         }
     }

@@ -62,7 +62,42 @@ __global__ void k_wave_prims(const u32* __restrict__ in, u32* __restrict__ out) 
     o[7] = readlane_u32(v, 37);
 }
 
+/* in: [case][lane][2] = a lane's eight bytes, halo[case] = the four bytes in front of lane 0's
+   out: [case][lane][6] = kmer_stream (24 bits), the stream from kmer_pack + v_perm (the form k_stats uses), kmer_pack_dot of
+   both dwords, kmer_pack >> 24 of both dwords */
+__global__ void k_kmer_stream(const u32* __restrict__ in, const u32* __restrict__ halo, u32* __restrict__ out) {
+    const int lane = lane_id();
+    const u32 d0 = in[((size_t)blockIdx.x * 64 + lane) * 2], d1 = in[((size_t)blockIdx.x * 64 + lane) * 2 + 1];
+    const u32 h = halo[blockIdx.x];
+    u32* o = out + ((size_t)blockIdx.x * 64 + lane) * 6;
+    const u32 v0 = kmer_codes(d0), v1 = kmer_codes(d1);
+    o[0] = kmer_stream(v0, v1, kmer_pack_dot(kmer_codes(h))) & 0xFFFFFFu;
+    const u32 up = wave_prev_u32(d1, 0u);
+    const u32 vh = kmer_codes(lane > 0 ? up : h);
+    o[1] = perm_b32(kmer_pack(vh), perm_b32(kmer_pack(v0), kmer_pack(v1), 0x0c0c0703u), 0x0c070100u);
+    o[2] = kmer_pack_dot(v0);
+    o[3] = kmer_pack_dot(v1);
+    o[4] = kmer_pack(v0) >> 24;
+    o[5] = kmer_pack(v1) >> 24;
+}
+
 extern "C" {
+int prims_kmer_stream(const uint32_t* in, const uint32_t* halo, uint32_t* out, int n_cases) {
+    u32 *din = nullptr, *dh = nullptr, *dout = nullptr;
+    const size_t ni = (size_t)n_cases * 64 * 2 * 4, no = (size_t)n_cases * 64 * 6 * 4;
+    if (hipMalloc((void**)&din, ni) != hipSuccess || hipMalloc((void**)&dout, no) != hipSuccess ||
+        hipMalloc((void**)&dh, (size_t)n_cases * 4) != hipSuccess)
+        return 1;
+    (void)hipMemcpy(din, in, ni, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dh, halo, (size_t)n_cases * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_kmer_stream, dim3(n_cases), dim3(64), 0, 0, din, dh, dout);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+    (void)hipMemcpy(out, dout, no, hipMemcpyDeviceToHost);
+    (void)hipFree(din);
+    (void)hipFree(dh);
+    (void)hipFree(dout);
+    return rc;
+}
 int prims_sliced_max(const uint32_t* in, const unsigned long long* act, uint32_t* out, int n_cases, int nb) {
     u32 *din = nullptr, *dout = nullptr;
     unsigned long long* dact = nullptr;

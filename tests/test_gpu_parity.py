@@ -147,6 +147,18 @@ def test_sorted_statistics_pass_slice_groups_bit_exact(orc, engine_mod, monkeypa
     _run_both(orc, engine_mod, CASES["full_pipeline"], seq, qual, off, via="device")
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("case", ["defaults_adapters", "full_pipeline"])
+def test_sorted_statistics_pass_row_setup_bit_exact(orc, engine_mod, monkeypatch, seed, case):
+    """k_stats_sorted's row set-up (tests/test_kernels_emu.py::_reads_for_row_setup): odd bytes and U's around the lane and tile
+    boundaries of the 5-mer stream, reads ending right at them, clean reads"""
+    from tests.test_kernels_emu import _reads_for_row_setup
+    monkeypatch.setenv("FPL_STATS_MIN_BUCKET", "1")
+    monkeypatch.setenv("FPL_STATS_PER", "128")
+    seq, qual, off = _reads_for_row_setup(seed, n=3000)
+    _run_both(orc, engine_mod, CASES[case], seq, qual, off, via="device")
+
+
 def test_multi_adapter_fasta_bit_exact(orc, engine_mod):
     fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA",
              "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG",

@@ -22,7 +22,33 @@ def prims():
     L.prims_sliced_max.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.prims_wave.restype = C.c_int
     L.prims_wave.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.prims_kmer_stream.restype = C.c_int
+    L.prims_kmer_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return L
+
+
+def test_kmer_stream_from_dot4_packs_and_the_neighbours_pack(prims):
+    """kmer_stream (k_stats_sorted's row set-up): a dword's four 2-bit codes packed by v_dot4, the previous lane's finished pack
+    through DPP -- against the v_perm form on the same device and against numpy"""
+    rng = np.random.default_rng(3)
+    n = 2048
+    letters = np.frombuffer(b"ACGTUNacgt", dtype=np.uint8)
+    by = letters[rng.integers(0, 5, (n, 64, 8))]
+    by[::5] = letters[rng.integers(0, len(letters), by[::5].shape)]
+    halo_b = letters[rng.integers(0, 5, (n, 4))]
+    inp = np.ascontiguousarray(by).view(np.uint32).reshape(n, 64, 2)
+    halo = np.ascontiguousarray(halo_b).view(np.uint32).reshape(n)
+    out = np.zeros((n, 64, 6), np.uint32)
+    assert prims.prims_kmer_stream(inp.ctypes.data, halo.ctypes.data, out.ctypes.data, n) == 0
+    code = lambda b: ((b & 2) | ((b >> 2) & 1)).astype(np.uint32)  # noqa: E731  (Stats::base2val for A T/U C G)
+    pack = lambda c: (c[..., 0] << 6) | (c[..., 1] << 4) | (c[..., 2] << 2) | c[..., 3]  # noqa: E731
+    p0, p1 = pack(code(by[:, :, 0:4])), pack(code(by[:, :, 4:8]))
+    ph = np.concatenate([pack(code(halo_b))[:, None], p1[:, :-1]], axis=1)
+    want = (ph << 16) | (p0 << 8) | p1
+    assert np.array_equal(out[:, :, 2], p0) and np.array_equal(out[:, :, 3], p1)
+    assert np.array_equal(out[:, :, 4], p0) and np.array_equal(out[:, :, 5], p1)
+    assert np.array_equal(out[:, :, 1], want)
+    assert np.array_equal(out[:, :, 0], want)
 
 
 @pytest.mark.parametrize("nb", [6, 7])

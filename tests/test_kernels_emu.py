@@ -153,6 +153,52 @@ def test_emulated_sorted_statistics_pass_slice_groups(orc, monkeypatch, hi_tile,
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
+def _reads_for_row_setup(seed, n=120):
+    """reads for the row set-up of k_stats_sorted: bytes that are no bases (N, lower case, X) and U's planted where the 5-mer
+    stream crosses from one lane's eight bytes into the next and from one 512-cycle tile into the next (the four bases in
+    front of a tile come through a register of their own), reads that END within a few bytes of those boundaries, clean
+    reads (every row takes the constant-increment path) and reads with a single odd byte (one row takes the exact path)"""
+    rng = np.random.default_rng(9100 + seed)
+    reads = []
+    odd = np.frombuffer(b"NnacgtXU", dtype=np.uint8)
+    for i in range(n):
+        kind = i % 6
+        if kind == 0:
+            L = int(rng.choice([512, 1024, 1536])) + int(rng.integers(-5, 10))
+        elif kind == 1:
+            L = int(rng.integers(300, 1800))
+        else:
+            L = int(rng.integers(1030, 1700))
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].copy()
+        q = rng.integers(33 + 8, 33 + 45, L).astype(np.uint8)
+        if kind >= 2:
+            spots = []
+            for base in (512, 1024, 8 * int(rng.integers(1, L // 8))):
+                spots += [base + d for d in rng.integers(-6, 6, int(rng.integers(1, 4)))]
+            if kind == 4:
+                spots = spots[:1]
+            for p_ in spots:
+                if 40 <= p_ < L - 40:
+                    s[p_] = ord("U") if kind == 5 else int(rng.choice(odd))
+        reads.append((s, q))
+    return synth.pack(reads)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1)])
+def test_emulated_sorted_statistics_pass_row_setup(orc, monkeypatch, opts):
+    """k_stats_sorted's row set-up: the 5-mer stream of a lane from its own two v_dot4 packs and its neighbour's finished one
+    (lane 0: the halo register of the group of four rows), the validity test without the neighbour's bytes"""
+    monkeypatch.setenv("FPL_STATS_MIN_BUCKET", "1")
+    monkeypatch.setenv("FPL_STATS_PER", "64")
+    cfg = orc.Config(abi.FplOptions.default(**opts), synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = _reads_for_row_setup(1, n=90)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
 def test_emulated_kernels_multi_adapter(orc):
     fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA", "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG"]
     cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER, fasta)
