@@ -239,8 +239,11 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         for (int i = 1; i <= N_STAGES; i++) mark(i);
         return;
     }
+    /* (profiling only, tools/overlap_probe.py: FPL_DEBUG_FLAGS 0x1000 stops a batch behind k_resolve / k_redo, 0x2000 runs only
+       what follows them, on the state an earlier batch of the context left) */
+    const bool run_front = !(a.dbg & 0x2000), run_back = !(a.dbg & 0x1000);
     /* 1: one wave per read, grid-stride; cap the grid so the LDS accumulators flush rarely */
-    {
+    if (run_front) {
         u32 blocks = cdiv(n, KWAVES);
 #ifndef FPL_TRIM_BLOCKS_PER_CU
 #define FPL_TRIM_BLOCKS_PER_CU 112 /* static grid-stride: more, shorter blocks even the load out (16: 3.80 ms, 112: 3.57 ms on the bench batch) */
@@ -272,7 +275,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                        a.ads, a.state, a.counters, a.C);
     }
     mark(1);
-    {
+    if (run_front) {
         u32 blocks = cdiv(n, KWAVES);
         const u32 cap = SCAN_BLOCKS_PER_CU * a.n_cu; /* what registers / LDS admit */
         if (blocks > cap) blocks = cap;
@@ -294,7 +297,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                        (const ReadState*)a.state, a.recs, a.wins, a.counters, a.C, a.work_ctr, chunk);
     }
     mark(2);
-    {
+    if (run_front) {
         /* lane = read: confirmations, gaps, records, counters, plan; the reads a middle adapter splits go on the REDO list */
         /* (sixteen waves per block and no more than two blocks per CU: every block ends with a few hundred global atomics on
            the same dozen cache lines -- its median histograms -- and those serialise: 977 blocks spent 0.1 ms on them) */
@@ -317,7 +320,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                        (const u32*)(a.work_ctr + 3), a.work_ctr + 4, a.counters, a.C);
         }
     }
-    if (a.defer) {
+    if (a.defer && run_front) {
         u32 blocks = cdiv(n, KWAVES);
         const u32 cap = 8 * a.n_cu;
         if (blocks > cap) blocks = cap;
@@ -326,6 +329,10 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                    a.frag_off, a.frag_len, a.frag_cyc, a.work_ctr + 1, a.counters, a.C);
     }
     mark(3);
+    if (!run_back) {
+        for (int i = 4; i <= N_STAGES; i++) mark(i);
+        return;
+    }
     const u32 n_tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
     /* the post-only pass over the EXTRA list (fragments of split reads, far-trimmed reads): the statistics kernel, then its reduce */
     bool extra_forked = false;
@@ -374,7 +381,10 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         extra_forked = a.aux != nullptr && a.extra_scratch != nullptr;
         if (extra_forked) FPL_FORK_MARK(a, stream);
         /* persistent blocks, two per CU (what the LDS tables allow) */
-        FPL_LAUNCH((k_stats_sorted<SWAVES>), dim3(2 * a.n_cu), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
+#ifndef FPL_STATS_BLOCKS_PER_CU
+#define FPL_STATS_BLOCKS_PER_CU 2 /* persistent blocks of 16 waves and 80 KB of LDS: what a CU holds */
+#endif
+        FPL_LAUNCH((k_stats_sorted<SWAVES>), dim3(FPL_STATS_BLOCKS_PER_CU * a.n_cu), dim3(SWAVES * 64), stream, a.seq, a.qual, a.n_bytes,
                    (const uint64_t*)a.st_off, (const u32*)a.st_len, (const u32*)a.st_e, a.sort_ws, max_slices, n_tiles, a.counters,
                    a.stats_scratch, a.stats_flags, a.C, hi_tile, max_rows);
         if (extra_forked) launch_extra(FPL_FORK(a, stream), a.extra_scratch, a.extra_flags, false);
