@@ -134,6 +134,10 @@ __device__ unsigned long long g_fpl_prof[64];
                             per million reads, round 4): loads return in order, so whatever the group at hand loads next waits for the
                             touches of the group after it; there is no prefetch instruction on gfx950 that leaves vmcnt alone */
 #endif
+#ifndef FPL_OPT_INCVALU
+#define FPL_OPT_INCVALU 1 /* k_stats_sorted: a byte's packed increment built on the vector unit instead of read from a 256-entry LDS table:
+                             the kernel's limit is the LDS array (24 LDS instructions per row of 512 bytes were 16 now), 5.10 -> 4.93 ms */
+#endif
 #ifndef FPL_OPT_STATSETUP
 #define FPL_OPT_STATSETUP 1 /* k_stats_sorted: a row's 5-mer stream from v_dot4 packs and the NEIGHBOUR's finished pack (one DPP move), lane 0's
                                halo once per group of four rows -- instead of packing the neighbour's bytes a second time in every lane */
@@ -4806,11 +4810,12 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                u32* __restrict__ sw, u32 max_slices, u32 n_tiles, long long* __restrict__ counters,
                u64* __restrict__ scratch, u8* __restrict__ flags, u32 C, u32 hi_tile, u32 max_rows) {
     (void)C;
-    __shared__ u64 lds_all[1024 + 256 + 8 * FS_BSTRIDE];
-    static_assert(sizeof(u64) * (1024 + 256 + 8 * FS_BSTRIDE) <= 81920, "two blocks per CU");
+    constexpr int N_INC = FPL_OPT_INCVALU ? 0 : 256;
+    __shared__ u64 lds_all[1024 + N_INC + 8 * FS_BSTRIDE];
+    static_assert(sizeof(u64) * (1024 + N_INC + 8 * FS_BSTRIDE) <= 81920, "two blocks per CU");
     u32* const kmer = (u32*)lds_all; /* [0,1024): 5-mers counted pre-filter only; [1024,2048): pre- AND post-filter */
-    u64* const inc_of = lds_all + 1024; /* the packed increment of every quality byte */
-    u64* const tbl = inc_of + 256;      /* [8][FS_T pre | FS_T not-post] */
+    u64* const inc_of = lds_all + 1024; /* (without FPL_OPT_INCVALU: the packed increment of every quality byte) */
+    u64* const tbl = inc_of + N_INC;    /* [8][FS_T pre | FS_T not-post] */
     u32* const kpre = kmer;
     u32* const kpost = kmer + 1024;
     __shared__ u32 any_work, cur_item, cls_mask;
@@ -4820,7 +4825,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     const u8* qual_end = qual + n_bytes;
     long long* kg0 = counters + FPL_OFF_PRE(C) + FPL_ST_KMER(C);
     long long* kg1 = counters + FPL_OFF_POST(C) + FPL_ST_KMER(C);
-    for (u32 q = threadIdx.x; q < 256; q += blockDim.x)
+    for (u32 q = threadIdx.x; q < (u32)N_INC; q += blockDim.x)
         inc_of[q] = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);
     const u32 n_slices = uniform_u32(sw[SW_NSLICES]);
     const u32 n_groups = uniform_u32(sw[SW_NGROUPS]);
@@ -5056,7 +5061,23 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                    measured the same: this kernel issues 20 vector instructions per 64 bytes and the vector unit is what it
                    waits for, profiles/r02_ab) */
 #define FPL_FS_Q(k) ((qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF)
+#if FPL_OPT_INCVALU
+                /* the packed increment of a byte on the vector unit instead of out of the LDS table: the Q20 / Q30 bits of four
+                   qualities at once (bit 7 of q + 75 / q + 65: qualities are < 128), moved to where two of the four need them
+                   (bits 4 / 18 of the high word) */
+                u32 dq[4];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const u32 t20 = (qw[j] + 0x4B4B4B4Bu) & 0x80808080u, t30 = (qw[j] + 0x41414141u) & 0x80808080u;
+                    dq[2 * j] = (t20 >> 3) | (t30 << 11);
+                    dq[2 * j + 1] = (t20 >> 19) | (t30 >> 5);
+                }
+#define FPL_FS_INC(k) (((u64)((dq[(k) >> 1] >> (8 * ((k)&1))) & 0x40010u) << 32) | (FPL_FS_Q(k) | (1u << 22)))
+                u64 inc_n = FPL_FS_INC(0);
+#else
+#define FPL_FS_INC(k) inc_of[FPL_FS_Q(k)]
                 u64 inc_n = inc_of[FPL_FS_Q(0)];
+#endif
 #define FPL_FB_BYTE(k, NPM, KM, FULL)                                                                             \
     if (FULL || (k) < nv_row) {                                                                                   \
         const u32 bb = (sw2[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                   \
@@ -5078,7 +5099,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
         (void)nv_row;                                                                                             \
         _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                           \
             const u64 inc = inc_n;                                                                                \
-            if (k < 7) inc_n = inc_of[FPL_FS_Q(k + 1)];                                                           \
+            if (k < 7) inc_n = FPL_FS_INC(k + 1);                                                                 \
             FPL_FB_BYTE(k, NPM, KM, FULL)                                                                         \
         }                                                                                                         \
     }
@@ -5108,6 +5129,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
 #undef FPL_FB_ROW
 #undef FPL_FB_BYTE
 #undef FPL_FS_Q
+#undef FPL_FS_INC
 #undef FPL_FS_NVALID
             }
         }
