@@ -134,6 +134,10 @@ __device__ unsigned long long g_fpl_prof[64];
                             per million reads, round 4): loads return in order, so whatever the group at hand loads next waits for the
                             touches of the group after it; there is no prefetch instruction on gfx950 that leaves vmcnt alone */
 #endif
+#ifndef FPL_OPT_CLSPERM
+#define FPL_OPT_CLSPERM 0 /* k_stats_sorted: the LDS cell of a byte through one v_perm per byte (+ two instructions per dword) instead of
+                             v_bfe + v_mad per byte: four vector instructions fewer per row and SLOWER (4.92 -> 4.99 ms, round 4) */
+#endif
 #ifndef FPL_OPT_INCVALU
 #define FPL_OPT_INCVALU 1 /* k_stats_sorted: a byte's packed increment built on the vector unit instead of read from a 256-entry LDS table:
                              the kernel's limit is the LDS array (24 LDS instructions per row of 512 bytes were 16 now), 5.10 -> 4.93 ms */
@@ -4821,6 +4825,8 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     __shared__ u32 any_work, cur_item, cls_mask;
     const int lane = lane_id();
     const u32 lane8 = 8u * (u32)lane;
+    const u32 lane_lo = lane8 & 0xFFu, lane_hi4 = (lane8 >> 8) * 0x01010101u; /* (FPL_OPT_CLSPERM) */
+    static_assert(8 * FS_BSTRIDE == 8192, "a class row of the LDS tables is 8192 bytes apart from the next: FPL_FS_CELL");
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
     long long* kg0 = counters + FPL_OFF_PRE(C) + FPL_ST_KMER(C);
@@ -5061,6 +5067,14 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                    measured the same: this kernel issues 20 vector instructions per 64 bytes and the vector unit is what it
                    waits for, profiles/r02_ab) */
 #define FPL_FS_Q(k) ((qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF)
+#if FPL_OPT_CLSPERM
+                /* the cell of byte k: class << 13 | lane << 3 -- the high byte of that is class << 5 | lane >> 5, made for four
+                   bytes at once; one v_perm per byte puts it on top of the lane's constant low byte */
+                const u32 chi[2] = {((sw2[0] << 5) & 0xE0E0E0E0u) | lane_hi4, ((sw2[1] << 5) & 0xE0E0E0E0u) | lane_hi4};
+#define FPL_FS_CELL(k) perm_b32(chi[(k) >> 2], lane_lo, 0x0c0c0400u + ((u32)((k)&3) << 8))
+#else
+#define FPL_FS_CELL(k) mad_u24((sw2[(k) >> 2] >> (8 * ((k)&3))) & 7u, 8 * FS_BSTRIDE, lane8)
+#endif
 #if FPL_OPT_INCVALU
                 /* the packed increment of a byte on the vector unit instead of out of the LDS table: the Q20 / Q30 bits of four
                    qualities at once (bit 7 of q + 75 / q + 65: qualities are < 128), moved to where two of the four need them
@@ -5080,8 +5094,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
 #endif
 #define FPL_FB_BYTE(k, NPM, KM, FULL)                                                                             \
     if (FULL || (k) < nv_row) {                                                                                   \
-        const u32 bb = (sw2[(k) >> 2] >> (8 * ((k)&3))) & 0xFF;                                                   \
-        u64* const cellp = (u64*)((char*)tbl + mad_u24(bb & 7u, 8 * FS_BSTRIDE, lane8)); /* (byte offset: one op) */ \
+        u64* const cellp = (u64*)((char*)tbl + FPL_FS_CELL(k)); /* (byte offset of the (class, lane) cell) */      \
         atomicAdd(&cellp[(k)*64], inc);                                                                           \
         if (NPM && ((npmask >> (k)) & 1u)) atomicAdd(&cellp[(k)*64 + FS_T], inc);                                 \
         const u32 kidx = (W >> (2 * (7 - (k)))) & 0x3FFu;                                                         \
@@ -5129,6 +5142,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
 #undef FPL_FB_ROW
 #undef FPL_FB_BYTE
 #undef FPL_FS_Q
+#undef FPL_FS_CELL
 #undef FPL_FS_INC
 #undef FPL_FS_NVALID
             }
