@@ -678,8 +678,8 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     }
     a.n_cu = ctx->n_cu;
     a.dbg = ctx->dbg;
-    if ((a.dbg & 0x2000) && !ctx->probe_primed) { /* (profiling only: the first batch of a back-only context runs whole) */
-        a.dbg &= ~0x2000;
+    if ((a.dbg & 0xA000) && !ctx->probe_primed) { /* (profiling only: the first batch of a back-only / scan-only context runs whole) */
+        a.dbg &= ~0xB000;
         ctx->probe_primed = true;
     }
     a.tune = ctx->tune;

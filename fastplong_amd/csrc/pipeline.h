@@ -242,8 +242,10 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     /* (profiling only, tools/overlap_probe.py: FPL_DEBUG_FLAGS 0x1000 stops a batch behind k_resolve / k_redo, 0x2000 runs only
        what follows them, on the state an earlier batch of the context left) */
     const bool run_front = !(a.dbg & 0x2000), run_back = !(a.dbg & 0x1000);
+    /* (... and 0x4000: of the front half only the end trims, 0x8000: only the scan) */
+    const bool run_trim = run_front && !(a.dbg & 0x8000), run_scan = run_front && !(a.dbg & 0x4000);
     /* 1: one wave per read, grid-stride; cap the grid so the LDS accumulators flush rarely */
-    if (run_front) {
+    if (run_trim) {
         u32 blocks = cdiv(n, KWAVES);
 #ifndef FPL_TRIM_BLOCKS_PER_CU
 #define FPL_TRIM_BLOCKS_PER_CU 112 /* static grid-stride: more, shorter blocks even the load out (16: 3.80 ms, 112: 3.57 ms on the bench batch) */
@@ -275,7 +277,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                        a.ads, a.state, a.counters, a.C);
     }
     mark(1);
-    if (run_front) {
+    if (run_scan) {
         u32 blocks = cdiv(n, KWAVES);
         const u32 cap = SCAN_BLOCKS_PER_CU * a.n_cu; /* what registers / LDS admit */
         if (blocks > cap) blocks = cap;
@@ -297,7 +299,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                        (const ReadState*)a.state, a.recs, a.wins, a.counters, a.C, a.work_ctr, chunk);
     }
     mark(2);
-    if (run_front) {
+    if (run_front && !(a.dbg & 0xC000)) {
         /* lane = read: confirmations, gaps, records, counters, plan; the reads a middle adapter splits go on the REDO list */
         /* (sixteen waves per block and no more than two blocks per CU: every block ends with a few hundred global atomics on
            the same dozen cache lines -- its median histograms -- and those serialise: 977 blocks spent 0.1 ms on them) */

@@ -12,10 +12,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=1_000_000)
 ap.add_argument("--workload", default="c3_full_pipeline")
 ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--median-len", type=int, default=0)
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 wl = bench.WORKLOADS[a.workload]
+if a.median_len:
+    wl = dict(wl, gen=dict(wl["gen"], median_len=a.median_len))
 opt = abi.FplOptions.default(**wl["opt"])
 seq_t, qual_t, off_t, max_len, s_ad, e_ad, fasta = bench.make_batch(wl, a.reads, 0, dev)
 n = off_t.numel() - 1
@@ -70,3 +73,28 @@ for spec in a.libs:
         t.append(dt / a.steps * 1e3)
     print("%-40s front alone %.3f  back alone %.3f  (sum %.3f)   front beside back %.3f ms per pair -> %.1f Gbases/s if a pipeline did that" % (
         "", t[0], t[1], t[0] + t[1], t[2], nb / t[2] / 1e6))
+    # the end trims of one batch (latency of per-lane loads) beside the scan of another (vector issue): 0x5000 = trims only, 0x9000 = scan only
+    halves = []
+    for flag in (str(0x5000), str(0x9000)):
+        os.environ["FPL_DEBUG_FLAGS"] = flag
+        for k, v in kv:
+            os.environ[k] = v
+        halves.append(engine.Engine(opt, s_ad, e_ad, fasta, device=0, max_cycles=max_len, lib=L))
+        for k, _v in kv:
+            os.environ.pop(k, None)
+    os.environ.pop("FPL_DEBUG_FLAGS", None)
+    for j in range(2):
+        halves[j].process_device(seq_t, qual_t, off_t, max_len, res[j], streams[j].cuda_stream)
+    t = []
+    for who in ((0,), (1,), (0, 1), (1, 0)):
+        for warm in (True, False):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(3 if warm else a.steps):
+                for j in who:
+                    halves[j].process_device(seq_t, qual_t, off_t, max_len, res[j], streams[j].cuda_stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        t.append(dt / a.steps * 1e3)
+    print("%-40s trims alone %.3f  scan alone %.3f  (sum %.3f)   trims beside scan %.3f (trims launched first) / %.3f (scan first) ms per pair" % (
+        "", t[0], t[1], t[0] + t[1], t[2], t[3]))
