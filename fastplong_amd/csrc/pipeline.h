@@ -187,9 +187,18 @@ inline u32 stats_items_per_slice(u32 n_items, u32 mean_len, u32 n_cu, const Stat
 constexpr u32 FS_EXTRA_PER = 1024;
 constexpr u32 FS_EXTRA_BLOCKS = 32; /* (64: 0.07 ms more on the 1 M-read batch: every block zeroes and hands over 70 KiB) */
 inline u32 stats_extra_per(const StatsTune& tune) { return tune.extra_per ? tune.extra_per : FS_EXTRA_PER; }
-inline u32 stats_extra_blocks(u32 n_reads, const StatsTune& tune) {
+/* heavy_tiles / n_cu given: the pass runs on the side stream, beside the reduce of k_stats_sorted -- fewer, longer blocks then (every
+   block zeroes and hands over its tables whatever it counted), as long as the tiles that hold most of the items -- those below the
+   mean read length -- still bring about five blocks per four CUs: 18 per tile on the bench batch (0.60 -> 0.56 ms for the reduce +
+   what is left of the pass), 16 on configs[3] (2.03 -> 1.7), 32 for 2 kb reads (16 there: 0.28 -> 0.47).  Never more than
+   FS_EXTRA_BLOCKS: what the scratch buffers are sized for. */
+inline u32 stats_extra_blocks(u32 n_reads, const StatsTune& tune, u32 heavy_tiles = 0, u32 n_cu = 0) {
     const u32 b = cdiv(2 * (n_reads ? n_reads : 1), stats_extra_per(tune));
-    const u32 cap = tune.extra_blocks ? tune.extra_blocks : FS_EXTRA_BLOCKS;
+    u32 cap = tune.extra_blocks ? tune.extra_blocks : FS_EXTRA_BLOCKS;
+    if (!tune.extra_blocks && heavy_tiles && n_cu) {
+        cap = cdiv(5 * n_cu / 4, heavy_tiles);
+        cap = cap < 8 ? 8 : cap;
+    }
     return b < cap ? b : (cap < FS_EXTRA_BLOCKS ? cap : FS_EXTRA_BLOCKS);
 }
 /* items a block may accumulate before it must empty its tables (test hook: force that path) */
@@ -340,7 +349,8 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     bool extra_forked = false;
     auto launch_extra = [&](fpl_stream_t st, u64* scratch, u8* flags, bool reduce) {
         const u32 n_items = a.defer ? a.bm.item_cap : 2 * n; /* upper bound; the kernel reads the real count */
-        const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n, a.tune); /* slabs per tile */
+        const u32 gx = stats_extra_blocks(a.defer ? (n_items + 1) / 2 : n, a.tune, extra_forked ? (u32)(a.n_bytes / n) / FS_T + 1 : 0,
+                                          a.n_cu); /* slabs per tile */
         if (!reduce) {
             FPL_MEMSET(flags, (size_t)gx * n_tiles + n_tiles, st);
             FPL_LAUNCH((k_stats<SWAVES, true>), dim3(gx, n_tiles), dim3(SWAVES * 64), st, a.seq, a.qual, a.n_bytes,
