@@ -39,6 +39,42 @@ def _qual(rng, n, mu, sigma):
     return q
 
 
+def wide_qualities(qual, off, seed, share=0.7):
+    """Overwrite the qualities of `share` of the reads with bytes from the WHOLE FASTQ range '!'..'~' (33..126; `_qual` stays
+    within Q2..Q50): per read one of -- uniform over 33..126, all '~' (what PacBio HiFi reads mostly carry), all '!', the top of
+    the range (84..126), the bottom (33..35), runs of 1..300 bytes alternating between the two ends, '~' with a sprinkle of lower
+    bytes.  Returns a new array; the bases and offsets are untouched."""
+    rng = np.random.default_rng(seed)
+    q = qual.copy()
+    for i in range(len(off) - 1):
+        a, b = int(off[i]), int(off[i + 1])
+        L = b - a
+        if L == 0 or rng.random() >= share:
+            continue
+        kind = int(rng.integers(0, 7))
+        if kind == 0:
+            q[a:b] = rng.integers(33, 127, L)
+        elif kind == 1:
+            q[a:b] = 126
+        elif kind == 2:
+            q[a:b] = 33
+        elif kind == 3:
+            q[a:b] = rng.integers(84, 127, L)
+        elif kind == 4:
+            q[a:b] = rng.integers(33, 36, L)
+        elif kind == 5:
+            p, hi = a, bool(rng.integers(2))
+            while p < b:
+                run = int(rng.integers(1, 301))
+                q[p:min(b, p + run)] = rng.integers(120, 127) if hi else rng.integers(33, 36)
+                p, hi = p + run, not hi
+        else:
+            q[a:b] = 126
+            m = rng.random(L) < 0.05
+            q[a:b][m] = rng.integers(33, 127, int(m.sum()))
+    return q
+
+
 def make_read(rng, length, mu=18.0, sigma=8.0, start_ad=None, end_ad=None, p_start=0.7, p_end=0.6,
               err=0.10, p_polya=0.05, p_middle=0.01, n_rate=0.001, lead_max=30):
     """One ONT-like read: body of iid ACGT (+N), optional noisy adapters at the ends after

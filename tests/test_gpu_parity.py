@@ -685,6 +685,107 @@ def test_bench_sized_batch_no_hooks_bit_exact(orc, engine_mod, monkeypatch, work
     assert "no hook set" in what
 
 
+WIDE_QUAL_CASES = {
+    # thresholds inside the reference's own option ranges (src/options.cpp:133-181: -q / -e 0..93, cut qualities 1..30) ...
+    "full_pipeline": CASES["full_pipeline"]["opt"],
+    "q60_e60_cut30": dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=4, cut_front_quality=30, cut_tail_quality=30,
+                          polyx=1, complexity_filter=1, qualified_qual=33 + 60, unqualified_percent_limit=30, avg_qual_req=60),
+    "q93_e93": dict(cut_front=1, cut_tail=1, cut_front_window=1, cut_tail_window=1000, cut_front_quality=30, cut_tail_quality=1,
+                    qualified_qual=33 + 93, unqualified_percent_limit=0, avg_qual_req=93, break_enabled=0),
+    # ... and beyond them (the C-ABI takes any integer; the arithmetic is the same)
+    "cut60_q80": dict(cut_front=1, cut_tail=1, cut_front_window=7, cut_tail_window=3, cut_front_quality=60, cut_tail_quality=85,
+                      polyx=1, qualified_qual=33 + 80, unqualified_percent_limit=50, avg_qual_req=75, complexity_filter=1),
+    "break_mask_hi": dict(cut_front=1, break_enabled=1, break_window=20, break_quality=70, mask_enabled=1, mask_window=9, mask_quality=88,
+                          n_base_percent_limit=95, unqualified_percent_limit=90),
+}
+
+
+def _wide_quality_batch(seed, n_ont=900, n_adv=1500, median_len=2500):
+    a = synth.ont_like(n_ont, seed=seed, median_len=median_len, p_middle=0.05)
+    b = synth.adversarial(n_adv, seed=seed + 1)
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
+    return seq, synth.wide_qualities(qual, off, seed + 2), off
+
+
+@pytest.mark.parametrize("sorted_stats", [True, False])
+@pytest.mark.parametrize("name", sorted(WIDE_QUAL_CASES))
+def test_full_quality_byte_range_bit_exact(orc, engine_mod, monkeypatch, name, sorted_stats):
+    """Quality bytes over the whole FASTQ range '!'..'~' (every other generator stays within Q2..Q50): reads of all '~' (HiFi),
+    all '!', uniform 33..126, the two ends of the range in alternating runs -- through the FORCED k_trim_ends_batched
+    (tests/conftest.py) and the forced k_stats_sorted (packed 22-bit raw-quality sums, the Q20 / Q30 tests as bit 7 of q + 75 /
+    q + 65, the v_dot4 packs) or the unsorted k_stats, with thresholds up to the top of the reference's option ranges and beyond"""
+    if sorted_stats:
+        monkeypatch.setenv("FPL_STATS_SORT_MIN", "1")
+    else:
+        monkeypatch.delenv("FPL_STATS_SORT_MIN", raising=False)
+    seq, qual, off = _wide_quality_batch(900 + len(name))
+    assert qual.min() == 33 and qual.max() == 126
+    okw = WIDE_QUAL_CASES[name]
+    if okw.get("break_enabled") or okw.get("mask_enabled"):
+        cfg = orc.Config(abi.FplOptions.default(**okw), synth.START_ADAPTER, synth.END_ADAPTER)
+        C = int(np.diff(off.astype(np.int64)).max())
+        want_res, want_cnt, want_f, want_r = orc.process_batch_ex(cfg, seq, qual, off, max_cycles=C)
+        eng = engine_mod.Engine(cfg.opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=C)
+        got_res = eng.process_host(seq, qual, off)
+        got_f, got_r = eng.fragments()
+        got_cnt = eng.counters()
+        eng.close()
+        parity.assert_fragments_equal(got_f, got_r, want_f, want_r)
+        parity.assert_results_equal(got_res, want_res, seq, off)
+        parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+        return
+    _, cnt = _run_both(orc, engine_mod, dict(opt=okw, start=synth.START_ADAPTER, end=synth.END_ADAPTER), seq, qual, off, via="device")
+    v = abi.CountersView(cnt, int(np.diff(off.astype(np.int64)).max()), 2)
+    assert v.pre.base_qual_hist[126] > 0 and v.pre.base_qual_hist[33] > 0
+
+
+def test_full_quality_byte_range_fasta_chain_bit_exact(orc, engine_mod):
+    """the same qualities through k_trim_ends<2> (64-adapter FASTA chain; its trimAndCut / polyX are the wave-per-read forms)"""
+    seq, qual, off, ads = synth.hifi_like(60, seed=9, mean_len=5000, sd_len=1500, n_adapters=64)
+    qual = synth.wide_qualities(qual, off, 17, share=0.9)
+    cfgd = dict(opt=dict(cut_front=1, cut_tail=1, cut_front_quality=30, cut_tail_quality=30, qualified_qual=33 + 60, avg_qual_req=50),
+                start=ads[0], end=synth.revcomp(ads[0]))
+    _run_both(orc, engine_mod, cfgd, seq, qual, off, fasta=sorted(ads))
+
+
+def test_full_quality_byte_range_bench_sized_no_hooks_bit_exact(orc, engine_mod, monkeypatch):
+    """160 000 reads with qualities over 33..126 and NO hook in the environment: the kernels the library picks by its own size rules
+    (k_trim_ends_batched, k_stats_sorted with slices of 16 320 reads -- 16 320 x 126 is what the 22-bit fields have to hold),
+    every record and every counter against the oracle on 16 host threads"""
+    import torch
+
+    import bench
+
+    for k in ("FPL_TRIM_BATCH_MIN", "FPL_STATS_SORT_MIN", "FPL_STATS_MIN_BUCKET", "FPL_STATS_PER"):
+        monkeypatch.delenv(k, raising=False)
+    wl = dict(bench.WORKLOADS["c3_full_pipeline"])
+    wl["gen"] = dict(wl["gen"], median_len=1500)
+    rig = bench.Rig()
+    dev = torch.device("cuda", 0)
+    seq_t, qual_t, off_t, max_len, ad_start, ad_end, ad_fasta = rig.make_batch(wl, 160_000, 0, dev)
+    n = off_t.numel() - 1
+    # per-read modes as in synth.wide_qualities, built on the device: 0 keep, 1 all '~', 2 all '!', 3 uniform 33..126, 4 84..126
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    mode = torch.randint(0, 5, (n,), generator=g, device=dev)
+    # the first 20 000 reads all '~' and nothing else: one slice of k_stats_sorted whose cells hold nothing but the largest byte
+    mode[:20_000] = 1
+    per_base = torch.repeat_interleave(mode, off_t[1:] - off_t[:-1])
+    uni = torch.randint(33, 127, (qual_t.numel(),), generator=g, device=dev, dtype=torch.int64).to(torch.uint8)
+    qual_t = torch.where(per_base == 1, torch.full_like(qual_t, 126), qual_t)
+    qual_t = torch.where(per_base == 2, torch.full_like(qual_t, 33), qual_t)
+    qual_t = torch.where(per_base == 3, uni, qual_t)
+    qual_t = torch.where(per_base == 4, torch.clamp(uni, min=84), qual_t).contiguous()
+    del per_base, uni
+    opt = abi.FplOptions.default(**dict(wl["opt"], qualified_qual=33 + 40, avg_qual_req=30))
+    verdict, what, pn = _bench_parity(bench, rig, opt, (ad_start, ad_end, ad_fasta), seq_t, qual_t, off_t, max_len, n, 0)
+    assert verdict == "ok" and pn == n, verdict
+    assert "no hook set" in what
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_long_trim_scans_fall_back_bit_exact(orc, engine_mod, seed):
     """k_trim_ends_batched: lanes whose trimAndCut / polyX scans outlast the iteration cap are redone by the wave-per-read forms"""

@@ -90,6 +90,35 @@ def test_emulated_kernels_match_oracle_ont_like(orc):
     assert (want_res["n_frag"] == 2).any()  # the middle-adapter split path ran
 
 
+@pytest.mark.parametrize("sorted_stats", [True, False])
+@pytest.mark.parametrize("okw", [
+    dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1),
+    dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=4, cut_front_quality=30, cut_tail_quality=30, polyx=1,
+         qualified_qual=33 + 60, unqualified_percent_limit=30, avg_qual_req=60),
+    dict(cut_front=1, cut_tail=1, cut_front_window=7, cut_tail_window=3, cut_front_quality=60, cut_tail_quality=85,
+         qualified_qual=33 + 93, unqualified_percent_limit=50, avg_qual_req=93)])
+def test_emulated_full_quality_byte_range(orc, monkeypatch, okw, sorted_stats):
+    """quality bytes over '!'..'~' (synth.wide_qualities; the other generators stay within Q2..Q50) with thresholds up to the top of
+    the reference's option ranges (src/options.cpp:133-181) and beyond -- the emulator builds the kernels' C forms, the -m gpu
+    test of the same name the v_dot4 / inline-asm ones"""
+    if sorted_stats:
+        monkeypatch.setenv("FPL_STATS_MIN_BUCKET", "1")
+    cfg = orc.Config(abi.FplOptions.default(**okw), synth.START_ADAPTER, synth.END_ADAPTER)
+    a = synth.ont_like(40, seed=31, median_len=900, p_middle=0.1, p_polya=0.2)
+    b = synth.adversarial(80, seed=32)
+    reads = []
+    for (s_, q_, o_) in (a, b):
+        reads += [(s_[int(o_[i]):int(o_[i + 1])], q_[int(o_[i]):int(o_[i + 1])]) for i in range(len(o_) - 1)]
+    seq, qual, off = synth.pack(reads)
+    qual = synth.wide_qualities(qual, off, 33)
+    assert qual.min() == 33 and qual.max() == 126
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
 def test_emulated_wave_per_read_trim_kernel(orc, monkeypatch):
     """k_trim_ends<1>, what batches of fewer than 65 536 reads take (the suite forces k_trim_ends_batched elsewhere)"""
     monkeypatch.delenv("FPL_TRIM_BATCH_MIN", raising=False)
