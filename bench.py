@@ -380,7 +380,7 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
             for line in p.stderr.splitlines():
                 if line.startswith("host pipeline:"):
                     pipe = float(line.split("wall ")[1].split(" s")[0])
-                if line.startswith(("host pipeline:", "start-up:", "reports:", "since launch:", "chunk parsers")):
+                if line.startswith(("host pipeline:", "start-up:", "reports:", "since launch:", "chunk parsers", "counter merge:")):
                     keep.append(line)
             runs[name] = {"rc": p.returncode, "process_seconds": dt, "value": nb * copies / dt / 1e9,
                           "pipeline_seconds": pipe, "pipeline_value": (nb * copies / pipe / 1e9) if pipe else None, "stages": keep}

@@ -82,6 +82,7 @@ struct fpl_ctx {
     static constexpr int EV_RING = 128;
     hipEvent_t ev[EV_RING][N_STAGES + 1] = {};
     int ev_calls = 0; /* batches recorded since fpl_enable_timing() */
+    bool ev_ready = false; /* the whole event ring exists */
     std::string err;
 };
 
@@ -438,6 +439,9 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
        the in-place sum on the context's stream -- so that the loader, the communicator set-up and the call are exercised on a
        box with a single GPU; the buffer must come out unchanged. */
     if (n == 1 && !rccl_forced()) return FPL_OK;
+    /* (the loader, the communicator cache and the library's path are all behind g_comms.m: a host may merge while a thread of
+       its own is still inside fpl_comm_init) */
+    std::lock_guard<std::mutex> keep(g_comms.m);
     if (!g_rccl.load(ctx->err)) return FPL_ERR_STATE;
 #define FPL_NCCL(call)                                                                                   \
     do {                                                                                                 \
@@ -449,7 +453,6 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
     } while (0)
     int rc = FPL_OK;
     /* the communicators fpl_comm_init made for exactly these devices, else a set of this call's own */
-    std::lock_guard<std::mutex> keep(g_comms.m);
     const bool kept = g_comms.matches(ctxs, n);
     std::vector<ncclComm_t> own;
     if (!kept) {
@@ -483,7 +486,13 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
     return rc;
 }
 
-const char* fpl_rccl_library(void) { return g_rccl.path.c_str(); }
+const char* fpl_rccl_library(void) {
+    /* a copy taken under the lock (the loader may be running on another thread); it stays valid until the next call on this thread */
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> g(g_comms.m);
+    copy = g_rccl.path;
+    return copy.c_str();
+}
 
 int fpl_reset_counters(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
@@ -504,14 +513,16 @@ static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_r
     ctx->scratch_slabs = 0;
     const size_t cap = slabs + slabs / 4;
     FPL_HIP(hipMalloc((void**)&ctx->d_stats_scratch, cap * (size_t)FS_SLAB * sizeof(u64)));
-    FPL_HIP(hipMalloc((void**)&ctx->d_stats_flags, cap + cap / 8 + 4096)); /* slab flags + tile flags */
+    FPL_HIP(hipMalloc((void**)&ctx->d_stats_flags, 2 * cap + 64)); /* slab flags + tile flags: tiles <= slabs, whatever the shape */
     ctx->scratch_slabs = cap;
     return FPL_OK;
 }
 
 /* slabs of the post-only pass when it has a stream of its own: FS_EXTRA_BLOCKS per cycle tile */
-static int ensure_extra_scratch(fpl_ctx* ctx, u32 n_reads, u32 max_read_len) {
+static int ensure_extra_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_read_len) {
     if (!ctx->overlap || ctx->hcfg.defer) return FPL_OK;
+    /* only the sorted pass forks the post-only pass onto the side stream; a batch that takes the plain walk needs none of this */
+    if (!stats_takes_sorted(n_reads, n_bytes, max_read_len, ctx->n_cu, ctx->tune, ctx->hcfg.defer)) return FPL_OK;
     const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, FS_T);
     const size_t slabs = (size_t)stats_extra_blocks(n_reads, ctx->tune) * n_tiles;
     if (slabs <= ctx->extra_slabs) return FPL_OK;
@@ -523,7 +534,7 @@ static int ensure_extra_scratch(fpl_ctx* ctx, u32 n_reads, u32 max_read_len) {
     ctx->extra_slabs = 0;
     const size_t cap = slabs + slabs / 4;
     FPL_HIP(hipMalloc((void**)&ctx->d_extra_scratch, cap * (size_t)FS_SLAB * sizeof(u64)));
-    FPL_HIP(hipMalloc((void**)&ctx->d_extra_flags, cap + cap / 8 + 4096));
+    FPL_HIP(hipMalloc((void**)&ctx->d_extra_flags, 2 * cap + 64)); /* (slab flags + tile flags) */
     ctx->extra_slabs = cap;
     return FPL_OK;
 }
@@ -630,7 +641,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         if (r != FPL_OK) return r;
         r = ensure_scratch(ctx, n_reads, n_bytes, max_read_len);
         if (r != FPL_OK) return r;
-        r = ensure_extra_scratch(ctx, n_reads, max_read_len);
+        r = ensure_extra_scratch(ctx, n_reads, n_bytes, max_read_len);
         if (r != FPL_OK) return r;
         r = ensure_sort_ws(ctx, n_reads, n_bytes);
         if (r != FPL_OK) return r;
@@ -822,10 +833,21 @@ void fpl_host_free(void* p) {
 
 int fpl_enable_timing(fpl_ctx* ctx, int enable) {
     if (!ctx) return FPL_ERR_ARG;
-    if (enable && !ctx->ev[0][0]) {
+    if (enable && !ctx->ev_ready) { /* all or nothing: a ring with holes would hand null events to hipEventRecord later */
         FPL_HIP(hipSetDevice(ctx->device));
-        for (int r = 0; r < fpl_ctx::EV_RING; r++)
-            for (int i = 0; i <= N_STAGES; i++) FPL_HIP(hipEventCreate(&ctx->ev[r][i]));
+        hipError_t bad = hipSuccess;
+        for (int r = 0; r < fpl_ctx::EV_RING && bad == hipSuccess; r++)
+            for (int i = 0; i <= N_STAGES && bad == hipSuccess; i++) bad = hipEventCreate(&ctx->ev[r][i]);
+        if (bad != hipSuccess) {
+            for (int r = 0; r < fpl_ctx::EV_RING; r++)
+                for (int i = 0; i <= N_STAGES; i++) {
+                    if (ctx->ev[r][i]) (void)hipEventDestroy(ctx->ev[r][i]);
+                    ctx->ev[r][i] = nullptr;
+                }
+            ctx->timing = 0;
+            FPL_HIP(bad);
+        }
+        ctx->ev_ready = true;
     }
     ctx->timing = enable ? 1 : 0;
     ctx->ev_calls = 0;

@@ -148,8 +148,11 @@ constexpr int N_STAGES = 7;
 static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_resolve", "k_stats_prep", "k_stats", "k_stats_reduce",
                                                   "k_stats_extra"};
 /* k_resolve = k_resolve + k_redo (+ k_break_mask with --break / --mask); k_stats_prep = the bucket kernels of the sorted pass;
-   k_stats = k_stats_sorted (or the unsorted k_stats) alone; k_stats_extra = the post-only pass and its reduce.  k_trim_ends,
-   k_scan and k_stats are single launches: their event times are kernel durations */
+   k_stats = k_stats_sorted (or the unsorted k_stats) alone; k_stats_extra = the post-only pass and its reduce -- when that pass
+   runs on the context's side stream (the sorted pass with overlap on: the usual case for large batches) its kernel runs BESIDE
+   stages k_stats / k_stats_reduce and only the join + its reduce are left in this stage; the events sit on the main stream, so
+   the side kernel's own duration is rocprofv3's to report (profiles/: k_stats<.., true>), and FPL_NO_OVERLAP=1 puts it back in
+   line.  k_trim_ends, k_scan and k_stats are single launches: their event times are kernel durations */
 
 /* capacities of the lists k_break_mask appends to: every region is at least one window long, so an output
    read or a piece costs at least window + 1 bytes of input beyond the two fragments a read starts with */
@@ -236,6 +239,16 @@ inline size_t stats_scratch_slabs(u32 n_reads, uint64_t n_bytes, u32 max_read_le
     if (FPL_OPT_SORTSTATS) slices = stats_sorted_max_slices(n_reads, per, tune);
     if (slices < FS_EXTRA_BLOCKS) slices = FS_EXTRA_BLOCKS;
     return (size_t)slices * n_tiles;
+}
+
+/* does a batch take the sorted statistics pass?  (the persistent blocks number their (tile, slice) items with 32 bits; a batch
+ * beyond that -- hundreds of millions of reads next to a read of hundreds of megabases -- takes the plain walk; with --break /
+ * --mask no read is counted post-filter by the sorted pass: the plain walk does) */
+inline bool stats_takes_sorted(u32 n_reads, uint64_t n_bytes, u32 max_read_len, u32 n_cu, const StatsTune& tune, bool defer) {
+    if (!FPL_OPT_SORTSTATS || defer || n_reads == 0 || !stats_use_sorted(n_reads, tune)) return false;
+    const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, FS_T);
+    const u32 per = stats_items_per_slice(n_reads, (u32)(n_bytes / n_reads), n_cu, tune);
+    return (uint64_t)stats_sorted_max_slices(n_reads, per, tune) * n_tiles < 0xFFFFFFF0ull;
 }
 
 template <class Mark>
@@ -363,11 +376,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         }
     };
     const u32 per_sorted = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
-    /* (the persistent blocks number their (tile, slice) items with 32 bits; a batch beyond that -- hundreds of millions of
-       reads next to a read of hundreds of megabases -- takes the plain walk) */
-    if (FPL_OPT_SORTSTATS && !a.defer && stats_use_sorted(n, a.tune) &&
-        (uint64_t)stats_sorted_max_slices(n, per_sorted, a.tune) * n_tiles < 0xFFFFFFF0ull) {
-        /* (with --break / --mask no read is counted post-filter by this pass: the plain walk below does) */
+    if (stats_takes_sorted(n, a.n_bytes, a.max_read_len, a.n_cu, a.tune, a.defer)) {
         const u32 per = per_sorted;
         const u32 max_slices = stats_sorted_max_slices(n, per, a.tune);
         FPL_MEMSET(a.sort_ws, (size_t)SW_SLICES * sizeof(u32), stream);

@@ -48,7 +48,11 @@ using namespace std;
 
 static void error_exit(const string& msg) { /* src/util.h:270-273 */
     cerr << "ERROR: " << msg << endl;
-    exit(-1);
+    /* the reference's exit(-1) status without its static destructors: a thread of this process may still be inside
+       fpl_comm_init (ncclCommInitAll) or a device call when an error ends the run, and tearing the library's statics down under it
+       can crash or hang at exit */
+    fflush(NULL);
+    _exit(255);
 }
 
 struct Flag {
@@ -523,7 +527,8 @@ int main(int argc, char* argv[]) {
     {
         vector<fpl_ctx*> ctxs;
         for (auto& D : dev) ctxs.push_back(D.ctx);
-        if (nGpus > 1 || getenv("FPL_RCCL_FORCE")) commMaker = thread([ctxs]() mutable { (void)fpl_comm_init(ctxs.data(), (int32_t)ctxs.size()); });
+        /* FPL_NO_COMM_PREINIT=1: no thread here, the merge makes the communicators itself (the round-3 order) */
+        if ((nGpus > 1 || getenv("FPL_RCCL_FORCE")) && !getenv("FPL_NO_COMM_PREINIT")) commMaker = thread([ctxs]() mutable { (void)fpl_comm_init(ctxs.data(), (int32_t)ctxs.size()); });
     }
     const double tCreate = clk();
     if (cmd.exist("verbose"))
@@ -1036,13 +1041,19 @@ int main(int argc, char* argv[]) {
     {
         vector<fpl_ctx*> ctxs;
         for (auto& D : dev) ctxs.push_back(D.ctx);
-        if (commMaker.joinable()) commMaker.join();
+        const double tJ0 = now();
+        const bool commMade = commMaker.joinable();
+        if (commMade) commMaker.join();
+        /* (what the end of the run waited for the communicators: the first use of RCCL in a process takes seconds, a short run
+           is over before it is) */
+        if (cmd.exist("verbose") && commMade) cerr << "counter merge: waited " << now() - tJ0 << " s for fpl_comm_init after the last batch" << endl;
         const double tM0 = now();
         const int rc = fpl_allreduce_counters(ctxs.data(), (int32_t)ctxs.size());
         if (cmd.exist("verbose") && fpl_rccl_library()[0]) cerr << "counter merge: " << now() - tM0 << " s" << endl;
         if (rc != FPL_OK) error_exit(string("fpl_allreduce_counters: ") + fpl_strerror(rc) + " " + fpl_last_error(ctxs[0]));
         if (cmd.exist("verbose") && fpl_rccl_library()[0])
             cerr << "counter merge: one all-reduce over " << ctxs.size() << " device(s), RCCL from " << fpl_rccl_library() << endl;
+        if (commMade) (void)fpl_comm_init(nullptr, 0); /* the kept communicators go back before any context does */
     }
     const uint32_t C = fpl_max_cycles(dev[0].ctx);
     const size_t ncnt = fpl_counters_len(dev[0].ctx);

@@ -8,6 +8,8 @@
 #include <map>
 #include <sstream>
 #include <thread>
+#include <utility>
+#include <vector>
 
 using namespace std;
 
@@ -208,28 +210,21 @@ bool write_json(const string& path, const ReportInputs& in) {
         ofs << padding << "\t" << "\"read_start_adapter\": \"" << read_adapter_name(start) << "\"," << endl;
         ofs << padding << "\t" << "\"read_end_adapter\": \"" << read_adapter_name(end) << "\"," << endl;
         ofs << padding << "\t" << "\"read_adapter_counts\": " << "{";
-        { /* outputAdaptersJson, src/filterresult.cpp:134-169 */
-            auto m = adapter_map(in);
-            long total = 0;
-            for (auto& kv : m) total += kv.second;
-            if (total != 0) {
-                const double reportThreshold = 0.01;
-                const double dTotal = (double)total;
-                bool firstItem = true;
-                long reported = 0;
-                for (auto& kv : m) {
-                    if (kv.second / dTotal < reportThreshold) continue;
-                    if (!firstItem) ofs << ", ";
-                    else firstItem = false;
-                    ofs << "\"" << kv.first << "\":" << kv.second;
-                    reported += kv.second;
+        { /* what outputAdaptersJson prints (src/filterresult.cpp:134-169): the keys that hold at least 1 % of all trimmed
+             reads, in map order, then the rest as "others" -- here the items are collected first and joined afterwards */
+            const auto keys = adapter_map(in);
+            long all = 0;
+            for (const auto& kv : keys) all += kv.second;
+            vector<std::pair<string, long>> items;
+            long rest = all;
+            for (const auto& kv : keys)
+                if (all != 0 && !(kv.second / (double)all < 0.01)) {
+                    items.emplace_back(kv.first, kv.second);
+                    rest -= kv.second;
                 }
-                long unreported = total - reported;
-                if (unreported > 0) {
-                    if (!firstItem) ofs << ", ";
-                    ofs << "\"" << "others" << "\":" << unreported;
-                }
-            }
+            if (all != 0 && rest > 0) items.emplace_back("others", rest);
+            for (size_t i = 0; i < items.size(); i++)
+                ofs << (i ? ", " : "") << "\"" << items[i].first << "\":" << items[i].second;
         }
         ofs << "}";
         ofs << endl;

@@ -42,7 +42,14 @@ def test_cli_makes_the_communicators_ahead_of_the_merge(tmp_path, stub_env):
     clog = tmp_path / "comm.log"
     p, out, _ = run_cli(tmp_path, CASES[0], dict(stub_env, FPL_STUB_COMM_LOG=str(clog)), 3)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    assert open(clog).read().splitlines() == ["comm_init 3 0 1 2", "allreduce 3 0 1 2"]
+    # (... and the kept communicators are handed back right after the merge, before any context goes)
+    assert open(clog).read().splitlines() == ["comm_init 3 0 1 2", "allreduce 3 0 1 2", "comm_init 0"]
+    assert b"for fpl_comm_init after the last batch" in p.stderr
+    clog.unlink()
+    # FPL_NO_COMM_PREINIT=1: no thread beside the batches, the merge makes its own communicators
+    p, out, _ = run_cli(tmp_path, CASES[0], dict(stub_env, FPL_STUB_COMM_LOG=str(clog), FPL_NO_COMM_PREINIT="1"), 3)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert open(clog).read().splitlines() == ["allreduce 3 0 1 2"]
     clog.unlink()
     p, out, _ = run_cli(tmp_path, CASES[0], dict(stub_env, FPL_STUB_COMM_LOG=str(clog)), 1, devices=1)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
