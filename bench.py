@@ -231,7 +231,60 @@ CLI_FLAGS = {
 
 E2E_TIMEOUT_S = 180  # one CLI run of the end-to-end leg (seconds)
 E2E_SPLIT = 16  # files (and per-worker writer threads) of the to_split_files run: --split 16 -w 16
-E2E_RUNS = (("to_dev_null_first_pass", "/dev/null"), ("to_dev_null", "/dev/null"), ("to_file", None), ("to_split_files", None))
+NULLDEV_DEVICES = 8  # the host_ceiling runs: bin/fastplong_amd --gpus 8 against tools/nulldev (a device that takes no time)
+# One CLI run of the end-to-end leg: name, where the trimmed FASTQ goes (None: a file in the scratch directory), extra flags,
+# "null": run against the null device library with that many devices (the host side alone), "input": which file it reads
+# ("fq" the plain text; "gz_multi" / "gz_single": a gzip copy of the first GZ_READS reads, made of many members / of one)
+E2E_RUNS = (
+    dict(name="to_dev_null_first_pass", target="/dev/null"),
+    dict(name="to_dev_null", target="/dev/null"),
+    dict(name="to_file", target=None),
+    dict(name="to_split_files", target=None, flags=["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)]),
+    # batches large enough for the kernel forms the headline times (csrc/pipeline.h: k_trim_ends_batched from 65 536 reads,
+    # k_stats_sorted from 150 000): the CLI's batches are its parsers' chunks
+    dict(name="chunk_512mb", target="/dev/null", flags=["--chunk_mb", "512", "--reader_threads", "8"]),
+    dict(name="chunk_1536mb", target="/dev/null", flags=["--chunk_mb", "1536", "--reader_threads", "4"]),
+    dict(name="gz_in_multi", target="/dev/null", input="gz_multi"),
+    dict(name="gz_in_single", target="/dev/null", input="gz_single"),
+    dict(name="gz_in_single_stream", target="/dev/null", input="gz_single", flags=["--gz_stream"]),
+    dict(name="gz_out", target="GZ", input="fq_sub"),
+    dict(name="null8_to_dev_null", target="/dev/null", null=NULLDEV_DEVICES),
+    dict(name="null8_to_split_files", target=None, null=NULLDEV_DEVICES, flags=["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)]),
+    dict(name="null8_to_file", target=None, null=NULLDEV_DEVICES),
+)
+GZ_READS = 50_000  # reads of the gzip legs (the first reads of the batch)
+E2E_DEFAULT_RUNS = ("to_dev_null_first_pass", "to_dev_null", "to_file", "to_split_files", "gz_in_multi", "gz_in_single",
+                    "gz_in_single_stream", "gz_out")
+
+
+def gzip_single_member(src, dst, level=1):
+    """src -> dst as ONE gzip member: libdeflate through ctypes when the image has it (one call on the whole text), else zlib"""
+    import ctypes as C
+
+    data = open(src, "rb").read()
+    try:
+        L = C.CDLL("libdeflate.so.0")
+        L.libdeflate_alloc_compressor.restype = C.c_void_p
+        L.libdeflate_gzip_compress_bound.restype = C.c_size_t
+        L.libdeflate_gzip_compress_bound.argtypes = [C.c_void_p, C.c_size_t]
+        L.libdeflate_gzip_compress.restype = C.c_size_t
+        L.libdeflate_gzip_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.libdeflate_free_compressor.argtypes = [C.c_void_p]
+        comp = L.libdeflate_alloc_compressor(level)
+        cap = L.libdeflate_gzip_compress_bound(comp, len(data))
+        buf = C.create_string_buffer(cap)
+        n = L.libdeflate_gzip_compress(comp, data, len(data), buf, cap)
+        L.libdeflate_free_compressor(comp)
+        assert n > 0
+        with open(dst, "wb") as f:
+            f.write(buf.raw[:n])
+        return "libdeflate level %d" % level
+    except (OSError, AssertionError, AttributeError):
+        import gzip
+
+        with gzip.open(dst, "wb", compresslevel=level) as f:
+            f.write(data)
+        return "zlib level %d" % level
 
 
 def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1, copies=None, with_pcie=True, run_names=None):
@@ -298,7 +351,9 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
     copies = copies or n_gpus
     per_copy = 2.0 * nb + 16.0 * n_reads
     # room per copy of the input in the scratch directory: the text itself, and as much again (+ slack) when a run writes its output there
-    writes = any(t is None and (not run_names or nm in run_names) for nm, t in E2E_RUNS)
+    run_names = tuple(run_names) if run_names else E2E_DEFAULT_RUNS
+    specs = [r for r in E2E_RUNS if r["name"] in run_names]
+    writes = any(r.get("target") is None for r in specs)
     room = 2.3 if writes else 1.2
     tmp = None
     head = mem_headroom()
@@ -343,21 +398,58 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
                     f.write(">ad%03d\n%s\n" % (i, a))
             cmd += ["-a", fa]
         runs = {}
+        json_check = None
+        # gzip copies of the first GZ_READS reads for the gz legs: many members (what bgzip, fastp / fastplong and this host write;
+        # made by this host: -o x.fq.gz with every stage off) and ONE member (what `gzip file.fq` writes; libdeflate through ctypes)
+        sub = os.path.join(tmp, "fpl_e2e_%d.sub.fq" % os.getpid())
+        gz_multi, gz_single, gz_outp = sub + ".multi.gz", sub + ".single.gz", sub + ".out.fq.gz"
+        n_sub = min(n_reads, GZ_READS)
+        nb_sub = int(off[n_sub])
+        if any(r.get("input", "fq") != "fq" for r in specs):
+            rc = host.fplh_write_fastq_ex(sub.encode(), seq.ctypes.data, qual.ctypes.data, off.ctypes.data, n_sub, b"r", 16, 0)
+            assert rc == 0
+            t0 = time.perf_counter()
+            subprocess.run([build.CLI, "-i", sub, "-o", gz_multi, "-A", "-Q", "-L", "-j", js, "-h", html], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=E2E_TIMEOUT_S, check=True)
+            t1 = time.perf_counter()
+            single_by = gzip_single_member(sub, gz_single)
+            res["gz_inputs"] = "%d reads, %.2f GB of text -> %.2f GB in many members (this host, %.1f s), %.2f GB in one member (%s, %.1f s)" % (
+                n_sub, os.path.getsize(sub) / 1e9, os.path.getsize(gz_multi) / 1e9, t1 - t0, os.path.getsize(gz_single) / 1e9,
+                single_by, time.perf_counter() - t1)
+        null_dir = None
+        if any(r.get("null") for r in specs):
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            from nulldev import build as null_build
+
+            null_dir = os.path.dirname(null_build.build())
         # the first pass over a file that has only just been written pays the kernel's first-touch bookkeeping of its
         # page-cache pages (every read marks them accessed / moves them between LRU lists, under contention from 16
         # parser threads): it is reported, the steady state is the second pass
-        for name, target in E2E_RUNS:
-            if run_names and name not in run_names:
-                continue
-            target = target or outp
+        for spec in specs:
+            name = spec["name"]
+            target = spec.get("target")
+            target = gz_outp if target == "GZ" else (target or outp)
+            which = spec.get("input", "fq")
+            infile = {"fq": fq, "fq_sub": sub, "gz_multi": gz_multi, "gz_single": gz_single}[which]
+            run_bases = nb * copies if which == "fq" else nb_sub
             # one file on tmpfs takes 6-9 GB/s whoever writes it (page-cache insertion of ONE inode serialises in the kernel);
             # --split N gives every worker's writer thread a file of its own
-            split = ["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)] if name == "to_split_files" else []
+            flags = list(spec.get("flags", []))
+            env = dict(os.environ, FPLH_T0=repr(time.time()), FPLH_TIMING="1")
+            run_cmd = [build.CLI, "-i", infile] + cmd[3:]
+            if spec.get("null"):  # the host side alone: N devices that take no time (tools/nulldev/fpl_null.cpp)
+                env["LD_LIBRARY_PATH"] = null_dir + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+                env["FPL_NULL_DEVICES"] = str(spec["null"])
+                run_cmd = [a for a in run_cmd]
+                if "--gpus" in run_cmd:
+                    i = run_cmd.index("--gpus")
+                    del run_cmd[i:i + 2]
+                run_cmd += ["--gpus", str(spec["null"])]
             t0 = time.perf_counter()
             # (a run that does not come back must not take the bench line with it: its own session, so that the whole process
             # group can be killed, and a bounded wait for its pipes afterwards -- a process stuck in the driver may never close them)
-            proc = subprocess.Popen(cmd + split + ["-o", target], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                    start_new_session=True, env=dict(os.environ, FPLH_T0=repr(time.time()), FPLH_TIMING="1"))
+            proc = subprocess.Popen(run_cmd + flags + ["-o", target], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                    start_new_session=True, env=env)
             try:
                 so, se = proc.communicate(timeout=E2E_TIMEOUT_S)
             except subprocess.TimeoutExpired:
@@ -380,29 +472,44 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
             for line in p.stderr.splitlines():
                 if line.startswith("host pipeline:"):
                     pipe = float(line.split("wall ")[1].split(" s")[0])
-                if line.startswith(("host pipeline:", "start-up:", "reports:", "since launch:", "chunk parsers", "counter merge:")):
+                if line.startswith(("host pipeline:", "start-up:", "reports:", "since launch:", "chunk parsers", "counter merge:", "kernel forms:", "input:")):
                     keep.append(line)
-            runs[name] = {"rc": p.returncode, "process_seconds": dt, "value": nb * copies / dt / 1e9,
-                          "pipeline_seconds": pipe, "pipeline_value": (nb * copies / pipe / 1e9) if pipe else None, "stages": keep}
+            runs[name] = {"rc": p.returncode, "process_seconds": dt, "value": run_bases / dt / 1e9, "bases": run_bases,
+                          "pipeline_seconds": pipe, "pipeline_value": (run_bases / pipe / 1e9) if pipe else None, "stages": keep}
+            if flags:
+                runs[name]["flags"] = " ".join(flags)
+            if name == "to_dev_null" and p.returncode == 0:  # (the report of THIS run: later runs write the same file names)
+                jr = json.load(open(js))
+                json_check = {"reads_in": jr["summary"]["before_filtering"]["total_reads"],
+                              "reads_out": jr["summary"]["after_filtering"]["total_reads"],
+                              "ok": jr["summary"]["before_filtering"]["total_reads"] == n_reads * copies}
+            if which != "fq" and p.returncode == 0:  # the gz legs must see every read of their input too
+                jr = json.load(open(js))
+                runs[name]["reads_in"] = jr["summary"]["before_filtering"]["total_reads"]
+                runs[name]["ok"] = runs[name]["reads_in"] == n_sub
+            if spec.get("null"):
+                runs[name]["what"] = ("the HOST side alone: bin/fastplong_amd --gpus %d against tools/nulldev (devices that take no time, "
+                                      "no page-locking, no PCIe traffic) on the %d CPUs of this box" % (spec["null"], len(os.sched_getaffinity(0))))
             if p.returncode != 0:
                 runs[name]["stderr_tail"] = p.stderr[-500:]
-            if split:
+            if "--split" in flags:
                 parts = sorted(glob.glob(os.path.join(tmp, "*." + os.path.basename(outp))))
                 runs[name]["files"] = len(parts)
                 runs[name]["bytes_written"] = sum(os.path.getsize(f) for f in parts)
-                runs[name]["what"] = "--split %d -w %d: %d files, one writer thread per worker (writev gather lists)" % (
+                runs[name]["what"] = runs[name].get("what", "") + " --split %d -w %d: %d files, one writer thread per worker (writev gather lists)" % (
                     E2E_SPLIT, E2E_SPLIT, len(parts))
                 for f in parts:
                     try:
                         os.remove(f)
                     except OSError:
                         pass
-            elif target == outp and os.path.exists(outp):
-                runs[name]["bytes_written"] = os.path.getsize(outp)
-            try:
-                os.remove(outp)
-            except OSError:
-                pass
+            elif target in (outp, gz_outp) and os.path.exists(target):
+                runs[name]["bytes_written"] = os.path.getsize(target)
+            for f in (outp, gz_outp):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
         res["cli"] = runs
         if runs.get("to_dev_null", {}).get("rc") == 0:
             res["value"] = runs["to_dev_null"]["value"]
@@ -413,12 +520,10 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
                            "whole process; cli.to_file = the same with the trimmed FASTQ written to tmpfs; "
                            "pipeline_value = without process start-up (HIP context) and the report writers" % (
                                " --gpus %d" % n_gpus if n_gpus > 1 else ""))
-            jr = json.load(open(js))
-            res["json_check"] = {"reads_in": jr["summary"]["before_filtering"]["total_reads"],
-                                 "reads_out": jr["summary"]["after_filtering"]["total_reads"],
-                                 "ok": jr["summary"]["before_filtering"]["total_reads"] == n_reads * copies}
+            if json_check:
+                res["json_check"] = json_check
     finally:
-        for f in [fq, outp, js, html, fa] + glob.glob(os.path.join(tmp, "*." + os.path.basename(outp))):
+        for f in [fq, outp, js, html, fa, fq.replace('.fq', '.sub.fq')] + glob.glob(os.path.join(tmp, "fpl_e2e_%d.sub.fq.*" % os.getpid())) + glob.glob(os.path.join(tmp, "*." + os.path.basename(outp))):
             try:
                 os.remove(f)
             except OSError:
@@ -696,7 +801,8 @@ def main(argv=None, rig=None):
         if args.e2e_copies > 1:
             try:
                 big = end_to_end(args.workload, opt, adapters, seq_t, qual_t, off_t, ne, copies=args.e2e_copies,
-                                 with_pcie=False, run_names=("to_dev_null", "to_file", "to_split_files"))
+                                 with_pcie=False, run_names=("to_dev_null", "to_file", "to_split_files", "chunk_512mb", "chunk_1536mb",
+                                            "null8_to_dev_null", "null8_to_split_files", "null8_to_file"))
                 out["e2e"]["large_input"] = big
             except Exception as e:
                 out["e2e"]["large_input"] = {"error": repr(e)[:300]}

@@ -4,7 +4,7 @@ Pure declarations: importing this module needs neither a GPU nor the built libra
 """
 import ctypes as C
 
-FPL_ABI_VERSION = 5
+FPL_ABI_VERSION = 6
 FPL_MAX_IN_FLIGHT = 2
 FPL_MAX_ADAPTER_LEN = 255
 FPL_END_WINDOW = 200

@@ -83,6 +83,7 @@ struct fpl_ctx {
     hipEvent_t ev[EV_RING][N_STAGES + 1] = {};
     int ev_calls = 0; /* batches recorded since fpl_enable_timing() */
     bool ev_ready = false; /* the whole event ring exists */
+    uint64_t forms[6] = {0, 0, 0, 0, 0, 0}; /* fpl_get_batch_forms */
     std::string err;
 };
 
@@ -494,8 +495,15 @@ const char* fpl_rccl_library(void) {
     return copy.c_str();
 }
 
+int fpl_get_batch_forms(const fpl_ctx* ctx, uint64_t out[6]) {
+    if (!ctx || !out) return FPL_ERR_ARG;
+    for (int i = 0; i < 6; i++) out[i] = ctx->forms[i];
+    return FPL_OK;
+}
+
 int fpl_reset_counters(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
+    for (int i = 0; i < 6; i++) ctx->forms[i] = 0;
     FPL_HIP(hipSetDevice(ctx->device));
     FPL_HIP(hipDeviceSynchronize());
     FPL_HIP(hipMemset(ctx->d_counters, 0, fpl_counters_len(ctx) * sizeof(long long)));
@@ -694,6 +702,13 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         ctx->probe_primed = true;
     }
     a.tune = ctx->tune;
+    if (n_reads) { /* which forms this batch takes (the same predicates enqueue_batch asks) */
+        ctx->forms[0]++;
+        ctx->forms[1] += n_reads;
+        ctx->forms[2] += trim_takes_batched(n_reads, a.trim_mode, a.tune) ? 1 : 0;
+        ctx->forms[3] += stats_takes_sorted(n_reads, n_bytes, max_read_len, a.n_cu, a.tune, a.defer) ? 1 : 0;
+        if (n_reads > ctx->forms[4]) ctx->forms[4] = n_reads;
+    }
     const bool timing = ctx->timing != 0;
     const int slot = ctx->ev_calls % fpl_ctx::EV_RING;
     hipError_t ev_err = hipSuccess;

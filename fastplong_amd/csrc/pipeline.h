@@ -221,7 +221,7 @@ inline u32 stats_sorted_max_slices(u32 n_reads, u32 per, const StatsTune& tune) 
  * unsorted pass it wins from about 200 k reads of 9 kb on (1 M: 6.7 -> 5.9 ms, 300 k: 2.19 -> 2.05, 100 k: 0.87 -> 1.00), and a
  * batch of a few thousand reads would hand nearly every read to the EXTRA pass (no front trim is shared by 256 of them).
  * A test hook that sets the bucket threshold asks for the sorted pass whatever the size. */
-constexpr u32 FS_SORT_MIN_READS = 150000;
+constexpr u32 FS_SORT_MIN_READS = FPL_FORM_STATS_SORTED_MIN;
 inline bool stats_use_sorted(u32 n_reads, const StatsTune& tune) {
     if (tune.sort_min) return n_reads >= tune.sort_min;
     if (tune.min_bucket) return true;
@@ -251,6 +251,16 @@ inline bool stats_takes_sorted(u32 n_reads, uint64_t n_bytes, u32 max_read_len, 
     return (uint64_t)stats_sorted_max_slices(n_reads, per, tune) * n_tiles < 0xFFFFFFF0ull;
 }
 
+#ifndef FPL_OPT_BATCH
+#define FPL_OPT_BATCH 1 /* the usual adapter set goes through k_trim_ends_batched (confirmations 64 reads at a time) */
+#endif
+/* do the end trims of a batch run in k_trim_ends_batched (the usual adapter set, 64 reads per wave)? */
+constexpr u32 TRIM_BATCH_MIN_READS = FPL_FORM_TRIM_BATCHED_MIN;
+inline bool trim_takes_batched(u32 n_reads, int trim_mode, const StatsTune& tune) {
+    const u32 batch_min = tune.trim_batch_min ? tune.trim_batch_min : TRIM_BATCH_MIN_READS;
+    return trim_mode == 1 && FPL_OPT_BATCH && n_reads >= batch_min;
+}
+
 template <class Mark>
 inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) {
     (void)stream;
@@ -275,13 +285,9 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         const u32 cap = FPL_TRIM_BLOCKS_PER_CU * a.n_cu;
         if (blocks > cap) blocks = cap;
         /* the usual adapter sets have their own, much smaller instantiations (DevConfig::trim_mode) */
-#ifndef FPL_OPT_BATCH
-#define FPL_OPT_BATCH 1 /* the usual adapter set goes through k_trim_ends_batched (confirmations 64 reads at a time) */
-#endif
         /* (a wave of the batched kernel walks its 64 reads one after the other through the per-read phases: 0.4 ms however few
            groups there are -- 2 000 reads: 0.42 ms against 0.03 for a wave per read; the two meet at about 100 k reads) */
-        const u32 batch_min = a.tune.trim_batch_min ? a.tune.trim_batch_min : 65536u;
-        if (a.trim_mode == 1 && FPL_OPT_BATCH && n >= batch_min) {
+        if (trim_takes_batched(n, a.trim_mode, a.tune)) {
             /* a wave takes 64 reads per round: enough waves to fill the chip, few enough to keep every wave a few rounds long */
             u32 gblocks = cdiv(cdiv(n, 64u), KWAVES);
             const u32 gcap = FPL_TRIM_WAVES_PER_SIMD_BATCHED * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */

@@ -599,10 +599,12 @@ int main(int argc, char* argv[]) {
                     munmap((void*)chunkMem, (size_t)reserved);
                     chunkMem = nullptr;
                 }
+                if (!chunkMem && cmd.exist("verbose"))
+                    cerr << "input: gzip text not expanded in memory (" << clk() - t0 << " s spent finding out): the sequential reader streams it" << endl;
                 if (chunkMem) { /* (the mapping lives until the process ends) */
                     chunkFileSize = sz;
                     if (cmd.exist("verbose"))
-                        cerr << "gzip members inflated into memory: " << sz << " bytes of text in " << clk() - t0 << " s" << endl;
+                        cerr << "input: gzip members inflated into memory: " << sz << " bytes of text in " << clk() - t0 << " s" << endl;
                 }
             }
         }
@@ -1026,6 +1028,21 @@ int main(int argc, char* argv[]) {
              << " s" << (chunked ? " (busiest of " + to_string(readerThreads) + " chunk parsers; " + to_string(nRedo) + " chunks parsed again, " + to_string(tRedo) + " s)" : string())
              << ", copies + kernels (waits) " << g << " s, format (" << fmtThreads << " threads) " << f << " s, write " << tWrite
              << " s" << endl;
+    }
+    if (cmd.exist("verbose")) { /* which kernel forms the batches took: the library picks by batch size (csrc/pipeline.h) */
+        uint64_t f[6] = {0, 0, 0, 0, 0, 0};
+        for (auto& D : dev) {
+            uint64_t g[6] = {0, 0, 0, 0, 0, 0};
+            if (fpl_get_batch_forms(D.ctx, g) == FPL_OK) {
+                for (int i = 0; i < 4; i++) f[i] += g[i];
+                f[4] = max(f[4], g[4]);
+            }
+        }
+        if (f[0])
+            cerr << "kernel forms: " << f[0] << " batches, mean " << f[1] / f[0] << " reads (largest " << f[4] << "); end trims: " << f[2]
+                 << " through k_trim_ends_batched (64 reads per wave, from " << FPL_FORM_TRIM_BATCHED_MIN << " reads on), " << f[0] - f[2]
+                 << " one wave per read; statistics: " << f[3] << " through k_stats_sorted (from " << FPL_FORM_STATS_SORTED_MIN
+                 << " reads on), " << f[0] - f[3] << " through the two-update k_stats" << endl;
     }
     for (OutFile* o : {&fout, &ffail})
         if (*o) {

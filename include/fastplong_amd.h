@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 5
+#define FPL_ABI_VERSION 6
 
 /* limits */
 #define FPL_MAX_ADAPTER_LEN 255 /* longest adapter the device path accepts            */
@@ -363,6 +363,20 @@ int fpl_pick_adapter(int32_t device, const uint8_t* seq, const uint64_t* off, ui
                      int32_t is_rna, fpl_adapter_pick* out);
 int fpl_reset_counters(fpl_ctx* ctx);
 int fpl_synchronize(fpl_ctx* ctx);
+
+/*
+ * Which kernel forms the batches of a context took since fpl_create() / fpl_reset_counters() (ABI v6).  The library picks
+ * per batch, by the batch's size: the end trims run in k_trim_ends_batched (64 reads per wave) from FPL_FORM_TRIM_BATCHED_MIN
+ * reads on and one wave per read below, the statistics pass is k_stats_sorted (one table update per base) from
+ * FPL_FORM_STATS_SORTED_MIN reads on and the two-update k_stats below (csrc/pipeline.h) -- a host that flushes small batches
+ * never runs the forms a large resident batch is timed on, and this call says so.  The reference has no counterpart (its
+ * unit of work is a pack of 16 reads, src/common.h:33).
+ *   out[0] batches   out[1] reads   out[2] batches through k_trim_ends_batched   out[3] batches through k_stats_sorted
+ *   out[4] reads of the largest batch   out[5] reserved (0)
+ */
+#define FPL_FORM_TRIM_BATCHED_MIN 65536
+#define FPL_FORM_STATS_SORTED_MIN 150000
+int fpl_get_batch_forms(const fpl_ctx* ctx, uint64_t out[6]);
 
 /*
  * Per-kernel timing, measured with HIP events recorded on the stream the kernels are launched

@@ -18,6 +18,7 @@ from tests.stub import build as stub_build
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
+ROOT = os.path.dirname(HERE)
 CASES = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
 
 
@@ -199,3 +200,41 @@ def test_cli_split_outputs_per_worker_writer_threads(tmp_path, stub_env, orc, mo
     assert sorted(got) == sorted(want) and len(want) >= 6
     for k in want:
         assert got[k] == want[k], k
+
+
+def test_cli_against_the_null_device_is_the_host_side_alone(tmp_path):
+    """tools/nulldev (measurement infrastructure behind bench.py's e2e host_ceiling runs): eight devices that take no time and call
+    every read one passing fragment -- the CLI then writes its input back out, batch by batch over eight device threads, and the
+    reports carry the totals; the library exports every symbol the header declares (the CLI links against that set)"""
+    import ctypes as C
+    import re
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from nulldev import build as null_build
+
+    lib = null_build.build()
+    build.build_host()
+    L = C.CDLL(lib)
+    for name in sorted(set(re.findall(r"\b(fpl_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "fastplong_amd.h")).read()))):
+        if name not in ("fpl_process_batch_device", "fpl_counters_device_ptr", "fpl_enable_timing", "fpl_get_kernel_times", "fpl_wait_"):
+            assert hasattr(L, name), name  # (the device-pointer calls and the kernel timers have no meaning without a device)
+    assert L.fpl_abi_version() == abi.FPL_ABI_VERSION
+    text = gz(os.path.join(GOLD, CASES[0], "in.fq.gz"))
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(lib) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
+               FPL_NULL_DEVICES="8", FPLH_CHUNK_BYTES="30000")
+    p = subprocess.run([build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "-s", "ACGTACGTACGTACGTACGT", "-e", "TTGCATTGCATTGCATTGCA",
+                        "-j", str(tmp_path / "o.json"), "-h", str(tmp_path / "o.html"), "--gpus", "8", "--reader_threads", "3", "-V"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = text.split(b"\n")
+    want = b"".join(lines[i] + b"\n" + lines[i + 1] + b"\n" + lines[i + 2] + b"\n" + lines[i + 3] + b"\n" for i in range(0, len(lines) - 1, 4))
+    assert (tmp_path / "out.fq").read_bytes() == want
+    j = json.load(open(tmp_path / "o.json"))
+    assert j["summary"]["before_filtering"]["total_reads"] == (len(lines) - 1) // 4 == j["filtering_result"]["passed_filter_reads"]
+    # nine devices are one too many for eight
+    p = subprocess.run([build.CLI, "-i", str(inp), "-o", "/dev/null", "-s", "ACGTACGTACGTACGTACGT", "-e", "TTGCATTGCATTGCATTGCA", "--gpus", "9",
+                        "-j", str(tmp_path / "o.json"), "-h", str(tmp_path / "o.html")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+    assert p.returncode != 0

@@ -152,7 +152,7 @@ def test_cli_gather_output_reproduces_golden_on_gpu(tmp_path, case, how):
     got = p.stdout if how != "file_forced" else (tmp_path / "out.fq").read_bytes()
     assert got == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
     if how == "gz_input":
-        assert b"gzip members inflated into memory" in p.stderr and b"chunk parsers" in p.stderr
+        assert b"input: gzip members inflated into memory" in p.stderr and b"chunk parsers" in p.stderr
 
 
 @pytest.mark.gpu

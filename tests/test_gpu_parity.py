@@ -786,6 +786,43 @@ def test_full_quality_byte_range_bench_sized_no_hooks_bit_exact(orc, engine_mod,
     assert "no hook set" in what
 
 
+def test_batch_forms_say_which_kernels_a_batch_took(engine_mod, monkeypatch):
+    """fpl_get_batch_forms (ABI v6): the library picks k_trim_ends_batched / k_stats_sorted by the batch's size; a host that
+    flushes small batches runs the other forms, and this call is how it finds out"""
+    import torch
+
+    for k in ("FPL_TRIM_BATCH_MIN", "FPL_STATS_SORT_MIN", "FPL_STATS_MIN_BUCKET", "FPL_STATS_PER"):
+        monkeypatch.delenv(k, raising=False)
+    opt = abi.FplOptions.default(cut_front=1, cut_tail=1, polyx=1)
+    seq, qual, off = synth.ont_like(2000, seed=3, median_len=600)
+    eng = engine_mod.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=int(np.diff(off.astype(np.int64)).max()))
+    eng.process_host(seq, qual, off)
+    eng.process_host(seq[:int(off[500])], qual[:int(off[500])], off[:501])
+    assert eng.batch_forms() == dict(batches=2, reads=2500, trim_batched=0, stats_sorted=0, largest=2000)
+    eng.reset_counters()
+    assert eng.batch_forms()["batches"] == 0
+    # 160 000 short reads: both thresholds crossed
+    n = 160_000
+    lens = torch.full((n,), 400, dtype=torch.int64)
+    off_t = torch.zeros(n + 1, dtype=torch.int64)
+    off_t[1:] = torch.cumsum(lens, 0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    st = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")[torch.randint(0, 4, (n * 400,), generator=g, device="cuda")]
+    qt = torch.randint(40, 70, (n * 400,), generator=g, device="cuda", dtype=torch.int64).to(torch.uint8)
+    eng.process_device(st, qt, off_t.cuda(), 400)
+    torch.cuda.synchronize()
+    assert eng.batch_forms() == dict(batches=1, reads=n, trim_batched=1, stats_sorted=1, largest=n)
+    eng.close()
+    # the test hooks move the thresholds, and the report follows what really ran
+    monkeypatch.setenv("FPL_TRIM_BATCH_MIN", "1")
+    monkeypatch.setenv("FPL_STATS_SORT_MIN", "1")
+    eng = engine_mod.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=int(np.diff(off.astype(np.int64)).max()))
+    eng.process_host(seq, qual, off)
+    assert eng.batch_forms() == dict(batches=1, reads=2000, trim_batched=1, stats_sorted=1, largest=2000)
+    eng.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_long_trim_scans_fall_back_bit_exact(orc, engine_mod, seed):
     """k_trim_ends_batched: lanes whose trimAndCut / polyX scans outlast the iteration cap are redone by the wave-per-read forms"""
