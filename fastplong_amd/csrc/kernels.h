@@ -153,6 +153,17 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_PAIR_MIN_LANES
 #define FPL_PAIR_MIN_LANES 12 /* ... when at least this many lanes are left for it (a packed tile costs ~100 instructions more) */
 #endif
+#ifndef FPL_OPT_TRIMTOUCH
+#define FPL_OPT_TRIMTOUCH 1 /* k_trim_ends_batched: a phase asks for the cache lines its dependent loads will walk into -- both ends of the
+                               qualities and of the bases in front of trimAndCut / polyX, the second line of a window in front of a window
+                               scan -- all at once, so that a lane sits out ONE trip to memory per phase instead of one per line
+                               (section timers, profiles/r05_trim: trimAndCut + polyX were a third of the kernel's wave cycles) */
+#endif
+#ifndef FPL_OPT_TRIMREG
+#define FPL_OPT_TRIMREG 1 /* k_trim_ends_batched: the first 16 steps of trimAndCut's two window scans and the first 32 of polyX's tail scan
+                             run out of 16-byte blocks loaded up front (a lane's step count is the wave's loop count, so the byte a step
+                             needs sits at a compile-time place of the block) instead of one dependent byte load per step */
+#endif
 #ifndef FPL_OPT_PARTLANES
 #define FPL_OPT_PARTLANES 1 /* k_trim_ends_batched: the partial-pattern searches with lane = read on the columns the search
                                pass leaves open (partial16_candidates / partial16_resolve_lanes) instead of a wave and 184
@@ -1548,6 +1559,36 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
 constexpr int LANE_SCAN_CAP = 160;
 constexpr int LANE_SCAN_WMAX = 16; /* windows beyond this take the wave-per-read form for every read (the warm-up sum is a loop) */
 
+/* byte K (0..15, compile time) of a 16-byte block */
+template <int K>
+__device__ __forceinline__ u32 byte16(const u32x4& v) {
+    const u32 d = K < 4 ? v.x : (K < 8 ? v.y : (K < 12 ? v.z : v.w));
+    return (d >> (8 * (K & 3))) & 0xFFu;
+}
+/* the sum of the first n (0..16, wave-uniform) bytes of a block / of its last n */
+__device__ __forceinline__ u32 sum_first_bytes(const u32x4& v, int n) {
+    const u32 d[4] = {v.x, v.y, v.z, v.w};
+    u32 t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = n - 4 * k;
+        const u32 bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
+        t = sum_bytes(d[k] & bm, t);
+    }
+    return t;
+}
+__device__ __forceinline__ u32 sum_last_bytes(const u32x4& v, int n) {
+    const u32 d[4] = {v.w, v.z, v.y, v.x};
+    u32 t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = n - 4 * k;
+        const u32 bm = c >= 4 ? ~0u : (c <= 0 ? 0u : ~((1u << (8 * (4 - c))) - 1u));
+        t = sum_bytes(d[k] & bm, t);
+    }
+    return t;
+}
+
 /* Filter::trimAndCut, src/filter.cpp:130-232, one read per lane: sq / ql = this lane's read (length l).
    Out: alive (false: the reference returns NULL), [s, e) in coordinates of the read, slow (see above). */
 __device__ __forceinline__ void trim_and_cut_lanes(const u8* __restrict__ sq, const u8* __restrict__ ql, int l, bool valid,
@@ -1567,14 +1608,50 @@ __device__ __forceinline__ void trim_and_cut_lanes(const u8* __restrict__ sq, co
         e_out = front + rlen;
         return;
     }
+    u32 touch = 0;
+    if (FPL_OPT_TRIMTOUCH && valid && l > 0) {
+        /* the four lines the scans below (and polyX behind them) start in: requested together, consumed one after the other */
+        const int h = min(front, l - 1), t = max(l - 1 - tail, 0);
+        touch = (u32)ql[h] + (u32)ql[t] + (u32)sq[h] + (u32)sq[t];
+    }
     if (cf) { /* :159-189 */
         const int w = cfg->cut_front_w, thr = cfg->cut_front_thr;
         if (l - front - tail - w <= 0) alive = false;
         const int lim = l - tail - w; /* the loop runs while s < lim */
         int s = front, total = 0, it = 0;
-        if (alive)
+        bool fin = false; /* this lane's scan is over (the first 16 steps below may end it) */
+        /* the first 16 steps out of two blocks: step k adds qual[front + w - 1 + k] and takes qual[front + k - 1] out again -- byte k
+           of A, byte k - 1 of S, whichever lane (front and w are the same for all; the lanes that stop drop out) */
+        const bool reg = FPL_OPT_TRIMREG && alive && w <= 16 && front + w + 15 <= l;
+        if (FPL_OPT_TRIMREG && wave_ballot(reg)) { /* (wave-uniform) */
+            u32x4 A = {0, 0, 0, 0}, S = {0, 0, 0, 0};
+            if (reg) {
+                A = load16(ql + front + w - 1);
+                S = load16(ql + front);
+                total = (int)sum_first_bytes(S, w - 1);
+            }
+            bool run = reg && s < lim;
+            fin = reg && !run;
+#define FPL_CF_STEP(K)                                                                  \
+    if (wave_ballot(run)) {                                                             \
+        const int t2 = total + (int)byte16<K>(A) - (K > 0 ? (int)byte16<(K > 0 ? K - 1 : 0)>(S) : 0); \
+        total = run ? t2 : total;                                                       \
+        const bool stop = run && total >= thr;                                          \
+        fin = fin || stop;                                                              \
+        run = run && !stop;                                                             \
+        s += run ? 1 : 0;                                                               \
+        const bool out = run && s >= lim;                                               \
+        fin = fin || out;                                                               \
+        run = run && !out;                                                              \
+    }
+            FPL_CF_STEP(0) FPL_CF_STEP(1) FPL_CF_STEP(2) FPL_CF_STEP(3) FPL_CF_STEP(4) FPL_CF_STEP(5) FPL_CF_STEP(6) FPL_CF_STEP(7)
+            FPL_CF_STEP(8) FPL_CF_STEP(9) FPL_CF_STEP(10) FPL_CF_STEP(11) FPL_CF_STEP(12) FPL_CF_STEP(13) FPL_CF_STEP(14) FPL_CF_STEP(15)
+#undef FPL_CF_STEP
+            it = reg ? 16 : 0; /* (a lane still running has made 16 steps; for the others the count no longer matters) */
+        }
+        if (alive && !reg)
             for (int i = 0; i < w - 1; i++) total += ql[front + i];
-        while (alive && !slow && s < lim) {
+        while (alive && !slow && !fin && s < lim) {
             total += ql[s + w - 1];
             if (s > front) total -= ql[s - 1];
             if (total >= thr) break; /* total / w >= 33 + q */
@@ -1594,9 +1671,39 @@ __device__ __forceinline__ void trim_and_cut_lanes(const u8* __restrict__ sq, co
         const int w = cfg->cut_tail_w, thr = cfg->cut_tail_thr;
         if (l - front - tail - w <= 0) alive = false;
         int t = l - tail - 1, total = 0, it = 0;
-        if (alive && !slow)
+        bool fin = false;
+        /* the mirror image: step k adds qual[T0 - w + 1 - k] and takes qual[T0 + 1 - k] out again (T0 = l - tail - 1, a lane's own):
+           byte 15 - k of the block that ENDS at T0 - w + 1, byte 16 - k of the block that ends at T0 */
+        const bool reg = FPL_OPT_TRIMREG && alive && !slow && w <= 16 && t >= w + 14;
+        if (FPL_OPT_TRIMREG && wave_ballot(reg)) { /* (wave-uniform) */
+            u32x4 A = {0, 0, 0, 0}, S = {0, 0, 0, 0};
+            if (reg) {
+                A = load16(ql + t - w + 1 - 15);
+                S = load16(ql + t - 15);
+                total = (int)sum_last_bytes(S, w - 1); /* qual[t - w + 2 .. t] */
+            }
+            bool run = reg && t - w >= front;
+            fin = reg && !run;
+#define FPL_CT_STEP(K)                                                                  \
+    if (wave_ballot(run)) {                                                             \
+        const int t2 = total + (int)byte16<15 - K>(A) - (K > 0 ? (int)byte16<(K > 0 ? 16 - K : 0)>(S) : 0); \
+        total = run ? t2 : total;                                                       \
+        const bool stop = run && total >= thr;                                          \
+        fin = fin || stop;                                                              \
+        run = run && !stop;                                                             \
+        t -= run ? 1 : 0;                                                               \
+        const bool out = run && t - w < front;                                          \
+        fin = fin || out;                                                               \
+        run = run && !out;                                                              \
+    }
+            FPL_CT_STEP(0) FPL_CT_STEP(1) FPL_CT_STEP(2) FPL_CT_STEP(3) FPL_CT_STEP(4) FPL_CT_STEP(5) FPL_CT_STEP(6) FPL_CT_STEP(7)
+            FPL_CT_STEP(8) FPL_CT_STEP(9) FPL_CT_STEP(10) FPL_CT_STEP(11) FPL_CT_STEP(12) FPL_CT_STEP(13) FPL_CT_STEP(14) FPL_CT_STEP(15)
+#undef FPL_CT_STEP
+            it = reg ? 16 : 0;
+        }
+        if (alive && !slow && !reg)
             for (int i = 0; i < w - 1; i++) total += ql[t - i]; /* qual[t - w + 2 .. t] */
-        while (alive && !slow && t - w >= front) {
+        while (alive && !slow && !fin && t - w >= front) {
             total += ql[t - w + 1];
             if (t < l - tail - 1) total -= ql[t + 1];
             if (total >= thr) break;
@@ -1614,6 +1721,11 @@ __device__ __forceinline__ void trim_and_cut_lanes(const u8* __restrict__ sq, co
     if (rlen <= 0 || front >= l - 1) alive = false; /* :221-222 */
     s_out = front;
     e_out = front + rlen;
+#if !defined(FPL_EMU)
+    if (FPL_OPT_TRIMTOUCH) asm volatile("" ::"v"(touch)); /* (keeps the touch loads alive) */
+#else
+    (void)touch;
+#endif
 }
 
 /* PolyX::trimPolyX, src/polyx.cpp:11-78, one read per lane: r = first base of r1 (rlen bases).  Returns the new
@@ -1625,7 +1737,40 @@ __device__ __forceinline__ int trim_polyx_lanes(const u8* __restrict__ r, int rl
     int cA = 0, cT = 0, cC = 0, cG = 0;
     int P = rlen; /* value of pos when the scan ends without a break */
     int pos = 0, it = 0;
-    while (active && !slow && pos < rlen) {
+    bool fin = false;
+    /* the first 32 steps out of the read's last 32 bytes, loaded up front: step k looks at byte 31 - k of them, whichever lane */
+    const bool reg = FPL_OPT_TRIMREG && active && !slow && rlen >= 32;
+    if (FPL_OPT_TRIMREG && wave_ballot(reg)) { /* (wave-uniform) */
+        u32x4 R0 = {0, 0, 0, 0}, R1 = {0, 0, 0, 0};
+        if (reg) {
+            R0 = load16(r + rlen - 16);
+            R1 = load16(r + rlen - 32);
+        }
+        bool run = reg; /* (rlen >= 32: no lane runs out of read here) */
+#define FPL_PX_STEP(K)                                                                                          \
+    if (wave_ballot(run)) {                                                                                     \
+        const u32 c = K < 16 ? byte16<15 - (K & 15)>(R0) : byte16<15 - (K & 15)>(R1);                            \
+        const int isn = c == 'N' ? 1 : 0;                                                                       \
+        cA += run ? ((c == 'A' ? 1 : 0) + isn) : 0;                                                             \
+        cT += run ? ((c == 'T' ? 1 : 0) + isn) : 0;                                                             \
+        cC += run ? ((c == 'C' ? 1 : 0) + isn) : 0;                                                             \
+        cG += run ? ((c == 'G' ? 1 : 0) + isn) : 0;                                                             \
+        constexpr int cmp = K + 1, allowed = cmp / 8 < 5 ? cmp / 8 : 5;                                         \
+        const bool need = (cmp - cA > allowed) && (cmp - cT > allowed) && (cmp - cC > allowed) && (cmp - cG > allowed); \
+        const bool stop = run && need && (K >= 8 || K + 1 >= compareReq - 1);                                   \
+        P = stop ? K : P;                                                                                       \
+        fin = fin || stop;                                                                                      \
+        run = run && !stop;                                                                                     \
+        pos += run ? 1 : 0;                                                                                     \
+    }
+        FPL_PX_STEP(0) FPL_PX_STEP(1) FPL_PX_STEP(2) FPL_PX_STEP(3) FPL_PX_STEP(4) FPL_PX_STEP(5) FPL_PX_STEP(6) FPL_PX_STEP(7)
+        FPL_PX_STEP(8) FPL_PX_STEP(9) FPL_PX_STEP(10) FPL_PX_STEP(11) FPL_PX_STEP(12) FPL_PX_STEP(13) FPL_PX_STEP(14) FPL_PX_STEP(15)
+        FPL_PX_STEP(16) FPL_PX_STEP(17) FPL_PX_STEP(18) FPL_PX_STEP(19) FPL_PX_STEP(20) FPL_PX_STEP(21) FPL_PX_STEP(22) FPL_PX_STEP(23)
+        FPL_PX_STEP(24) FPL_PX_STEP(25) FPL_PX_STEP(26) FPL_PX_STEP(27) FPL_PX_STEP(28) FPL_PX_STEP(29) FPL_PX_STEP(30) FPL_PX_STEP(31)
+#undef FPL_PX_STEP
+        it = reg ? 32 : 0;
+    }
+    while (active && !slow && !fin && pos < rlen) {
         const u32 c = r[rlen - pos - 1];
         cA += (c == 'A' || c == 'N');
         cT += (c == 'T' || c == 'N');
@@ -1708,6 +1853,9 @@ __device__ __forceinline__ void ham_scan_lanes(const u8* __restrict__ r1, int rl
         if (left < 4) w &= (1u << (8 * left)) - 1u;
         return onehot4(w);
     };
+    u32 touch = 0;
+    if (FPL_OPT_TRIMTOUCH && navail > 64) /* the window's second (and third) cache line, asked for now */
+        touch = (u32)*(base + min(navail - 1, 112)) + (u32)*(base + min(navail - 1, 207));
     u32 W[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) W[k] = nibbles(2 * k) | (nibbles(2 * k + 1) << 16);
@@ -1745,6 +1893,11 @@ __device__ __forceinline__ void ham_scan_lanes(const u8* __restrict__ r1, int rl
         }
     }
     if (hit >= 0) cand = -1;
+#if !defined(FPL_EMU)
+    if (FPL_OPT_TRIMTOUCH) asm volatile("" ::"v"(touch));
+#else
+    (void)touch;
+#endif
 }
 
 /* Global edit distance <= thr? between the adapter slice [shift, shift + m) (m <= 32; peqf = word 0 of the adapter's Peq
@@ -1998,6 +2151,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
     __shared__ TrimLds<WAVES> lds;
     __shared__ int thr_lds[40]; /* DevConfig::thr[0..32] */
     __shared__ u32 cand_lds[FPL_OPT_PARTLANES ? WAVES : 1][PART_WORDS][64]; /* per lane: the columns its partial-pattern search may end at */
+    PROF_INIT();
     const int lane = lane_id();
     u32(*const cand)[64] = cand_lds[FPL_OPT_PARTLANES ? wave_in_block() : 0];
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x) acc.fr[i] = 0;
@@ -2083,6 +2237,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         int v_mpos = -1; /* full match decided at this r1 position */
         int v_cand = -1; /* candidate of the window scan that still needs its edit distance */
 
+        PROF(0) /* dequeue, offsets */
         /* ---- P1a: trimAndCut and polyX, lane = read */
         bool v_slow = false;
         {
@@ -2107,6 +2262,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             v_alive = alive ? 1 : 0;
             v_slow = slow;
         }
+        PROF(1) /* trimAndCut + polyX, lane = read */
         /* ---- P1b: the reads whose scans ran long (and every read when a cut window is wide), lanes = positions */
         for (u64 todo = wave_ballot(v_slow); todo;) {
             const int j = __ffsll(todo) - 1;
@@ -2135,11 +2291,13 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             lane_set(v_e, j, e);
             lane_set(v_alive, j, alive ? 1 : 0);
         }
+        PROF(2) /* their wave-per-read fallback */
         /* ---- P1c: start adapter window scan, lane = read (searchAdapter, asRightAsPossible, :109-131) */
         if (do_start) {
             const bool act = v_alive && (v_e - v_s) >= FPL_PATTERN_LEN;
             ham_scan_lanes<true>(seq + v_o0 + v_s, v_e - v_s, act, ad1h0, alen0, thrA0, seq_end, v_mpos, v_cand);
         }
+        PROF(3) /* window scan, start */
         /* ---- P2: the candidates' edit distance, 64 reads at once */
         if (do_start) {
             const bool need = v_cand >= 0;
@@ -2149,6 +2307,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
                 v_mpos = ok ? v_cand : v_mpos;
             }
         }
+        PROF(4) /* candidate confirmation, start */
         /* ---- P3: partial-pattern search at the start for the reads without a full match (:202-216) */
         int v_ppos = -1;
         if (do_start) {
@@ -2197,6 +2356,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
                 lane_set(v_ppos, j, best != ~0ull ? (int)(u32)best : -1);
             }
         }
+        PROF(5) /* partial-pattern search, start */
         /* ---- P4: confirm the partial matches; finish the start trim (:185-193, :218-233) */
         if (do_start) {
             const int rlen = v_e - v_s;
@@ -2223,6 +2383,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             v_trim += got;
             if (kl > 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
         }
+        PROF(6) /* partial confirmation, start */
         /* ---- P5: end adapter window scan, lane = read (searchAdapter, asLeftAsPossible, :84-107) */
         v_mpos = -1;
         v_cand = -1;
@@ -2230,6 +2391,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             const bool act = v_alive && (v_e - v_s) >= FPL_PATTERN_LEN;
             ham_scan_lanes<false>(seq + v_o0 + v_s, v_e - v_s, act, ad1h1, alen1, thrA1, seq_end, v_mpos, v_cand);
         }
+        PROF(7) /* window scan, end */
         /* ---- P6 */
         if (do_end) {
             const bool need = v_cand >= 0;
@@ -2239,6 +2401,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
                 v_mpos = ok ? v_cand : v_mpos;
             }
         }
+        PROF(8) /* candidate confirmation, end */
         /* ---- P7: partial-pattern search walking in from the tail (:273-286) */
         v_ppos = -1;
         if (do_end) {
@@ -2300,6 +2463,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
                 lane_set(v_ppos, j, pos > 0 ? pos : -1); /* :288 strict */
             }
         }
+        PROF(9) /* partial-pattern search, end */
         /* ---- P8: confirm; finish the end trim (:256-264, :288-299); the records */
         if (do_end) {
             const int rlen = v_e - v_s;
@@ -2340,12 +2504,14 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             st.pad = 0;
             state[g0 + lane] = st;
         }
+        PROF(10) /* partial confirmation, end; counters; state */
 #if FPL_OPT_TRIMPF && !defined(FPL_EMU)
         asm volatile("" ::"v"(pf_keep)); /* (keeps the touch loads alive; they have long returned) */
 #elif FPL_OPT_TRIMPF
         (void)pf_keep;
 #endif
     }
+    PROF_FLUSH(32);
     __syncthreads();
     long long* fr = counters + FPL_OFF_FR(C);
     long long* keyh = counters + FPL_OFF_KEYHIST(C);

@@ -202,7 +202,10 @@ inline u32 stats_extra_blocks(u32 n_reads, const StatsTune& tune, u32 heavy_tile
         cap = cdiv(5 * n_cu / 4, heavy_tiles);
         cap = cap < 8 ? 8 : cap;
     }
-    return b < cap ? b : (cap < FS_EXTRA_BLOCKS ? cap : FS_EXTRA_BLOCKS);
+    /* never more than FS_EXTRA_BLOCKS: that is what the side stream's slabs are sized for (a batch of 150 000 .. 163 000 reads
+       shorter than a cycle tile used to get 2 n / 1024 blocks here -- found by tests/test_gpu_parity.py::test_batch_forms_...) */
+    const u32 lim = cap < (u32)FS_EXTRA_BLOCKS ? cap : (u32)FS_EXTRA_BLOCKS;
+    return b < lim ? b : lim;
 }
 /* items a block may accumulate before it must empty its tables (test hook: force that path) */
 inline u32 stats_extra_max_acc(const StatsTune& tune) { return tune.extra_acc ? tune.extra_acc : CS_MAX_ITEMS_PER_SLICE; }

@@ -25,9 +25,15 @@ for it in range(2):
 v = np.array(out[:], dtype=np.float64)
 names = {"k_scan": (0, ["dequeue/meta/prefetch", "hist_zero", "body scan", "hist_totals(body)", "ends", "hist_totals(all)",
                         "median+acc", "lev confirm (rest)", "filter+frag stats", "result/plan/fbuf", "pre-lev", "lev_pair32_run"]),
-         "k_trim_ends": (16, ["meta", "trim_and_cut", "polyX", "start adapter", "end adapter", "state write"])}
+         "k_trim_ends": (16, ["meta", "trim_and_cut", "polyX", "start adapter", "end adapter", "state write"]),
+         "k_trim_ends_batched": (32, ["dequeue, offsets", "trimAndCut + polyX (lane = read)", "their wave-per-read fallback", "window scan, start",
+                                      "candidate confirmation, start", "partial-pattern search, start", "partial confirmation, start",
+                                      "window scan, end", "candidate confirmation, end", "partial-pattern search, end",
+                                      "partial confirmation, end + state"])}
 for k, (b, nm) in names.items():
     tot = v[b:b + 12].sum()
+    if tot == 0:
+        continue
     print(k, "total wave-cycles %.3g, per read %.0f" % (tot, tot / n))
     for i, s in enumerate(nm):
         print("   %-24s %5.1f%%  %8.0f cyc/read" % (s, 100 * v[b + i] / tot, v[b + i] / n))
