@@ -50,9 +50,6 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_REDO_PREFETCH
 #define FPL_REDO_PREFETCH 1 /* k_redo: the next tile's cache lines are touched one tile ahead */
 #endif
-#ifndef FPL_OPT_REDO_DYN
-#define FPL_OPT_REDO_DYN 0 /* k_redo takes its items off a device counter (work_ctr[4]) instead of walking the list with a fixed stride */
-#endif
 #ifndef FPL_REDO_WAVES
 #define FPL_REDO_WAVES 8 /* k_redo: waves per block; three such blocks fit a CU (LDS: 4.5 KiB per wave, 70 VGPRs) */
 #endif
@@ -74,16 +71,8 @@ __device__ unsigned long long g_fpl_prof[64];
                           2: the ragged last tile of a range too -- measured the same (6.756 vs 6.753 ms, 2 kb reads 10.62 vs
                           10.54 ms, profiles/r02_ab), so the ragged tile keeps the byte-masked variants */
 #endif
-#ifndef FPL_OPT_ROWGUARD
-#define FPL_OPT_ROWGUARD 0 /* k_stats_sorted: one wave-uniform bounds test per row instead of one per lane and load -- 9 % SLOWER
-                              side by side (5.92 -> 6.44 ms): the second copy of the loads costs four more spilled registers */
-#endif
 #ifndef FPL_OPT_CSA16
 #define FPL_OPT_CSA16 1 /* k_scan match counts: carry-save groups of sixteen adapter bases where the adapter has them */
-#endif
-#ifndef FPL_OPT_PREFETCH
-#define FPL_OPT_PREFETCH 0 /* k_scan touches the lines of a read's next tile one tile ahead (range_scan_fast): 2 % slower side by side --
-                              the other waves of the SIMD already cover the trip to HBM */
 #endif
 #ifndef FPL_OPT_BCNT
 #define FPL_OPT_BCNT 1 /* v_bcnt_u32_b32 with its addend in the passFilter sums (sums32) */
@@ -110,11 +99,6 @@ __device__ unsigned long long g_fpl_prof[64];
 #ifndef FPL_OPT_VALADDC
 #define FPL_OPT_VALADDC 1 /* sliced_max: the value bit by bit through add-with-carry */
 #endif
-#ifndef FPL_OPT_PFNEXT
-#define FPL_OPT_PFNEXT 0 /* k_scan: the last tile of a read touches the lines of the next read's head (L2 prefetch across the read
-                            boundary).  Measured SLOWER: 5.47 -> 5.69 ms at 8 kb reads, 2.18 -> 2.41 ms at 2 kb -- a read's first tile is not
-                            what its wave waits for */
-#endif
 #ifndef FPL_OPT_PADSCALAR
 #define FPL_OPT_PADSCALAR 1 /* k_scan: the ragged last tile of a range is padded with wave-uniform byte masks (one lane is cut by
                                the end of the range, and which one is a scalar) instead of per-lane ones: 25 instead of 97 vector
@@ -128,15 +112,6 @@ __device__ unsigned long long g_fpl_prof[64];
 #endif
 #ifndef FPL_OPT_PACKRED
 #define FPL_OPT_PACKRED 1 /* k_scan / k_redo: the wave reductions behind a range scan take two values each where the range's length allows */
-#endif
-#ifndef FPL_OPT_TRIMPF
-#define FPL_OPT_TRIMPF 0 /* k_trim_ends_batched: the cache lines of the NEXT group of 64 reads requested a group ahead -- SLOWER (1.24 -> 1.42 ms
-                            per million reads, round 4): loads return in order, so whatever the group at hand loads next waits for the
-                            touches of the group after it; there is no prefetch instruction on gfx950 that leaves vmcnt alone */
-#endif
-#ifndef FPL_OPT_CLSPERM
-#define FPL_OPT_CLSPERM 0 /* k_stats_sorted: the LDS cell of a byte through one v_perm per byte (+ two instructions per dword) instead of
-                             v_bfe + v_mad per byte: four vector instructions fewer per row and SLOWER (4.92 -> 4.99 ms, round 4) */
 #endif
 #ifndef FPL_OPT_INCVALU
 #define FPL_OPT_INCVALU 1 /* k_stats_sorted: a byte's packed increment built on the vector unit instead of read from a 256-entry LDS table:
@@ -2188,41 +2163,11 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
     /* groups of 64 reads are handed out through one counter (zeroed before the batch): the grid is what the chip holds
        at once, and no wave idles while another still has rounds to go */
     const u32 n_groups = (n_reads + 63) / 64;
-#if FPL_OPT_TRIMPF
-    /* this kernel is the first to touch a read: every phase's first byte of a lane is a trip to HBM, one behind the other.  A wave
-       therefore holds TWO groups -- the one it works on and the next one, whose reads' first and last lines (bases and
-       qualities) it requests now, a whole group's work ahead of their use */
-    u32 grp_next = 0;
-    if (lane == 0) grp_next = atomicAdd(group_ctr, 1u);
-    grp_next = readlane_u32(grp_next, 0);
-#endif
     for (;;) {
-#if FPL_OPT_TRIMPF
-        const u32 grp = grp_next;
-        if (grp >= n_groups) break;
-        {
-            u32 nx = 0;
-            if (lane == 0) nx = atomicAdd(group_ctr, 1u);
-            grp_next = readlane_u32(nx, 0);
-        }
-        u32 pf_keep = 0;
-        if (grp_next < n_groups && (u32)lane < min(64u, n_reads - grp_next * 64)) {
-            const uint64_t po0 = off[grp_next * 64 + lane], po1 = off[grp_next * 64 + lane + 1];
-            if (po1 > po0) {
-                const uint64_t hl = po1 - po0 < 384 ? po1 - 1 : po0 + 383, tl = po1 - po0 < 384 ? po0 : po1 - 384;
-                /* the first / last 384 bytes of the bases (cut, polyX, the 200-base windows of both adapter searches), the first /
-                   last 128 of the qualities (cut): one byte per 128-byte line */
-                pf_keep = (u32)seq[po0] + seq[min(po0 + 128, hl)] + seq[min(po0 + 256, hl)] + seq[hl] + (u32)seq[po1 - 1] +
-                          seq[max(po1 - 129, tl)] + seq[max(po1 - 257, tl)] + seq[tl] + (u32)qual[po0] + qual[min(po0 + 127, po1 - 1)] +
-                          (u32)qual[po1 - 1] + qual[max(po1 - 128, po0)];
-            }
-        }
-#else
         u32 grp = 0;
         if (lane == 0) grp = atomicAdd(group_ctr, 1u);
         grp = readlane_u32(grp, 0);
         if (grp >= n_groups) break;
-#endif
         const u32 g0 = grp * 64;
         const int gn = (int)min(64u, n_reads - g0);
         FPL_TRIM_STAT(0, 1);
@@ -2505,11 +2450,6 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             state[g0 + lane] = st;
         }
         PROF(10) /* partial confirmation, end; counters; state */
-#if FPL_OPT_TRIMPF && !defined(FPL_EMU)
-        asm volatile("" ::"v"(pf_keep)); /* (keeps the touch loads alive; they have long returned) */
-#elif FPL_OPT_TRIMPF
-        (void)pf_keep;
-#endif
     }
     PROF_FLUSH(32);
     __syncthreads();
@@ -3529,7 +3469,7 @@ struct PairIO {
 /* NB: bit-planes the match counts need (6 when both adapters have <= 32 bases, else 7).  h = this wave's histogram
  * slice.  Returns the number of bytes the masked tiles parked in bin 0 of the histogram (hist_dumped): the caller takes
  * them out of that bin's total. */
-template <bool SUMS, bool HAM, bool LEAN = false, int NB = 7, bool PREFETCH = (FPL_OPT_PREFETCH != 0), bool PAIR = false>
+template <bool SUMS, bool HAM, bool LEAN = false, int NB = 7, bool PREFETCH = false, bool PAIR = false>
 __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const u8* __restrict__ qb, int a, int b,
                                                const u8* __restrict__ seq_end, const u8* __restrict__ qual_end,
                                                ScanWaveLds* __restrict__ w, u32* __restrict__ h, int qualified_qual, RangeSums& sums,
@@ -3580,14 +3520,6 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
         if (PREFETCH && !LEAN) {
             const int line = 128 * (lane & 31), nx = t0 + ADV + line;
             if (line < ADV + 128 && nx < blen) pf = (u32)(lane < 32 ? rb : qb)[a + nx];
-        }
-        /* ... and in the last tile of a range the 4 KB behind it: the reads of a wave's chunk lie one behind the other, so that
-           is what is left of this read and the head of the NEXT one -- whose first tile otherwise costs a whole trip to HBM
-           with nothing to overlap it (short reads: a third of k_scan's time per read) */
-        if (FPL_OPT_PFNEXT && NB < 7 && !PREFETCH && !LEAN && SUMS && t0 + ADV >= blen) { /* wave-uniform; (NB < 7: the instance of the usual
-                                                                                              configuration -- the general one has no register to spare) */
-            const u8* const pp = (lane < 32 ? rb : qb) + b + 128 * (lane & 31);
-            if (pp < (lane < 32 ? seq_end : qual_end)) pf = (u32)*pp;
         }
         /* pair packing: does the next read's head ride in this tile, and from which lane on (hb; 64: no) */
         int hb = 64;
@@ -3799,7 +3731,7 @@ __device__ __forceinline__ u32 range_scan_fast(const u8* __restrict__ rb, const 
             }
         }
 #if !defined(FPL_EMU)
-        if ((PREFETCH || (FPL_OPT_PFNEXT && NB < 7 && SUMS)) && !LEAN) asm volatile("" ::"v"(pf)); /* (keeps the touch load alive; it has long returned) */
+        if (PREFETCH && !LEAN) asm volatile("" ::"v"(pf)); /* (keeps the touch load alive; it has long returned) */
 #else
         (void)pf;
 #endif
@@ -4230,7 +4162,7 @@ k_scan(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             /* the next read's head may ride in this read's last tile when the histogram is not needed again before this
                read's totals are taken: no trimmed end so long that it takes a scan of its own (below) */
             pio.allow = have_next && ham && !defer && s <= SC_END_PF && l - e <= SC_END_PF;
-            dumped = range_scan_fast<true, true, false, NB, (FPL_OPT_PREFETCH != 0), true>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, &ads[0],
+            dumped = range_scan_fast<true, true, false, NB, false, true>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, &ads[0],
                                                                                           &ads[1], key0, key1, ham, &pio);
         } else if (SHORT || (ham && cfg->ham_fast)) /* (SHORT: also the reads without an adapter search, through do_ham) */
             dumped = range_scan_fast<true, true, false, NB>(rb, qb, s, e, seq_end, qual_end, wl, h, qq, sm, &ads[0], &ads[1], key0, key1, ham);
@@ -4613,22 +4545,14 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
     const u32 n_long = redo_count[2], n_items = n_long + redo_count[0]; /* (long reads first) */
     u32 nbuf = 0; /* entries in this wave's buffer of EXTRA-list entries (wave-uniform) */
     /* The list is walked with a fixed stride, long reads first (REDO_LONG).  Taking the items off a device counter
-       (FPL_OPT_REDO_DYN: the dequeue k_scan uses, one item at a time) evens the hundredfold spread of the items' lengths out no
+       (the dequeue k_scan uses, one item at a time; round 4, since removed) evens the hundredfold spread of the items' lengths out no
        better than the ordering does and costs one same-address atomic per wave and item: 6 144 waves + 14 000 items on one word
        are 0.24 ms of a 0.16 ms kernel (c3, measured side by side in round 4).  Round 3 saw a build of that loop that never
        ended on the GPU; its code had a second loop header BEHIND the dequeue that tested the stale lane-0 value again.  Today's
        build of either form has the atomic in the loop header (tools/dequeue_isa.py checks that for every work-counter loop of
        the library, tests/test_isa_dequeue.py runs it). */
-#if FPL_OPT_REDO_DYN
-    for (;;) {
-        u32 it = 0;
-        if (lane == 0) it = atomicAdd(redo_next, 1u);
-        it = readlane_u32(it, 0);
-        if (it >= n_items) break;
-#else
     (void)redo_next;
     for (u32 it = blockIdx.x * WAVES + wave_in_block(); it < n_items; it += gridDim.x * WAVES) {
-#endif
         const RedoItem item = redo[it < n_long ? it : n_reads - 1u - (it - n_long)];
         const u32 ri = uniform_u32(item.ri);
         const int gs = uniform_i32((int)item.gs), glen = uniform_i32((int)item.glen);
@@ -4996,7 +4920,6 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     __shared__ u32 any_work, cur_item, cls_mask;
     const int lane = lane_id();
     const u32 lane8 = 8u * (u32)lane;
-    const u32 lane_lo = lane8 & 0xFFu, lane_hi4 = (lane8 >> 8) * 0x01010101u; /* (FPL_OPT_CLSPERM) */
     static_assert(8 * FS_BSTRIDE == 8192, "a class row of the LDS tables is 8192 bytes apart from the next: FPL_FS_CELL");
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
@@ -5141,15 +5064,9 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                     EG[g] = readlane_u32(E, bit);
                     const uint64_t start = readlane_u64(st, bit);
                     if (LG[g] > c0) {
-                        /* (wave-uniform: the whole row lies inside the batch -- every row but the last few of the last read --
-                           so the lanes need no bounds test of their own) */
-                        if (FPL_OPT_ROWGUARD && start + tile_start + FS_T <= n_bytes) {
-                            __builtin_memcpy(&svG[g], seq + start + c0, 8);
-                            __builtin_memcpy(&qvG[g], qual + start + c0, 8);
-                        } else {
-                            svG[g] = load8_guard(seq + start + c0, seq_end);
-                            qvG[g] = load8_guard(qual + start + c0, qual_end);
-                        }
+                        /* (one wave-uniform bounds test per row instead of one per lane and load measured 9 % SLOWER, round 3) */
+                        svG[g] = load8_guard(seq + start + c0, seq_end);
+                        qvG[g] = load8_guard(qual + start + c0, qual_end);
                     }
                     if (FPL_OPT_STATSETUP) {
                         if (lane == g && tile_start >= 4) haloAll = load4_guard(seq + start + tile_start - 4, seq_end);
@@ -5238,14 +5155,8 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                    measured the same: this kernel issues 20 vector instructions per 64 bytes and the vector unit is what it
                    waits for, profiles/r02_ab) */
 #define FPL_FS_Q(k) ((qw[(k) >> 2] >> (8 * ((k)&3))) & 0xFF)
-#if FPL_OPT_CLSPERM
-                /* the cell of byte k: class << 13 | lane << 3 -- the high byte of that is class << 5 | lane >> 5, made for four
-                   bytes at once; one v_perm per byte puts it on top of the lane's constant low byte */
-                const u32 chi[2] = {((sw2[0] << 5) & 0xE0E0E0E0u) | lane_hi4, ((sw2[1] << 5) & 0xE0E0E0E0u) | lane_hi4};
-#define FPL_FS_CELL(k) perm_b32(chi[(k) >> 2], lane_lo, 0x0c0c0400u + ((u32)((k)&3) << 8))
-#else
+                /* (the cell through one v_perm per byte on a per-dword high byte instead: four instructions fewer, 1.4 % slower, round 4) */
 #define FPL_FS_CELL(k) mad_u24((sw2[(k) >> 2] >> (8 * ((k)&3))) & 7u, 8 * FS_BSTRIDE, lane8)
-#endif
 #if FPL_OPT_INCVALU
                 /* the packed increment of a byte on the vector unit instead of out of the LDS table: the Q20 / Q30 bits of four
                    qualities at once (bit 7 of q + 75 / q + 65: qualities are < 128), moved to where two of the four need them

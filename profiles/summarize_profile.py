@@ -45,11 +45,40 @@ def per_kernel(pattern, counters):
     return {kn: {c: sum(v) / len(v) for c, v in d.items()} for kn, d in acc.items()}
 
 
-def main(out, wl):
+def timed_stats(trace_csv, n_timed, dst):
+    """per kernel over its LAST n_timed dispatches (the timed steps of the bench command; the warm-up launches come first):
+    calls, average / min / max duration -- the rows of rocprofv3's --stats table without the warm-up launches"""
+    per = {}
+    for row in csv.DictReader(open(trace_csv)):
+        try:
+            per.setdefault(row["Kernel_Name"], []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+        except (KeyError, ValueError):
+            continue
+    rows = []
+    for name, ts in per.items():
+        ts.sort()
+        launches_per_step = max(1, len(ts) // (n_timed + 4))  # (a kernel launched several times per step keeps all of a step's launches)
+        d = [e - s for s, e in ts[-n_timed * launches_per_step:]]
+        rows.append((sum(d), name, len(d), sum(d) / len(d), min(d), max(d)))
+    rows.sort(reverse=True)
+    with open(dst, "w") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "TimedCalls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+        for tot, name, n, avg, lo, hi in rows:
+            w.writerow([name, n, tot, round(avg, 1), lo, hi])
+
+
+def main(out, wl, n_timed=0):
     work = os.path.join(out, "work_" + wl)
     stats = sorted(glob.glob(os.path.join(work, "stats", "**", "*kernel_stats.csv"), recursive=True))
     if stats:
         shutil.copy(stats[-1], os.path.join(out, "kernel_stats_%s.csv" % wl))
+    trace = sorted(glob.glob(os.path.join(work, "stats", "**", "*kernel_trace.csv"), recursive=True))
+    if trace and n_timed > 0:
+        try:
+            timed_stats(trace[-1], n_timed, os.path.join(out, "kernel_stats_timed_%s.csv" % wl))
+        except (OSError, ValueError, ZeroDivisionError) as e:
+            print("timed stats failed:", e)
     bench = {}
     try:
         bench = json.loads(open(os.path.join(out, "bench_%s.json" % wl)).read().strip().splitlines()[-1])
@@ -117,4 +146,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "--merge":
         merge(sys.argv[2])
     else:
-        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "c3_full_pipeline")
+        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "c3_full_pipeline", int(sys.argv[3]) if len(sys.argv) > 3 else 0)
