@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# the library runs a batch on up to three streams side by side (the caller's, the post-only statistics pass, the next batch's end
+# trims): with the runtime's default of four hardware queues per device and torch's own streams, two of them can land on one queue
+# and then run in submission order.  Read when the HIP runtime starts, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -626,6 +631,12 @@ def main(argv=None, rig=None):
     # all ranks agree on the per-cycle capacity so that the counter buffers line up for the all-reduce
     C = fdist.agree_capacity(max_len, device=dev)
     eng = rig.engine(opt, ad_start, ad_end, ad_fasta, local_rank, C)
+    # the batch is resident in HBM before the timed region starts: say so, and the library starts the end trims of step k + 1
+    # beside the kernels of step k (fpl_assume_inputs_ready; the asynchronous host path does the same from its own copy events)
+    trim_ahead = False
+    if hasattr(eng, "assume_inputs_ready") and not os.environ.get("FPL_NO_TRIM_AHEAD"):
+        eng.assume_inputs_ready(True)
+        trim_ahead = True
     res_t = torch.empty(n * 36, dtype=torch.uint8, device=dev)
     stream = rig.stream(dev)
 
@@ -730,6 +741,9 @@ def main(argv=None, rig=None):
                     if (args.set or args.median_len) else "", wl["config"], n, wl["reads_desc"], wl["flags"]),
                 "reads_per_gpu": n, "bases_per_gpu": n_bases, "max_read_len": max_len,
                 "parallelism": "shard%d (independent read shards, one RCCL all-reduce of the counters)" % world,
+                "pipelining": ("the steps are enqueued back to back on one stream; the end trims of step k + 1 run on a stream of their own beside "
+                               "the kernels of step k (fpl_assume_inputs_ready: the batch is resident), so kernel_ms.k_trim_ends is what is LEFT of "
+                               "them in line -- their own duration is rocprofv3's (profiles/)") if trim_ahead else "none: every kernel of a step in line",
             },
             "roofline": {
                 # priced against the HBM roofline as the contract prescribes (algorithmic bytes / kernel time / 8 TB/s);

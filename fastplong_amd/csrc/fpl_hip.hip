@@ -53,6 +53,21 @@ struct fpl_ctx {
     u64* d_extra_scratch = nullptr; /* the post-only pass's own slabs / flags (it runs on s_aux beside the reduce of k_stats_sorted) */
     u8* d_extra_flags = nullptr;
     size_t extra_slabs = 0;
+    /* The end trims of batch k + 1 beside the kernels of batch k ("trim ahead"): the trim kernel is the first of a batch, needs
+       nothing of the batch before, and is bound by memory latency where k_scan / k_stats_sorted are bound by instruction issue
+       -- 0.5 ms of a 12.5 ms step when two whole batches run side by side (round 4, tools/overlap_probe.py).  It writes
+       ReadState[] and takes its groups off a work counter: both exist twice, batches alternate.  A batch qualifies when its
+       inputs are known to be complete on the device before its predecessor is done: the asynchronous path (its own H2D
+       event), or a caller's promise (fpl_assume_inputs_ready). */
+    ReadState* d_state2 = nullptr;
+    hipStream_t s_trim = nullptr;
+    hipEvent_t ev_trim_done = nullptr, ev_batch_done[2] = {nullptr, nullptr}, ev_stats_done[2] = {nullptr, nullptr};
+    int ahead_gate = 1;             /* FPL_TRIM_AHEAD_GATE: 1 the trims of batch k + 1 start when the statistics kernel of batch k is done
+                                       (beside its reduce / post-only tail), 0 as soon as batch k - 1 is done (beside everything of batch k) */
+    uint64_t batch_no = 0;          /* batches enqueued (parity picks the buffers) */
+    bool trim_ahead = true;         /* FPL_NO_TRIM_AHEAD=1 (read in fpl_create) turns it off */
+    bool inputs_ready = false;      /* fpl_assume_inputs_ready */
+    hipEvent_t next_inputs_event = nullptr; /* (set by the asynchronous path around its call of fpl_process_batch_device) */
     hipStream_t s_aux = nullptr;    /* owned: the side stream of a batch (pipeline.h: FPL_FORK / FPL_JOIN) */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;            /* FPL_NO_OVERLAP=1 (read in fpl_create): everything on the one stream */
@@ -157,6 +172,10 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
     for (int i = 0; i < n_fasta; i++)
         if (fasta[i].len < 0 || fasta[i].len > FPL_MAX_ADAPTER_LEN || (fasta[i].len && !fasta[i].seq)) return FPL_ERR_ADAPTER;
     int ndev = 0;
+    /* (a context of the host-pointer path drives five streams -- kernels, two copy streams, two side streams; the runtime's default
+       of four hardware queues per device would make two of them share one.  Only read when the runtime starts: a host that made HIP
+       calls before its first fpl_create keeps what it had) */
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FPL_ERR_NO_DEVICE;
     fpl_ctx* ctx = new (std::nothrow) fpl_ctx();
     if (!ctx) return FPL_ERR_ARG;
@@ -167,10 +186,19 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         hipDeviceProp_t prop;
         FPL_HIP(hipGetDeviceProperties(&prop, device));
         ctx->n_cu = prop.multiProcessorCount > 0 ? (u32)prop.multiProcessorCount : 256;
-        FPL_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        FPL_HIP(hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
-        FPL_HIP(hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+        /* (the side streams first, the three streams of the host-pointer path when that path is first used -- ensure_host_streams:
+           the runtime deals its hardware queues out to the streams in turn, four by default, and two streams that share a queue
+           run in submission order, i.e. not beside each other.  A process that only hands over device pointers has the caller's
+           stream, s_aux and s_trim: three queues.) */
         FPL_HIP(hipStreamCreateWithFlags(&ctx->s_aux, hipStreamNonBlocking));
+        FPL_HIP(hipStreamCreateWithFlags(&ctx->s_trim, hipStreamNonBlocking));
+        FPL_HIP(hipEventCreateWithFlags(&ctx->ev_trim_done, hipEventDisableTiming));
+        FPL_HIP(hipEventCreateWithFlags(&ctx->ev_batch_done[0], hipEventDisableTiming));
+        FPL_HIP(hipEventCreateWithFlags(&ctx->ev_batch_done[1], hipEventDisableTiming));
+        FPL_HIP(hipEventCreateWithFlags(&ctx->ev_stats_done[0], hipEventDisableTiming));
+        FPL_HIP(hipEventCreateWithFlags(&ctx->ev_stats_done[1], hipEventDisableTiming));
+        if (const char* e = getenv("FPL_TRIM_AHEAD_GATE")) ctx->ahead_gate = atoi(e);
+        if (const char* e = getenv("FPL_NO_TRIM_AHEAD")) ctx->trim_ahead = atoi(e) == 0;
         FPL_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         FPL_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         if (const char* e = getenv("FPL_NO_OVERLAP")) ctx->overlap = atoi(e) == 0;
@@ -204,7 +232,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
         FPL_HIP(hipMemcpy(ctx->d_cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
         FPL_HIP(hipMalloc((void**)&ctx->d_ads, sizeof(DevAdapter) * ads.size()));
         FPL_HIP(hipMemcpy(ctx->d_ads, ads.data(), sizeof(DevAdapter) * ads.size(), hipMemcpyHostToDevice));
-        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, WORK_CTR_WORDS * sizeof(u32)));
+        FPL_HIP(hipMalloc((void**)&ctx->d_work_ctr, 2 * WORK_CTR_WORDS * sizeof(u32))); /* (two sets: batches alternate) */
         ctx->C = max_cycles ? max_cycles : 1;
         int r = alloc_counters(ctx, ctx->C, &ctx->d_counters);
         if (r != FPL_OK) return r;
@@ -242,6 +270,13 @@ void fpl_destroy(fpl_ctx* ctx) {
     if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
     if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
+    if (ctx->s_trim) (void)hipStreamDestroy(ctx->s_trim);
+    if (ctx->ev_trim_done) (void)hipEventDestroy(ctx->ev_trim_done);
+    for (hipEvent_t e : ctx->ev_batch_done)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_stats_done)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->d_state2) (void)hipFree(ctx->d_state2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int r = 0; r < fpl_ctx::EV_RING; r++)
@@ -472,11 +507,11 @@ int fpl_allreduce_counters(fpl_ctx** ctxs, int32_t n) {
             rc = FPL_ERR_HIP;
             break;
         }
-        FPL_NCCL(g_rccl.AllReduce(ctxs[i]->d_counters, ctxs[i]->d_counters, len, ncclInt64, ncclSum, comms[(size_t)i], ctxs[i]->stream));
+        FPL_NCCL(g_rccl.AllReduce(ctxs[i]->d_counters, ctxs[i]->d_counters, len, ncclInt64, ncclSum, comms[(size_t)i], ctxs[i]->s_aux));
     }
     FPL_NCCL(g_rccl.GroupEnd());
     for (int i = 0; i < n; i++) {
-        if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipStreamSynchronize(ctxs[i]->s_aux) != hipSuccess) {
             if (rc == FPL_OK) ctx->err = "synchronizing the all-reduce failed";
             rc = FPL_ERR_HIP;
         }
@@ -493,6 +528,12 @@ const char* fpl_rccl_library(void) {
     std::lock_guard<std::mutex> g(g_comms.m);
     copy = g_rccl.path;
     return copy.c_str();
+}
+
+int fpl_assume_inputs_ready(fpl_ctx* ctx, int yes) {
+    if (!ctx) return FPL_ERR_ARG;
+    ctx->inputs_ready = yes != 0;
+    return FPL_OK;
 }
 
 int fpl_get_batch_forms(const fpl_ctx* ctx, uint64_t out[6]) {
@@ -600,9 +641,11 @@ static int ensure_workspace(fpl_ctx* ctx, u32 n_reads) {
     if (n_reads <= ctx->ws_reads) return FPL_OK;
     FPL_HIP(hipDeviceSynchronize());
     if (ctx->d_state) (void)hipFree(ctx->d_state);
-    ctx->d_state = nullptr;
+    if (ctx->d_state2) (void)hipFree(ctx->d_state2);
+    ctx->d_state = ctx->d_state2 = nullptr;
     ctx->ws_reads = 0;
     FPL_HIP(hipMalloc((void**)&ctx->d_state, sizeof(ReadState) * (size_t)n_reads));
+    FPL_HIP(hipMalloc((void**)&ctx->d_state2, sizeof(ReadState) * (size_t)n_reads));
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_redo) (void)hipFree(ctx->d_redo);
     if (ctx->d_wins) (void)hipFree(ctx->d_wins);
@@ -655,7 +698,24 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         if (r != FPL_OK) return r;
         r = ensure_break_mask(ctx, n_reads, n_bytes);
         if (r != FPL_OK) return r;
-        FPL_HIP(hipMemsetAsync(ctx->d_work_ctr, 0, WORK_CTR_WORDS * sizeof(u32), stream));
+    }
+    /* which of the two ReadState[] / work-counter sets this batch takes, and whether its end trims start ahead of the main stream */
+    const int par = (int)(ctx->batch_no & 1);
+    u32* const work_ctr = ctx->d_work_ctr + par * WORK_CTR_WORDS;
+    hipEvent_t inputs_ev = ctx->next_inputs_event;
+    ctx->next_inputs_event = nullptr;
+    const bool ahead = n_reads && ctx->trim_ahead && ctx->overlap && !ctx->dbg && !ctx->hcfg.defer && ctx->batch_no > 0 &&
+                       (inputs_ev || ctx->inputs_ready) && trim_worth_ahead(n_reads, ctx->tune);
+    if (n_reads) {
+        if (ahead) {
+            /* the set was last used two batches ago; the trims also wait for this batch's inputs when an event says when they are in */
+            FPL_HIP(hipStreamWaitEvent(ctx->s_trim, ctx->ev_batch_done[par], 0));
+            if (ctx->ahead_gate) FPL_HIP(hipStreamWaitEvent(ctx->s_trim, ctx->ev_stats_done[par ^ 1], 0)); /* (the batch before this one) */
+            if (inputs_ev) FPL_HIP(hipStreamWaitEvent(ctx->s_trim, inputs_ev, 0));
+            FPL_HIP(hipMemsetAsync(work_ctr, 0, WORK_CTR_WORDS * sizeof(u32), ctx->s_trim));
+        } else {
+            FPL_HIP(hipMemsetAsync(work_ctr, 0, WORK_CTR_WORDS * sizeof(u32), stream));
+        }
     }
     if (ctx->hcfg.defer && ctx->bm.counts) FPL_HIP(hipMemsetAsync(ctx->bm.counts, 0, 4 * sizeof(u32), stream));
     BatchArgs a;
@@ -667,7 +727,12 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.max_read_len = max_read_len;
     a.cfg = ctx->d_cfg;
     a.ads = ctx->d_ads;
-    a.state = ctx->d_state;
+    a.state = par ? ctx->d_state2 : ctx->d_state;
+    if (ctx->trim_ahead && ctx->overlap) a.ev_stats_done = (void*)ctx->ev_stats_done[par];
+    if (ahead) {
+        a.trim_stream = ctx->s_trim;
+        a.ev_trim_done = (void*)ctx->ev_trim_done;
+    }
     a.results = d_results;
     a.frag_off = ctx->d_frag_off;
     a.frag_len = ctx->d_frag_len;
@@ -678,7 +743,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.scan_short = ctx->hcfg.scan_short != 0;
     a.counters = ctx->d_counters;
     a.C = ctx->C;
-    a.work_ctr = ctx->d_work_ctr;
+    a.work_ctr = work_ctr;
     a.recs = ctx->d_recs;
     a.wins = ctx->d_wins;
     a.redo = ctx->d_redo;
@@ -720,11 +785,23 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     });
     FPL_HIP(hipGetLastError());
     FPL_HIP(ev_err);
+    if (n_reads) {
+        FPL_HIP(hipEventRecord(ctx->ev_batch_done[par], stream));
+        ctx->batch_no++;
+    }
     if (timing) ctx->ev_calls++;
     return FPL_OK;
 }
 
 /* device staging of one slot for a batch of this size (grown with 25 % headroom; a grow waits for the device) */
+static int ensure_host_streams(fpl_ctx* ctx) {
+    if (ctx->stream) return FPL_OK;
+    FPL_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    FPL_HIP(hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
+    FPL_HIP(hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+    return FPL_OK;
+}
+
 static int ensure_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, u32 n_reads, uint64_t n_bytes) {
     if (n_bytes > sl.st_bytes || !sl.d_seq) {
         FPL_HIP(hipDeviceSynchronize());
@@ -793,7 +870,9 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qua
         const u32 l = (u32)(off[i + 1] - off[i]);
         if (l > max_len) max_len = l;
     }
-    int r = ensure_slot(ctx, sl, n_reads, n_bytes);
+    int r = ensure_host_streams(ctx);
+    if (r != FPL_OK) return r;
+    r = ensure_slot(ctx, sl, n_reads, n_bytes);
     if (r != FPL_OK) return r;
     /* (the slot's previous batch has been waited for -- FPL_MAX_IN_FLIGHT slots, FIFO -- so its buffers are free) */
     auto enqueue = [&]() -> int {
@@ -804,7 +883,9 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qua
         FPL_HIP(hipMemcpyAsync(sl.d_off, off, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, ctx->s_h2d));
         FPL_HIP(hipEventRecord(sl.ev_h2d, ctx->s_h2d));
         FPL_HIP(hipStreamWaitEvent(ctx->stream, sl.ev_h2d, 0));
+        ctx->next_inputs_event = sl.ev_h2d; /* (the end trims may start as soon as the copies are in: beside the previous batch) */
         const int rd = fpl_process_batch_device(ctx, sl.d_seq, sl.d_qual, sl.d_off, n_reads, n_bytes, max_len, sl.d_results, ctx->stream);
+        ctx->next_inputs_event = nullptr;
         if (rd != FPL_OK) return rd;
         /* the records leave on their own stream, so that they do not queue behind the next batch's input copies */
         FPL_HIP(hipEventRecord(sl.ev_kern, ctx->stream));
@@ -818,9 +899,9 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qua
     if (r != FPL_OK) {
         /* "nothing is in flight" is what the caller reads into an error here: it recycles the host arrays at once.  Copies or
            kernels that did get enqueued before the failing call may still read them (and the slot): wait them out first. */
-        (void)hipStreamSynchronize(ctx->s_h2d);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamSynchronize(ctx->s_d2h);
+        if (ctx->s_h2d) (void)hipStreamSynchronize(ctx->s_h2d);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->s_d2h) (void)hipStreamSynchronize(ctx->s_d2h);
         return r;
     }
     ctx->submitted++;

@@ -116,6 +116,11 @@ struct BatchArgs {
     u8* stats_flags;      /* n_tiles tile flags + one byte per slab, zeroed before each statistics pass */
     u64* extra_scratch = nullptr; /* the post-only (EXTRA) pass's own slabs and flags: it runs beside k_stats_sorted's reduce */
     u8* extra_flags = nullptr;
+    fpl_stream_t trim_stream = nullptr; /* the end trims go here -- ahead of the main stream, beside the previous batch -- and the main
+                                            stream waits for ev_trim_done in front of k_scan (device build only; set up by the caller) */
+    void* ev_trim_done = nullptr;
+    void* ev_stats_done = nullptr; /* recorded behind the statistics kernel: where the NEXT batch's end trims may start (what is left
+                                      of this batch then -- the reduce, the post-only pass -- leaves most of the chip idle) */
     fpl_stream_t aux = nullptr;   /* side stream + the two events that tie it to the main stream (device build only) */
     void* ev_fork = nullptr;
     void* ev_join = nullptr;
@@ -263,6 +268,10 @@ inline bool trim_takes_batched(u32 n_reads, int trim_mode, const StatsTune& tune
     const u32 batch_min = tune.trim_batch_min ? tune.trim_batch_min : TRIM_BATCH_MIN_READS;
     return trim_mode == 1 && FPL_OPT_BATCH && n_reads >= batch_min;
 }
+/* is a batch large enough for its end trims to be worth a stream of their own (two more event hand-overs per batch)? */
+inline bool trim_worth_ahead(u32 n_reads, const StatsTune& tune) {
+    return n_reads >= (tune.trim_batch_min ? tune.trim_batch_min : TRIM_BATCH_MIN_READS);
+}
 
 template <class Mark>
 inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) {
@@ -281,6 +290,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     const bool run_trim = run_front && !(a.dbg & 0x8000), run_scan = run_front && !(a.dbg & 0x4000);
     /* 1: one wave per read, grid-stride; cap the grid so the LDS accumulators flush rarely */
     if (run_trim) {
+        const fpl_stream_t ts = a.trim_stream ? a.trim_stream : stream;
         u32 blocks = cdiv(n, KWAVES);
 #ifndef FPL_TRIM_BLOCKS_PER_CU
 #define FPL_TRIM_BLOCKS_PER_CU 112 /* static grid-stride: more, shorter blocks even the load out (16: 3.80 ms, 112: 3.57 ms on the bench batch) */
@@ -295,17 +305,23 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
             u32 gblocks = cdiv(cdiv(n, 64u), KWAVES);
             const u32 gcap = FPL_TRIM_WAVES_PER_SIMD_BATCHED * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
             if (gblocks > gcap) gblocks = gcap;
-            FPL_LAUNCH((k_trim_ends_batched<KWAVES>), dim3(gblocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+            FPL_LAUNCH((k_trim_ends_batched<KWAVES>), dim3(gblocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                        a.ads, a.state, a.counters, a.C, a.work_ctr + 2);
         } else if (a.trim_mode == 1)
-            FPL_LAUNCH((k_trim_ends<KWAVES, 1>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+            FPL_LAUNCH((k_trim_ends<KWAVES, 1>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                        a.ads, a.state, a.counters, a.C);
         else if (a.trim_mode == 2)
-            FPL_LAUNCH((k_trim_ends<KWAVES, 2>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+            FPL_LAUNCH((k_trim_ends<KWAVES, 2>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                        a.ads, a.state, a.counters, a.C);
         else
-            FPL_LAUNCH((k_trim_ends<KWAVES, 0>), dim3(blocks), block, stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+            FPL_LAUNCH((k_trim_ends<KWAVES, 0>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                        a.ads, a.state, a.counters, a.C);
+#ifndef FPL_EMU
+        if (a.trim_stream) {
+            (void)hipEventRecord((hipEvent_t)a.ev_trim_done, a.trim_stream);
+            (void)hipStreamWaitEvent(stream, (hipEvent_t)a.ev_trim_done, 0);
+        }
+#endif
     }
     mark(1);
     if (run_scan) {
@@ -418,6 +434,9 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                    (const uint64_t*)a.st_off, (const u32*)a.st_len, (const u32*)a.st_e, a.sort_ws, max_slices, n_tiles, a.counters,
                    a.stats_scratch, a.stats_flags, a.C, hi_tile, max_rows);
         if (extra_forked) launch_extra(FPL_FORK(a, stream), a.extra_scratch, a.extra_flags, false);
+#ifndef FPL_EMU
+        if (a.ev_stats_done) (void)hipEventRecord((hipEvent_t)a.ev_stats_done, stream);
+#endif
         mark(5);
         FPL_LAUNCH(k_stats_reduce_sorted, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, (const u32*)a.sort_ws, max_slices, n_tiles, a.counters, a.C);
@@ -430,6 +449,9 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                    a.off, (const u32*)nullptr, (const u32*)nullptr, (const ReadState*)a.state, n, (const u32*)nullptr, per,
                    n_slices,
                    CS_MAX_ITEMS_PER_SLICE, a.counters, a.stats_scratch, a.stats_flags, a.C);
+#ifndef FPL_EMU
+        if (a.ev_stats_done) (void)hipEventRecord((hipEvent_t)a.ev_stats_done, stream);
+#endif
         mark(5);
         FPL_LAUNCH(k_stats_reduce, dim3(16 * FS_T / 256, n_tiles), dim3(256), stream, (const u64*)a.stats_scratch,
                    (const u8*)a.stats_flags, n_slices, n_tiles, a.counters, a.C, 1);

@@ -18,7 +18,7 @@ EXPORTS = [
     "fpl_reserve_cycles", "fpl_counters_device_ptr", "fpl_get_counters", "fpl_reset_counters", "fpl_synchronize",
     "fpl_enable_timing", "fpl_get_kernel_times", "fpl_fragment_counts", "fpl_get_fragments",
     "fpl_process_batch_async", "fpl_wait", "fpl_in_flight", "fpl_host_alloc", "fpl_host_free", "fpl_allreduce_counters",
-    "fpl_count_end_kmers", "fpl_pick_adapter", "fpl_rccl_library", "fpl_comm_init", "fpl_get_batch_forms",
+    "fpl_count_end_kmers", "fpl_pick_adapter", "fpl_rccl_library", "fpl_comm_init", "fpl_get_batch_forms", "fpl_assume_inputs_ready",
 ]
 
 
@@ -103,6 +103,8 @@ def load_library(path=None):
     L.fpl_allreduce_counters.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
     L.fpl_comm_init.restype = C.c_int
     L.fpl_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
+    L.fpl_assume_inputs_ready.restype = C.c_int
+    L.fpl_assume_inputs_ready.argtypes = [C.c_void_p, C.c_int]
     L.fpl_get_batch_forms.restype = C.c_int
     L.fpl_get_batch_forms.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fpl_rccl_library.restype = C.c_char_p
@@ -274,6 +276,11 @@ class Engine:
 
     def enable_timing(self, on=True):
         self._check(self.L.fpl_enable_timing(self.h, int(on)), "fpl_enable_timing")
+
+    def assume_inputs_ready(self, yes=True):
+        """the batches handed to process_device are complete on the device when the call is made (resident tensors): the end trims
+        of a batch may then start beside the previous batch's kernels (fpl_assume_inputs_ready)"""
+        self._check(self.L.fpl_assume_inputs_ready(self.h, int(bool(yes))), "fpl_assume_inputs_ready")
 
     def batch_forms(self):
         """-> dict: batches, reads, through k_trim_ends_batched, through k_stats_sorted, largest batch (fpl_get_batch_forms)"""

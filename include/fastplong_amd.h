@@ -374,6 +374,15 @@ int fpl_synchronize(fpl_ctx* ctx);
  *   out[0] batches   out[1] reads   out[2] batches through k_trim_ends_batched   out[3] batches through k_stats_sorted
  *   out[4] reads of the largest batch   out[5] reserved (0)
  */
+/*
+ * A promise about fpl_process_batch_device (ABI v6): yes != 0 says that d_seq / d_qual / d_off of every later call are COMPLETE
+ * on the device when the call is made -- resident data, or copies the caller has already waited for -- not merely ordered on
+ * the call's stream.  The library then starts the end trims of a batch beside the kernels of the batch before it (they are
+ * bound by memory latency, the scan and the statistics pass by instruction issue).  Without the promise only the library's own
+ * asynchronous path (fpl_process_batch_async: it knows when its copies are in) does that.  Results are the same either way.
+ */
+int fpl_assume_inputs_ready(fpl_ctx* ctx, int yes);
+
 #define FPL_FORM_TRIM_BATCHED_MIN 65536
 #define FPL_FORM_STATS_SORTED_MIN 150000
 int fpl_get_batch_forms(const fpl_ctx* ctx, uint64_t out[6]);

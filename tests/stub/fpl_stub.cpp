@@ -251,6 +251,7 @@ int fpl_reset_counters(fpl_ctx* ctx) {
     return FPL_OK;
 }
 int fpl_synchronize(fpl_ctx*) { return FPL_OK; }
+int fpl_assume_inputs_ready(fpl_ctx* ctx, int) { return ctx ? FPL_OK : FPL_ERR_ARG; }
 int fpl_get_batch_forms(const fpl_ctx* ctx, uint64_t out[6]) { /* (no kernels here: nothing to report but zeros) */
     if (!ctx || !out) return FPL_ERR_ARG;
     for (int i = 0; i < 6; i++) out[i] = 0;

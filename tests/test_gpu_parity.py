@@ -786,6 +786,39 @@ def test_full_quality_byte_range_bench_sized_no_hooks_bit_exact(orc, engine_mod,
     assert "no hook set" in what
 
 
+@pytest.mark.parametrize("sorted_stats", [False, True])
+def test_end_trims_ahead_of_the_previous_batch_bit_exact(orc, engine_mod, monkeypatch, sorted_stats):
+    """fpl_assume_inputs_ready (ABI v6): with resident inputs the end trims of batch k + 1 run on a stream of their own beside the
+    kernels of batch k (two ReadState[] / work-counter sets, batches alternate).  Five different batches back to back, sizes up
+    and down (the workspace grows in between), against the same batches through a context without the promise -- every record,
+    every counter -- and against the oracle for the last one"""
+    import torch
+
+    if sorted_stats:
+        monkeypatch.setenv("FPL_STATS_SORT_MIN", "1")
+    opt = abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1)
+    batches = [synth.ont_like(n, seed=60 + i, median_len=700, p_middle=0.05) for i, n in enumerate([900, 1500, 700, 2500, 1100])]
+    C = max(int(np.diff(o.astype(np.int64)).max()) for _, _, o in batches)
+    out = {}
+    for promise in (False, True):
+        eng = engine_mod.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=C)
+        if promise:
+            eng.assume_inputs_ready(True)
+        dev_batches = [(torch.from_numpy(s_).cuda(), torch.from_numpy(q_).cuda(), torch.from_numpy(o_.astype(np.int64)).cuda(), len(o_) - 1)
+                       for s_, q_, o_ in batches]
+        torch.cuda.synchronize()  # (the promise: complete on the device when the calls are made)
+        res = [eng.process_device(st, qt, ot, C) for st, qt, ot, _ in dev_batches]  # all five enqueued before anything is waited for
+        torch.cuda.synchronize()
+        out[promise] = ([eng.results_to_numpy(r, b[3]) for r, b in zip(res, dev_batches)], eng.counters())
+        eng.close()
+    for a, b, (s_, _, o_) in zip(out[False][0], out[True][0], batches):
+        parity.assert_results_equal(b, a, s_, o_)
+    assert np.array_equal(out[False][1], out[True][1])
+    cfg = orc.Config(opt, synth.START_ADAPTER, synth.END_ADAPTER)
+    want_res, _ = orc.process_batch(cfg, *batches[-1], max_cycles=C)
+    parity.assert_results_equal(out[True][0][-1], want_res, batches[-1][0], batches[-1][2])
+
+
 def test_batch_forms_say_which_kernels_a_batch_took(engine_mod, monkeypatch):
     """fpl_get_batch_forms (ABI v6): the library picks k_trim_ends_batched / k_stats_sorted by the batch's size; a host that
     flushes small batches runs the other forms, and this call is how it finds out"""

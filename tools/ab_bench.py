@@ -3,6 +3,7 @@ Measurement aid: per-kernel times of several builds of libfastplong_amd.so (tool
 batch, same box, interleaved rounds -- boxes of the pool differ by a few per cent, so kernel variants are only comparable
 side by side."""
 import argparse, os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (as bench.py: the library's side streams want hardware queues of their own)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -14,6 +15,7 @@ ap.add_argument("--workload", default="c3_full_pipeline")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--median-len", type=int, default=0)
+ap.add_argument("--ahead", action="store_true", help="fpl_assume_inputs_ready: the end trims of a step beside the step before")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -37,6 +39,8 @@ for spec in a.libs:  # lib.so or lib.so@FLAGS (FPL_DEBUG_FLAGS for a build with 
     for k, v in kv:
         os.environ[k] = v
     engs.append((spec, engine.Engine(opt, s_ad, e_ad, fasta, device=0, max_cycles=max_len, lib=L)))
+    if a.ahead or "AHEAD=1" in envs:
+        engs[-1][1].assume_inputs_ready(True)
     for k, _v in kv:
         os.environ.pop(k, None)
 os.environ.pop("FPL_DEBUG_FLAGS", None)
