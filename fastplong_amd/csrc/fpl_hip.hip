@@ -175,7 +175,8 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
     /* (a context of the host-pointer path drives five streams -- kernels, two copy streams, two side streams; the runtime's default
        of four hardware queues per device would make two of them share one.  Only read when the runtime starts: a host that made HIP
        calls before its first fpl_create keeps what it had) */
-    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    static std::once_flag hwq_once; /* (a host may create its contexts on several threads at once: setenv is not thread-safe) */
+    std::call_once(hwq_once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); });
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FPL_ERR_NO_DEVICE;
     fpl_ctx* ctx = new (std::nothrow) fpl_ctx();
     if (!ctx) return FPL_ERR_ARG;

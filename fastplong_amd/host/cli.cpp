@@ -284,6 +284,9 @@ using fplh::gzip_member;
 using fplh::SplitOutput;
 
 int main(int argc, char* argv[]) {
+    /* (before any other thread exists: a context drives five streams, the runtime's default is four hardware queues per device and
+       two streams on one queue run in submission order -- fpl_create asks for the same, but setenv belongs where one thread runs) */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (argc == 1) {
         cerr << "fastplong_amd: fastplong's per-read hot path on MI355X" << endl << "version 0.4.1-compatible" << endl;
         return 0;
