@@ -37,11 +37,13 @@ def build_hip(force=False, verbose=False):
     if force or _newer(LIB, srcs):
         # the atomic optimizer rewrites every single-lane LDS accumulator update into a wave reduction: pure
         # overhead for the per-read bookkeeping of k_scan / k_trim_ends
+        tmp = "%s.tmp.%d" % (LIB, os.getpid())  # (into a file of this process's own, then renamed: nobody ever maps a half-written library)
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-               "-amdgpu-atomic-optimizer-strategy=None", "-o", LIB, srcs[0]]
+               "-amdgpu-atomic-optimizer-strategy=None", "-o", tmp, srcs[0]]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
     return LIB
 
 
@@ -60,23 +62,27 @@ def build_host(force=False, verbose=False):
     lib_cpps = [s for s in cpps if not s.endswith("cli.cpp")]
     hdr = os.path.join(ROOT, "include", "fastplong_amd.h")
     if force or _newer(HOST_LIB, srcs + [hdr]):
+        tmp = "%s.tmp.%d" % (HOST_LIB, os.getpid())
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
-               "-o", HOST_LIB] + lib_cpps + ["-ldl", "-lz"]
+               "-o", tmp] + lib_cpps + ["-ldl", "-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        os.replace(tmp, HOST_LIB)
     cli_src = os.path.join(HOST, "cli.cpp")
     if os.path.exists(cli_src) and (force or _newer(CLI, srcs + [hdr, LIB])):
         build_hip(force, verbose)
         os.makedirs(os.path.dirname(CLI), exist_ok=True)
         rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
         # the CLI only knows the C-ABI: HIP and RCCL stay behind libfastplong_amd.so (RCCL is dlopen'ed on first use)
-        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", CLI, cli_src, "-L" + HERE, "-lfastplong_host",
+        tmp = "%s.tmp.%d" % (CLI, os.getpid())  # (a test run with several workers may find the binary stale in all of them at once)
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", tmp, cli_src, "-L" + HERE, "-lfastplong_host",
                "-lfastplong_amd", "-Wl,-rpath,$ORIGIN/../fastplong_amd", "-Wl,-rpath," + os.path.join(rocm, "lib"),
                "-Wl,-rpath-link," + os.path.join(rocm, "lib"), "-ldl", "-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        os.replace(tmp, CLI)
     return HOST_LIB
 
 

@@ -741,6 +741,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     a.bm = ctx->bm;
     a.defer = ctx->hcfg.defer != 0;
     a.trim_mode = ctx->hcfg.trim_mode;
+    a.n_fasta = ctx->hcfg.n_fasta;
     a.scan_short = ctx->hcfg.scan_short != 0;
     a.counters = ctx->d_counters;
     a.C = ctx->C;

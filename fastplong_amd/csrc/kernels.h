@@ -1246,7 +1246,7 @@ __global__ void __launch_bounds__(WAVES * 64, MODE == 1 ? FPL_TRIM_WAVES_PER_SIM
                                               : (MODE == 2 && FPL_OPT_FASTAFILTER) ? 4 : FPL_TRIM_WAVES_PER_SIMD)
 k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
             uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
-            ReadState* __restrict__ state, long long* __restrict__ counters, u32 C) {
+            ReadState* __restrict__ state, long long* __restrict__ counters, u32 C, int from_state) {
     __shared__ TrimBlockAcc acc;
     __shared__ TrimLds<WAVES> lds;
     constexpr bool FILT = MODE == 2 && FPL_OPT_FASTAFILTER != 0;
@@ -1279,21 +1279,35 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     const u32 n_waves = gridDim.x * WAVES;
     long long* keyh = counters + FPL_OFF_KEYHIST(C);
     PROF_INIT();
+    /* chain only (MODE 2, from_state != 0: wave-uniform): trimAndCut, polyX and the two command-line adapters are done --
+       k_trim_ends_batched<.., 8, true> left r1 and the bases they took in state[] (lane = read there: a fraction of what the
+       wave-per-read forms below cost for them) -- and this kernel runs the FASTA chain from there */
+    const bool chain_only = MODE == 2 && from_state != 0;
     for (u32 ri = wave_global; ri < n_reads; ri += n_waves) {
         const uint64_t o0 = off[ri];
         const int l = (int)(off[ri + 1] - o0);
         const u8* sq = seq + o0;
         const u8* ql = qual + o0;
-        int s, e;
+        int s = 0, e = 0;
         PROF(0)
         /* the read's one trip to memory: its first and last TRIM_WIN bytes, bases and qualities, into LDS */
         const int tail0 = max(0, l - TRIM_WIN);
-        stage_ends<MODE != 0>(win_s, win_e, win_hq, win_tq, win4_s, win4_e, sq, ql, l, tail0, seq_end, qual_end);
+        bool alive;
+        int trimmed_pre = 0;
+        if (chain_only) {
+            const ReadState ps = state[ri];
+            s = (int)uniform_u32(ps.s);
+            e = (int)uniform_u32(ps.e);
+            alive = uniform_u32(ps.dropped) == 0;
+            trimmed_pre = (int)uniform_u32(ps.pad);
+        } else {
+            stage_ends<MODE != 0>(win_s, win_e, win_hq, win_tq, win4_s, win4_e, sq, ql, l, tail0, seq_end, qual_end);
+        }
         const EndsView vs = {sq, (const u8*)win_s, (const u8*)win_e, tail0};
         const EndsView vq = {ql, (const u8*)win_hq, (const u8*)win_tq, tail0};
-        bool alive = trim_and_cut_wave(vs, vq, l, cfg, s, e);
+        if (!chain_only) alive = trim_and_cut_wave(vs, vq, l, cfg, s, e);
         PROF(1)
-        if (alive && cfg->polyx) { /* src/seprocessor.cpp:198-201 */
+        if (!chain_only && alive && cfg->polyx) { /* src/seprocessor.cpp:198-201 */
             int poly, tl;
             const int nl = trim_polyx_wave(vs, s, e - s, cfg->polyx_min_len, poly, tl);
             e = s + nl;
@@ -1304,8 +1318,10 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
         }
         PROF(2) /* polyX */
         if (alive && cfg->adapter_enabled) { /* src/seprocessor.cpp:205-216 */
-            int trimmed = 0, kl;
-            if (cfg->has_start && (MODE != 0 || ads[0].len <= 64)) {
+            int trimmed = trimmed_pre, kl;
+            if (chain_only) {
+                /* (the command-line adapters have had their turn) */
+            } else if (cfg->has_start && (MODE != 0 || ads[0].len <= 64)) {
                 /* the start trim only looks at r1[0, 200): still inside the staged head of the read unless trimAndCut
                    took more than TRIM_WIN - 200 bases (then the window is fetched again) */
                 const int wl = min(e - s, FPL_END_WINDOW);
@@ -1323,7 +1339,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(3) /* start adapter */
-            if (cfg->has_end && (MODE != 0 || ads[1].len <= 64)) {
+            if (chain_only) {
+            } else if (cfg->has_end && (MODE != 0 || ads[1].len <= 64)) {
                 /* the end trim only looks at the last 200 bases of r1 */
                 const int rlen = e - s, wl = min(rlen, FPL_END_WINDOW);
                 int bias = tail0 - s; /* (the staged tail of the read starts at byte tail0) */
@@ -1800,8 +1817,9 @@ __device__ __forceinline__ u32 onehot4(u32 w) {
  * in a descending scan).  END: asLeftAsPossible over p in [max(0, rlen - 200), rlen - alen): hit = the SMALLEST p within thr,
  * else cand = the largest p among the minima.  hit / cand are -1 when there is none.  A few hundred vector instructions per
  * 64 reads and end where the scan with lanes = positions (one read at a time) took as many per read. */
-template <bool START>
-__device__ __forceinline__ void ham_scan_lanes(const u8* __restrict__ r1, int rlen, bool active, const u32 (&ad1h)[4], int alen,
+/* NW: words of one-hot nibbles the window holds -- 4 for adapters of <= 32 bases, 8 for <= 64 */
+template <bool START, int NW = 4>
+__device__ __forceinline__ void ham_scan_lanes(const u8* __restrict__ r1, int rlen, bool active, const u32 (&ad1h)[NW], int alen,
                                                int thr, const u8* __restrict__ seq_end, int& hit, int& cand) {
     hit = -1;
     cand = -1;
@@ -1831,21 +1849,20 @@ __device__ __forceinline__ void ham_scan_lanes(const u8* __restrict__ r1, int rl
     u32 touch = 0;
     if (FPL_OPT_TRIMTOUCH && navail > 64) /* the window's second (and third) cache line, asked for now */
         touch = (u32)*(base + min(navail - 1, 112)) + (u32)*(base + min(navail - 1, 207));
-    u32 W[4];
+    u32 W[NW];
 #pragma unroll
-    for (int k = 0; k < 4; k++) W[k] = nibbles(2 * k) | (nibbles(2 * k + 1) << 16);
+    for (int k = 0; k < NW; k++) W[k] = nibbles(2 * k) | (nibbles(2 * k + 1) << 16);
     int bestmm = 0x7fffffff;
-    u32 nxt = nibbles(8);
+    u32 nxt = nibbles(2 * NW);
     for (int i0 = 0; i0 < npmax; i0 += 4) { /* wave-uniform trip count */
         const u32 cur = nxt;
-        nxt = nibbles(i0 / 4 + 9); /* (requested one step ahead of its use) */
+        nxt = nibbles(i0 / 4 + 2 * NW + 1); /* (requested one step ahead of its use) */
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + u;
             u32 matches = popc32(W[0] & ad1h[0]);
-            matches = popc_acc(W[1] & ad1h[1], matches);
-            matches = popc_acc(W[2] & ad1h[2], matches);
-            matches = popc_acc(W[3] & ad1h[3], matches);
+#pragma unroll
+            for (int k = 1; k < NW; k++) matches = popc_acc(W[k] & ad1h[k], matches);
             const int mm = alen - (int)matches;
             const bool in = i < np;
             const int p = p_lo + i;
@@ -1861,10 +1878,9 @@ __device__ __forceinline__ void ham_scan_lanes(const u8* __restrict__ r1, int rl
                 bestmm = better ? mm : bestmm;
             }
             /* slide by one base: the next nibble of the stream enters at the top */
-            W[0] = alignbit(W[1], W[0], 4);
-            W[1] = alignbit(W[2], W[1], 4);
-            W[2] = alignbit(W[3], W[2], 4);
-            W[3] = (W[3] >> 4) | (((cur >> (4 * u)) & 15u) << 28);
+#pragma unroll
+            for (int k = 0; k + 1 < NW; k++) W[k] = alignbit(W[k + 1], W[k], 4);
+            W[NW - 1] = (W[NW - 1] >> 4) | (((cur >> (4 * u)) & 15u) << 28);
         }
     }
     if (hit >= 0) cand = -1;
@@ -1912,6 +1928,50 @@ __device__ __forceinline__ bool lev_lanes32(const u8* __restrict__ text, int m, 
         }
     }
     return need && score <= thr;
+}
+
+/* ... the same for pattern slices of up to 64 columns (adapters of 33..64 bases): 64-bit columns, the text fetched 16 bytes at a time */
+__device__ __forceinline__ bool lev_lanes64(const u8* __restrict__ text, int m, int shift, int thr, bool need,
+                                            const uint64_t (*__restrict__ peqf)[1], const u8* __restrict__ seq_end) {
+    const int mm = need ? m : 0;
+    const u64 mask = mm >= 64 ? ~0ull : ((1ull << mm) - 1ull);
+    const u32 topsh = mm > 0 ? (u32)(mm - 1) : 0u;
+    const int mmax = (int)wave_max_u32((u32)mm);
+    u64 Pv = ~0ull, Mv = 0;
+    int score = mm;
+    for (int t0 = 0; t0 < mmax; t0 += 16) { /* wave-uniform */
+        u32 w[4] = {0, 0, 0, 0};
+        if (need && t0 < mm) {
+            const u32x4 a = load16_guard(text + t0, seq_end);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int t = t0 + u;
+            const u32 c = (w[u >> 2] >> (8 * (u & 3))) & 0xFFu;
+            const u64 Eq = (peqf[c][0] >> shift) & mask;
+            const u64 Xv = Eq | Mv;
+            const u64 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            u64 Ph = Mv | ~(Xh | Pv);
+            u64 Mh = Pv & Xh;
+            const int sc = score + (int)((Ph >> topsh) & 1ull) - (int)((Mh >> topsh) & 1ull);
+            Ph = (Ph << 1) | 1ull;
+            Mh <<= 1;
+            const bool act = t < mm; /* this lane's text has a column t */
+            score = act ? sc : score;
+            const u64 nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
+            Pv = act ? nPv : Pv;
+            Mv = act ? nMv : Mv;
+        }
+    }
+    return need && score <= thr;
+}
+/* the one the adapter length of the instantiation asks for */
+template <int NW>
+__device__ __forceinline__ bool lev_lanes_nw(const u8* __restrict__ text, int m, int shift, int thr, bool need,
+                                             const uint64_t (*__restrict__ peqf)[1], const u8* __restrict__ seq_end) {
+    if (NW <= 4) return lev_lanes32(text, m, shift, thr, need, peqf, seq_end);
+    return lev_lanes64(text, m, shift, thr, need, peqf, seq_end);
 }
 
 /* Can the 16-base partial pattern (peq16 = its Peq table, in LDS) match ANY 16-byte window of the n text bytes at
@@ -2117,14 +2177,18 @@ __device__ __forceinline__ void lane_set(int& v, int j, int x) { v = lane_id() =
 #define FPL_TRIM_WAVES_PER_SIMD_BATCHED 5 /* (the lane-per-read phases hold a read's state and a sliding window per lane: 72 registers
                                              spilled 51 of them -- 1.80 ms per million reads at 7 waves per SIMD, 1.55 at 6, 1.48 at 5) */
 #endif
-template <int WAVES>
+/* NW: words of one-hot nibbles per window scan -- 4: both command-line adapters have <= 32 bases (DevConfig::trim_mode 1), 8: <= 64
+   (trim_mode 2).  CHAIN: a FASTA chain follows (k_trim_ends<.., 2> with `pre` = the ReadState records written here): the bases the
+   two command-line adapters took ride along in ReadState::pad and FilterResult::addReadTrimmed is left to the chain kernel, which
+   knows the read's total (src/seprocessor.cpp:205-216) */
+template <int WAVES, int NW = 4, bool CHAIN = false>
 __global__ void __launch_bounds__(WAVES * 64, FPL_TRIM_WAVES_PER_SIMD_BATCHED)
 k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
                     uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
                     ReadState* __restrict__ state, long long* __restrict__ counters, u32 C, u32* __restrict__ group_ctr) {
     __shared__ TrimBlockAcc acc;
     __shared__ TrimLds<WAVES> lds;
-    __shared__ int thr_lds[40]; /* DevConfig::thr[0..32] */
+    __shared__ int thr_lds[72]; /* DevConfig::thr[0..64] */
     __shared__ u32 cand_lds[FPL_OPT_PARTLANES ? WAVES : 1][PART_WORDS][64]; /* per lane: the columns its partial-pattern search may end at */
     PROF_INIT();
     const int lane = lane_id();
@@ -2137,7 +2201,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         lds.peqf[0][i][0] = ads[0].peq_full[i][0];
         lds.peqf[1][i][0] = ads[1].peq_full[i][0];
     }
-    for (u32 i = threadIdx.x; i < 40; i += blockDim.x) thr_lds[i] = i <= 32 ? cfg->thr[i] : 0;
+    for (u32 i = threadIdx.x; i < 72; i += blockDim.x) thr_lds[i] = i <= 64 ? cfg->thr[i] : 0;
     __syncthreads();
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
@@ -2153,9 +2217,9 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
     const int alen0 = ads[0].len, alen1 = ads[1].len;
     constexpr int plen = FPL_PATTERN_LEN; /* (both adapters have >= 16 bases here) */
     const int thrA0 = cfg->thr[alen0], thrA1 = cfg->thr[alen1], thrP = cfg->thr[plen];
-    u32 ad1h0[4], ad1h1[4];
+    u32 ad1h0[NW], ad1h1[NW];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NW; k++) {
         ad1h0[k] = uniform_u32(ads[0].onehot[k]);
         ad1h1[k] = uniform_u32(ads[1].onehot[k]);
     }
@@ -2240,7 +2304,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         /* ---- P1c: start adapter window scan, lane = read (searchAdapter, asRightAsPossible, :109-131) */
         if (do_start) {
             const bool act = v_alive && (v_e - v_s) >= FPL_PATTERN_LEN;
-            ham_scan_lanes<true>(seq + v_o0 + v_s, v_e - v_s, act, ad1h0, alen0, thrA0, seq_end, v_mpos, v_cand);
+            ham_scan_lanes<true, NW>(seq + v_o0 + v_s, v_e - v_s, act, ad1h0, alen0, thrA0, seq_end, v_mpos, v_cand);
         }
         PROF(3) /* window scan, start */
         /* ---- P2: the candidates' edit distance, 64 reads at once */
@@ -2248,7 +2312,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             const bool need = v_cand >= 0;
             FPL_TRIM_STAT(2, __popcll(wave_ballot(need)));
             if (wave_ballot(need)) {
-                const bool ok = lev_lanes32(seq + v_o0 + v_s + v_cand, alen0, 0, thrA0, need, lds.peqf[0], seq_end);
+                const bool ok = lev_lanes_nw<NW>(seq + v_o0 + v_s + v_cand, alen0, 0, thrA0, need, lds.peqf[0], seq_end);
                 v_mpos = ok ? v_cand : v_mpos;
             }
         }
@@ -2309,7 +2373,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             const bool need = v_ppos >= 0;
             bool pok = false;
             if (wave_ballot(need))
-                pok = lev_lanes32(seq + v_o0 + v_s + v_ppos + plen - cmplen, cmplen, alen0 - cmplen, thr_lds[need ? cmplen : 0], need,
+                pok = lev_lanes_nw<NW>(seq + v_o0 + v_s + v_ppos + plen - cmplen, cmplen, alen0 - cmplen, thr_lds[need ? cmplen : 0], need,
                                   lds.peqf[0], seq_end);
             int kl = 0, got = 0;
             if (v_mpos >= 0) {
@@ -2334,7 +2398,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
         v_cand = -1;
         if (do_end) {
             const bool act = v_alive && (v_e - v_s) >= FPL_PATTERN_LEN;
-            ham_scan_lanes<false>(seq + v_o0 + v_s, v_e - v_s, act, ad1h1, alen1, thrA1, seq_end, v_mpos, v_cand);
+            ham_scan_lanes<false, NW>(seq + v_o0 + v_s, v_e - v_s, act, ad1h1, alen1, thrA1, seq_end, v_mpos, v_cand);
         }
         PROF(7) /* window scan, end */
         /* ---- P6 */
@@ -2342,7 +2406,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             const bool need = v_cand >= 0;
             FPL_TRIM_STAT(5, __popcll(wave_ballot(need)));
             if (wave_ballot(need)) {
-                const bool ok = lev_lanes32(seq + v_o0 + v_s + v_cand, alen1, 0, thrA1, need, lds.peqf[1], seq_end);
+                const bool ok = lev_lanes_nw<NW>(seq + v_o0 + v_s + v_cand, alen1, 0, thrA1, need, lds.peqf[1], seq_end);
                 v_mpos = ok ? v_cand : v_mpos;
             }
         }
@@ -2416,7 +2480,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             const bool need = v_ppos >= 0;
             bool pok = false;
             if (wave_ballot(need))
-                pok = lev_lanes32(seq + v_o0 + v_s + (rlen - plen - v_ppos), cmplen, 0, thr_lds[need ? cmplen : 0], need, lds.peqf[1],
+                pok = lev_lanes_nw<NW>(seq + v_o0 + v_s + (rlen - plen - v_ppos), cmplen, 0, thr_lds[need ? cmplen : 0], need, lds.peqf[1],
                                   seq_end);
             int kl = 0, got = 0;
             if (v_mpos >= 0) {
@@ -2433,9 +2497,11 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             v_trim += got;
             if (kl > 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
         }
-        if (do_ad) { /* FilterResult::addReadTrimmed */
+        if (do_ad && !CHAIN) { /* FilterResult::addReadTrimmed */
             const u64 nt = wave_ballot(v_trim > 0);
-            const u32 tb = wave_sum_u32((u32)v_trim);
+            /* (only the reads whose total is positive are booked: with an adapter beyond 32 bases a trim at a read shorter than the
+               adapter returns a NEGATIVE count -- pos = min(pos + ext, rlen - alen) -- as the reference's does, src/adaptertrimmer.cpp:224-232) */
+            const u32 tb = wave_sum_u32(v_trim > 0 ? (u32)v_trim : 0u);
             if (nt && lane == 0) {
                 atomicAdd(&acc.fr[FPL_FR_ADAPTER_READS], (u64)__popcll(nt));
                 atomicAdd(&acc.fr[FPL_FR_ADAPTER_BASES], (u64)tb);
@@ -2446,7 +2512,7 @@ k_trim_ends_batched(const u8* __restrict__ seq, const u8* __restrict__ qual, con
             st.s = v_alive ? (u32)v_s : 0;
             st.e = v_alive ? (u32)v_e : 0;
             st.dropped = v_alive ? 0 : 1;
-            st.pad = 0;
+            st.pad = CHAIN ? (u32)v_trim : 0u; /* (what the two command-line adapters took: the chain kernel adds its own and books the read) */
             state[g0 + lane] = st;
         }
         PROF(10) /* partial confirmation, end; counters; state */

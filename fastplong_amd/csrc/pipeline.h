@@ -99,6 +99,7 @@ struct BatchArgs {
     BmLists bm = {nullptr, nullptr, 0, 0, 0, nullptr}; /* fragment / region lists of k_break_mask */
     bool defer = false;      /* DevConfig::defer on the host side */
     int trim_mode = 0;       /* DevConfig::trim_mode on the host side */
+    int n_fasta = 0;         /* DevConfig::n_fasta on the host side */
     bool scan_short = false; /* DevConfig::scan_short on the host side */
     long long* counters;
     u32 C;
@@ -266,7 +267,7 @@ inline bool stats_takes_sorted(u32 n_reads, uint64_t n_bytes, u32 max_read_len, 
 constexpr u32 TRIM_BATCH_MIN_READS = FPL_FORM_TRIM_BATCHED_MIN;
 inline bool trim_takes_batched(u32 n_reads, int trim_mode, const StatsTune& tune) {
     const u32 batch_min = tune.trim_batch_min ? tune.trim_batch_min : TRIM_BATCH_MIN_READS;
-    return trim_mode == 1 && FPL_OPT_BATCH && n_reads >= batch_min;
+    return (trim_mode == 1 || trim_mode == 2) && FPL_OPT_BATCH && n_reads >= batch_min;
 }
 /* is a batch large enough for its end trims to be worth a stream of their own (two more event hand-overs per batch)? */
 inline bool trim_worth_ahead(u32 n_reads, const StatsTune& tune) {
@@ -305,17 +306,29 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
             u32 gblocks = cdiv(cdiv(n, 64u), KWAVES);
             const u32 gcap = FPL_TRIM_WAVES_PER_SIMD_BATCHED * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
             if (gblocks > gcap) gblocks = gcap;
-            FPL_LAUNCH((k_trim_ends_batched<KWAVES>), dim3(gblocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
-                       a.ads, a.state, a.counters, a.C, a.work_ctr + 2);
+            if (a.trim_mode == 1)
+                FPL_LAUNCH((k_trim_ends_batched<KWAVES>), dim3(gblocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+                           a.ads, a.state, a.counters, a.C, a.work_ctr + 2);
+            else if (a.n_fasta == 0) /* command-line adapters of 33..64 bases, no FASTA list: the lane-per-read kernel is all there is */
+                FPL_LAUNCH((k_trim_ends_batched<KWAVES, 8, false>), dim3(gblocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+                           a.ads, a.state, a.counters, a.C, a.work_ctr + 2);
+            else {
+                /* a FASTA chain: trimAndCut, polyX and the two command-line adapters with lane = read, then the chain with a wave per
+                   read from the state the first kernel left (c5: 4.3 of the chain kernel's 15 ms were those four steps) */
+                FPL_LAUNCH((k_trim_ends_batched<KWAVES, 8, true>), dim3(gblocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+                           a.ads, a.state, a.counters, a.C, a.work_ctr + 2);
+                FPL_LAUNCH((k_trim_ends<KWAVES, 2>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+                           a.ads, a.state, a.counters, a.C, 1);
+            }
         } else if (a.trim_mode == 1)
             FPL_LAUNCH((k_trim_ends<KWAVES, 1>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
-                       a.ads, a.state, a.counters, a.C);
+                       a.ads, a.state, a.counters, a.C, 0);
         else if (a.trim_mode == 2)
             FPL_LAUNCH((k_trim_ends<KWAVES, 2>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
-                       a.ads, a.state, a.counters, a.C);
+                       a.ads, a.state, a.counters, a.C, 0);
         else
             FPL_LAUNCH((k_trim_ends<KWAVES, 0>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
-                       a.ads, a.state, a.counters, a.C);
+                       a.ads, a.state, a.counters, a.C, 0);
 #ifndef FPL_EMU
         if (a.trim_stream) {
             (void)hipEventRecord((hipEvent_t)a.ev_trim_done, a.trim_stream);

@@ -77,6 +77,7 @@ extern "C" int emu_process_batch(const fpl_options* opt, const char* start, int 
     a.bm = BmLists{frags.data(), regs.data(), frag_cap, reg_cap, item_cap, bm_counts};
     a.defer = cfg.defer != 0;
     a.trim_mode = cfg.trim_mode;
+    a.n_fasta = cfg.n_fasta;
     a.scan_short = cfg.scan_short != 0;
     a.counters = (long long*)counters;
     a.C = C;

@@ -15,7 +15,7 @@ def test_work_counter_dequeues_in_the_built_library():
     lib = build.build_hip()
     sites = {dequeue_isa.kernel_name(k): v for k, v in dequeue_isa.check(lib).items()}
     # the kernels that take chunks of reads / groups of 64 reads off a device counter, wave by wave
-    for k in ("k_scan<4,1>", "k_scan<4,0>", "k_trim_ends_batched<4>"):  # (k_stats_sorted's block-wide dequeue goes through LDS)
+    for k in ("k_scan<4,1>", "k_scan<4,0>", "k_trim_ends_batched<4,4,0>", "k_trim_ends_batched<4,8,0>", "k_trim_ends_batched<4,8,1>"):  # (k_stats_sorted's block-wide dequeue goes through LDS)
         assert k in sites, (k, sorted(sites))
     for k, v in sites.items():
         for addr, cmp_addr, ok, why in v:

@@ -274,6 +274,31 @@ def test_emulated_batched_trim_kernel_adapter_lengths(orc, la, lb):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
+@pytest.mark.parametrize("la,lb,nfa", [(40, 50, 0), (64, 33, 0), (40, 50, 3)])
+def test_emulated_batched_trim_kernel_adapters_beyond_32_bases(orc, la, lb, nfa):
+    """k_trim_ends_batched<.., 8, ..>: command-line adapters of 33..64 bases (64-base one-hot windows, 64-column confirmations), alone
+    and as the front end of a FASTA chain (k_trim_ends<2> then starts from the ReadState records).  Reads shorter than the adapter
+    make a trim return a NEGATIVE count (pos = min(pos + ext, rlen - alen)): only reads whose total is positive are booked"""
+    rng = np.random.default_rng(la * 100 + lb)
+    start = "".join("ACGT"[i] for i in rng.integers(0, 4, la))
+    end = "".join("ACGT"[i] for i in rng.integers(0, 4, lb))
+    fasta = ["".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.choice([16, 24, 40, 64])))) for _ in range(nfa)]
+    cfg = orc.Config(abi.FplOptions.default(cut_front=1, polyx=1, trimming_extension=10), start, end, fasta)
+    seq, qual, off = synth.adversarial(230, seed=la + lb, start_adapter=start, end_adapter=end, fasta=fasta)
+    reads = [(seq[int(off[i]):int(off[i + 1])], qual[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    for k in range(30):  # the start adapter's last 16 bases and a few more: a partial match in a read shorter than alen - 16
+        r = np.frombuffer((start[-16:] + "".join("ACGT"[i] for i in rng.integers(0, 4, 2 + k % 6))).encode(), np.uint8)
+        reads.append((r, np.full(len(r), 70, np.uint8)))
+    seq, qual, off = synth.pack(reads)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    if la >= 40:
+        assert (want_res["r1_len"][-30:] == 0).any()  # (Read::trimFront with a negative count erased the read)
+
+
 def _reads_with_long_scans(seed, n=40):
     """reads whose trimAndCut / polyX scans run long: low-quality heads and tails of 100..500 bases (a sliding window finds
     nothing good for hundreds of positions), poly-A tails and N runs beyond the lane-per-read forms' iteration cap, and a few
