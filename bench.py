@@ -254,6 +254,7 @@ E2E_RUNS = (
     dict(name="gz_in_single_stream", target="/dev/null", input="gz_single", flags=["--gz_stream"]),
     dict(name="gz_out", target="GZ", input="fq_sub"),
     dict(name="null8_to_dev_null", target="/dev/null", null=NULLDEV_DEVICES),
+    dict(name="null8_to_dev_null_rt16", target="/dev/null", null=NULLDEV_DEVICES, flags=["--reader_threads", "16"]),
     dict(name="null8_to_split_files", target=None, null=NULLDEV_DEVICES, flags=["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)]),
     dict(name="null8_to_file", target=None, null=NULLDEV_DEVICES),
 )
@@ -816,7 +817,8 @@ def main(argv=None, rig=None):
             try:
                 big = end_to_end(args.workload, opt, adapters, seq_t, qual_t, off_t, ne, copies=args.e2e_copies,
                                  with_pcie=False, run_names=("to_dev_null", "to_file", "to_split_files", "chunk_512mb", "chunk_1536mb",
-                                            "null8_to_dev_null", "null8_to_split_files", "null8_to_file"))
+                                            "null8_to_dev_null", "null8_to_dev_null_rt16", "null8_to_split_files",
+                                            "null8_to_file"))
                 out["e2e"]["large_input"] = big
             except Exception as e:
                 out["e2e"]["large_input"] = {"error": repr(e)[:300]}
