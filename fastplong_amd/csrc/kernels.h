@@ -1170,6 +1170,85 @@ __device__ __forceinline__ u32 fasta_may_trim32(const FastaPeqLds* __restrict__ 
     /* bit 0: the whole adapter may match, bit 1: its partial pattern; bits 8..: where (blocks of 32 columns) */
     return a_ok ? ((fullF ? 1u : 0u) | (partF ? 2u : 0u) | ((partF ? blocks : 0u) << 8)) : 0u;
 }
+/* fasta_may_trim32 with fewer instructions per window byte (22 -> 18), for adapters of 23 bases and more (every lane of the wave):
+   the same verdicts.
+   - The two scores live in ONE register as 7-bit fields, each with a bias that puts "score > threshold" into the field's top bit
+     (score + 63 - thr: 0 .. 127 for scores up to 64): the partial pattern's at bits 0..6, the adapter's from bit topF - 15 (>= 7) on,
+     so that one shift by 15 and one AND with a per-lane mask bring both taps of Ph (of Mh) to their fields' low bits; a column
+     adds the one and subtracts the other (no field ever leaves 0 .. 127: a score moves by one and is an edit distance).  ANDing
+     the register over the columns keeps a field's top bit exactly when the score stayed above its threshold in all of them:
+     seven instructions where two bit-field extracts, an add / subtract and a minimum per score took nine.
+   - Eight columns whose bytes all exist are stepped without a test per column, their window bytes come from one address
+     register with constant offsets, and a byte's table row goes into the address arithmetic as the (wave-uniform) vector
+     value it is loaded as instead of through a scalar register. */
+#ifndef FPL_OPT_FILTPACK
+#define FPL_OPT_FILTPACK 1
+#endif
+template <bool START>
+__device__ __forceinline__ u32 fasta_may_trim32p(const FastaPeqLds* __restrict__ t, const u8* __restrict__ rowc, int boff, int n,
+                                                  int alen, int thrA, int thrP, bool a_ok) {
+    const int lane = lane_id();
+    const int m = min(alen, 32); /* >= 23 */
+    u32 Pv = m >= 32 ? ~0u : ((1u << m) - 1u), Mv = 0;
+    const u32 sF = (u32)(m - 1) - 15u;       /* the adapter's field: bits sF .. sF + 6 */
+    const u32 MK = 1u | (1u << sF);          /* the two taps behind the shift by 15 */
+    u32 sc = (u32)(16 + 63 - thrP) | ((u32)(m + 63 - thrA) << sF);
+    u32 acc = sc | 0x7Fu; /* (the adapter's score before the first column counts, the partial pattern's does not: as fasta_may_trim32) */
+    u32 blocks = 0;
+    const u32* const wf = &t->w[0][START ? 2 : 3][lane];
+#define FPL_FILT_COL(Eq_)                                            \
+    {                                                                \
+        const u32 Eq = (Eq_);                                        \
+        const u32 Xv = Eq | Mv;                                      \
+        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;                 \
+        u32 Ph = Mv | ~(Xh | Pv);                                    \
+        u32 Mh = Pv & Xh;                                            \
+        sc = sc + ((Ph >> 15) & MK) - ((Mh >> 15) & MK);             \
+        acc &= sc;                                                   \
+        Ph <<= 1;                                                    \
+        Mh <<= 1;                                                    \
+        Pv = Mh | ~(Xv | Ph);                                        \
+        Mv = Ph & Xv;                                                \
+    }
+    for (int j0 = 0; j0 < n; j0 += 32) { /* (n <= 200: seven blocks at most) */
+        const int j1 = min(n, j0 + 32);
+        for (int jj = j0; jj < j1; jj += 8) {
+            u32 Eqs[8];
+            if (jj + 8 <= j1) { /* wave-uniform: eight columns of the window */
+                const u8* const pb = rowc + boff + (START ? n - 8 - jj : jj);
+                u32 cb[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) cb[u] = (u32)pb[START ? 7 - u : u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) Eqs[u] = wf[cb[u] * (4u * 64u)]; /* (the row: the same value in every lane) */
+#pragma unroll
+                for (int u = 0; u < 8; u++) FPL_FILT_COL(Eqs[u])
+            } else {
+                u32 cb[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = min(jj + u, n - 1);
+                    cb[u] = (u32)rowc[(START ? n - 1 - j : j) + boff];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) Eqs[u] = wf[cb[u] * (4u * 64u)];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (jj + u < j1) FPL_FILT_COL(Eqs[u]) /* wave-uniform */
+            }
+        }
+        blocks |= ((~acc >> 6) & 1u) << (j0 >> 5);
+        acc |= 0x7Fu;
+    }
+#undef FPL_FILT_COL
+    const bool fullF = ((acc >> (sF + 6u)) & 1u) == 0u;
+    bool partF = blocks != 0;
+    if (FPL_OPT_FASTANEAR && !fullF) {
+        const int jn = n - alen + 16;
+        partF = (jn <= 0 ? blocks : (blocks & (~0u << (jn >> 5)))) != 0;
+    }
+    return a_ok ? ((fullF ? 1u : 0u) | (partF ? 2u : 0u) | ((partF ? blocks : 0u) << 8)) : 0u;
+}
 /* The positions p of a partial-pattern search (window of 16 bases at p, src/adaptertrimmer.cpp:202-216 / :273-286) that the
    filter's verdict leaves open, [lo, hi]: column j of the run is the LAST byte of the end trim's window p = n - 1 - j (its
    windows end at byte n - 1 - p of the staged tail), and -- the start trim's run walks its window backwards -- the FIRST byte
@@ -1283,6 +1362,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
        k_trim_ends_batched<.., 8, true> left r1 and the bases they took in state[] (lane = read there: a fraction of what the
        wave-per-read forms below cost for them) -- and this kernel runs the FASTA chain from there */
     const bool chain_only = MODE == 2 && from_state != 0;
+    bool pq_zeroed = false; /* wave-uniform */
     for (u32 ri = wave_global; ri < n_reads; ri += n_waves) {
         const uint64_t o0 = off[ri];
         const int l = (int)(off[ri + 1] - o0);
@@ -1362,6 +1442,10 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                each adapter's 16-column Peq table is copied next to them (4 loads per lane) */
             bool stale_s = true, stale_e = true;
             uint16_t* const pq = lds.peq16w[wave_in_block()];
+            if (FILT && !pq_zeroed) { /* (with the filter only the four letters' words are ever written: the rest stays zero) */
+                for (int i = lane; i < 256; i += 64) pq[i] = 0;
+                pq_zeroed = true;
+            }
             /* which adapters of the current group of 64 can trim the start / the end of r1 as it is now (fasta_may_trim) */
             u64 may_s = ~0ull, may_e = ~0ull;
             u64 full_s = ~0ull, part_s = ~0ull, full_e = ~0ull, part_e = ~0ull; /* ... and which of its two searches could succeed */
@@ -1398,16 +1482,27 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
 #if FPL_OPT_FASTAFILTER == 2
                 /* (a trim at one end leaves the other end's window -- and with it that end's verdicts -- as they were, unless r1
                    has become shorter than the window) */
+                /* (wave-uniform: every adapter of the group -- a lane without one borrows adapter a's length -- has the 23 bases
+                   the packed form of the filter needs) */
+                const bool packed = FPL_OPT_FILTPACK && wave_ballot(alen < 23 || (u32)thrA > 63u || (u32)thrP > 63u) == 0; /* (thresholds: the bias 63 - thr) */
                 if (dirty_s) {
-                    verd_s = fasta_may_trim32<true>(fp, (const u8*)winr_s, 0, wl, alen, thrA, thrP, a_ok);
+                    verd_s = packed ? fasta_may_trim32p<true>(fp, (const u8*)winr_s, 0, wl, alen, thrA, thrP, a_ok)
+                                    : fasta_may_trim32<true>(fp, (const u8*)winr_s, 0, wl, alen, thrA, thrP, a_ok);
                     fn_s = wl;
+#ifdef FPL_EMU /* (the emulator holds the packed form against the plain one, verdict by verdict) */
+                    if (packed && verd_s != fasta_may_trim32<true>(fp, (const u8*)winr_s, 0, wl, alen, thrA, thrP, a_ok)) emu_fail("fasta_may_trim32p<start>");
+#endif
                     full_s = wave_ballot((verd_s & 1u) != 0);
                     part_s = wave_ballot((verd_s & 2u) != 0);
                     may_s = full_s | part_s;
                 }
                 if (dirty_e) {
-                    verd_e = fasta_may_trim32<false>(fp, (const u8*)winr_e, 0, wl, alen, thrA, thrP, a_ok);
+                    verd_e = packed ? fasta_may_trim32p<false>(fp, (const u8*)winr_e, 0, wl, alen, thrA, thrP, a_ok)
+                                    : fasta_may_trim32<false>(fp, (const u8*)winr_e, 0, wl, alen, thrA, thrP, a_ok);
                     fn_e = wl;
+#ifdef FPL_EMU
+                    if (packed && verd_e != fasta_may_trim32<false>(fp, (const u8*)winr_e, 0, wl, alen, thrA, thrP, a_ok)) emu_fail("fasta_may_trim32p<end>");
+#endif
                     full_e = wave_ballot((verd_e & 1u) != 0);
                     part_e = wave_ballot((verd_e & 2u) != 0);
                     may_e = full_e | part_e;
@@ -1453,7 +1548,11 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     if (stale_s) stage_window(win_s, sq + s, min(e - s, FPL_END_WINDOW), seq_end, win4_s, winr_s);
                     stale_s = false;
                     wave_sync();
-                    for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_start[i];
+                    if (FILT) { /* (A / C / G / T adapters: the four words are in the filter's table -- the start trim's reversed) */
+                        if (lane < 4) pq[(0x47544341u >> (8 * lane)) & 0xFFu] = (uint16_t)(FPL_OPT_FASTAFILTER == 2 ? __brev(fp->w[lane][2][a & 63]) >> 16 : fp->w[lane][2][a & 63]);
+                    } else {
+                        for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_start[i];
+                    }
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_s, 0, e - s, win4_s};
@@ -1476,7 +1575,11 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     if (stale_e) stage_window(win_e, sq + e - wl, wl, seq_end, win4_e, winr_e);
                     stale_e = false;
                     wave_sync();
-                    for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_end[i];
+                    if (FILT) {
+                        if (lane < 4) pq[(0x47544341u >> (8 * lane)) & 0xFFu] = (uint16_t)fp->w[lane][3][a & 63];
+                    } else {
+                        for (int i = lane; i < 256; i += 64) pq[i] = (uint16_t)ad->peq16_end[i];
+                    }
                     wave_sync();
                     const int s0 = s, e0 = e;
                     const Win<true> wn = {nullptr, win_e, rlen - wl, rlen, win4_e};
@@ -4586,7 +4689,11 @@ k_resolve(const u8* __restrict__ seq, const uint64_t* __restrict__ off, u32 n_re
  * (passFilter sums, quality histogram -> code, median; src/seprocessor.cpp:265-281) and the gap between them -- the three
  * histograms add up to the one k_scan booked post-filter when r1 passed as a whole, which is taken back here -- and writes the
  * read's record, counters and plan. */
-template <int WAVES>
+/* PLAN: the read's plan for the statistics pass is written here too (a split read with ONE passing output read next to its start is
+ * counted post-filter by the single pass).  Without it -- the sorted pass, whose bucket kernels then need nothing of this kernel and
+ * run beside it -- state[] is only read: a split read keeps the plan "not post" that the trim kernel left, and every passing
+ * fragment goes on the EXTRA list. */
+template <int WAVES, bool PLAN>
 __global__ void __launch_bounds__(WAVES * 64)
 k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads, uint64_t n_bytes,
        const DevConfig* __restrict__ cfg, ReadState* __restrict__ state, const ScanRec* __restrict__ recs,
@@ -4699,7 +4806,7 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
         if (d1) atomicAdd(&acc.bqh[1][2 * lane + 1], (u64)(long long)(int)d1);
         /* one passing output read that starts within FS_SMAX bases of the read's start (Read::breakByGap drops an empty
            side): the statistics pass counts it post-filter as a window of the read, like an unsplit r1 */
-        const bool to_post = nf == 1 && r_pass[0] && r_fs[0] <= (u32)FS_SMAX;
+        const bool to_post = PLAN && nf == 1 && r_pass[0] && r_fs[0] <= (u32)FS_SMAX;
         if (lane == 0) {
             fpl_read_result res;
             res.r1_start = (u32)s;
@@ -4714,13 +4821,15 @@ k_redo(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* 
             res.median_q_post[0] = (u8)r_med[0]; res.median_q_post[1] = (u8)r_med[1];
             res.reserved[0] = res.reserved[1] = res.reserved[2] = 0;
             results[ri] = res;
-            ReadState ns = st;
-            ns.pad = to_post ? PLAN_TO_POST : 0u;
-            if (to_post) { /* the window the statistics pass works on is the fragment, not r1 */
-                ns.s = r_fs[0];
-                ns.e = r_fs[0] + r_fl[0];
+            if (PLAN) {
+                ReadState ns = st;
+                ns.pad = to_post ? PLAN_TO_POST : 0u;
+                if (to_post) { /* the window the statistics pass works on is the fragment, not r1 */
+                    ns.s = r_fs[0];
+                    ns.e = r_fs[0] + r_fl[0];
+                }
+                state[ri] = ns;
             }
-            state[ri] = ns;
             /* passing fragments wait in this wave's buffer for a place on the EXTRA list */
             u32 slot = nbuf;
             if (r_pass[0] && !to_post) {

@@ -56,6 +56,7 @@ struct StatsTune {
     u32 hi_tile = 0;        /* FPL_STATS_HI_TILE: (value - 1) = the first cycle tile whose k_stats_sorted items are groups of slices */
     u32 group = 0;          /* FPL_STATS_GROUP: slices per group */
     u32 group_rows = 0;     /* FPL_STATS_GROUP_ROWS: rows a group's slab may take before it is handed over (test hook: small) */
+    u32 redo_inline = 0;    /* FPL_REDO_INLINE=1: k_redo stays on the main stream (measurement aid) */
     u32 scan_chunk = 0;     /* FPL_SCAN_CHUNK: reads a k_scan wave takes per dequeue, whatever the batch size (the built-in rule gives small
                                batches chunks of one read: no wave then has a NEXT read whose head could ride in a last tile) */
     u32 trim_batch_min = 0; /* FPL_TRIM_BATCH_MIN: batches of fewer reads take k_trim_ends<1> (a wave per read) instead of
@@ -75,6 +76,7 @@ inline StatsTune stats_tune_from_env() {
     t.sort_min = get("FPL_STATS_SORT_MIN");
     t.trim_batch_min = get("FPL_TRIM_BATCH_MIN");
     t.scan_chunk = get("FPL_SCAN_CHUNK");
+    t.redo_inline = get("FPL_REDO_INLINE");
     t.hi_tile = get("FPL_STATS_HI_TILE");
     t.group = get("FPL_STATS_GROUP");
     t.group_rows = get("FPL_STATS_GROUP_ROWS");
@@ -359,6 +361,18 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                        (const ReadState*)a.state, a.recs, a.wins, a.counters, a.C, a.work_ctr, chunk);
     }
     mark(2);
+    /* the sorted statistics pass starts from two zeroed buffers: cleared here, in front of k_resolve, where nothing runs beside the
+       fill kernels (behind it they share the chip with k_redo on the side stream and take 0.1 ms to find room) */
+    bool sorted_zeroed = false;
+    auto zero_sorted_ws = [&]() {
+        if (sorted_zeroed) return;
+        const u32 tiles = cdiv(a.max_read_len ? a.max_read_len : 1, FS_T);
+        const u32 ms = stats_sorted_max_slices(n, stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune), a.tune);
+        FPL_MEMSET(a.sort_ws, (size_t)SW_SLICES * sizeof(u32), stream);
+        FPL_MEMSET(a.stats_flags, (size_t)ms * tiles + tiles, stream);
+        sorted_zeroed = true;
+    };
+    if (run_front && run_back && !(a.dbg & 0xC000) && stats_takes_sorted(n, a.n_bytes, a.max_read_len, a.n_cu, a.tune, a.defer)) zero_sorted_ws();
     if (run_front && !(a.dbg & 0xC000)) {
         /* lane = read: confirmations, gaps, records, counters, plan; the reads a middle adapter splits go on the REDO list */
         /* (sixteen waves per block and no more than two blocks per CU: every block ends with a few hundred global atomics on
@@ -377,9 +391,24 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
 #endif
             u32 dblocks = cdiv(n, DW);
             if (dblocks > FPL_REDO_BLOCKS_PER_CU * a.n_cu) dblocks = FPL_REDO_BLOCKS_PER_CU * a.n_cu;
-            FPL_LAUNCH((k_redo<DW>), dim3(dblocks), dim3(DW * 64), stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.state,
-                       (const ScanRec*)a.recs, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, (const RedoItem*)a.redo,
-                       (const u32*)(a.work_ctr + 3), a.work_ctr + 4, a.counters, a.C);
+            /* the sorted statistics pass takes the split reads as the trim kernel's plan has them ("not post"): k_redo then writes
+               no plan, the bucket kernels and k_stats_sorted need nothing of it, and -- when that pass forks the side stream for
+               its post-only part anyway -- it runs there, in front of that part, beside them (0.15 ms of a mostly idle chip on
+               the bench batch; the fragments it finds go on the EXTRA list, which only the post-only pass reads) */
+            const bool sorted = run_back && stats_takes_sorted(n, a.n_bytes, a.max_read_len, a.n_cu, a.tune, a.defer);
+            fpl_stream_t rs = stream;
+            if (sorted && a.aux != nullptr && a.extra_scratch != nullptr && !a.tune.redo_inline) {
+                FPL_FORK_MARK(a, stream);
+                rs = FPL_FORK(a, stream);
+            }
+            if (sorted)
+                FPL_LAUNCH((k_redo<DW, false>), dim3(dblocks), dim3(DW * 64), rs, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.state,
+                           (const ScanRec*)a.recs, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, (const RedoItem*)a.redo,
+                           (const u32*)(a.work_ctr + 3), a.work_ctr + 4, a.counters, a.C);
+            else
+                FPL_LAUNCH((k_redo<DW, true>), dim3(dblocks), dim3(DW * 64), stream, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg, a.state,
+                           (const ScanRec*)a.recs, a.results, a.frag_off, a.frag_len, a.work_ctr + 1, (const RedoItem*)a.redo,
+                           (const u32*)(a.work_ctr + 3), a.work_ctr + 4, a.counters, a.C);
         }
     }
     if (a.defer && run_front) {
@@ -417,8 +446,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     if (stats_takes_sorted(n, a.n_bytes, a.max_read_len, a.n_cu, a.tune, a.defer)) {
         const u32 per = per_sorted;
         const u32 max_slices = stats_sorted_max_slices(n, per, a.tune);
-        FPL_MEMSET(a.sort_ws, (size_t)SW_SLICES * sizeof(u32), stream);
-        FPL_MEMSET(a.stats_flags, (size_t)max_slices * n_tiles + n_tiles, stream);
+        zero_sorted_ws();
         const u32 nblk = cdiv(n, FS_SORT_READS);
         u32* const blkcnt = a.sort_ws + SW_SLICES + 6 * (size_t)max_slices;
         FPL_LAUNCH(k_bucket_count, dim3(nblk), dim3(FS_SORT_BLK), stream, (const ReadState*)a.state, n, blkcnt);

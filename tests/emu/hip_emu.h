@@ -16,6 +16,8 @@
 #include <atomic>
 #include <barrier>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -118,12 +120,22 @@ inline T __shfl_down(T v, unsigned d, int = 64) {
 template <class T>
 inline T __shfl_xor(T v, int m, int = 64) { return emu_shfl_idx(v, emu::t_lane ^ m); }
 
+/* a kernel's own consistency check failed (FPL_EMU-only code in csrc/kernels.h) */
+[[noreturn]] inline void emu_fail(const char* what) {
+    fprintf(stderr, "emulator: consistency check failed: %s\n", what);
+    abort();
+}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
 inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+inline unsigned __brev(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i);
+    return r;
+}
 
 template <class T>
 inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
