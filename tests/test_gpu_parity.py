@@ -173,6 +173,32 @@ def test_hifi_like_64_adapters_bit_exact(orc, engine_mod):
     _run_both(orc, engine_mod, cfgd, seq, qual, off, fasta=sorted(ads))
 
 
+@pytest.mark.parametrize("lens,ed_max,n_ad,seed", [((30, 45), 0.25, 64, 1), ((23, 24, 31, 32, 33, 64), 0.25, 70, 2), ((23, 40, 64), 0.4, 9, 3),
+                                                   ((32, 64), 1.0, 5, 4), ((22, 23, 30), 0.25, 9, 5)])
+def test_fasta_filter_packed_scores_bit_exact(orc, engine_mod, lens, ed_max, n_ad, seed):
+    """k_trim_ends<2>: adapter sets whose every adapter has 23 bases or more take the packed-score form of the lane-per-adapter
+    filter (fasta_may_trim32p; tests/test_kernels_emu.py holds it against the plain form verdict by verdict).  ed_max 1.0: the
+    thresholds leave the packed fields' range (plain form); the set with a 22-mer: plain form as a whole; 70 adapters: two groups"""
+    rng = np.random.default_rng(1000 + seed)
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, int(n)))  # noqa: E731
+    fasta = [rnd(rng.integers(lens[0], lens[-1] + 1) if len(lens) == 2 else rng.choice(lens)) for _ in range(n_ad)]
+    start, end = fasta[0], synth.revcomp(fasta[0])
+    seq, qual, off = synth.adversarial(300, seed=40 + seed, start_adapter=start, end_adapter=end, fasta=fasta)
+    reads = [(seq[int(off[i]):int(off[i + 1])], qual[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    for k in range(240):  # an adapter (whole, or its partial pattern and a few bases more) with up to three errors at an end of a random read
+        ad = fasta[int(rng.integers(0, len(fasta)))]
+        body = rnd(rng.integers(40, 2000))
+        piece = list(ad if k % 3 else (ad[-(16 + k % 9):] if k % 2 else ad[:16 + k % 9]))
+        for _ in range(k % 4):
+            piece[int(rng.integers(0, len(piece)))] = "ACGT"[int(rng.integers(0, 4))]
+        piece = "".join(piece)
+        r = np.frombuffer(((piece + body) if k % 2 else (body + piece)).encode(), np.uint8)
+        reads.append((r, np.full(len(r), 70, np.uint8)))
+    seq, qual, off = synth.pack(reads)
+    res, cnt = _run_both(orc, engine_mod, dict(opt=dict(ed_max=ed_max, trimming_extension=5), start=start, end=end), seq, qual, off, fasta=fasta)
+    assert (res["r1_start"] > 0).any()
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_FUZZ_FASTA_FROM", "0")),
                                             int(os.environ.get("FPL_FUZZ_FASTA_FROM", "0")) + int(os.environ.get("FPL_FUZZ_FASTA", "8")))))
 def test_random_fasta_sets_of_16_to_64_mers_bit_exact(orc, engine_mod, seed):
