@@ -155,7 +155,8 @@ inline void pipeline_join(const BatchArgs& a, hipStream_t stream) {
 constexpr int N_STAGES = 7;
 static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_resolve", "k_stats_prep", "k_stats", "k_stats_reduce",
                                                   "k_stats_extra"};
-/* k_resolve = k_resolve + k_redo (+ k_break_mask with --break / --mask); k_stats_prep = the bucket kernels of the sorted pass;
+/* k_resolve = k_resolve + k_redo (+ k_break_mask with --break / --mask; with the sorted statistics pass k_redo runs on the side stream,
+   beside stage k_stats_prep, and its time shows there); k_stats_prep = the bucket kernels of the sorted pass;
    k_stats = k_stats_sorted (or the unsorted k_stats) alone; k_stats_extra = the post-only pass and its reduce -- when that pass
    runs on the context's side stream (the sorted pass with overlap on: the usual case for large batches) its kernel runs BESIDE
    stages k_stats / k_stats_reduce and only the join + its reduce are left in this stage; the events sit on the main stream, so
