@@ -1196,19 +1196,20 @@ __device__ __forceinline__ u32 fasta_may_trim32p(const FastaPeqLds* __restrict__
     u32 acc = sc | 0x7Fu; /* (the adapter's score before the first column counts, the partial pattern's does not: as fasta_may_trim32) */
     u32 blocks = 0;
     const u32* const wf = &t->w[0][START ? 2 : 3][lane];
-#define FPL_FILT_COL(Eq_)                                            \
-    {                                                                \
-        const u32 Eq = (Eq_);                                        \
-        const u32 Xv = Eq | Mv;                                      \
-        const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;                 \
-        u32 Ph = Mv | ~(Xh | Pv);                                    \
-        u32 Mh = Pv & Xh;                                            \
-        sc = sc + ((Ph >> 15) & MK) - ((Mh >> 15) & MK);             \
-        acc &= sc;                                                   \
-        Ph <<= 1;                                                    \
-        Mh <<= 1;                                                    \
-        Pv = Mh | ~(Xv | Ph);                                        \
-        Mv = Ph & Xv;                                                \
+/* (the recurrence in nine instructions: Xh = ((Eq & Pv) + Pv) ^ Pv | Eq and Xv = Eq | Mv never exist on their own -- with s = (Eq & Pv) + Pv,
+   Ph = Mv | ~(s | Pv | Eq), Mh = Pv & ((s ^ Pv) | Eq), and behind the shift Pv' = (Mh << 1) | ~(Eq | Mv | Ph'), Mv' = Ph' & (Eq | Mv) are
+   three-input functions, v_bitop3, and the shift of Mh rides in a v_lshl_or) */
+#define FPL_FILT_COL(Eq_)                                                                 \
+    {                                                                                     \
+        const u32 Eq = (Eq_);                                                             \
+        const u32 s = (Eq & Pv) + Pv;                                                     \
+        u32 Ph = Mv | bitop3<0x01>(s, Pv, Eq);        /* Mv | ~(s | Pv | Eq) */           \
+        const u32 Mh = bitop3<0x8C>(s, Pv, Eq);       /* Pv & ((s ^ Pv) | Eq) */          \
+        sc = sc + ((Ph >> 15) & MK) - ((Mh >> 15) & MK);                                  \
+        acc &= sc;                                                                        \
+        Ph <<= 1;                                                                         \
+        Pv = lshl_or<1>(Mh, bitop3<0x01>(Eq, Mv, Ph)); /* (Mh << 1) | ~(Eq | Mv | Ph) */  \
+        Mv = bitop3<0xE0>(Ph, Eq, Mv);                 /* Ph & (Eq | Mv) */               \
     }
     for (int j0 = 0; j0 < n; j0 += 32) { /* (n <= 200: seven blocks at most) */
         const int j1 = min(n, j0 + 32);
