@@ -2151,18 +2151,15 @@ __device__ __forceinline__ u32 partial16_candidates(const u8* __restrict__ text,
         for (int t = 0; t < 16; t++) {
             const u32 c = (w[t >> 2] >> (8 * (t & 3))) & 0xFFu;
             const u32 Eq = peq16[c];
-            const u32 Xv = Eq | Mv;
-            const u32 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-            u32 Ph = Mv | ~(Xh | Pv);
-            u32 Mh = Pv & Xh;
-            const int sc = x + (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
+            /* (the recurrence as nine instructions, see fasta_may_trim32p.  A lane whose text has ended runs on: what it computes
+               behind its last column is masked out of h below and nothing of it comes back into a column that counts) */
+            const u32 s = (Eq & Pv) + Pv;
+            u32 Ph = Mv | bitop3<0x01>(s, Pv, Eq);  /* Mv | ~(s | Pv | Eq) */
+            const u32 Mh = bitop3<0x8C>(s, Pv, Eq); /* Pv & ((s ^ Pv) | Eq) */
+            x += (int)((Ph >> 15) & 1u) - (int)((Mh >> 15) & 1u);
             Ph <<= 1;
-            Mh <<= 1;
-            const bool act = c0 + t < nn;
-            const u32 nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
-            x = act ? sc : x;
-            Pv = act ? nPv : Pv;
-            Mv = act ? nMv : Mv;
+            Pv = lshl_or<1>(Mh, bitop3<0x01>(Eq, Mv, Ph)); /* (Mh << 1) | ~(Eq | Mv | Ph) */
+            Mv = bitop3<0xE0>(Ph, Eq, Mv);                 /* Ph & (Eq | Mv) */
             bits = alignbit(bits, (u32)x, 31); /* (bits << 1) | sign(x): column c0 + t ends up at bit 15 - t */
         }
         const int nv = nn - c0; /* columns of this block that exist in this lane's text */
