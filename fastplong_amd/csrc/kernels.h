@@ -3057,7 +3057,9 @@ k_stats_reduce(const u64* __restrict__ scratch, const u8* __restrict__ flags, u3
     const bool here = flags[tile] != 0, next = tile + 1 < n_tiles && flags[tile + 1] != 0;
     if (!here && !next) return; /* block-uniform */
     const u32 cc = is_post ? cell - 8 * FS_T : cell;
-    const u32 cls = cc / FS_T, x = cc % FS_T; /* x = cycle within the tile */
+    /* (threads in slot order, as in k_stats_reduce_sorted: a wave's loads of a slab are consecutive bytes, pre and post) */
+    const u32 cls = cc / FS_T, tj = cc % FS_T;
+    const u32 x = (tj & 63u) * 8u + (tj >> 6); /* x = cycle within the tile */
     u64 qsum = 0, cnt = 0, q20 = 0, q30 = 0;
     if (!is_post) {
         if (!with_pre || !here) return;
@@ -5429,8 +5431,12 @@ k_stats_reduce_sorted(const u64* __restrict__ scratch, const u8* __restrict__ fl
     if (!here && !next) return; /* block-uniform */
     const u32 n_slices = sw[SW_NSLICES];
     const u32 cc = is_post ? cell - 8 * FS_T : cell;
-    const u32 cls = cc / FS_T, x = cc % FS_T;
-    const u32 slot_pre = (x & 7) * 64 + (x >> 3);
+    /* threads in SLOT order: thread j of a class row owns the cycle whose slab slot is j (slot(x) = (x % 8) * 64 + x / 8), so a
+       wave's 64 loads of a slab are 512 consecutive bytes -- with threads in cycle order they were eight pieces of 64 bytes; a
+       front trim moves every thread's slot by the same amount, so the shifted post reads stay consecutive too */
+    const u32 cls = cc / FS_T, tj = cc % FS_T;
+    const u32 x = (tj & 63u) * 8u + (tj >> 6);
+    const u32 slot_pre = tj;
     u64 qsum = 0, cnt = 0, q20 = 0, q30 = 0;
     u64 nsum = 0, ncnt = 0, n20 = 0, n30 = 0; /* post: what lies behind the reads' ends */
     for (u32 base = 0; base < n_slices; base += 256) { /* block-uniform */
