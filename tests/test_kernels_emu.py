@@ -259,22 +259,21 @@ def test_emulated_kernels_byte_scan_fallback(orc):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
-@pytest.mark.parametrize("lens,ed_max,seed", [((30, 45), 0.25, 1), ((23, 24, 31, 32, 33, 64), 0.25, 2), ((23, 40, 64), 0.4, 3),
-                                              ((32, 64), 1.0, 4), ((22, 23, 30), 0.25, 5)])
+@pytest.mark.parametrize("lens,ed_max,seed", [((30, 45), 0.25, 1), ((23, 24, 31, 32, 33, 64), 0.4, 2), ((32, 64), 1.0, 4), ((22, 23, 30), 0.25, 5)])
 def test_emulated_fasta_filter_packed_scores(orc, lens, ed_max, seed):
     """k_trim_ends<2>: adapter sets whose every adapter has 23 bases or more take the packed-score form of the lane-per-adapter
     filter (fasta_may_trim32p).  The emulator build compares each of its verdicts with the plain form's and aborts on a
     difference; the records and counters are the oracle's.  ed_max 1.0 puts the thresholds beyond the packed fields' bias (plain
     form), the set with a 22-mer takes the plain form as a whole; adapters planted at both ends, whole and cut short"""
     rng = np.random.default_rng(1000 + seed)
-    n_ad = 9 if seed != 2 else 70  # (70: two groups of 64 lanes)
+    n_ad = 7 if seed != 2 else 66  # (66: two groups of 64 lanes)
     fasta = ["".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(lens[0], lens[-1] + 1) if len(lens) == 2 else rng.choice(lens))))
              for _ in range(n_ad)]
     start, end = fasta[0], synth.revcomp(fasta[0])
     cfg = orc.Config(abi.FplOptions.default(ed_max=ed_max, trimming_extension=5), start, end, fasta)
-    seq, qual, off = synth.adversarial(90, seed=40 + seed, start_adapter=start, end_adapter=end, fasta=fasta)
+    seq, qual, off = synth.adversarial(30 if seed != 2 else 12, seed=40 + seed, start_adapter=start, end_adapter=end, fasta=fasta)
     reads = [(seq[int(off[i]):int(off[i + 1])], qual[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
-    for k in range(60):  # an adapter (whole, or its partial pattern and a few bases more) with up to three errors at an end of a random read
+    for k in range(36 if seed != 2 else 18):  # an adapter (whole, or its partial pattern and a few bases more) with up to three errors at an end of a random read
         ad = fasta[int(rng.integers(0, len(fasta)))]
         body = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(40, 400))))
         piece = list(ad if k % 3 else (ad[-(16 + k % 9):] if k % 2 else ad[:16 + k % 9]))
