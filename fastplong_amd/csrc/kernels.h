@@ -967,9 +967,10 @@ __device__ __forceinline__ int trim_end_wave(const Win<LDSWIN>& win, int& s, int
 
 /* LDS accumulator of one k_trim_ends block: FilterResult scalars + the key histogram of the
  * two command-line adapters (the FASTA slots go straight to global atomics). */
+template <bool SLIM = false> /* SLIM: the chain-only instantiation, which trims with neither command-line adapter */
 struct TrimBlockAcc {
     u64 fr[FPL_FR_LEN];
-    u32 key[2 * 2 * FPL_KEY_STRIDE];
+    u32 key[SLIM ? 1 : 2 * 2 * FPL_KEY_STRIDE];
 };
 
 /* LDS copies for the two command-line adapters: their 16-column Peq tables, their full Peq tables,
@@ -981,13 +982,13 @@ struct TrimBlockAcc {
 #ifndef FPL_TRIM_WAVES_PER_SIMD_SHORT
 #define FPL_TRIM_WAVES_PER_SIMD_SHORT 7 /* (8 would cap it at 64 VGPRs: spills) */
 #endif
-template <int WAVES>
+template <int WAVES, bool SLIM = false> /* SLIM (chain only): no command-line adapter tables, no quality windows */
 struct TrimLds {
-    uint16_t peq16[2][256];        /* [0] = start adapter's peq16_start, [1] = end adapter's peq16_end (16 columns) */
-    uint64_t peqf[2][256][1];      /* word 0 of the full Peq tables: adapters of <= 64 bases (longer ones use the global tables) */
+    uint16_t peq16[SLIM ? 1 : 2][SLIM ? 1 : 256]; /* [0] = start adapter's peq16_start, [1] = end adapter's peq16_end (16 columns) */
+    uint64_t peqf[SLIM ? 1 : 2][SLIM ? 1 : 256][1]; /* word 0 of the full Peq tables: adapters of <= 64 bases (longer ones use the global tables) */
     /* per wave: the first / last TRIM_WIN bytes of the read being trimmed (stage_ends), [0] bases at the head, [1] bases
        at the tail, [2] / [3] the qualities; + 8 zero dwords the dword-aligned reads of the last positions run into */
-    u32 win[WAVES][4][TRIM_WIN / 4 + 8];
+    u32 win[WAVES][SLIM ? 2 : 4][TRIM_WIN / 4 + 8];
     u32 win4[WAVES][2][TRIM_WIN / 8 + 8]; /* the two base windows as one-hot nibbles (+ what a shifted read runs into) */
     uint16_t peq16w[WAVES][256];   /* per wave: the 16-column Peq table of the FASTA adapter being tried */
 };
@@ -1181,6 +1182,9 @@ __device__ __forceinline__ u32 fasta_may_trim32(const FastaPeqLds* __restrict__ 
    - Eight columns whose bytes all exist are stepped without a test per column, their window bytes come from one address
      register with constant offsets, and a byte's table row goes into the address arithmetic as the (wave-uniform) vector
      value it is loaded as instead of through a scalar register. */
+#ifndef FPL_OPT_ONEFP
+#define FPL_OPT_ONEFP 1 /* k_trim_ends<.., 2, true>: one filter table per block when there is one group of FASTA adapters */
+#endif
 #ifndef FPL_OPT_FILTPACK
 #define FPL_OPT_FILTPACK 1
 #endif
@@ -1319,36 +1323,51 @@ __device__ __forceinline__ bool fasta_may_trim(const FastaPeqLds* __restrict__ t
    16..32 bases; 2 = every adapter (command-line and FASTA) has 16..64 bases.  Modes 1 and 2 leave the global-memory
    paths, the short-pattern variants and the multi-word Levenshtein out (mode 1 also the FASTA chain): a fraction of
    the code, fewer scalar registers to spill */
-template <int WAVES, int MODE>
+#ifndef FPL_TRIM_WPS_ONEFP
+#define FPL_TRIM_WPS_ONEFP 7 /* (c5 side by side: 4 waves per SIMD 10.64 ms, 5 9.93, 6 9.64, 7 9.48, 8 9.61) */
+#endif
+/* ONEFP (MODE 2, at most 64 FASTA adapters: one group of lanes; launched for the chain alone, behind k_trim_ends_batched): the filter's
+   Peq table is the same for every read and wave, so the block holds ONE copy, filled once, instead of one per wave (20 of the
+   block's 40 KB of LDS), and an instantiation that only ever runs the chain needs neither the command-line adapters' tables, nor
+   the quality windows, nor their key histograms (11 KB more) or the registers of the code in front of the chain: 13 KB of LDS and
+   72 vector registers, seven waves per SIMD instead of four -- the exact trims are strings of dependent LDS round trips that more
+   waves hide (k_trim_ends<2> on c5 10.64 -> 9.48 ms, profiles/r05_v3/ab_filter_packed.txt) */
+template <int WAVES, int MODE, bool ONEFP = false>
 /* (MODE 2 with the adapter filter holds two 64-column Myers states per lane next to the exact trims' registers: 4 waves
    per SIMD, up to 128 VGPRs) */
 __global__ void __launch_bounds__(WAVES * 64, MODE == 1 ? FPL_TRIM_WAVES_PER_SIMD_SHORT
-                                              : (MODE == 2 && FPL_OPT_FASTAFILTER) ? 4 : FPL_TRIM_WAVES_PER_SIMD)
+                                              : (MODE == 2 && FPL_OPT_FASTAFILTER) ? (ONEFP ? FPL_TRIM_WPS_ONEFP : 4) : FPL_TRIM_WAVES_PER_SIMD)
 k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint64_t* __restrict__ off, u32 n_reads,
             uint64_t n_bytes, const DevConfig* __restrict__ cfg, const DevAdapter* __restrict__ ads,
             ReadState* __restrict__ state, long long* __restrict__ counters, u32 C, int from_state) {
-    __shared__ TrimBlockAcc acc;
-    __shared__ TrimLds<WAVES> lds;
+    constexpr bool CO = ONEFP; /* this instantiation only ever runs the chain (launched with from_state != 0) */
+    __shared__ TrimBlockAcc<CO> acc;
+    __shared__ TrimLds<WAVES, CO> lds;
     constexpr bool FILT = MODE == 2 && FPL_OPT_FASTAFILTER != 0;
-    __shared__ FastaPeqLds fpeq[FILT ? WAVES : 1]; /* per wave: the Peq words of the FASTA adapters being filtered */
+    static_assert(!ONEFP || FILT, "ONEFP is a form of the filtered chain");
+    __shared__ FastaPeqLds fpeq[FILT && !ONEFP ? WAVES : 1]; /* per wave: the Peq words of the FASTA adapters being filtered */
+    if (ONEFP && wave_in_block() == 0) { /* (n_fasta <= 64: lane = adapter, once per block; the barrier below publishes it) */
+        const bool a_ok = lane_id() < cfg->n_fasta;
+        fasta_peq_store(&fpeq[0], &ads[2 + (a_ok ? lane_id() : 0)], a_ok);
+    }
     const int lane = lane_id();
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x) acc.fr[i] = 0;
-    for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x) acc.key[i] = 0;
-    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
-        lds.peq16[0][i] = (uint16_t)ads[0].peq16_start[i];
-        lds.peq16[1][i] = (uint16_t)ads[1].peq16_end[i];
-        lds.peqf[0][i][0] = ads[0].peq_full[i][0];
-        lds.peqf[1][i][0] = ads[1].peq_full[i][0];
+    for (u32 i = threadIdx.x; !CO && i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x) acc.key[CO ? 0 : i] = 0;
+    for (u32 i = threadIdx.x; !CO && i < 256; i += blockDim.x) {
+        lds.peq16[0][CO ? 0 : i] = (uint16_t)ads[0].peq16_start[i];
+        lds.peq16[CO ? 0 : 1][CO ? 0 : i] = (uint16_t)ads[1].peq16_end[i];
+        lds.peqf[0][CO ? 0 : i][0] = ads[0].peq_full[i][0];
+        lds.peqf[CO ? 0 : 1][CO ? 0 : i][0] = ads[1].peq_full[i][0];
     }
     __syncthreads();
     const u8* seq_end = seq + n_bytes;
     const u8* qual_end = qual + n_bytes;
-    FastaPeqLds* const fp = &fpeq[FILT ? wave_in_block() : 0];
-    int fp_group = -1; /* the group of 64 FASTA adapters whose words fp holds */
+    FastaPeqLds* const fp = &fpeq[FILT && !ONEFP ? wave_in_block() : 0];
+    int fp_group = ONEFP ? 0 : -1; /* the group of 64 FASTA adapters whose words fp holds */
     u32* const win_s = lds.win[wave_in_block()][0];  /* head of the read, bases (later: the start trim's window) */
     u32* const win_e = lds.win[wave_in_block()][1];  /* tail of the read, bases (later: the end trim's window) */
-    u32* const win_hq = lds.win[wave_in_block()][2]; /* head / tail, qualities */
-    u32* const win_tq = lds.win[wave_in_block()][3];
+    u32* const win_hq = lds.win[wave_in_block()][CO ? 0 : 2]; /* head / tail, qualities (chain only: never touched) */
+    u32* const win_tq = lds.win[wave_in_block()][CO ? 1 : 3];
     u32* const win4_s = MODE != 0 ? lds.win4[wave_in_block()][0] : nullptr; /* (only the reduced instantiations scan nibbles) */
     u32* const win4_e = MODE != 0 ? lds.win4[wave_in_block()][1] : nullptr;
     __shared__ u32 winr[FILT ? WAVES : 1][2][TRIM_WIN / 4 + 8]; /* the two windows as Peq-table rows (stage_window's dstr) */
@@ -1362,7 +1381,7 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     /* chain only (MODE 2, from_state != 0: wave-uniform): trimAndCut, polyX and the two command-line adapters are done --
        k_trim_ends_batched<.., 8, true> left r1 and the bases they took in state[] (lane = read there: a fraction of what the
        wave-per-read forms below cost for them) -- and this kernel runs the FASTA chain from there */
-    const bool chain_only = MODE == 2 && from_state != 0;
+    const bool chain_only = CO || (MODE == 2 && from_state != 0);
     bool pq_zeroed = false; /* wave-uniform */
     for (u32 ri = wave_global; ri < n_reads; ri += n_waves) {
         const uint64_t o0 = off[ri];
@@ -1413,11 +1432,11 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                 }
                 const Win<true> wn = {nullptr, win_s, bias, e - s, win4_s};
                 trimmed += trim_start_wave<MODE>(wn, s, e, &ads[0], lds.peq16[0], lds.peqf[0], cfg, kl);
-                if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
+                if (!CO && kl > 0 && lane == 0) atomicAdd(&acc.key[CO ? 0 : (0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             } else if (MODE == 0 && cfg->has_start) {
                 const Win<false> wn = {sq + s, nullptr, 0, e - s};
                 trimmed += trim_start_wave<0>(wn, s, e, &ads[0], ads[0].peq16_start, ads[0].peq_full, cfg, kl);
-                if (kl > 0 && lane == 0) atomicAdd(&acc.key[(0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
+                if (!CO && kl > 0 && lane == 0) atomicAdd(&acc.key[CO ? 0 : (0 * 2 + 0) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(3) /* start adapter */
             if (chain_only) {
@@ -1430,12 +1449,12 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
                     bias = rlen - wl;
                 }
                 const Win<true> wn = {nullptr, win_e, bias, rlen, win4_e};
-                trimmed += trim_end_wave<MODE>(wn, s, e, &ads[1], lds.peq16[1], lds.peqf[1], cfg, kl);
-                if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
+                trimmed += trim_end_wave<MODE>(wn, s, e, &ads[1], lds.peq16[CO ? 0 : 1], lds.peqf[CO ? 0 : 1], cfg, kl);
+                if (!CO && kl > 0 && lane == 0) atomicAdd(&acc.key[CO ? 0 : (1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             } else if (MODE == 0 && cfg->has_end) {
                 const Win<false> wn = {sq + s, nullptr, 0, e - s};
                 trimmed += trim_end_wave<0>(wn, s, e, &ads[1], ads[1].peq16_end, ads[1].peq_full, cfg, kl);
-                if (kl > 0 && lane == 0) atomicAdd(&acc.key[(1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
+                if (!CO && kl > 0 && lane == 0) atomicAdd(&acc.key[CO ? 0 : (1 * 2 + 1) * FPL_KEY_STRIDE + kl], 1u);
             }
             PROF(4) /* end adapter */
             /* trimByMultiSequences, src/adaptertrimmer.cpp:42-57: every FASTA adapter at both ends, in order.  The
@@ -1618,8 +1637,8 @@ k_trim_ends(const u8* __restrict__ seq, const u8* __restrict__ qual, const uint6
     long long* fr = counters + FPL_OFF_FR(C);
     for (u32 i = threadIdx.x; i < FPL_FR_LEN; i += blockDim.x)
         if (acc.fr[i]) atomicAdd((u64*)&fr[i], acc.fr[i]);
-    for (u32 i = threadIdx.x; i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x)
-        if (acc.key[i]) atomicAdd((u64*)&keyh[i], (u64)acc.key[i]);
+    for (u32 i = threadIdx.x; !CO && i < 2 * 2 * FPL_KEY_STRIDE; i += blockDim.x)
+        if (acc.key[CO ? 0 : i]) atomicAdd((u64*)&keyh[i], (u64)acc.key[CO ? 0 : i]);
 }
 
 /* -----------------------------------------------------------------------------------------

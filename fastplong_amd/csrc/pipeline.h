@@ -320,8 +320,12 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                    read from the state the first kernel left (c5: 4.3 of the chain kernel's 15 ms were those four steps) */
                 FPL_LAUNCH((k_trim_ends_batched<KWAVES, 8, true>), dim3(gblocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
                            a.ads, a.state, a.counters, a.C, a.work_ctr + 2);
-                FPL_LAUNCH((k_trim_ends<KWAVES, 2>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
-                           a.ads, a.state, a.counters, a.C, 1);
+                if (FPL_OPT_ONEFP && a.n_fasta <= 64) /* one group of adapters: one Peq table per block */
+                    FPL_LAUNCH((k_trim_ends<KWAVES, 2, true>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+                               a.ads, a.state, a.counters, a.C, 1);
+                else
+                    FPL_LAUNCH((k_trim_ends<KWAVES, 2>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
+                               a.ads, a.state, a.counters, a.C, 1);
             }
         } else if (a.trim_mode == 1)
             FPL_LAUNCH((k_trim_ends<KWAVES, 1>), dim3(blocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
