@@ -259,21 +259,22 @@ def test_emulated_kernels_byte_scan_fallback(orc):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
-@pytest.mark.parametrize("lens,ed_max,seed", [((30, 45), 0.25, 1), ((23, 24, 31, 32, 33, 64), 0.4, 2), ((32, 64), 1.0, 4), ((22, 23, 30), 0.25, 5)])
+@pytest.mark.parametrize("lens,ed_max,seed", [((30, 45), 0.25, 1), ((23, 24, 31, 32, 33, 64), 0.25, 2), ((23, 40, 64), 0.4, 3),
+                                              ((32, 64), 1.0, 4), ((22, 23, 30), 0.25, 5), ((23, 64), 0.1, 6), ((30, 45), 0.0, 7)])
 def test_emulated_fasta_filter_packed_scores(orc, lens, ed_max, seed):
     """k_trim_ends<2>: adapter sets whose every adapter has 23 bases or more take the packed-score form of the lane-per-adapter
     filter (fasta_may_trim32p).  The emulator build compares each of its verdicts with the plain form's and aborts on a
     difference; the records and counters are the oracle's.  ed_max 1.0 puts the thresholds beyond the packed fields' bias (plain
     form), the set with a 22-mer takes the plain form as a whole; adapters planted at both ends, whole and cut short"""
     rng = np.random.default_rng(1000 + seed)
-    n_ad = 7 if seed != 2 else 66  # (66: two groups of 64 lanes)
+    n_ad = 9 if seed not in (2, 7) else 70  # (70: two groups of 64 lanes)
     fasta = ["".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(lens[0], lens[-1] + 1) if len(lens) == 2 else rng.choice(lens))))
              for _ in range(n_ad)]
     start, end = fasta[0], synth.revcomp(fasta[0])
     cfg = orc.Config(abi.FplOptions.default(ed_max=ed_max, trimming_extension=5), start, end, fasta)
-    seq, qual, off = synth.adversarial(30 if seed != 2 else 12, seed=40 + seed, start_adapter=start, end_adapter=end, fasta=fasta)
+    seq, qual, off = synth.adversarial(150, seed=40 + seed, start_adapter=start, end_adapter=end, fasta=fasta)
     reads = [(seq[int(off[i]):int(off[i + 1])], qual[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
-    for k in range(36 if seed != 2 else 18):  # an adapter (whole, or its partial pattern and a few bases more) with up to three errors at an end of a random read
+    for k in range(120):  # an adapter (whole, or its partial pattern and a few bases more) with up to three errors at an end of a random read
         ad = fasta[int(rng.integers(0, len(fasta)))]
         body = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(40, 400))))
         piece = list(ad if k % 3 else (ad[-(16 + k % 9):] if k % 2 else ad[:16 + k % 9]))
@@ -672,12 +673,12 @@ def _random_fasta_case(seed):
         start = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.choice(lens))))
     if rng.random() < 0.3:
         end = "".join("ACGTN"[i] for i in rng.integers(0, 5, int(rng.choice(lens))))
-    a = synth.adversarial(int(os.environ.get("FPL_EMU_FUZZ_READS", "36")), seed=seed,
+    a = synth.adversarial(int(os.environ.get("FPL_EMU_FUZZ_READS", "60")), seed=seed,
                           start_adapter=start or synth.START_ADAPTER, end_adapter=end or synth.END_ADAPTER, fasta=fasta)
-    # FPL_EMU_FUZZ_LONG (soaks; 5 x slower): a few longer reads (several cycle tiles / scan tiles, middle adapters) with the
-    # command-line pair or one FASTA adapter at the ends
+    # a few longer reads (several cycle tiles / scan tiles, middle adapters) with the command-line pair or one FASTA adapter at the
+    # ends (FPL_EMU_FUZZ_LONG=0 leaves them out)
     ends = (fasta[0], synth.revcomp(fasta[0])) if (fasta and rng.random() < 0.5) else (start or synth.START_ADAPTER, end or synth.END_ADAPTER)
-    b = synth.ont_like(4 if os.environ.get("FPL_EMU_FUZZ_LONG") else 0, seed=seed, median_len=int(rng.choice([600, 1500, 4000])), start_adapter=ends[0][:120],
+    b = synth.ont_like(4 if os.environ.get("FPL_EMU_FUZZ_LONG", "1") != "0" else 0, seed=seed, median_len=int(rng.choice([600, 1500, 4000])), start_adapter=ends[0][:120],
                        end_adapter=ends[1].replace("N", "A")[:120], p_middle=0.4, p_polya=0.2)
     reads = []
     for (s_, q_, o_) in (a, b):
@@ -688,10 +689,11 @@ def _random_fasta_case(seed):
 
 # 408: a 7-base FASTA adapter whose partial match sits at the last of its 193 end positions (beyond three rounds of 64)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_EMU_FUZZ_FROM", "0")),
-                                            int(os.environ.get("FPL_EMU_FUZZ_FROM", "0")) + int(os.environ.get("FPL_EMU_FUZZ", "1")))) + [408])
+                                            int(os.environ.get("FPL_EMU_FUZZ_FROM", "0")) + int(os.environ.get("FPL_EMU_FUZZ", "40")))) + [408])
 def test_emulated_random_fasta_cases(orc, seed):
     """random options x random command-line / FASTA adapter sets (every length class, so all instantiations of
-    k_trim_ends / k_scan) on the emulator; FPL_EMU_FUZZ=<n> widens it for a soak on CPU"""
+    k_trim_ends / k_scan) on the emulator, 40 seeds by default (a quarter of a second each since the emulator's lanes are fibers);
+    FPL_EMU_FUZZ=<n> FPL_EMU_FUZZ_FROM=<first> widen it for a soak on the CPU"""
     okw, start, end, fasta, seq, qual, off = _random_fasta_case(seed)
     cfg = orc.Config(abi.FplOptions.default(**okw), start, end, fasta)
     C = max(1, int(np.diff(off.astype(np.int64)).max()))
