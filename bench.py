@@ -28,6 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# why cpu_baseline.kind is "port" and not "reference": the reference's own per-read path does not compile in this image
+REFERENCE_BLOCKED_BY = ["src/adaptertrimmer.cpp:4 #include <hwy/highway.h> (Highway absent)",
+                        "src/fastqreader.h:35 #include <igzip_lib.h> (ISA-L absent)"]
+LINE_LIMIT = 4096  # bytes of the stdout line: the driver keeps the last 8 KB of stdout and parses the last line
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_BASE = 2.0  # one seq byte + one quality byte, each read once
 
@@ -259,8 +264,10 @@ E2E_RUNS = (
     dict(name="null8_to_file", target=None, null=NULLDEV_DEVICES),
 )
 GZ_READS = 50_000  # reads of the gzip legs (the first reads of the batch)
-E2E_DEFAULT_RUNS = ("to_dev_null_first_pass", "to_dev_null", "to_file", "to_split_files", "gz_in_multi", "gz_in_single",
-                    "gz_in_single_stream", "gz_out")
+E2E_DEFAULT_RUNS = ("to_dev_null_first_pass", "to_dev_null", "to_file", "to_split_files")
+E2E_FULL_RUNS = E2E_DEFAULT_RUNS + ("gz_in_multi", "gz_in_single", "gz_in_single_stream", "gz_out")
+E2E_LARGE_RUNS = ("to_dev_null", "to_file", "to_split_files", "chunk_512mb", "chunk_1536mb", "null8_to_dev_null",
+                  "null8_to_dev_null_rt16", "null8_to_split_files", "null8_to_file")
 
 
 def gzip_single_member(src, dst, level=1):
@@ -537,6 +544,102 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
     return res
 
 
+def _r(x, nd=6):
+    """floats to `nd` significant digits (the line is for reading; the full object keeps every digit)"""
+    return float("%.*g" % (nd, x)) if isinstance(x, float) else x
+
+
+def compact_line(out):
+    """The stdout line: the contract's fields, `roofline`, `cpu_baseline`, the two self-checks and an `e2e` of scalars --
+    numbers and short strings only.  Everything else (per-stage prose of the CLI runs, descriptions) stays in the full
+    object (--full-json and stderr)."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config", {})
+    c["config"] = {"workload": cfg.get("workload", "")[:160], "reads_per_gpu": cfg.get("reads_per_gpu"),
+                   "bases_per_gpu": cfg.get("bases_per_gpu"), "max_read_len": cfg.get("max_read_len"),
+                   "parallelism": cfg.get("parallelism", "").split(" ")[0], "trims_ahead": not cfg.get("pipelining", "none").startswith("none")}
+    rf = out.get("roofline")
+    if rf:
+        c["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "limited_by", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                    "traffic_source", "algorithmic_bytes_per_launch")}
+        c["roofline"]["kernel_ms"] = {k: _r(v) for k, v in (rf.get("kernel_ms") or {}).items()}
+        if rf.get("kernel_ms_in_line"):
+            c["roofline"]["k_trim_ends_ms_in_line"] = _r(rf["kernel_ms_in_line"].get("k_trim_ends"))
+        if rf.get("issue"):
+            c["roofline"]["issue_frac_of_kernel_time"] = _r(rf["issue"]["frac_of_kernel_time"])
+        pa = rf.get("path") or {}
+        c["roofline"]["path"] = {k: _r(pa.get(k)) for k in ("achieved", "frac", "measured_bytes_per_base")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = dict(cb, value=_r(cb["value"]), sample=cb["sample"][:120])
+    if "counters_check" in out:
+        c["counters_check"] = out["counters_check"]
+    if "parity_sample" in out:
+        c["parity_sample"] = out["parity_sample"][:200]
+    e = out.get("e2e")
+    if e:
+        ce = {"unit": "Gbases/s", "n_gpus": e.get("n_gpus"), "reads": e.get("reads")}
+        if "error" in e:
+            ce["error"] = e["error"][:200]
+
+        def leg(runs, name, key="value"):
+            r = (runs or {}).get(name)
+            return _r(r.get(key), 4) if r and r.get("rc") == 0 and r.get(key) is not None else None
+
+        runs = e.get("cli") or {}
+        ce["value"] = _r(e.get("value"), 4)
+        ce["pipeline_value"] = leg(runs, "to_dev_null", "pipeline_value")
+        ce["first_pass"] = leg(runs, "to_dev_null_first_pass")
+        ce["to_file"] = leg(runs, "to_file")
+        ce["to_split"] = leg(runs, "to_split_files")
+        if e.get("pcie_call"):
+            ce["pcie_call"] = _r(e["pcie_call"]["value"], 4)
+        if e.get("json_check"):
+            ce["json_ok"] = e["json_check"].get("ok")
+        for name, short in (("gz_in_multi", "gz_in"), ("gz_in_single", "gz_in_single"), ("gz_out", "gz_out")):
+            if name in runs:
+                ce[short] = leg(runs, name)
+        big = e.get("large_input") or {}
+        if big:
+            br = big.get("cli") or {}
+            ce["large"] = {"reads": big.get("reads"), "value": leg(br, "to_dev_null"), "pipeline_value": leg(br, "to_dev_null", "pipeline_value"),
+                           "to_file": leg(br, "to_file"), "to_split": leg(br, "to_split_files"),
+                           "chunk_512mb": leg(br, "chunk_512mb"), "chunk_1536mb": leg(br, "chunk_1536mb"),
+                           "null8": leg(br, "null8_to_dev_null", "pipeline_value"), "null8_rt16": leg(br, "null8_to_dev_null_rt16", "pipeline_value"),
+                           "null8_to_file": leg(br, "null8_to_file")}
+            if "error" in big:
+                ce["large"] = {"error": big["error"][:200]}
+        failed = [n for n, r in list(runs.items()) + list((big.get("cli") or {}).items()) if r.get("rc") != 0]
+        if failed:
+            ce["failed_runs"] = failed
+        c["e2e"] = ce
+    return c
+
+
+def emit(out, full_path):
+    """the full object -> `full_path` and stderr; its compact form -> ONE stdout line of at most LINE_LIMIT bytes"""
+    full = json.dumps(out)
+    if full_path:
+        try:
+            os.makedirs(os.path.dirname(full_path) or ".", exist_ok=True)
+            with open(full_path, "w") as f:
+                f.write(full + "\n")
+        except OSError as e:
+            print("bench.py: could not write %s: %s" % (full_path, e), file=sys.stderr)
+    print(full, file=sys.stderr, flush=True)
+    c = compact_line(out)
+    c["full"] = full_path
+    line = json.dumps(c)
+    if len(line) > LINE_LIMIT:  # never again a line the driver cannot read: shed the optional objects, longest first
+        for k in ("e2e", "counters_check", "parity_sample"):
+            if len(line) <= LINE_LIMIT:
+                break
+            c[k] = "see " + str(full_path)
+            line = json.dumps(c)
+    print(line, flush=True)
+
+
 class Rig:
     """What the rank code of main() stands on: the device, the collective backend, where the batch and the engine come
     from.  bench.py always runs the default -- a GPU, RCCL, the HIP library; tests/test_distributed_gloo.py swaps in CPU
@@ -591,6 +694,11 @@ def main(argv=None, rig=None):
     ap.add_argument("--workload", default="c3_full_pipeline", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-bases", type=float, default=6e9, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--set", default="", help="ablation only: comma separated fpl_options overrides, e.g. adapter_enabled=0")
+    ap.add_argument("--e2e-full", action="store_true",
+                    help="also run the long end-to-end legs: gzip in / out, the large input (--e2e-copies) with --chunk_mb and the "
+                         "null-device host-ceiling runs (minutes; the default run keeps to /dev/null, one file, --split on --e2e-reads)")
+    ap.add_argument("--full-json", default=os.path.join("gpurun_out", "bench_full.json"),
+                    help="where the FULL result object goes (the stdout line is its compact form, a few KB)")
     ap.add_argument("--hbm-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     args = ap.parse_args(argv)
@@ -799,6 +907,7 @@ def main(argv=None, rig=None):
             out["parity_sample_what"] = pwhat
             if with_cpu:
                 out["cpu_baseline"] = {"value": pb / odt / 1e9, "unit": "Gbases/s", "cores": min(threads, pn), "kind": "port",
+                                       "reference_buildable": False, "blocked_by": REFERENCE_BLOCKED_BY,
                                        "sample": "first %d reads (%d bases) of the same batch, oracle/liboracle.so, %d threads, %.1f s "
                                                  "(the run whose records and counters parity_sample compares)" % (pn, pb, min(threads, pn), odt)}
         elif args.cpu_bases > 0 and world == 1:
@@ -810,6 +919,7 @@ def main(argv=None, rig=None):
             _, _, odt = oracle_prefix(opt, adapters, seq_t[:pb].cpu().numpy(), qual_t[:pb].cpu().numpy(), offc[:pn + 1].astype(_np.uint64),
                                       C, threads)
             out["cpu_baseline"] = {"value": pb / odt / 1e9, "unit": "Gbases/s", "cores": min(threads, pn), "kind": "port",
+                                   "reference_buildable": False, "blocked_by": REFERENCE_BLOCKED_BY,
                                    "sample": "first %d reads (%d bases) of the same batch, oracle/liboracle.so, %d threads, %.1f s" % (
                                        pn, pb, min(threads, pn), odt)}
     eng.close()  # (idempotent)
@@ -835,18 +945,17 @@ def main(argv=None, rig=None):
             dist.barrier(group=cpu_group)
     elif run_e2e and rank == 0:
         ne = min(n, args.e2e_reads)
-        out["e2e"] = end_to_end(args.workload, opt, adapters, seq_t, qual_t, off_t, ne)
-        if args.e2e_copies > 1:
+        out["e2e"] = end_to_end(args.workload, opt, adapters, seq_t, qual_t, off_t, ne,
+                                run_names=E2E_FULL_RUNS if args.e2e_full else E2E_DEFAULT_RUNS)
+        if args.e2e_full and args.e2e_copies > 1:
             try:
                 big = end_to_end(args.workload, opt, adapters, seq_t, qual_t, off_t, ne, copies=args.e2e_copies,
-                                 with_pcie=False, run_names=("to_dev_null", "to_file", "to_split_files", "chunk_512mb", "chunk_1536mb",
-                                            "null8_to_dev_null", "null8_to_dev_null_rt16", "null8_to_split_files",
-                                            "null8_to_file"))
+                                 with_pcie=False, run_names=E2E_LARGE_RUNS)
                 out["e2e"]["large_input"] = big
             except Exception as e:
                 out["e2e"]["large_input"] = {"error": repr(e)[:300]}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, args.full_json)
     if world > 1:
         if cpu_group is not None:
             dist.barrier(group=cpu_group)

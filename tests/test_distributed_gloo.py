@@ -117,7 +117,7 @@ class _StandInEngine:
         pass
 
 
-def _bench_rank(rank, world, port, outdir):
+def _stand_in_rig():
     sys.path.insert(0, ROOT)
     import bench
 
@@ -142,6 +142,11 @@ def _bench_rank(rank, world, port, outdir):
         def engine(self, opt, ad_start, ad_end, ad_fasta, local_rank, C):
             return _StandInEngine(opt, ad_start, ad_end, ad_fasta, C)
 
+    return bench, Rig()
+
+
+def _bench_rank(rank, world, port, outdir):
+    bench, rig = _stand_in_rig()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import contextlib
@@ -150,7 +155,7 @@ def _bench_rank(rank, world, port, outdir):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--reads", "25", "--cpu-bases", "0",
-                    "--e2e-reads", "0"], rig=Rig())
+                    "--e2e-reads", "0", "--full-json", os.path.join(outdir, "full_%d.json" % rank)], rig=rig)
     with open(os.path.join(outdir, "out_%d.txt" % rank), "w") as f:
         f.write(buf.getvalue())
 
@@ -191,3 +196,43 @@ def test_bench_rank_code_path_gloo(orc, tmp_path):
     assert cc["ok"] is True and cc["expected_reads_in"] == steps * world * reads
     assert line["parity_sample"] == "ok", line["parity_sample"]
     assert line["roofline"]["path"]["frac"] > 0 and line["roofline"]["bound"] == "hbm"
+
+
+def test_bench_line_is_one_short_json_line(orc, tmp_path, monkeypatch, capsys):
+    """The driver parses the LAST stdout line and keeps 8 KB of stdout: bench.py's line must stay a few KB whatever the
+    end-to-end leg collected (round 5's 21.6 KB line was lost).  bench.main at N = 1 with the stand-in engine, then the
+    compact form of an object carrying a round-5-sized `e2e`."""
+    import json
+
+    bench, rig = _stand_in_rig()
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    full = tmp_path / "full.json"
+    bench.main(["--steps", "2", "--warmup", "1", "--reads", "30", "--cpu-bases", "1", "--e2e-reads", "0", "--full-json", str(full)], rig=rig)
+    cap = capsys.readouterr()
+    lines = [l for l in cap.out.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_LIMIT
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline",
+              "counters_check", "parity_sample"):
+        assert k in line, k
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["bound"] == "hbm" and "kernel_ms" in line["roofline"]
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["reference_buildable"] is False and len(cb["blocked_by"]) == 2 and cb["value"] > 0
+    whole = json.loads(open(full).read())
+    assert whole["value"] == line["value"] and line["full"] == str(full)
+    # a round-5-sized end-to-end object must not lengthen the line beyond the limit
+    stage = ["host pipeline: 1622 batches, wall 8.35295 s; busy: parse 0.98072 s " + "x" * 400] * 6
+    run = lambda v: {"rc": 0, "process_seconds": 1.0, "value": v, "bases": 10, "pipeline_seconds": 0.5, "pipeline_value": 2 * v, "stages": stage,
+                     "what": "y" * 300}
+    names = [r["name"] for r in bench.E2E_RUNS]
+    whole["e2e"] = {"reads": 1000000, "bases": 9 * 10**9, "n_gpus": 1, "value": 15.4, "pcie_call": {"value": 27.0, "what": "z" * 200},
+                    "cli": {n: run(10.0 + i) for i, n in enumerate(names)}, "json_check": {"ok": True},
+                    "large_input": {"reads": 3000000, "cli": {n: run(20.0 + i) for i, n in enumerate(names)}}}
+    assert len(json.dumps(whole)) > 20000
+    bench.emit(whole, str(tmp_path / "full2.json"))
+    out2 = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(out2) == 1 and len(out2[0]) < bench.LINE_LIMIT
+    l2 = json.loads(out2[0])
+    assert l2["e2e"]["value"] == 15.4 and l2["e2e"]["to_file"] == 12.0 and l2["e2e"]["large"]["null8"] is not None
+    assert l2["roofline"] == line["roofline"] and l2["cpu_baseline"] == line["cpu_baseline"]
