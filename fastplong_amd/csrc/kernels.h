@@ -117,6 +117,18 @@ __device__ unsigned long long g_fpl_prof[64];
 #define FPL_OPT_INCVALU 1 /* k_stats_sorted: a byte's packed increment built on the vector unit instead of read from a 256-entry LDS table:
                              the kernel's limit is the LDS array (24 LDS instructions per row of 512 bytes were 16 now), 5.10 -> 4.93 ms */
 #endif
+#ifndef FPL_OPT_KMER6
+#define FPL_OPT_KMER6 1 /* k_stats_sorted: in the rows whose tile lies inside r1 the 5-mer updates of two neighbouring windows are ONE update of a
+                           6-mer table (4096 bins: window k is the 6-mer's first five bases, window k + 1 its last five; unfolded at the
+                           hand-over) -- four ds_add_u32 per 8 bytes and lane instead of eight, into four times the bins.  The table's 16 KB
+                           come out of the per-cycle cells: the class rows 0 and 2 of the LDS tables (bytes whose low three bits are 000 or
+                           010: no base letter of any case) hold the two 5-mer tables and the block's scalars, and such bytes are counted
+                           with global atomics (exact, never taken by DNA) */
+#endif
+#ifndef FPL_OPT_INCPERM
+#define FPL_OPT_INCPERM 1 /* k_stats_sorted: the Q20 / Q30 half of a byte's packed increment through one v_perm per byte (20 instead of 32
+                             vector instructions per row of 512 bytes) */
+#endif
 #ifndef FPL_OPT_STATSETUP
 #define FPL_OPT_STATSETUP 1 /* k_stats_sorted: a row's 5-mer stream from v_dot4 packs and the NEIGHBOUR's finished pack (one DPP move), lane 0's
                                halo once per group of four rows -- instead of packing the neighbour's bytes a second time in every lane */
@@ -5105,15 +5117,34 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                u32* __restrict__ sw, u32 max_slices, u32 n_tiles, long long* __restrict__ counters,
                u64* __restrict__ scratch, u8* __restrict__ flags, u32 C, u32 hi_tile, u32 max_rows) {
     (void)C;
+    (void)counters;
     constexpr int N_INC = FPL_OPT_INCVALU ? 0 : 256;
+#if FPL_OPT_KMER6
+    /* 80 KB to the byte: [8][FS_T pre | FS_T not-post] cells (64 KB) + the 6-mer table (16 KB).  Class row 0 of the cells is the two
+       5-mer tables, class row 2 the block's scalars (FPL_OPT_KMER6 above) */
+    static_assert(FPL_OPT_INCVALU && FPL_OPT_STATSETUP, "FPL_OPT_KMER6 has no room for the increment table and builds on the v_dot4 row set-up");
+    __shared__ u64 lds_all[8 * FS_BSTRIDE + 2048];
+    static_assert(sizeof(u64) * (8 * FS_BSTRIDE + 2048) <= 81920, "two blocks per CU");
+    u32* const k6 = (u32*)lds_all;   /* 6-mers of window pairs counted pre- AND post-filter (in front: a ds offset holds 16 bits) */
+    u64* const tbl = lds_all + 2048;
+    u64* const inc_of = lds_all; /* (unused) */
+    u32* const kmer = (u32*)tbl;  /* class row 0: [0,1024) 5-mers counted pre-filter only; [1024,2048): pre- AND post-filter */
+    u32* const scal = (u32*)(tbl + 2 * FS_BSTRIDE);   /* class row 2 */
+    u32& any_work = scal[0];
+    u32& cur_item = scal[1];
+    u32& cls_mask = scal[2];
+    constexpr u32 LDS_ROWS = 0xFAu; /* the class rows that are cells: 1, 3 .. 7 */
+#else
     __shared__ u64 lds_all[1024 + N_INC + 8 * FS_BSTRIDE];
     static_assert(sizeof(u64) * (1024 + N_INC + 8 * FS_BSTRIDE) <= 81920, "two blocks per CU");
     u32* const kmer = (u32*)lds_all; /* [0,1024): 5-mers counted pre-filter only; [1024,2048): pre- AND post-filter */
     u64* const inc_of = lds_all + 1024; /* (without FPL_OPT_INCVALU: the packed increment of every quality byte) */
     u64* const tbl = inc_of + N_INC;    /* [8][FS_T pre | FS_T not-post] */
+    __shared__ u32 any_work, cur_item, cls_mask;
+    constexpr u32 LDS_ROWS = 0xFFu;
+#endif
     u32* const kpre = kmer;
     u32* const kpost = kmer + 1024;
-    __shared__ u32 any_work, cur_item, cls_mask;
     const int lane = lane_id();
     const u32 lane8 = 8u * (u32)lane;
     static_assert(8 * FS_BSTRIDE == 8192, "a class row of the LDS tables is 8192 bytes apart from the next: FPL_FS_CELL");
@@ -5169,7 +5200,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
         {
             u32 m = 0;
             for (u32 i = threadIdx.x; i < 8 * FS_T; i += blockDim.x)
-                if (tbl[(i / FS_T) * FS_BSTRIDE + (i % FS_T)]) m |= 1u << (i / FS_T);
+                if (((LDS_ROWS >> (i / FS_T)) & 1u) && tbl[(i / FS_T) * FS_BSTRIDE + (i % FS_T)]) m |= 1u << (i / FS_T);
             if (m) atomicOr(&cls_mask, m);
         }
         __syncthreads();
@@ -5193,7 +5224,12 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
 #endif
         }
         for (u32 i = threadIdx.x; i < 1024 && !(FPL_ABL & 64); i += blockDim.x) {
-            const u32 both = kpost[i], pre_only = kpre[i];
+            u32 both = kpost[i];
+            const u32 pre_only = kpre[i];
+#if FPL_OPT_KMER6
+            /* 5-mer i is the first five bases of the 6-mers 4 i .. 4 i + 3 and the last five of the 6-mers i + 1024 a */
+            both += k6[4 * i] + k6[4 * i + 1] + k6[4 * i + 2] + k6[4 * i + 3] + k6[i] + k6[i + 1024] + k6[i + 2048] + k6[i + 3072];
+#endif
             if (both + pre_only) atomicAdd((u64*)&kg0[i], (u64)both + pre_only);
             if (both) atomicAdd((u64*)&kg1[i], (u64)both);
         }
@@ -5222,8 +5258,14 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
         open = false;
     }
     if (!open) {
+#if FPL_OPT_KMER6
+        /* (class row 0 = the 5-mer tables, zeroed as cells; class row 2 = the scalars: left alone) */
+        for (u32 i = threadIdx.x; i < 8 * FS_BSTRIDE + 2048; i += blockDim.x)
+            if (i / FS_BSTRIDE != 4) lds_all[i] = 0; /* (words 4096 .. 5119 of the array = class row 2: the scalars) */
+#else
         for (u32 i = threadIdx.x; i < 8 * FS_BSTRIDE; i += blockDim.x) tbl[i] = 0;
         for (u32 i = threadIdx.x; i < 2048; i += blockDim.x) kmer[i] = 0;
+#endif
         __syncthreads();
         open = true;
         held = 0;
@@ -5245,6 +5287,10 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
             u32x2 svG[CS_GROUP], qvG[CS_GROUP];
             u32 haloG[CS_GROUP], LG[CS_GROUP], EG[CS_GROUP];
             u32 haloAll = 0; /* lane g: the four bases in front of row g's tile */
+#if FPL_OPT_KMER6
+            int bitG[CS_GROUP];
+            u32 odd_rows = 0; /* wave-uniform: (lane of the read + 1) of the group's rows that hold a byte of class 0 or 2, a byte each */
+#endif
 #pragma unroll
             for (int g = 0; g < CS_GROUP; g++) {
                 /* (lanes behind the end of the read load nothing: with the set-up below they hold 'A's, so that they do not
@@ -5253,9 +5299,15 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                 qvG[g] = {0, 0};
                 haloG[g] = 0;
                 LG[g] = EG[g] = 0;
+#if FPL_OPT_KMER6
+                bitG[g] = 0;
+#endif
                 if (m) {
                     const int bit = __ffsll(m) - 1;
                     m &= m - 1;
+#if FPL_OPT_KMER6
+                    bitG[g] = bit;
+#endif
                     LG[g] = readlane_u32(L, bit);
                     EG[g] = readlane_u32(E, bit);
                     const uint64_t start = readlane_u64(st, bit);
@@ -5343,6 +5395,15 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                 }
 #endif
                 const int p0 = (int)c0;
+#if FPL_OPT_KMER6
+                if (!allok) { /* wave-uniform.  (A row of A, C, G, T holds no byte of the classes 0 and 2; elsewhere ask) */
+                    const u32 z = ~((sw2[0] | (sw2[0] >> 2)) & (sw2[1] | (sw2[1] >> 2))) & 0x01010101u; /* a byte whose bits 0 and 2 are clear */
+                    if (wave_ballot(z != 0)) {
+                        odd_rows = (odd_rows << 8) | (u32)(bitG[g] + 1); /* wave-uniform: taken up behind the group */
+                        continue;
+                    }
+                }
+#endif
                 /* one byte.  NPM: bit k of npmask says whether byte k lies behind the end of r1 (it then also goes to the
                    not-post table); KM: the byte's 5-mer window is counted 0 pre-filter only, 1 pre- and post-filter, 2 as
                    bit k of kbodymask says */
@@ -5357,6 +5418,17 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                 /* the packed increment of a byte on the vector unit instead of out of the LDS table: the Q20 / Q30 bits of four
                    qualities at once (bit 7 of q + 75 / q + 65: qualities are < 128), moved to where two of the four need them
                    (bits 4 / 18 of the high word) */
+#if FPL_OPT_INCPERM
+                /* ... and the high word of byte k's increment as ONE v_perm: byte 0 from p20 (0x10 where q >= '5'), byte 2 from p30
+                   (0x04 where q >= '?') */
+                u32 p20[2], p30[2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    p20[j] = ((qw[j] + 0x4B4B4B4Bu) & 0x80808080u) >> 3;
+                    p30[j] = ((qw[j] + 0x41414141u) & 0x80808080u) >> 5;
+                }
+#define FPL_FS_INC(k) (((u64)perm_b32(p30[(k) >> 2], p20[(k) >> 2], 0x0c000c00u | ((4u + ((k)&3)) << 16) | ((k)&3)) << 32) | (FPL_FS_Q(k) | (1u << 22)))
+#else
                 u32 dq[4];
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
@@ -5365,6 +5437,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                     dq[2 * j + 1] = (t20 >> 19) | (t30 >> 5);
                 }
 #define FPL_FS_INC(k) (((u64)((dq[(k) >> 1] >> (8 * ((k)&1))) & 0x40010u) << 32) | (FPL_FS_Q(k) | (1u << 22)))
+#endif
                 u64 inc_n = FPL_FS_INC(0);
 #else
 #define FPL_FS_INC(k) inc_of[FPL_FS_Q(k)]
@@ -5396,6 +5469,35 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     }
                 if (tp && (int)tile_start >= s + 4 && (int)(tile_start + FS_T) <= e) {
                     /* wave-uniform: the whole tile lies inside r1 (and inside the read) */
+#if FPL_OPT_KMER6
+                    /* the 5-mer windows two at a time: the pair that ends at byte k (odd) is the 6-mer at bit 2 (7 - k) of the stream;
+                       it counts when both of its windows do, a window that counts alone goes to the 5-mer table */
+#define FPL_FB_ROW6(ALLOK)                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                               \
+        const u64 inc = inc_n;                                                                                    \
+        if (k < 7) inc_n = FPL_FS_INC(k + 1);                                                                     \
+        u64* const cellp = (u64*)((char*)tbl + FPL_FS_CELL(k));                                                   \
+        atomicAdd(&cellp[(k)*64], inc);                                                                           \
+        if (k & 1) atomicAdd(&k6[(W >> (2 * (7 - k))) & 0xFFFu], (ALLOK) ? 1u : ((ok2 >> (k - 1)) & 1u));         \
+    }
+                    if (allok) {
+                        const u32 ok2 = 0;
+                        (void)ok2;
+                        FPL_FB_ROW6(true)
+                    } else {
+                        const u32 ok2 = okmask & (okmask >> 1);
+                        FPL_FB_ROW6(false)
+                        u32 alone = okmask & ~((ok2 & 0x55u) * 3u) & 0xFFu;
+                        if (wave_ballot(alone != 0)) { /* wave-uniform; the lanes next to an N */
+                            while (alone) {
+                                const int k = __ffsll((unsigned long long)alone) - 1;
+                                alone &= alone - 1;
+                                atomicAdd(&kpost[(W >> (2 * (7 - k))) & 0x3FFu], 1u);
+                            }
+                        }
+                    }
+#undef FPL_FB_ROW6
+#else
                     const u32 npmask = 0, kbodymask = 0xFFu;
                     (void)npmask;
                     (void)kbodymask;
@@ -5404,6 +5506,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
                     } else {
                         FPL_FB_ROW(false, 1, true)
                     }
+#endif
                 } else if (tp) { /* a tile that holds an end of r1 */
                     const u32 npmask = ~range_mask8(-1, e - p0) & 0xFFu, kbodymask = range_mask8(s + 4 - p0, e - p0);
                     FPL_FB_ROW(true, 2, false)
@@ -5424,6 +5527,67 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
 #undef FPL_FS_INC
 #undef FPL_FS_NVALID
             }
+#if FPL_OPT_KMER6
+            /* The rows that hold a byte of class 0 or 2 (no letter: the cells of those classes gave their LDS to the 5-mer tables):
+               read again and walked byte by byte, every test spelled out -- cells in LDS for the other classes, global atomics on the
+               counters for these two; the 5-mer windows one by one.  Right for any row (inside r1, across an end of r1, not counted
+               post-filter; whole or ragged); taken by none that holds DNA. */
+            while (odd_rows) { /* wave-uniform */
+                const int bit = (int)(odd_rows & 0xFFu) - 1;
+                odd_rows >>= 8;
+                const u32 itemL = readlane_u32(L, bit);
+                const int e = (int)readlane_u32(E, bit);
+                const u8* const rs = seq + readlane_u64(st, bit);
+                const u8* const rq = qual + readlane_u64(st, bit);
+                /* (this path must cost the rows of DNA nothing: its addresses are worked out here, from values the optimiser cannot
+                   trace to the loop around it -- hoisted, they took registers away from every row) */
+                u32 c0s = c0, l8s = lane8;
+                opaque_u32(c0s);
+                opaque_u32(l8s);
+                if (itemL <= c0s) continue; /* (per lane from here on: no wave-wide operation below) */
+                const int nv = (int)min(8u, itemL - c0s);
+                const u32x2 sv = load8_guard(rs + c0s, seq_end), qv = load8_guard(rq + c0s, qual_end);
+                const u32 hv = c0s >= 4 ? load4_guard(rs + c0s - 4, seq_end) : 0u;
+                const u32 vh = kmer_codes(hv), v0 = kmer_codes(sv.x), v1 = kmer_codes(sv.y);
+                const u32 Wr = (kmer_pack_dot(vh) << 16) | (kmer_pack_dot(v0) << 8) | kmer_pack_dot(v1);
+                const u32 ih = c0s >= 4 ? invalid_nibble(perm_lo(0x47435441u, vh), hv) : 0xFu;
+                const u32 inv = (invalid_nibble(perm_lo(0x47435441u, v1), sv.y) << 8) | (invalid_nibble(perm_lo(0x47435441u, v0), sv.x) << 4) | ih;
+                const u32 okm = ~(inv | (inv >> 1) | (inv >> 2) | (inv >> 3) | (inv >> 4)) & 0xFFu;
+                long long* const pre = counters + FPL_OFF_PRE(C);
+                long long* const post = counters + FPL_OFF_POST(C);
+#pragma unroll 1
+                for (int k = 0; k < nv; k++) {
+                    const u32 sh = 8u * (u32)(k & 3);
+                    const u32 b = ((k < 4 ? sv.x : sv.y) >> sh) & 0xFFu, q = ((k < 4 ? qv.x : qv.y) >> sh) & 0xFFu;
+                    const u32 cls = b & 7u;
+                    const int p = (int)c0s + k;
+                    if (cls == 0u || cls == 2u) {
+                        if ((u32)p < C) {
+                            atomicAdd((u64*)&pre[FPL_ST_CYC(p, 0, cls)], 1ull);
+                            atomicAdd((u64*)&pre[FPL_ST_CYC(p, 1, cls)], (u64)(long long)((int)q - 33));
+                            if (q >= '5') atomicAdd((u64*)&pre[FPL_ST_CYC(p, 2, cls)], 1ull);
+                            if (q >= '?') atomicAdd((u64*)&pre[FPL_ST_CYC(p, 3, cls)], 1ull);
+                            if (tp && p >= s && p < e) {
+                                const int pc = p - s;
+                                atomicAdd((u64*)&post[FPL_ST_CYC(pc, 0, cls)], 1ull);
+                                atomicAdd((u64*)&post[FPL_ST_CYC(pc, 1, cls)], (u64)(long long)((int)q - 33));
+                                if (q >= '5') atomicAdd((u64*)&post[FPL_ST_CYC(pc, 2, cls)], 1ull);
+                                if (q >= '?') atomicAdd((u64*)&post[FPL_ST_CYC(pc, 3, cls)], 1ull);
+                            }
+                        }
+                    } else {
+                        const u64 inc = (u64)q | (1ull << 22) | ((u64)(q >= '5') << 36) | ((u64)(q >= '?') << 50);
+                        u64* const cellp = (u64*)((char*)tbl + cls * (8u * FS_BSTRIDE) + l8s);
+                        atomicAdd(&cellp[k * 64], inc);
+                        if (tp && p >= e) atomicAdd(&cellp[k * 64 + FS_T], inc); /* behind the end of r1: not counted post-filter */
+                    }
+                    if ((okm >> k) & 1u) {
+                        const bool body = tp && p - 4 >= s && p < e; /* the window lies inside r1 */
+                        atomicAdd(&kmer[(body ? 1024u : 0u) + ((Wr >> (2 * (7 - k))) & 0x3FFu)], 1u);
+                    }
+                }
+            }
+#endif
         }
     }
     } /* slices of the item */

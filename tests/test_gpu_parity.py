@@ -159,6 +159,20 @@ def test_sorted_statistics_pass_row_setup_bit_exact(orc, engine_mod, monkeypatch
     _run_both(orc, engine_mod, CASES[case], seq, qual, off, via="device")
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("case", ["defaults_adapters", "full_pipeline"])
+def test_sorted_statistics_pass_kmer6_bit_exact(orc, engine_mod, monkeypatch, seed, case):
+    """k_stats_sorted's 6-mer table (tests/test_kernels_emu.py::_reads_for_kmer6): N's at every offset of a lane's eight bytes,
+    bytes of the base classes 0 and 2 in every kind of row -- the shipped instructions (ds_add_u32 on the 6-mer table, the global
+    atomics of the byte-by-byte rows)"""
+    from tests.test_kernels_emu import _reads_for_kmer6
+    monkeypatch.setenv("FPL_STATS_MIN_BUCKET", "1")
+    if seed == 2:
+        monkeypatch.setenv("FPL_STATS_PER", "128")
+    seq, qual, off = _reads_for_kmer6(seed, n=4000)
+    _run_both(orc, engine_mod, CASES[case], seq, qual, off, via="device")
+
+
 def test_multi_adapter_fasta_bit_exact(orc, engine_mod):
     fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA",
              "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG",

@@ -229,6 +229,68 @@ def test_emulated_sorted_statistics_pass_row_setup(orc, monkeypatch, opts):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
+def _reads_for_kmer6(seed, n=100):
+    """reads for the 6-mer table of k_stats_sorted (FPL_OPT_KMER6): N's at every offset of a lane's eight bytes (a window pair
+    that loses its first or its second window takes the 5-mer table), runs of N, bytes of the base classes 0 and 2 (low three
+    bits 000 / 010: '@' 'H' 'X' 'p' '*' 'B' 'R' 'j' -- counted with global atomics, their rows walked byte by byte) in rows
+    inside r1, across both ends of r1 (adapters at both ends, low-quality tails for the quality cut) and in reads that fail
+    (qualities below the limit), in the first tile (no bases in front of lane 0) and in ragged last rows"""
+    rng = np.random.default_rng(4600 + seed)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    odd = np.frombuffer(b"@HXp*BRj08", dtype=np.uint8)
+    sa = np.frombuffer(synth.START_ADAPTER.encode(), np.uint8)
+    ea = np.frombuffer(synth.END_ADAPTER.encode(), np.uint8)
+    reads = []
+    for i in range(n):
+        kind = i % 8
+        L = int(rng.integers(520, 2200)) if kind else int(rng.choice([512, 1024, 1032])) + int(rng.integers(-3, 4))
+        s = letters[rng.integers(0, 4, L)].copy()
+        q = rng.integers(33 + 12, 33 + 45, L).astype(np.uint8)
+        if kind in (1, 2, 5):  # adapters at the ends: r1 starts / ends inside a row
+            a = int(rng.integers(0, 25))
+            s[a:a + len(sa)] = sa
+            b = L - int(rng.integers(0, 25)) - len(ea)
+            s[b:b + len(ea)] = ea
+        if kind in (2, 6):  # low-quality ends for cut_front / cut_tail
+            q[:int(rng.integers(1, 60))] = 33 + 3
+            q[L - int(rng.integers(1, 60)):] = 33 + 3
+        if kind == 3:  # a read that fails the quality filter: counted pre-filter only
+            q[:] = rng.integers(33 + 2, 33 + 9, L).astype(np.uint8)
+        # N's: one per offset class, plus a run
+        for j in range(int(rng.integers(2, 9))):
+            p_ = 8 * int(rng.integers(4, L // 8 - 4)) + (j % 8)
+            s[p_] = ord("N")
+        if kind in (4, 5):
+            p_ = int(rng.integers(60, L - 60))
+            s[p_:p_ + int(rng.integers(2, 12))] = ord("N")
+        if kind in (1, 4, 7):  # two N's a few bases apart: a lane with two windows that count alone
+            p_ = 8 * int(rng.integers(8, L // 8 - 8)) + int(rng.integers(0, 8))
+            s[p_] = ord("N")
+            s[p_ + int(rng.choice([6, 7, 8, 9]))] = ord("N")
+        if kind in (5, 6, 7, 0):  # bytes without cells in LDS, anywhere: the ends included
+            for p_ in list(rng.integers(0, L, int(rng.integers(1, 5)))) + [0, L - 1][:int(rng.integers(0, 3))]:
+                s[int(p_)] = int(rng.choice(odd))
+        reads.append((s, q))
+    return synth.pack(reads)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1)])
+@pytest.mark.parametrize("per", [0, 64])
+def test_emulated_sorted_statistics_pass_kmer6(orc, monkeypatch, opts, per):
+    """k_stats_sorted with the 6-mer table: pairs of 5-mer windows as one update, windows that count alone, rows with bytes of
+    the base classes 0 and 2 (tests/test_kernels_emu.py::_reads_for_kmer6)"""
+    monkeypatch.setenv("FPL_STATS_MIN_BUCKET", "1")
+    if per:
+        monkeypatch.setenv("FPL_STATS_PER", str(per))
+    cfg = orc.Config(abi.FplOptions.default(**opts), synth.START_ADAPTER, synth.END_ADAPTER)
+    seq, qual, off = _reads_for_kmer6(1 + per, n=96)
+    C = int(np.diff(off.astype(np.int64)).max()) + 1
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    got_res, got_cnt = emu.process_batch(cfg, seq, qual, off, C)
+    parity.assert_results_equal(got_res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
 def test_emulated_kernels_multi_adapter(orc):
     fasta = ["ACGTTGCAATGCCGTA", "TTGACCAGTAGGCATCAGGATCCA", "GATTACA", "CCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGGAAAATTTTCCCCGGGG"]
     cfg = orc.Config(abi.FplOptions.default(), synth.START_ADAPTER, synth.END_ADAPTER, fasta)
