@@ -4,7 +4,7 @@ Pure declarations: importing this module needs neither a GPU nor the built libra
 """
 import ctypes as C
 
-FPL_ABI_VERSION = 6
+FPL_ABI_VERSION = 7
 FPL_MAX_IN_FLIGHT = 2
 FPL_MAX_ADAPTER_LEN = 255
 FPL_END_WINDOW = 200
@@ -25,6 +25,18 @@ FPL_ERR_HIP = -3
 FPL_ERR_ADAPTER = -4
 FPL_ERR_CAPACITY = -5
 FPL_ERR_STATE = -6
+
+FPL_TEXT_OK = 0
+FPL_TEXT_IRREGULAR = 1
+FPL_TEXT_TOO_MANY = 2
+
+
+class FplTextResult(C.Structure):
+    """struct fpl_text_result (fpl_wait_text)"""
+
+    _fields_ = [("n_reads", C.c_uint32), ("status", C.c_uint32), ("n_bases", C.c_uint64), ("bad_record", C.c_uint64),
+                ("max_read_len", C.c_uint32), ("n_lines", C.c_uint32)]
+
 
 # FAILED_TYPES, reference src/common.h:55-64
 FAILED_TYPES = [""] * FPL_FILTER_RESULT_TYPES

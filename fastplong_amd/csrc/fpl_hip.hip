@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "pipeline.h"
+#include "text_parse.h"
 
 using namespace fpl;
 
@@ -86,6 +87,24 @@ struct fpl_ctx {
         fpl_read_result* user_results = nullptr;
         u32 n_reads = 0;
         int rc = FPL_OK; /* error met while enqueueing, reported by fpl_wait */
+        /* a TEXT batch (fpl_process_text_async): the chunk's bytes, its line breaks, the records' line starts and lengths; stage 1
+           (copy + parse + the header's way back) is enqueued at submission, stage 2 (the per-read kernels, the records' and line
+           starts' way back) once the header is in -- by the next submission or by the wait, whichever comes first */
+        int kind = 0;          /* 0 CSR batch, 1 text batch */
+        int stage = 0;         /* text: 1 parse enqueued, 2 batch enqueued (or nothing to enqueue) */
+        uint64_t text_cap = 0; /* bytes d_text holds */
+        u32 rec_cap = 0;       /* records d_line / d_len / h_line hold */
+        u8* d_text = nullptr;
+        u32* d_nl = nullptr;
+        u32* d_blk = nullptr;
+        u32* d_line = nullptr;
+        u32* d_len = nullptr;
+        TextHeader* d_hdr = nullptr;
+        TextHeader* h_hdr = nullptr; /* pinned */
+        u32* h_line = nullptr;       /* pinned */
+        u32 h_line_cap = 0;
+        uint64_t text_bytes = 0;
+        hipEvent_t ev_parsed = nullptr;
     };
     Slot slot[FPL_MAX_IN_FLIGHT];
     u32 submitted = 0, waited = 0; /* batches handed to / collected from the asynchronous path */
@@ -207,6 +226,7 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
             FPL_HIP(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
             FPL_HIP(hipEventCreateWithFlags(&sl.ev_kern, hipEventDisableTiming));
             FPL_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+            FPL_HIP(hipEventCreateWithFlags(&sl.ev_parsed, hipEventDisableTiming));
         }
         DevConfig cfg;
         build_config(&cfg, opt, start_len, end_len, n_fasta);
@@ -260,10 +280,13 @@ void fpl_destroy(fpl_ctx* ctx) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& sl : ctx->slot) {
-        void* sp[] = {sl.d_seq, sl.d_qual, sl.d_off, sl.d_results};
+        void* sp[] = {sl.d_seq, sl.d_qual, sl.d_off, sl.d_results, sl.d_text, sl.d_nl, sl.d_blk, sl.d_line, sl.d_len, sl.d_hdr};
         for (void* p : sp)
             if (p) (void)hipFree(p);
         if (sl.h_results) (void)hipHostFree(sl.h_results);
+        if (sl.h_hdr) (void)hipHostFree(sl.h_hdr);
+        if (sl.h_line) (void)hipHostFree(sl.h_line);
+        if (sl.ev_parsed) (void)hipEventDestroy(sl.ev_parsed);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
         if (sl.ev_kern) (void)hipEventDestroy(sl.ev_kern);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
@@ -834,12 +857,169 @@ static int ensure_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, u32 n_reads, uint64_t n_
     return FPL_OK;
 }
 
+/* ---- FASTQ text in (ABI v7): csrc/text_parse.h ---- */
+static int ensure_text_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, uint64_t n_bytes) {
+    const u32 rec_cap = (u32)(n_bytes / 64 + 16);
+    int r = ensure_slot(ctx, sl, rec_cap, n_bytes / 2 + 64);
+    if (r != FPL_OK) return r;
+    if (!sl.d_hdr) {
+        FPL_HIP(hipMalloc((void**)&sl.d_hdr, sizeof(TextHeader)));
+        FPL_HIP(hipHostMalloc((void**)&sl.h_hdr, sizeof(TextHeader), hipHostMallocDefault));
+    }
+    if (n_bytes > sl.text_cap) {
+        FPL_HIP(hipDeviceSynchronize());
+        void* old[] = {sl.d_text, sl.d_nl, sl.d_blk, sl.d_line, sl.d_len};
+        for (void* p : old)
+            if (p) (void)hipFree(p);
+        sl.d_text = nullptr;
+        sl.d_nl = sl.d_blk = sl.d_line = sl.d_len = nullptr;
+        sl.text_cap = 0;
+        sl.rec_cap = 0;
+        const uint64_t cap = n_bytes + n_bytes / 4 + 4096;
+        const u32 rc = (u32)(cap / 64 + 16);
+        FPL_HIP(hipMalloc((void**)&sl.d_text, cap + 16));
+        FPL_HIP(hipMalloc((void**)&sl.d_nl, sizeof(u32) * 4 * (size_t)rc));
+        FPL_HIP(hipMalloc((void**)&sl.d_blk, sizeof(u32) * (size_t)(cap / TP_BLOCK_BYTES + 2)));
+        FPL_HIP(hipMalloc((void**)&sl.d_line, sizeof(u32) * 4 * (size_t)rc));
+        FPL_HIP(hipMalloc((void**)&sl.d_len, sizeof(u32) * (size_t)rc));
+        sl.text_cap = cap;
+        sl.rec_cap = rc;
+    }
+    return FPL_OK;
+}
+
+/* stage 2 of a text batch: the header is in -- enqueue the per-read kernels and the way back of the records and line starts */
+static int text_continue(fpl_ctx* ctx, fpl_ctx::Slot& sl) {
+    if (sl.kind != 1 || sl.stage != 1) return FPL_OK;
+    sl.stage = 2;
+    FPL_HIP(hipEventSynchronize(sl.ev_parsed));
+    const TextHeader h = *sl.h_hdr;
+    sl.n_reads = 0;
+    if (h.status != 0 || h.n_records == 0) return FPL_OK; /* nothing to run: fpl_wait_text reports */
+    const u32 n = h.n_records;
+    if (n > sl.h_line_cap) {
+        if (sl.h_line) (void)hipHostFree(sl.h_line);
+        sl.h_line = nullptr;
+        sl.h_line_cap = 0;
+        const u32 cap = n + n / 4 + 16;
+        FPL_HIP(hipHostMalloc((void**)&sl.h_line, sizeof(u32) * 4 * (size_t)cap, hipHostMallocDefault));
+        sl.h_line_cap = cap;
+    }
+    FPL_HIP(hipStreamWaitEvent(ctx->stream, sl.ev_parsed, 0));
+    ctx->next_inputs_event = sl.ev_parsed; /* (the end trims may start beside the batch before) */
+    const int rd = fpl_process_batch_device(ctx, sl.d_seq, sl.d_qual, sl.d_off, n, h.n_bases, h.max_len, sl.d_results, ctx->stream);
+    ctx->next_inputs_event = nullptr;
+    if (rd != FPL_OK) return rd;
+    FPL_HIP(hipEventRecord(sl.ev_kern, ctx->stream));
+    FPL_HIP(hipStreamWaitEvent(ctx->s_d2h, sl.ev_kern, 0));
+    FPL_HIP(hipMemcpyAsync(sl.h_results, sl.d_results, sizeof(fpl_read_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->s_d2h));
+    FPL_HIP(hipMemcpyAsync(sl.h_line, sl.d_line, sizeof(u32) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->s_d2h));
+    FPL_HIP(hipEventRecord(sl.ev_done, ctx->s_d2h));
+    sl.n_reads = n;
+    return FPL_OK;
+}
+static int text_continue_all(fpl_ctx* ctx) {
+    for (u32 k = ctx->waited; k != ctx->submitted; k++) { /* oldest first: the kernels keep the order of submission */
+        fpl_ctx::Slot& sl = ctx->slot[k % FPL_MAX_IN_FLIGHT];
+        if (sl.rc != FPL_OK) continue;
+        const int r = text_continue(ctx, sl);
+        if (r != FPL_OK) sl.rc = r; /* (reported by the wait for that batch) */
+    }
+    return FPL_OK;
+}
+
+int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) {
+    if (!ctx || (n_bytes && !text)) return FPL_ERR_ARG;
+    if (n_bytes > 0xFFFFFFF0ull) return FPL_ERR_ARG; /* (line positions are 32 bits wide: cut the file in smaller chunks) */
+    if (ctx->submitted - ctx->waited >= FPL_MAX_IN_FLIGHT) return FPL_ERR_STATE;
+    FPL_HIP(hipSetDevice(ctx->device));
+    if (ctx->hcfg.defer) return FPL_ERR_STATE; /* (--break / --mask read their fragment lists batch by batch: the CSR entry points) */
+    int r = text_continue_all(ctx);
+    if (r != FPL_OK) return r;
+    fpl_ctx::Slot& sl = ctx->slot[ctx->submitted % FPL_MAX_IN_FLIGHT];
+    sl.kind = 1;
+    sl.stage = 2;
+    sl.n_reads = 0;
+    sl.rc = FPL_OK;
+    sl.text_bytes = n_bytes;
+    r = ensure_host_streams(ctx);
+    if (r != FPL_OK) return r;
+    r = ensure_text_slot(ctx, sl, n_bytes);
+    if (r != FPL_OK) return r;
+    if (n_bytes == 0) {
+        memset(sl.h_hdr, 0, sizeof(TextHeader));
+        sl.h_hdr->bad_record = ~0ull;
+        ctx->submitted++;
+        return FPL_OK;
+    }
+    auto enqueue = [&]() -> int {
+        hipStream_t st = ctx->s_h2d; /* copy and parse on the copy stream: beside the kernels of the batch before */
+        FPL_HIP(hipMemcpyAsync(sl.d_text, text, n_bytes, hipMemcpyHostToDevice, st));
+        FPL_HIP(hipMemsetAsync(sl.d_hdr, 0, sizeof(TextHeader), st));
+        FPL_HIP(hipMemsetAsync(&sl.d_hdr->bad_record, 0xFF, sizeof(u64), st));
+        const u32 nblk = (u32)((n_bytes + TP_BLOCK_BYTES - 1) / TP_BLOCK_BYTES);
+        const u32 rec_cap = (u32)(n_bytes / 64 + 16);
+        hipLaunchKernelGGL(k_text_count, dim3(nblk), dim3(TP_THREADS), 0, st, (const u8*)sl.d_text, (u64)n_bytes, sl.d_blk, sl.d_hdr);
+        hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, st, sl.d_blk, nblk, sl.d_hdr);
+        hipLaunchKernelGGL(k_text_fill, dim3(nblk), dim3(TP_THREADS), 0, st, (const u8*)sl.d_text, (u64)n_bytes, (const u32*)sl.d_blk, sl.d_nl,
+                           4 * rec_cap);
+        const u32 rblk = std::min<u32>(std::max<u32>(1u, (rec_cap + 255u) / 256u), 4u * ctx->n_cu);
+        hipLaunchKernelGGL(k_text_records, dim3(rblk), dim3(256), 0, st, (const u8*)sl.d_text, (u64)n_bytes, (const u32*)sl.d_nl, rec_cap,
+                           sl.d_hdr, sl.d_line, sl.d_len);
+        hipLaunchKernelGGL(k_text_offsets, dim3(1), dim3(1024), 0, st, (const u32*)sl.d_len, rec_cap, sl.d_hdr, sl.d_off);
+        hipLaunchKernelGGL(k_text_gather, dim3(8 * ctx->n_cu), dim3(256), 0, st, (const u8*)sl.d_text, (const u32*)sl.d_line,
+                           (const u32*)sl.d_len, (const uint64_t*)sl.d_off, (const TextHeader*)sl.d_hdr, rec_cap, sl.d_seq, sl.d_qual);
+        FPL_HIP(hipGetLastError());
+        FPL_HIP(hipMemcpyAsync(sl.h_hdr, sl.d_hdr, sizeof(TextHeader), hipMemcpyDeviceToHost, st));
+        FPL_HIP(hipEventRecord(sl.ev_parsed, st));
+        return FPL_OK;
+    };
+    r = enqueue();
+    if (r != FPL_OK) {
+        if (ctx->s_h2d) (void)hipStreamSynchronize(ctx->s_h2d);
+        return r;
+    }
+    sl.stage = 1;
+    ctx->submitted++;
+    return FPL_OK;
+}
+
+int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts) {
+    if (!ctx || !out) return FPL_ERR_ARG;
+    if (ctx->submitted == ctx->waited) return FPL_ERR_STATE;
+    fpl_ctx::Slot& sl = ctx->slot[ctx->waited % FPL_MAX_IN_FLIGHT];
+    if (sl.kind != 1) return FPL_ERR_STATE; /* (a CSR batch: fpl_wait) */
+    memset(out, 0, sizeof(*out));
+    if (results) *results = nullptr;
+    if (line_starts) *line_starts = nullptr;
+    FPL_HIP(hipSetDevice(ctx->device));
+    if (sl.rc == FPL_OK) {
+        const int r = text_continue(ctx, sl);
+        if (r != FPL_OK) sl.rc = r;
+    }
+    ctx->waited++;
+    if (sl.rc != FPL_OK) return sl.rc;
+    const TextHeader& h = *sl.h_hdr;
+    out->n_lines = h.n_lines;
+    out->bad_record = h.bad_record;
+    out->status = (h.status & 1u) ? FPL_TEXT_IRREGULAR : (h.status & 2u) ? FPL_TEXT_TOO_MANY : FPL_TEXT_OK;
+    if (out->status != FPL_TEXT_OK || sl.n_reads == 0) return FPL_OK;
+    FPL_HIP(hipEventSynchronize(sl.ev_done));
+    out->n_reads = sl.n_reads;
+    out->n_bases = h.n_bases;
+    out->max_read_len = h.max_len;
+    if (results) *results = sl.h_results;
+    if (line_starts) *line_starts = sl.h_line;
+    return FPL_OK;
+}
+
 int fpl_in_flight(const fpl_ctx* ctx) { return ctx ? (int)(ctx->submitted - ctx->waited) : 0; }
 
 int fpl_wait(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
     if (ctx->submitted == ctx->waited) return FPL_ERR_STATE;
     fpl_ctx::Slot& sl = ctx->slot[ctx->waited % FPL_MAX_IN_FLIGHT];
+    if (sl.kind != 0) return FPL_ERR_STATE; /* (a text batch: fpl_wait_text) */
     ctx->waited++;
     if (sl.rc != FPL_OK) return sl.rc; /* nothing was enqueued behind the failure */
     if (sl.n_reads == 0) return FPL_OK;
@@ -857,7 +1037,12 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qua
     FPL_HIP(hipSetDevice(ctx->device));
     /* --break / --mask: the fragment lists of the batch in flight live in buffers this batch's kernels reuse */
     if (ctx->hcfg.defer && ctx->submitted != ctx->waited) return FPL_ERR_STATE;
+    {
+        const int rt = text_continue_all(ctx); /* (a text batch in flight gets its kernels in front of this batch's) */
+        if (rt != FPL_OK) return rt;
+    }
     fpl_ctx::Slot& sl = ctx->slot[ctx->submitted % FPL_MAX_IN_FLIGHT];
+    sl.kind = 0;
     sl.n_reads = n_reads;
     sl.user_results = results;
     sl.rc = FPL_OK;

@@ -19,6 +19,7 @@ EXPORTS = [
     "fpl_enable_timing", "fpl_get_kernel_times", "fpl_fragment_counts", "fpl_get_fragments",
     "fpl_process_batch_async", "fpl_wait", "fpl_in_flight", "fpl_host_alloc", "fpl_host_free", "fpl_allreduce_counters",
     "fpl_count_end_kmers", "fpl_pick_adapter", "fpl_rccl_library", "fpl_comm_init", "fpl_get_batch_forms", "fpl_assume_inputs_ready",
+    "fpl_process_text_async", "fpl_wait_text",
 ]
 
 
@@ -115,6 +116,10 @@ def load_library(path=None):
     L.fpl_pick_adapter.restype = C.c_int
     L.fpl_pick_adapter.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
                                    C.POINTER(abi.FplAdapterPick)]
+    L.fpl_process_text_async.restype = C.c_int
+    L.fpl_process_text_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.fpl_wait_text.restype = C.c_int
+    L.fpl_wait_text.argtypes = [C.c_void_p, C.POINTER(abi.FplTextResult), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     if L.fpl_abi_version() != abi.FPL_ABI_VERSION:
         raise FplError("ABI version mismatch")
     if path is None:
@@ -195,6 +200,26 @@ class Engine:
 
     def wait(self):
         self._check(self.L.fpl_wait(self.h), "fpl_wait")
+
+    def submit_text(self, text):
+        """fpl_process_text_async: a chunk of FASTQ text (a pinned uint8 array: pinned_array) that starts at a record and ends
+        behind one; the parse runs on the device"""
+        self._keep_text = getattr(self, "_keep_text", []) + [text]
+        self._keep_text = self._keep_text[-(abi.FPL_MAX_IN_FLIGHT + 1):]
+        self._check(self.L.fpl_process_text_async(self.h, text.ctypes.data, len(text)), "fpl_process_text_async")
+
+    def wait_text(self):
+        """fpl_wait_text -> (fpl_text_result as a dict, records [n] as a numpy copy, line starts [n, 4] as a numpy copy)"""
+        out = abi.FplTextResult()
+        rp, lp = C.c_void_p(), C.c_void_p()
+        self._check(self.L.fpl_wait_text(self.h, C.byref(out), C.byref(rp), C.byref(lp)), "fpl_wait_text")
+        info = {k: getattr(out, k) for k, _ in abi.FplTextResult._fields_}
+        n = out.n_reads
+        if out.status != 0 or n == 0:
+            return info, np.zeros(0, dtype=abi.RESULT_DTYPE), np.zeros((0, 4), np.uint32)
+        res = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint8)), shape=(n * 36,)).view(abi.RESULT_DTYPE).copy()
+        lines = np.ctypeslib.as_array(C.cast(lp, C.POINTER(C.c_uint32)), shape=(n, 4)).copy()
+        return info, res, lines
 
     def in_flight(self):
         return int(self.L.fpl_in_flight(self.h))

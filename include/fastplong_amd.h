@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 6
+#define FPL_ABI_VERSION 7
 
 /* limits */
 #define FPL_MAX_ADAPTER_LEN 255 /* longest adapter the device path accepts            */
@@ -292,6 +292,44 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qua
                             uint32_t n_reads, fpl_read_result* results);
 int fpl_wait(fpl_ctx* ctx);
 int fpl_in_flight(const fpl_ctx* ctx);
+
+/*
+ * (ABI v7) The reader's work on the device: FASTQ TEXT in, records out.  Replaces, for the per-read path, what
+ * FastqReader::read / ::getLine do per record on the reference's reader thread (src/fastqreader.cpp:219-347): the host
+ * hands over a chunk of the file's bytes as they lie there -- it must start at the '@' of a record and end behind the line
+ * break of a record's quality line, nothing else is asked of it -- and the device finds the line breaks, checks every record
+ * the way FastqReader::read does ('@', '+', as many qualities as bases, :312-341), lays bases and qualities out as the
+ * CSR batch the kernels take and runs the batch.  No base is copied on the host: the link carries the same 2.02 bytes per
+ * base as with fpl_process_batch_async.
+ *
+ *   fpl_process_text_async  uploads `text` (page-locked memory recommended) and starts the parse; returns at once.  `text`
+ *                           must stay valid until the batch has been waited for.  Shares the FPL_MAX_IN_FLIGHT slots and the
+ *                           FIFO order of fpl_process_batch_async.
+ *   fpl_wait_text           blocks until the OLDEST batch in flight (which must be a text batch) is complete.  *out says what
+ *                           the chunk held; results[i] is the record of read i and line_starts[4 i + j] the offset, in
+ *                           `text`, of line j of record i (0 name, 1 bases, 2 '+', 3 qualities) -- so the caller formats its
+ *                           output from the text it still holds.  Both arrays are the library's (page-locked) and stay valid
+ *                           until the second submission after this one.
+ *
+ * status FPL_TEXT_IRREGULAR: the chunk is not "four lines per record, every line ended by \n or \r\n, '@' and '+' in place,
+ * equal lengths" (blank lines, a lone \r, a missing final line break, a malformed record: bad_record is the first) -- NOTHING
+ * of it was processed or counted; the caller parses the chunk with its own reader (the reference's rules for such text are
+ * the sequential reader's: skipped lines, the error texts of :326-341) and submits it through fpl_process_batch_async.
+ * FPL_TEXT_TOO_MANY: more than n_bytes / 64 + 16 records (reads shorter than 30 bases on average): same treatment.
+ */
+#define FPL_TEXT_OK 0
+#define FPL_TEXT_IRREGULAR 1
+#define FPL_TEXT_TOO_MANY 2
+typedef struct fpl_text_result {
+    uint32_t n_reads;      /* records of the chunk (0 unless status is FPL_TEXT_OK) */
+    uint32_t status;       /* FPL_TEXT_* */
+    uint64_t n_bases;      /* bases of all reads */
+    uint64_t bad_record;   /* FPL_TEXT_IRREGULAR: index of the first record that failed a check, ~0 when the structure did */
+    uint32_t max_read_len; /* longest read */
+    uint32_t n_lines;      /* line breaks found */
+} fpl_text_result;
+int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes);
+int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts);
 
 /* Page-locked host memory for the arrays handed to fpl_process_batch[_async] (hipHostMalloc): the
  * DMA engines read it directly.  NULL when the allocation fails. */
