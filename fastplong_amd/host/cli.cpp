@@ -82,7 +82,7 @@ static const Flag FLAGS[] = {
     {"report_title", 'R', true, "fastplong report"}, {"thread", 'w', true, "3"}, {"split", 0, true, "0"},
     {"split_by_lines", 0, true, "0"}, {"split_prefix_digits", 0, true, "4"},
     {"gpus", 0, true, "1"}, {"batch_mbases", 0, true, "256"}, {"batch_reads", 0, true, "0"},
-    {"reader_threads", 0, true, "0"}, {"chunk_mb", 0, true, "32"}, {"gz_stream", 0, false, ""},
+    {"reader_threads", 0, true, "0"}, {"chunk_mb", 0, true, "32"}, {"gz_stream", 0, false, ""}, {"device_parse", 0, false, ""},
 };
 
 struct Args {
@@ -199,11 +199,11 @@ static void build_gather(const fplh::Batch& b, const fpl_read_result* res, vecto
     for (uint32_t i = first; i < n; i++) {
         const fpl_read_result& r = res[i];
         if (r.dropped) continue;
-        const char* name = b.text.data() + b.name_off[i];
+        const char* name = b.name_ptr(i);
         const uint32_t nl = b.name_len[i], sl = b.strand_len[i];
-        const char* strand = name + nl;
-        const uint8_t* sq = b.seq.data() + b.off[i];
-        const uint8_t* ql = b.qual.data() + b.off[i];
+        const char* strand = b.strand_ptr(i);
+        const uint8_t* sq = b.seq_ptr(i);
+        const uint8_t* ql = b.qual_ptr(i);
         for (int f = 0; f < r.n_frag; f++) {
             if (r.code[f] != FPL_PASS_FILTER) continue;
             const char* pf = prefix[r.kind[f] <= 2 ? r.kind[f] : 0];
@@ -628,7 +628,15 @@ int main(int argc, char* argv[]) {
     auto gz_name = [](const string& p) { return p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0; };
     const bool gzOut = !splitEnabled && (gz_name(out) || gz_name(failedOut)); /* (then up to four batches are formatted at a time) */
     const int nWork = (chunked ? readerThreads : 1) + (FPL_MAX_IN_FLIGHT + 1) * nGpus + 2 + (gzOut ? 3 : 0);
-    if (chunked) /* a chunk holds about half its bytes in bases: one block each for the bases and the qualities of a batch */
+    /* --device_parse: the chunk parsers only LOAD the file's bytes (page-locked), the device finds the records
+       (fpl_process_text_async); --break / --mask keep the host's reader (their fragment lists come back batch by batch through
+       the CSR entry points), and so do inputs that are not cut into chunks (pipes, a streamed gzip, a small file) */
+    const bool textMode = cmd.exist("device_parse") && chunked && !cmd.exist("break") && !cmd.exist("mask") && chunkBytes < (3ull << 30);
+    if (cmd.exist("device_parse") && !textMode && cmd.exist("verbose"))
+        cerr << "input: --device_parse does not apply (it needs an uncompressed file or multi-member gzip cut into chunks, --chunk_mb below 3072, no --break / --mask): the host parses" << endl;
+    if (chunked && textMode) /* one block holds a chunk's text and the stretch behind it that the last record may run into */
+        fplh::ByteBuf::set_arena((size_t)(chunkBytes + (5u << 20)), (size_t)nWork);
+    else if (chunked) /* a chunk holds about half its bytes in bases: one block each for the bases and the qualities of a batch */
         fplh::ByteBuf::set_arena((size_t)(chunkBytes / 2 + chunkBytes / 16 + (2u << 20)), 2 * (size_t)nWork);
     if (!chunked) {
         reader = new fplh::FastqReader(in);
@@ -741,6 +749,7 @@ int main(int argc, char* argv[]) {
     double tParse = 0, tWrite = 0, tRedo = 0;
     uint64_t nRedo = 0;
     vector<double> tGpu(nGpus, 0), tFormat(nFmt, 0);
+    std::atomic<uint64_t> nTextBatches{0}, nTextFallbacks{0}; /* --device_parse: chunks the device parsed / chunks handed back to the host's reader */
     string inputError; /* a malformed record: reported the way the sequential reader does, the input ends there */
     string ioError;    /* the input could not be read / decompressed to its end: the run fails (src/fastqreader.cpp:92-137) */
 
@@ -775,7 +784,7 @@ int main(int argc, char* argv[]) {
                 return it;
             };
             auto release = [&](fplh::ChunkedReader::Item it) { freeq.push((Work*)it.token); };
-            fplh::ChunkedReader cr(chunkFd, chunkFileSize, chunkBytes, readerThreads, acquire, release, chunkMem);
+            fplh::ChunkedReader cr(chunkFd, chunkFileSize, chunkBytes, readerThreads, acquire, release, chunkMem, textMode);
             fplh::ChunkedReader::Item it;
             uint64_t unmapped = 0;
             while (cr.next(it)) {
@@ -803,13 +812,48 @@ int main(int argc, char* argv[]) {
     vector<thread> devThreads;
     for (int d = 0; d < nGpus; d++)
         devThreads.emplace_back([&, d]() {
-            deque<Work*> inflight;
+            deque<Work*> inflight, redo;
             bool open = true;
             auto collect = [&]() {
                 Work* w = inflight.front();
                 inflight.pop_front();
                 const double t0 = now();
-                if (w->rc == FPL_OK) w->rc = fpl_wait(dev[d].ctx);
+                if (w->rc == FPL_OK && w->batch.text_backed && w->batch.off.empty()) {
+                    /* a chunk the device parsed: its records, and where their lines lie in the text this batch still holds */
+                    fpl_text_result tr;
+                    const fpl_read_result* rr = nullptr;
+                    const uint32_t* ls = nullptr;
+                    w->rc = fpl_wait_text(dev[d].ctx, &tr, &rr, &ls);
+                    if (w->rc == FPL_OK && tr.status == FPL_TEXT_OK) {
+                        w->res.assign(rr, rr + tr.n_reads);
+                        w->batch.adopt_lines(ls, tr.n_reads);
+                        nTextBatches++;
+                    } else if (w->rc == FPL_OK) {
+                        /* irregular text (blank lines, a lone \r, no line break at the end, a record the reference would stop at):
+                           nothing of it was counted -- the host's reader takes the chunk, by the reference's rules, and the batch
+                           goes in again through the CSR entry point */
+                        fplh::FastqReader::ChunkInfo ci;
+                        vector<char> window;
+                        fplh::Batch& b = w->batch;
+                        const uint64_t len = b.raw_len;
+                        const char* base = (const char*)b.raw.data() + b.raw_begin;
+                        b.text_backed = false;
+                        fplh::FastqReader::parse_chunk(-1, len, 0, len, true, window, b, ci, 1, base);
+                        nTextFallbacks++;
+                        if (ci.status == 3) {
+                            /* (the reference stops reading at a malformed record and finishes with what it has; chunks behind this
+                               one may be counted already here, so this mode refuses the input instead) */
+                            w->rc = FPL_ERR_STATE;
+                            w->err = ci.err + "\n--device_parse: the input has a malformed record; run without --device_parse to get the reference's behaviour (it stops reading there)";
+                        } else if (b.n() > 0) { /* in again, as a CSR batch, through the loop below (the slots are a FIFO) */
+                            tGpu[d] += now() - t0;
+                            redo.push_back(w);
+                            return;
+                        }
+                    }
+                } else if (w->rc == FPL_OK) {
+                    w->rc = fpl_wait(dev[d].ctx);
+                }
                 if (w->rc == FPL_OK && fragmentMode) { /* any number of output reads per read: fetch the list */
                     uint32_t nf = 0, nr = 0;
                     w->rc = fpl_fragment_counts(dev[d].ctx, &nf, &nr);
@@ -820,15 +864,19 @@ int main(int argc, char* argv[]) {
                         w->frags.index(w->batch.n());
                     }
                 }
-                if (w->rc != FPL_OK) w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
+                if (w->rc != FPL_OK && w->err.empty()) w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
                 tGpu[d] += now() - t0;
                 fmtq.push(w);
             };
             const size_t depth = fragmentMode ? 1 : FPL_MAX_IN_FLIGHT;
-            while (open || !inflight.empty()) {
+            while (open || !inflight.empty() || !redo.empty()) {
                 Work* w = nullptr;
                 bool got = false;
-                if (open && inflight.size() < depth) {
+                if (!redo.empty() && inflight.size() < depth) {
+                    w = redo.front();
+                    redo.pop_front();
+                    got = true;
+                } else if (open && inflight.size() < depth) {
                     if (inflight.empty()) {
                         w = devq[d].pop();
                         got = true;
@@ -839,9 +887,13 @@ int main(int argc, char* argv[]) {
                 if (got && !w) open = false;
                 if (got && w) {
                     w->res.resize(w->batch.n());
+                    w->err.clear();
                     const double t0 = now();
-                    w->rc = fpl_process_batch_async(dev[d].ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(),
-                                                    w->batch.n(), w->res.data());
+                    if (w->batch.text_backed)
+                        w->rc = fpl_process_text_async(dev[d].ctx, w->batch.raw.data() + w->batch.raw_begin, w->batch.raw_len);
+                    else
+                        w->rc = fpl_process_batch_async(dev[d].ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(),
+                                                        w->batch.n(), w->res.data());
                     tGpu[d] += now() - t0;
                     if (w->rc != FPL_OK) { /* nothing was enqueued: hand the error on in order */
                         w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
@@ -1032,6 +1084,9 @@ int main(int argc, char* argv[]) {
              << ", copies + kernels (waits) " << g << " s, format (" << fmtThreads << " threads) " << f << " s, write " << tWrite
              << " s" << endl;
     }
+    if (cmd.exist("verbose") && textMode)
+        cerr << "device parse: " << nTextBatches.load() << " chunks parsed on the device, " << nTextFallbacks.load()
+             << " handed back to the host's reader (irregular text)" << endl;
     if (cmd.exist("verbose")) { /* which kernel forms the batches took: the library picks by batch size (csrc/pipeline.h) */
         uint64_t f[6] = {0, 0, 0, 0, 0, 0};
         for (auto& D : dev) {

@@ -629,6 +629,36 @@ void Batch::clear() {
     name_off.clear();
     name_len.clear();
     strand_len.clear();
+    raw.clear();
+    raw_begin = raw_len = 0;
+    line.clear();
+    text_backed = false;
+}
+
+void Batch::adopt_lines(const uint32_t* ls, uint32_t n_records) {
+    const uint8_t* t = raw.data();
+    const uint32_t base = (uint32_t)raw_begin;
+    line.resize(4 * (size_t)n_records);
+    off.resize((size_t)n_records + 1);
+    name_len.resize(n_records);
+    strand_len.resize(n_records);
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < n_records; i++) {
+        uint32_t L[5];
+        for (int j = 0; j < 4; j++) L[j] = line[4 * (size_t)i + j] = ls[4 * (size_t)i + j] + base;
+        L[4] = i + 1 < n_records ? ls[4 * (size_t)i + 4] + base : base + (uint32_t)raw_len;
+        uint32_t ll[4];
+        for (int j = 0; j < 4; j++) { /* a line ends with "\n" or "\r\n" (regular text: the device checked) */
+            uint32_t e = L[j + 1] - 1;
+            if (e > L[j] && t[e - 1] == '\r') e--;
+            ll[j] = e - L[j];
+        }
+        name_len[i] = ll[0];
+        strand_len[i] = ll[2];
+        off[i] = run;
+        run += ll[1];
+    }
+    off[n_records] = run;
 }
 
 /* index of the first '\n' or '\r' in p[0, n), or n: one pass for both terminators */
@@ -1079,6 +1109,78 @@ bool FastqReader::parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b
     }
 }
 
+bool FastqReader::load_chunk_text(int fd, uint64_t file_size, uint64_t a, uint64_t b, uint64_t chunk_bytes, Batch& out, ChunkInfo& info,
+                                  const char* mem) {
+    info = ChunkInfo();
+    out.text_backed = true;
+    out.raw_begin = out.raw_len = 0;
+    if (a >= file_size) {
+        info.status = 2;
+        return true;
+    }
+    if (b > file_size) b = file_size;
+    const uint64_t w0 = a == 0 ? 0 : a - 1; /* (the guess looks at the byte in front of the cut) */
+    for (uint64_t slack = 4u << 20;; slack *= 4) {
+        const uint64_t w1 = min<uint64_t>(file_size, b + slack);
+        const size_t n = (size_t)(w1 - w0);
+        out.raw.resize_uninit(n);
+        char* wp = (char*)out.raw.data();
+        if (mem) {
+            memcpy(wp, mem + w0, n);
+        } else {
+            size_t x = 0;
+            while (x < n) {
+                const ssize_t r = pread(fd, wp + x, n - x, (off_t)(w0 + x));
+                if (r <= 0) {
+                    info.status = 4;
+                    info.err = "reading the input failed (file truncated while it was being read?)";
+                    return false;
+                }
+                x += (size_t)r;
+            }
+        }
+        FastqReader m(wp, n, w1 >= file_size);
+        /* parse_chunk's guess: the first header at or behind `pos` that validates, or the first one at or behind `limit`
+           (beyond its chunk nothing is taken anyway).  short_of_window: the search ran into the end of the window although the
+           file goes on -- look again with more of it */
+        bool short_of_window = false;
+        auto guess = [&](size_t pos, size_t limit) -> size_t {
+            Line ln;
+            if (wp[pos - 1] != '\n' && wp[pos - 1] != '\r') m.scan_line(pos, ln); /* finish the line we fell into */
+            for (;;) {
+                const size_t cand = m.next_at_line(pos);
+                if (cand >= n) {
+                    if (w1 < file_size) short_of_window = true;
+                    return n;
+                }
+                size_t t = cand;
+                Line l0, l1, l2, l3;
+                const int r0 = m.scan_line(t, l0), r1 = r0 == 1 ? m.scan_line(t, l1) : r0, r2 = r1 == 1 ? m.scan_line(t, l2) : r1,
+                          r3 = r2 == 1 ? m.scan_line(t, l3) : r2;
+                if ((r0 == 0 || r1 == 0 || r2 == 0 || r3 == 0) && cand < limit) { /* the window ends inside these four lines */
+                    short_of_window = true;
+                    return n;
+                }
+                const bool good = r3 == 1 && l2.n > 0 && l2.p[0] == '+' && l1.n == l3.n;
+                if (good || cand >= limit) return cand;
+                pos = cand;
+                m.scan_line(pos, ln); /* not a header: move past this line */
+            }
+        };
+        size_t first = (size_t)(a - w0), next = n;
+        if (a > 0) first = guess(first, (size_t)(b - w0));
+        if (!short_of_window && b < file_size) next = guess((size_t)(b - w0), (size_t)(min<uint64_t>(b + chunk_bytes, file_size) - w0));
+        if (short_of_window) continue;
+        if (first > next) first = next;
+        out.raw_begin = first;
+        out.raw_len = next - first;
+        if (out.raw_len > 0) info.first = w0 + first;
+        if (b >= file_size) info.status = 2; /* the end of the input */
+        else info.next = w0 + next;
+        return true;
+    }
+}
+
 static double g_t_pull = 0, g_t_scan = 0, g_t_copy = 0;
 struct TimingDump {
     ~TimingDump() {
@@ -1161,13 +1263,15 @@ struct ChunkedReader::Impl {
     vector<std::thread> threads;
     vector<double> busy;
     vector<char> window; /* of the calling thread, for chunks that are parsed again */
+    bool as_text = false;
 };
 
 ChunkedReader::ChunkedReader(int fd, uint64_t file_size, uint64_t chunk_bytes, int threads, std::function<Item()> acquire,
-                             std::function<void(Item)> release, const char* mem) {
+                             std::function<void(Item)> release, const char* mem, bool as_text) {
     d_ = new Impl;
     d_->fd = fd;
     d_->mem = mem;
+    d_->as_text = as_text;
     d_->file_size = file_size;
     d_->chunk_bytes = chunk_bytes ? chunk_bytes : 1;
     d_->n_chunks = (file_size + d_->chunk_bytes - 1) / d_->chunk_bytes;
@@ -1201,8 +1305,12 @@ ChunkedReader::ChunkedReader(int fd, uint64_t file_size, uint64_t chunk_bytes, i
                 }
                 ps.item.batch->clear();
                 const auto t0 = std::chrono::steady_clock::now();
-                FastqReader::parse_chunk(D.fd, D.file_size, k * D.chunk_bytes, (k + 1) * D.chunk_bytes, false, window,
-                                         *ps.item.batch, ps.info, 1, D.mem);
+                if (D.as_text)
+                    FastqReader::load_chunk_text(D.fd, D.file_size, k * D.chunk_bytes, (k + 1) * D.chunk_bytes, D.chunk_bytes,
+                                                 *ps.item.batch, ps.info, D.mem);
+                else
+                    FastqReader::parse_chunk(D.fd, D.file_size, k * D.chunk_bytes, (k + 1) * D.chunk_bytes, false, window,
+                                             *ps.item.batch, ps.info, 1, D.mem);
                 D.busy[t] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 {
                     lock_guard<mutex> g(D.parsed_mu);
@@ -1272,7 +1380,7 @@ bool ChunkedReader::next(Item& out) {
             lock_guard<mutex> g(D.take_mu);
             D.stop = true;
         }
-        if (ps.item.batch->n() > 0) {
+        if (ps.item.batch->has_records()) {
             out = ps.item;
             return true;
         }
@@ -1336,11 +1444,11 @@ void format_range(const Batch& b, const fpl_read_result* res, uint32_t first, ui
     for (uint32_t i = first; i < last; i++) {
         const fpl_read_result& r = res[i];
         if (r.dropped) continue;
-        const char* name = b.text.data() + b.name_off[i];
+        const char* name = b.name_ptr(i);
         const uint32_t nl = b.name_len[i], sl = b.strand_len[i];
-        const char* strand = name + nl;
-        const uint8_t* s = b.seq.data() + b.off[i];
-        const uint8_t* q = b.qual.data() + b.off[i];
+        const char* strand = b.strand_ptr(i);
+        const uint8_t* s = b.seq_ptr(i);
+        const uint8_t* q = b.qual_ptr(i);
         if (fl) { /* --break / --mask: any number of output reads, src/seprocessor.cpp:234-281 */
             const uint32_t f0 = fl->first[i], f1 = fl->first[i + 1];
             for (uint32_t k = f0; k < f1; k++) {

@@ -72,7 +72,26 @@ struct Batch {
     std::vector<char> text;           /* name and strand lines, back to back */
     std::vector<uint64_t> name_off;   /* n + 1 offsets into text for names   */
     std::vector<uint32_t> name_len, strand_len; /* strand line follows the name in `text` */
+    /* A TEXT-BACKED batch (--device_parse): `raw` holds a stretch of the file as it lies there, raw[raw_begin, raw_begin +
+       raw_len) are whole records; the DEVICE finds them (fpl_process_text_async) and the caller then fills off / name_len /
+       strand_len and `line` (four per read: where its name, bases, '+' line and qualities start in raw) from what comes
+       back -- no base is copied on the host, the output is formatted out of raw. */
+    ByteBuf raw;
+    uint64_t raw_begin = 0, raw_len = 0;
+    std::vector<uint32_t> line;
+    bool text_backed = false;
     uint32_t n() const { return off.empty() ? 0 : (uint32_t)(off.size() - 1); }
+    bool has_records() const { return n() > 0 || (text_backed && raw_len > 0); }
+    /* the four lines of read i, whichever form the batch has */
+    const char* name_ptr(uint32_t i) const { return text_backed ? (const char*)raw.data() + line[4 * (size_t)i] : text.data() + name_off[i]; }
+    const char* strand_ptr(uint32_t i) const {
+        return text_backed ? (const char*)raw.data() + line[4 * (size_t)i + 2] : text.data() + name_off[i] + name_len[i];
+    }
+    const uint8_t* seq_ptr(uint32_t i) const { return text_backed ? raw.data() + line[4 * (size_t)i + 1] : seq.data() + off[i]; }
+    const uint8_t* qual_ptr(uint32_t i) const { return text_backed ? raw.data() + line[4 * (size_t)i + 3] : qual.data() + off[i]; }
+    /* text-backed: off / name_len / strand_len from the line starts the device found (n records, offsets relative to
+       raw_begin as fpl_wait_text hands them out) */
+    void adopt_lines(const uint32_t* line_starts, uint32_t n_records);
     void clear();
 };
 
@@ -109,6 +128,12 @@ class FastqReader {
     /* (mem != nullptr: the input's bytes [0, file_size) are in memory there and are parsed in place; fd is not used) */
     static bool parse_chunk(int fd, uint64_t file_size, uint64_t a, uint64_t b, bool exact, std::vector<char>& window,
                             Batch& out, ChunkInfo& info, int threads, const char* mem = nullptr);
+    /* The same chunk as TEXT for the device to parse (Batch::raw): the bytes [a - 1, b + slack) are read into out.raw and only
+     * the two ends are looked at -- the first record of this chunk and the first record of the next, both by the guess
+     * parse_chunk makes -- so the records of the text are exactly those parse_chunk(.., exact = false) would take.  No line
+     * in between is scanned and no base copied a second time. */
+    static bool load_chunk_text(int fd, uint64_t file_size, uint64_t a, uint64_t b, uint64_t chunk_bytes, Batch& out, ChunkInfo& info,
+                                const char* mem = nullptr);
     bool ok() const { return fp_ != nullptr; }
     /* append records until the batch holds >= max_bases bases or max_reads reads; returns the
      * number of records appended (0 at end of input) */
@@ -170,8 +195,9 @@ class ChunkedReader {
         Batch* batch = nullptr;
         void* token = nullptr; /* the caller's handle for the batch (e.g. the Work object it lives in) */
     };
+    /* as_text: the parsers only LOAD their chunks (FastqReader::load_chunk_text, text-backed batches) */
     ChunkedReader(int fd, uint64_t file_size, uint64_t chunk_bytes, int threads, std::function<Item()> acquire,
-                  std::function<void(Item)> release, const char* mem = nullptr);
+                  std::function<void(Item)> release, const char* mem = nullptr, bool as_text = false);
     ~ChunkedReader();
     /* the next batch in input order; false at the end of the input (or behind a malformed record / read error) */
     bool next(Item& out);

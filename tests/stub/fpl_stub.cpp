@@ -21,12 +21,16 @@
 
 #include "../../include/fastplong_amd.h"
 #include "../../oracle/fpl_oracle.h"
+#include "text_stand_in.h"
 
 struct Pending {
     const uint8_t *seq, *qual;
     const uint64_t* off;
     uint32_t n;
     fpl_read_result* res;
+    const uint8_t* text = nullptr; /* a text batch (fpl_process_text_async): parsed in fpl_wait_text */
+    uint64_t text_bytes = 0;
+    bool is_text = false;
 };
 struct fpl_ctx {
     int device = 0;
@@ -39,6 +43,9 @@ struct fpl_ctx {
     std::deque<Pending> q;
     std::string err;
     orc_fraglist last = {nullptr, 0, 0, nullptr, 0, 0};
+    StandInText text_slot[FPL_MAX_IN_FLIGHT + 1]; /* what fpl_wait_text hands out stays valid for two more submissions */
+    std::vector<fpl_read_result> text_res[FPL_MAX_IN_FLIGHT + 1];
+    unsigned text_no = 0;
     int n_adapters() const { return 2 + (int)fasta.size(); }
 };
 
@@ -159,6 +166,7 @@ int fpl_in_flight(const fpl_ctx* ctx) { return ctx ? (int)ctx->q.size() : 0; }
 
 int fpl_wait(fpl_ctx* ctx) {
     if (!ctx || ctx->q.empty()) return FPL_ERR_STATE;
+    if (ctx->q.front().is_text) return FPL_ERR_STATE;
     const Pending p = ctx->q.front();
     ctx->q.pop_front();
     uint32_t maxlen = 0;
@@ -187,6 +195,48 @@ int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, con
                       fpl_read_result* results) {
     int rc = fpl_process_batch_async(ctx, seq, qual, off, n_reads, results);
     return rc == FPL_OK ? fpl_wait(ctx) : rc;
+}
+
+int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) {
+    if (!ctx || (n_bytes && !text)) return FPL_ERR_ARG;
+    if (ctx->q.size() >= FPL_MAX_IN_FLIGHT) return FPL_ERR_STATE;
+    if (ctx->opt.break_enabled || ctx->opt.mask_enabled) return FPL_ERR_STATE;
+    if (const char* lf = getenv("FPL_STUB_LOG")) {
+        std::lock_guard<std::mutex> g(g_log_m);
+        if (FILE* f = fopen(lf, "a")) {
+            fprintf(f, "%d text %llu\n", ctx->device, (unsigned long long)n_bytes);
+            fclose(f);
+        }
+    }
+    Pending p{nullptr, nullptr, nullptr, 0, nullptr};
+    p.text = text;
+    p.text_bytes = n_bytes;
+    p.is_text = true;
+    ctx->q.push_back(p);
+    return FPL_OK;
+}
+int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts) {
+    if (!ctx || !out || ctx->q.empty() || !ctx->q.front().is_text) return ctx && out ? FPL_ERR_STATE : FPL_ERR_ARG;
+    const Pending p = ctx->q.front();
+    ctx->q.pop_front();
+    const unsigned k = ctx->text_no++ % (FPL_MAX_IN_FLIGHT + 1);
+    StandInText& t = ctx->text_slot[k];
+    stand_in_parse(p.text, p.text_bytes, true, t);
+    *out = t.info;
+    if (results) *results = nullptr;
+    if (line_starts) *line_starts = nullptr;
+    if (t.info.status != FPL_TEXT_OK || t.info.n_reads == 0) return FPL_OK;
+    ctx->text_res[k].resize(t.info.n_reads);
+    /* the batch itself: through the CSR entry points above (same queue discipline: nothing else is in front of it now) */
+    std::deque<Pending> rest;
+    rest.swap(ctx->q);
+    int rc = fpl_process_batch_async(ctx, t.seq.data(), t.qual.data(), t.off.data(), t.info.n_reads, ctx->text_res[k].data());
+    if (rc == FPL_OK) rc = fpl_wait(ctx);
+    ctx->q.swap(rest);
+    if (rc != FPL_OK) return rc;
+    if (results) *results = ctx->text_res[k].data();
+    if (line_starts) *line_starts = t.line.data();
+    return FPL_OK;
 }
 
 void* fpl_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }

@@ -238,3 +238,92 @@ def test_cli_against_the_null_device_is_the_host_side_alone(tmp_path):
     p = subprocess.run([build.CLI, "-i", str(inp), "-o", "/dev/null", "-s", "ACGTACGTACGTACGTACGT", "-e", "TTGCATTGCATTGCATTGCA", "--gpus", "9",
                         "-j", str(tmp_path / "o.json"), "-h", str(tmp_path / "o.html")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
     assert p.returncode != 0
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cli_device_parse_reproduces_golden(tmp_path, stub_env, case):
+    """--device_parse: the chunk parsers only load the file's bytes, the DEVICE finds the records (fpl_process_text_async; here
+    the stub's CPU stand-in for the device) and the output is formatted out of the text -- the same bytes as the host's reader
+    gives, over two devices and chunks of 30 kB (every chunk boundary falls somewhere else in a record)"""
+    p, out, log = run_cli(tmp_path, case, stub_env, 2, extra=["--device_parse"])
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert (out / "out.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.out.fq.gz"))
+    assert (out / "failed.fq").read_bytes() == gz(os.path.join(GOLD, case, "expected.failed.fq.gz"))
+    got = [l for l in (out / "out.json").read_bytes().split(b"\n") if not l.startswith(b'\t"command":')]
+    assert got == gz(os.path.join(GOLD, case, "expected.json.gz")).split(b"\n")
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    if {"--break", "--mask", "-b", "-N"} & set(meta["flags"]):
+        assert b"--device_parse does not apply" in p.stderr  # (fragment lists come back through the CSR entry points)
+    else:
+        m = re.search(rb"device parse: (\d+) chunks parsed on the device, (\d+) handed back", p.stderr)
+        assert m and int(m.group(1)) >= 6 and int(m.group(2)) == 0, p.stderr[-800:]
+        # every submission was text (the stub logs one more line per text batch: its own CSR call behind the parse)
+        kinds = [l.split()[1] == "text" for l in open(log).read().splitlines()]
+        assert sum(kinds) == int(m.group(1)) and len(kinds) == 2 * sum(kinds)
+
+
+def _records(text):
+    ls = text.split(b"\n")
+    return [ls[i:i + 4] for i in range(0, len(ls) - 1, 4)]
+
+
+@pytest.mark.parametrize("what", ["blank lines", "crlf and no final line break", "junk line in front of a header"])
+def test_cli_device_parse_hands_irregular_chunks_to_the_host_reader(tmp_path, stub_env, what):
+    """text the reference's reader treats specially (src/fastqreader.cpp:219-347: blank lines and lines without '@' are skipped
+    in front of a header, "\\r\\n" and a missing last line break are fine) is refused by the device chunk by chunk and parsed by
+    the host's reader: the run's output is what it is without --device_parse"""
+    case = "c3_full"
+    recs = _records(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    parts = []
+    for i, r in enumerate(recs):
+        nl = b"\r\n" if (what.startswith("crlf") and i % 3) else b"\n"
+        if what == "blank lines" and i % 40 == 7:
+            parts.append(b"\n")
+        if what.startswith("junk") and i % 55 == 9:
+            parts.append(b"this line is no header\n")
+        parts.append(nl.join(r) + nl)
+    text = b"".join(parts)
+    if what.startswith("crlf"):
+        text = text[:-1] if text.endswith(b"\n") and not text.endswith(b"\r\n") else text[:-2]
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    outs = {}
+    for mode in ("host", "device"):
+        d = tmp_path / mode
+        d.mkdir()
+        inp = d / "in.fq"
+        inp.write_bytes(text)
+        cmd = [build.CLI, "-i", str(inp), "-o", str(d / "out.fq"), "--failed_out", str(d / "failed.fq"), "-j", str(d / "out.json"),
+               "-h", str(d / "out.html"), "--gpus", "2", "--reader_threads", "3", "-V"] + meta["flags"] + (["--device_parse"] if mode == "device" else [])
+        e = dict(stub_env, FPL_STUB_DEVICES="2", FPLH_CHUNK_BYTES="30000")
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        outs[mode] = (p, d)
+    for f in ("out.fq", "failed.fq"):
+        assert (outs["host"][1] / f).read_bytes() == (outs["device"][1] / f).read_bytes(), f
+    strip = lambda b: [l for l in b.split(b"\n") if not l.startswith(b'\t"command":')]  # noqa: E731
+    assert strip((outs["host"][1] / "out.json").read_bytes()) == strip((outs["device"][1] / "out.json").read_bytes())
+    m = re.search(rb"device parse: (\d+) chunks parsed on the device, (\d+) handed back", outs["device"][0].stderr)
+    assert m and int(m.group(2)) >= 1 and int(m.group(1)) >= 1, outs["device"][0].stderr[-800:]
+    if what == "blank lines":  # the reference's reader (and this host's) reads every record of such a file
+        assert len(_records((outs["device"][1] / "out.fq").read_bytes())) > 0.5 * len(recs)
+
+
+def test_cli_device_parse_refuses_a_malformed_record(tmp_path, stub_env):
+    """a record the reference stops reading at (qualities and bases of different lengths): with --device_parse the run fails with
+    the reference's message and says why (chunks behind the record may be counted already), without it the host's reader
+    ends the input there as the reference does"""
+    case = "c3_full"
+    recs = _records(gz(os.path.join(GOLD, case, "in.fq.gz")))
+    bad = len(recs) // 2
+    recs[bad][3] = recs[bad][3][:-2]
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(b"".join(b"\n".join(r) + b"\n" for r in recs))
+    meta = json.load(open(os.path.join(GOLD, case, "case.json")))
+    base = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"),
+            "--reader_threads", "3"] + meta["flags"]
+    e = dict(stub_env, FPL_STUB_DEVICES="1", FPLH_CHUNK_BYTES="30000")
+    p = subprocess.run(base + ["--device_parse"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+    assert p.returncode != 0 and b"sequence and quality have different length" in p.stderr and b"--device_parse" in p.stderr, p.stderr[-1500:]
+    p = subprocess.run(base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+    assert p.returncode == 0 and b"sequence and quality have different length" in p.stderr
+    assert len(_records((tmp_path / "out.fq").read_bytes())) > 0

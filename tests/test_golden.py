@@ -93,7 +93,8 @@ def test_oracle_reproduces_golden(orc, case):
 @pytest.mark.parametrize("case", CASES)
 # 37 reads per batch: several batches, counters accumulate (sequential reader); "chunks": the chunk-parallel reader with
 # chunks of 30 kB -- every cut falls inside some record -- and batches two deep in the copy / kernel stage
-@pytest.mark.parametrize("batch_reads", ["0", "37", "chunks"])
+# "device_parse": the same chunks, but only LOADED by the host -- the device finds the records (fpl_process_text_async)
+@pytest.mark.parametrize("batch_reads", ["0", "37", "chunks", "device_parse"])
 def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     build.build_all()
     meta = json.load(open(os.path.join(GOLD, case, "case.json")))
@@ -103,8 +104,8 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     cmd = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "--failed_out", str(tmp_path / "failed.fq"),
            "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html")] + flags
     env = dict(os.environ)
-    if batch_reads == "chunks":
-        cmd += ["--reader_threads", "3", "-V"]
+    if batch_reads in ("chunks", "device_parse"):
+        cmd += ["--reader_threads", "3", "-V"] + (["--device_parse"] if batch_reads == "device_parse" else [])
         env["FPLH_CHUNK_BYTES"] = "30000"
     else:
         cmd += ["--batch_reads", batch_reads]
@@ -124,11 +125,17 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
     assert b"reads passed filter: " in p.stderr and b"HTML report: " in p.stderr
     if batch_reads == "chunks":
         assert b"chunk parsers" in p.stderr  # (the chunk-parallel reader really ran)
+    if batch_reads == "device_parse":
+        if {"--break", "--mask", "-b", "-N"} & set(meta["flags"]):
+            assert b"--device_parse does not apply" in p.stderr
+        else:
+            m = re.search(rb"device parse: (\d+) chunks parsed on the device, (\d+) handed back", p.stderr)
+            assert m and int(m.group(1)) >= 3 and int(m.group(2)) == 0, p.stderr[-800:]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("how", ["stdout_pipe", "file_forced", "gz_input"])
+@pytest.mark.parametrize("how", ["stdout_pipe", "file_forced", "gz_input", "stdout_pipe_device_parse"])
 def test_cli_gather_output_reproduces_golden_on_gpu(tmp_path, case, how):
     """plain --out without --failed_out that is not a regular file (here: --stdout into a pipe) is written as gather lists
     over the batches' own arrays (writev, nothing is formatted); FPLH_GATHER_FILES forces the same for a file.  Same bytes
@@ -142,6 +149,8 @@ def test_cli_gather_output_reproduces_golden_on_gpu(tmp_path, case, how):
     flags = [f if f != "ADAPTERS.fa" else os.path.join(GOLD, case, "ADAPTERS.fa") for f in meta["flags"]]
     cmd = [build.CLI, "-i", str(inp), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"), "--reader_threads", "3", "-V"] + flags
     env = dict(os.environ, FPLH_CHUNK_BYTES="30000")
+    if how == "stdout_pipe_device_parse":  # the gather lists point into the chunk's text instead of CSR arrays
+        cmd += ["--device_parse"]
     if how != "file_forced":
         cmd += ["--stdout"]
     else:

@@ -20,11 +20,15 @@
 #include <vector>
 
 #include "../../include/fastplong_amd.h"
+#include "../../tests/stub/text_stand_in.h" /* (the text entry points: a CPU line scan stands in for the device's -- its cost counts against the host here) */
 
 struct Pending {
     const uint64_t* off;
     uint32_t n;
     fpl_read_result* res;
+    const uint8_t* text = nullptr;
+    uint64_t text_bytes = 0;
+    bool is_text = false;
 };
 struct fpl_ctx {
     int device = 0;
@@ -33,6 +37,9 @@ struct fpl_ctx {
     std::vector<int64_t> counters;
     std::deque<Pending> q;
     uint64_t reads = 0, bases = 0;
+    StandInText text_slot[FPL_MAX_IN_FLIGHT + 1];
+    std::vector<fpl_read_result> text_res[FPL_MAX_IN_FLIGHT + 1];
+    unsigned text_no = 0;
 };
 
 static int null_devices() {
@@ -102,8 +109,50 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t*, const uint8_t*, const 
     return FPL_OK;
 }
 int fpl_in_flight(const fpl_ctx* ctx) { return ctx ? (int)ctx->q.size() : 0; }
+int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) {
+    if (!ctx || (n_bytes && !text)) return FPL_ERR_ARG;
+    if (ctx->q.size() >= FPL_MAX_IN_FLIGHT) return FPL_ERR_STATE;
+    Pending p{nullptr, 0, nullptr};
+    p.text = text;
+    p.text_bytes = n_bytes;
+    p.is_text = true;
+    ctx->q.push_back(p);
+    return FPL_OK;
+}
+int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts) {
+    if (!ctx || !out) return FPL_ERR_ARG;
+    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
+    const Pending p = ctx->q.front();
+    ctx->q.pop_front();
+    const unsigned k = ctx->text_no++ % (FPL_MAX_IN_FLIGHT + 1);
+    StandInText& t = ctx->text_slot[k];
+    stand_in_parse(p.text, p.text_bytes, false, t);
+    *out = t.info;
+    if (results) *results = nullptr;
+    if (line_starts) *line_starts = nullptr;
+    if (t.info.status != FPL_TEXT_OK || t.info.n_reads == 0) return FPL_OK;
+    std::vector<fpl_read_result>& rr = ctx->text_res[k];
+    rr.resize(t.info.n_reads);
+    for (uint32_t i = 0; i < t.info.n_reads; i++) {
+        const uint32_t l = (uint32_t)(t.off[i + 1] - t.off[i]);
+        fpl_read_result r;
+        memset(&r, 0, sizeof r);
+        r.r1_len = l;
+        r.frag_len[0] = l;
+        r.n_frag = 1;
+        r.code[0] = FPL_PASS_FILTER;
+        r.median_q_pre = r.median_q_post[0] = 'I';
+        rr[i] = r;
+    }
+    ctx->reads += t.info.n_reads;
+    ctx->bases += t.info.n_bases;
+    if (t.info.max_read_len > ctx->C) relayout(ctx, t.info.max_read_len + t.info.max_read_len / 4);
+    if (results) *results = rr.data();
+    if (line_starts) *line_starts = t.line.data();
+    return FPL_OK;
+}
 int fpl_wait(fpl_ctx* ctx) {
-    if (!ctx || ctx->q.empty()) return FPL_ERR_STATE;
+    if (!ctx || ctx->q.empty() || ctx->q.front().is_text) return FPL_ERR_STATE;
     const Pending p = ctx->q.front();
     ctx->q.pop_front();
     uint32_t maxlen = 0;
