@@ -248,6 +248,8 @@ NULLDEV_DEVICES = 8  # the host_ceiling runs: bin/fastplong_amd --gpus 8 against
 E2E_RUNS = (
     dict(name="to_dev_null_first_pass", target="/dev/null"),
     dict(name="to_dev_null", target="/dev/null"),
+    # the same with the parse on the device: the host's chunk parsers only load the file's bytes (fpl_process_text_async)
+    dict(name="device_parse", target="/dev/null", flags=["--device_parse"]),
     dict(name="to_file", target=None),
     dict(name="to_split_files", target=None, flags=["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)]),
     # batches large enough for the kernel forms the headline times (csrc/pipeline.h: k_trim_ends_batched from 65 536 reads,
@@ -259,15 +261,16 @@ E2E_RUNS = (
     dict(name="gz_in_single_stream", target="/dev/null", input="gz_single", flags=["--gz_stream"]),
     dict(name="gz_out", target="GZ", input="fq_sub"),
     dict(name="null8_to_dev_null", target="/dev/null", null=NULLDEV_DEVICES),
+    dict(name="null8_device_parse", target="/dev/null", null=NULLDEV_DEVICES, flags=["--device_parse"]),
     dict(name="null8_to_dev_null_rt16", target="/dev/null", null=NULLDEV_DEVICES, flags=["--reader_threads", "16"]),
     dict(name="null8_to_split_files", target=None, null=NULLDEV_DEVICES, flags=["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)]),
     dict(name="null8_to_file", target=None, null=NULLDEV_DEVICES),
 )
 GZ_READS = 50_000  # reads of the gzip legs (the first reads of the batch)
-E2E_DEFAULT_RUNS = ("to_dev_null_first_pass", "to_dev_null", "to_file", "to_split_files")
+E2E_DEFAULT_RUNS = ("to_dev_null_first_pass", "to_dev_null", "device_parse", "to_file", "to_split_files")
 E2E_FULL_RUNS = E2E_DEFAULT_RUNS + ("gz_in_multi", "gz_in_single", "gz_in_single_stream", "gz_out")
-E2E_LARGE_RUNS = ("to_dev_null", "to_file", "to_split_files", "chunk_512mb", "chunk_1536mb", "null8_to_dev_null",
-                  "null8_to_dev_null_rt16", "null8_to_split_files", "null8_to_file")
+E2E_LARGE_RUNS = ("to_dev_null", "device_parse", "to_file", "to_split_files", "chunk_512mb", "chunk_1536mb", "null8_to_dev_null",
+                  "null8_device_parse", "null8_to_dev_null_rt16", "null8_to_split_files", "null8_to_file")
 
 
 def gzip_single_member(src, dst, level=1):
@@ -458,6 +461,9 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
                     i = run_cmd.index("--gpus")
                     del run_cmd[i:i + 2]
                 run_cmd += ["--gpus", str(spec["null"])]
+            import resource
+
+            ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
             t0 = time.perf_counter()
             # (a run that does not come back must not take the bench line with it: its own session, so that the whole process
             # group can be killed, and a bounded wait for its pipes afterwards -- a process stuck in the driver may never close them)
@@ -485,10 +491,14 @@ def end_to_end(workload, opt, adapters, seq_t, qual_t, off_t, n_reads, n_gpus=1,
             for line in p.stderr.splitlines():
                 if line.startswith("host pipeline:"):
                     pipe = float(line.split("wall ")[1].split(" s")[0])
-                if line.startswith(("host pipeline:", "start-up:", "reports:", "since launch:", "chunk parsers", "counter merge:", "kernel forms:", "input:")):
+                if line.startswith(("host pipeline:", "start-up:", "reports:", "since launch:", "chunk parsers", "counter merge:", "kernel forms:", "input:", "device parse:")):
                     keep.append(line)
+            ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+            cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
             runs[name] = {"rc": p.returncode, "process_seconds": dt, "value": run_bases / dt / 1e9, "bases": run_bases,
-                          "pipeline_seconds": pipe, "pipeline_value": (run_bases / pipe / 1e9) if pipe else None, "stages": keep}
+                          "pipeline_seconds": pipe, "pipeline_value": (run_bases / pipe / 1e9) if pipe else None, "stages": keep,
+                          # host CPU the whole process took (user + system, all threads): what bounds an N-device run on a host
+                          "cpu_seconds": cpu_s, "cpu_seconds_per_gbase": cpu_s / (run_bases / 1e9)}
             if flags:
                 runs[name]["flags"] = " ".join(flags)
             if name == "to_dev_null" and p.returncode == 0:  # (the report of THIS run: later runs write the same file names)
@@ -591,6 +601,10 @@ def compact_line(out):
         ce["value"] = _r(e.get("value"), 4)
         ce["pipeline_value"] = leg(runs, "to_dev_null", "pipeline_value")
         ce["first_pass"] = leg(runs, "to_dev_null_first_pass")
+        ce["device_parse"] = leg(runs, "device_parse")
+        ce["device_parse_pipeline"] = leg(runs, "device_parse", "pipeline_value")
+        ce["cpu_s_per_gbase"] = leg(runs, "to_dev_null", "cpu_seconds_per_gbase")
+        ce["device_parse_cpu_s_per_gbase"] = leg(runs, "device_parse", "cpu_seconds_per_gbase")
         ce["to_file"] = leg(runs, "to_file")
         ce["to_split"] = leg(runs, "to_split_files")
         if e.get("pcie_call"):
@@ -606,6 +620,7 @@ def compact_line(out):
             ce["large"] = {"reads": big.get("reads"), "value": leg(br, "to_dev_null"), "pipeline_value": leg(br, "to_dev_null", "pipeline_value"),
                            "to_file": leg(br, "to_file"), "to_split": leg(br, "to_split_files"),
                            "chunk_512mb": leg(br, "chunk_512mb"), "chunk_1536mb": leg(br, "chunk_1536mb"),
+                           "device_parse": leg(br, "device_parse"), "null8_device_parse": leg(br, "null8_device_parse", "pipeline_value"),
                            "null8": leg(br, "null8_to_dev_null", "pipeline_value"), "null8_rt16": leg(br, "null8_to_dev_null_rt16", "pipeline_value"),
                            "null8_to_file": leg(br, "null8_to_file")}
             if "error" in big:

@@ -234,5 +234,5 @@ def test_bench_line_is_one_short_json_line(orc, tmp_path, monkeypatch, capsys):
     out2 = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
     assert len(out2) == 1 and len(out2[0]) < bench.LINE_LIMIT
     l2 = json.loads(out2[0])
-    assert l2["e2e"]["value"] == 15.4 and l2["e2e"]["to_file"] == 12.0 and l2["e2e"]["large"]["null8"] is not None
+    assert l2["e2e"]["value"] == 15.4 and l2["e2e"]["to_file"] == 10.0 + names.index("to_file") and l2["e2e"]["large"]["null8"] is not None
     assert l2["roofline"] == line["roofline"] and l2["cpu_baseline"] == line["cpu_baseline"]
