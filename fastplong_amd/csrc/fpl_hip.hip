@@ -889,8 +889,15 @@ static int ensure_text_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, uint64_t n_bytes) {
 }
 
 /* stage 2 of a text batch: the header is in -- enqueue the per-read kernels and the way back of the records and line starts */
-static int text_continue(fpl_ctx* ctx, fpl_ctx::Slot& sl) {
+/* block = false (a submission): only when the header is in already -- the caller's copies then go out behind this batch's parse at
+   once, instead of after a round trip to the host between two chunks on the link.  Returns 1 when the batch is still parsing. */
+static int text_continue(fpl_ctx* ctx, fpl_ctx::Slot& sl, bool block) {
     if (sl.kind != 1 || sl.stage != 1) return FPL_OK;
+    if (!block) {
+        const hipError_t q = hipEventQuery(sl.ev_parsed);
+        if (q == hipErrorNotReady) return 1;
+        FPL_HIP(q);
+    }
     sl.stage = 2;
     FPL_HIP(hipEventSynchronize(sl.ev_parsed));
     const TextHeader h = *sl.h_hdr;
@@ -918,11 +925,12 @@ static int text_continue(fpl_ctx* ctx, fpl_ctx::Slot& sl) {
     sl.n_reads = n;
     return FPL_OK;
 }
-static int text_continue_all(fpl_ctx* ctx) {
+static int text_continue_all(fpl_ctx* ctx, bool block) {
     for (u32 k = ctx->waited; k != ctx->submitted; k++) { /* oldest first: the kernels keep the order of submission */
         fpl_ctx::Slot& sl = ctx->slot[k % FPL_MAX_IN_FLIGHT];
         if (sl.rc != FPL_OK) continue;
-        const int r = text_continue(ctx, sl);
+        const int r = text_continue(ctx, sl, block);
+        if (r == 1) break; /* still parsing: it, and everything behind it, later */
         if (r != FPL_OK) sl.rc = r; /* (reported by the wait for that batch) */
     }
     return FPL_OK;
@@ -934,7 +942,7 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
     if (ctx->submitted - ctx->waited >= FPL_MAX_IN_FLIGHT) return FPL_ERR_STATE;
     FPL_HIP(hipSetDevice(ctx->device));
     if (ctx->hcfg.defer) return FPL_ERR_STATE; /* (--break / --mask read their fragment lists batch by batch: the CSR entry points) */
-    int r = text_continue_all(ctx);
+    int r = text_continue_all(ctx, false);
     if (r != FPL_OK) return r;
     fpl_ctx::Slot& sl = ctx->slot[ctx->submitted % FPL_MAX_IN_FLIGHT];
     sl.kind = 1;
@@ -994,7 +1002,7 @@ int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** re
     if (line_starts) *line_starts = nullptr;
     FPL_HIP(hipSetDevice(ctx->device));
     if (sl.rc == FPL_OK) {
-        const int r = text_continue(ctx, sl);
+        const int r = text_continue(ctx, sl, true);
         if (r != FPL_OK) sl.rc = r;
     }
     ctx->waited++;
@@ -1038,7 +1046,7 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qua
     /* --break / --mask: the fragment lists of the batch in flight live in buffers this batch's kernels reuse */
     if (ctx->hcfg.defer && ctx->submitted != ctx->waited) return FPL_ERR_STATE;
     {
-        const int rt = text_continue_all(ctx); /* (a text batch in flight gets its kernels in front of this batch's) */
+        const int rt = text_continue_all(ctx, true); /* (a text batch in flight gets its kernels in front of this batch's) */
         if (rt != FPL_OK) return rt;
     }
     fpl_ctx::Slot& sl = ctx->slot[ctx->submitted % FPL_MAX_IN_FLIGHT];
