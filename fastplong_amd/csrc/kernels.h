@@ -125,6 +125,10 @@ __device__ unsigned long long g_fpl_prof[64];
                            010: no base letter of any case) hold the two 5-mer tables and the block's scalars, and such bytes are counted
                            with global atomics (exact, never taken by DNA) */
 #endif
+#ifndef FPL_OPT_KMERKEEP
+#define FPL_OPT_KMERKEEP 1 /* k_stats_sorted (with FPL_OPT_KMER6): the 5-mer / 6-mer tables of a persistent block live through all its items --
+                              zeroed once, flushed once -- instead of per (tile, slice) item: counts are sums, whichever item they came from */
+#endif
 #ifndef FPL_OPT_INCPERM
 #define FPL_OPT_INCPERM 1 /* k_stats_sorted: the Q20 / Q30 half of a byte's packed increment through one v_perm per byte (20 instead of 32
                              vector instructions per row of 512 bytes) */
@@ -5164,6 +5168,21 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
        one counter, tile by tile -- the heavy low tiles first.  A grid of one block per item leaves a fifth of the chip idle: the
        hardware hands blocks to the XCDs in turn and in order, so every XCD waits for the one whose slots are all taken by long
        blocks (block timeline in profiles/r02_ab) */
+    auto kmer_flush = [&]() { /* the 5-mer tables (and what the 6-mer table holds of them) into the counters */
+        for (u32 i = threadIdx.x; i < 1024 && !(FPL_ABL & 64); i += blockDim.x) {
+            u32 both = kpost[i];
+            const u32 pre_only = kpre[i];
+#if FPL_OPT_KMER6
+            /* 5-mer i is the first five bases of the 6-mers 4 i .. 4 i + 3 and the last five of the 6-mers i + 1024 a */
+            both += k6[4 * i] + k6[4 * i + 1] + k6[4 * i + 2] + k6[4 * i + 3] + k6[i] + k6[i + 1024] + k6[i + 2048] + k6[i + 3072];
+#endif
+            if (both + pre_only) atomicAdd((u64*)&kg0[i], (u64)both + pre_only);
+            if (both) atomicAdd((u64*)&kg1[i], (u64)both);
+        }
+    };
+#if FPL_OPT_KMER6 && FPL_OPT_KMERKEEP
+    for (u32 i = threadIdx.x; i < 2048 + FS_BSTRIDE; i += blockDim.x) lds_all[i] = 0; /* the 6-mer table and class row 0 (the 5-mer tables): once */
+#endif
     for (;;) {
     __syncthreads(); /* (everybody is done with the previous item's tables and cur_item) */
     if (threadIdx.x == 0) cur_item = atomicAdd(&sw[SW_WORK], 1u);
@@ -5223,16 +5242,7 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
             }
 #endif
         }
-        for (u32 i = threadIdx.x; i < 1024 && !(FPL_ABL & 64); i += blockDim.x) {
-            u32 both = kpost[i];
-            const u32 pre_only = kpre[i];
-#if FPL_OPT_KMER6
-            /* 5-mer i is the first five bases of the 6-mers 4 i .. 4 i + 3 and the last five of the 6-mers i + 1024 a */
-            both += k6[4 * i] + k6[4 * i + 1] + k6[4 * i + 2] + k6[4 * i + 3] + k6[i] + k6[i + 1024] + k6[i + 2048] + k6[i + 3072];
-#endif
-            if (both + pre_only) atomicAdd((u64*)&kg0[i], (u64)both + pre_only);
-            if (both) atomicAdd((u64*)&kg1[i], (u64)both);
-        }
+        if (!(FPL_OPT_KMER6 && FPL_OPT_KMERKEEP)) kmer_flush();
         __syncthreads(); /* (the tables may be zeroed again) */
     };
     bool open = false; /* block-uniform: the tables are zeroed and may hold rows */
@@ -5260,8 +5270,13 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     if (!open) {
 #if FPL_OPT_KMER6
         /* (class row 0 = the 5-mer tables, zeroed as cells; class row 2 = the scalars: left alone) */
+#if FPL_OPT_KMERKEEP
+        for (u32 i = threadIdx.x + FS_BSTRIDE; i < 8 * FS_BSTRIDE; i += blockDim.x) /* the cells: class rows 1, 3 .. 7 */
+            if (i / FS_BSTRIDE != 2) tbl[i] = 0;
+#else
         for (u32 i = threadIdx.x; i < 8 * FS_BSTRIDE + 2048; i += blockDim.x)
             if (i / FS_BSTRIDE != 4) lds_all[i] = 0; /* (words 4096 .. 5119 of the array = class row 2: the scalars) */
+#endif
 #else
         for (u32 i = threadIdx.x; i < 8 * FS_BSTRIDE; i += blockDim.x) tbl[i] = 0;
         for (u32 i = threadIdx.x; i < 2048; i += blockDim.x) kmer[i] = 0;
@@ -5593,6 +5608,10 @@ k_stats_sorted(const u8* __restrict__ seq, const u8* __restrict__ qual, uint64_t
     } /* slices of the item */
     if (open) hand_over(leader);
     }
+#if FPL_OPT_KMER6 && FPL_OPT_KMERKEEP
+    __syncthreads(); /* (the last item's rows are in) */
+    kmer_flush();
+#endif
 }
 
 /* Sum the slabs of one k_stats_sorted launch into the per-cycle counters (grid as k_stats_reduce: x = chunk of 256 cells,
