@@ -191,11 +191,11 @@ int fpl_create(fpl_ctx** out, const fpl_options* opt, const char* start_adapter,
     for (int i = 0; i < n_fasta; i++)
         if (fasta[i].len < 0 || fasta[i].len > FPL_MAX_ADAPTER_LEN || (fasta[i].len && !fasta[i].seq)) return FPL_ERR_ADAPTER;
     int ndev = 0;
-    /* (a context of the host-pointer path drives five streams -- kernels, two copy streams, two side streams; the runtime's default
-       of four hardware queues per device would make two of them share one.  Only read when the runtime starts: a host that made HIP
-       calls before its first fpl_create keeps what it had) */
-    static std::once_flag hwq_once; /* (a host may create its contexts on several threads at once: setenv is not thread-safe) */
-    std::call_once(hwq_once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+    /* (a context of the host-pointer path drives five streams -- kernels, two copy streams, two side streams; with the runtime's
+       default of four hardware queues per device two of them share one and run in submission order.  The HOST asks for more --
+       GPU_MAX_HW_QUEUES=8 in the environment before its first HIP call, as bin/fastplong_amd and bench.py do;
+       the library does not touch the process's environment: setenv races with getenv on the host's other threads and does
+       nothing once the runtime is up) */
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return FPL_ERR_NO_DEVICE;
     fpl_ctx* ctx = new (std::nothrow) fpl_ctx();
     if (!ctx) return FPL_ERR_ARG;

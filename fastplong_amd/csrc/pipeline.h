@@ -161,7 +161,12 @@ static const char* const STAGE_NAMES[N_STAGES] = {"k_trim_ends", "k_scan", "k_re
    runs on the context's side stream (the sorted pass with overlap on: the usual case for large batches) its kernel runs BESIDE
    stages k_stats / k_stats_reduce and only the join + its reduce are left in this stage; the events sit on the main stream, so
    the side kernel's own duration is rocprofv3's to report (profiles/: k_stats<.., true>), and FPL_NO_OVERLAP=1 puts it back in
-   line.  k_trim_ends, k_scan and k_stats are single launches: their event times are kernel durations */
+   line.  k_scan and k_stats are single launches: their event times are kernel durations.  k_trim_ends is a kernel duration only
+   when the trims run in line: with the end trims ahead of the main stream (fpl_assume_inputs_ready, or the asynchronous path's own
+   copy events) the stage holds what is LEFT of them when the main stream gets there -- usually nothing -- and the wait for
+   ev_trim_done lies between mark(1) and k_scan, i.e. in the k_scan stage; with a FASTA chain the stage is two launches
+   (k_trim_ends_batched<8 words, chain> + k_trim_ends<2>).  A caller that wants the trims' own duration times a few batches with
+   the promise withdrawn (bench.py: roofline.k_trim_ends_ms_in_line) or reads rocprofv3's table */
 
 /* capacities of the lists k_break_mask appends to: every region is at least one window long, so an output
    read or a piece costs at least window + 1 bytes of input beyond the two fragments a read starts with */

@@ -12,6 +12,10 @@ from . import abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfastplong_amd.so")
 
+# A context drives five streams; the HIP runtime's default is four hardware queues per device, and two streams on one queue run in
+# submission order.  The HOST asks for more, before its first HIP call (the library leaves the environment alone).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 EXPORTS = [
     "fpl_abi_version", "fpl_strerror", "fpl_last_error", "fpl_options_default", "fpl_create", "fpl_destroy",
     "fpl_process_batch_device", "fpl_process_batch", "fpl_max_cycles", "fpl_n_adapters", "fpl_counters_len",

@@ -430,7 +430,10 @@ int fpl_get_batch_forms(const fpl_ctx* ctx, uint64_t out[6]);
  * on.  fpl_enable_timing(ctx, 1) starts a measurement window; every later
  * fpl_process_batch_device() records one event set (a ring of 128).  fpl_get_kernel_times()
  * waits for the recorded events and returns, per kernel, the time SUMMED over the batches of
- * the window (n_batches of them); names[i] are static strings.
+ * the window (n_batches of them); names[i] are static strings.  The stages are those of csrc/pipeline.h (STAGE_NAMES); a stage
+ * whose kernels run on one of the context's side streams -- the end trims of a batch whose inputs were known to be in (see
+ * fpl_assume_inputs_ready), the post-only statistics pass of a large batch -- shows what is left of them IN LINE, not their
+ * duration: withdraw the promise / set FPL_NO_OVERLAP=1 for in-line timings, or use rocprofv3's kernel table.
  */
 #define FPL_MAX_KERNEL_TIMES 16
 int fpl_enable_timing(fpl_ctx* ctx, int enable);
