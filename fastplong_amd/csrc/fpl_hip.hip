@@ -592,10 +592,10 @@ static int ensure_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_r
 }
 
 /* slabs of the post-only pass when it has a stream of its own: FS_EXTRA_BLOCKS per cycle tile */
-static int ensure_extra_scratch(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes, u32 max_read_len) {
+static int ensure_extra_scratch(fpl_ctx* ctx, u32 n_reads, u32 max_read_len, bool sorted) {
     if (!ctx->overlap || ctx->hcfg.defer) return FPL_OK;
     /* only the sorted pass forks the post-only pass onto the side stream; a batch that takes the plain walk needs none of this */
-    if (!stats_takes_sorted(n_reads, n_bytes, max_read_len, ctx->n_cu, ctx->tune, ctx->hcfg.defer)) return FPL_OK;
+    if (!sorted) return FPL_OK;
     const u32 n_tiles = cdiv(max_read_len ? max_read_len : 1, FS_T);
     const size_t slabs = (size_t)stats_extra_blocks(n_reads, ctx->tune) * n_tiles;
     if (slabs <= ctx->extra_slabs) return FPL_OK;
@@ -711,12 +711,15 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         int r = fpl_reserve_cycles(ctx, max_read_len);
         if (r != FPL_OK) return r;
     }
+    /* which statistics pass the batch takes: asked ONCE -- the side stream's slabs, the launch sequence and the form counters all
+       follow this one answer (a drift between separate askings would size the slabs for one form and launch the other) */
+    const bool sorted_form = n_reads && stats_takes_sorted(n_reads, n_bytes, max_read_len, ctx->n_cu, ctx->tune, ctx->hcfg.defer != 0);
     if (n_reads) {
         int r = ensure_workspace(ctx, n_reads);
         if (r != FPL_OK) return r;
         r = ensure_scratch(ctx, n_reads, n_bytes, max_read_len);
         if (r != FPL_OK) return r;
-        r = ensure_extra_scratch(ctx, n_reads, n_bytes, max_read_len);
+        r = ensure_extra_scratch(ctx, n_reads, max_read_len, sorted_form);
         if (r != FPL_OK) return r;
         r = ensure_sort_ws(ctx, n_reads, n_bytes);
         if (r != FPL_OK) return r;
@@ -786,6 +789,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         a.ev_join = (void*)ctx->ev_join;
     }
     a.n_cu = ctx->n_cu;
+    a.sorted_form = sorted_form ? 1 : 0;
     a.dbg = ctx->dbg;
     if ((a.dbg & 0xA000) && !ctx->probe_primed) { /* (profiling only: the first batch of a back-only / scan-only context runs whole) */
         a.dbg &= ~0xB000;
@@ -796,7 +800,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         ctx->forms[0]++;
         ctx->forms[1] += n_reads;
         ctx->forms[2] += trim_takes_batched(n_reads, a.trim_mode, a.tune) ? 1 : 0;
-        ctx->forms[3] += stats_takes_sorted(n_reads, n_bytes, max_read_len, a.n_cu, a.tune, a.defer) ? 1 : 0;
+        ctx->forms[3] += sorted_form ? 1 : 0;
         if (n_reads > ctx->forms[4]) ctx->forms[4] = n_reads;
     }
     const bool timing = ctx->timing != 0;

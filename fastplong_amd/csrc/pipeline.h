@@ -127,6 +127,9 @@ struct BatchArgs {
     fpl_stream_t aux = nullptr;   /* side stream + the two events that tie it to the main stream (device build only) */
     void* ev_fork = nullptr;
     void* ev_join = nullptr;
+    int sorted_form = -1; /* does this batch take the sorted statistics pass?  Decided ONCE per batch by whoever builds the arguments
+                             (fpl_process_batch_device: the same answer sizes the side stream's slabs and counts the batch's forms);
+                             -1: enqueue_batch asks stats_takes_sorted itself (the emulator driver) */
     u32 n_cu;      /* compute units of the device (grid sizing) */
     int dbg = 0;   /* FPL_DEBUG_FLAGS ablation switches (profiling only) */
     StatsTune tune; /* tuning / test hooks, read from the environment once by whoever builds the arguments */
@@ -295,6 +298,8 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
     /* (profiling only, tools/overlap_probe.py: FPL_DEBUG_FLAGS 0x1000 stops a batch behind k_resolve / k_redo, 0x2000 runs only
        what follows them, on the state an earlier batch of the context left) */
     const bool run_front = !(a.dbg & 0x2000), run_back = !(a.dbg & 0x1000);
+    /* one answer per batch, wherever it is asked below */
+    const bool takes_sorted = a.sorted_form >= 0 ? a.sorted_form != 0 : stats_takes_sorted(n, a.n_bytes, a.max_read_len, a.n_cu, a.tune, a.defer);
     /* (... and 0x4000: of the front half only the end trims, 0x8000: only the scan) */
     const bool run_trim = run_front && !(a.dbg & 0x8000), run_scan = run_front && !(a.dbg & 0x4000);
     /* 1: one wave per read, grid-stride; cap the grid so the LDS accumulators flush rarely */
@@ -382,7 +387,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         FPL_MEMSET(a.stats_flags, (size_t)ms * tiles + tiles, stream);
         sorted_zeroed = true;
     };
-    if (run_front && run_back && !(a.dbg & 0xC000) && stats_takes_sorted(n, a.n_bytes, a.max_read_len, a.n_cu, a.tune, a.defer)) zero_sorted_ws();
+    if (run_front && run_back && !(a.dbg & 0xC000) && takes_sorted) zero_sorted_ws();
     if (run_front && !(a.dbg & 0xC000)) {
         /* lane = read: confirmations, gaps, records, counters, plan; the reads a middle adapter splits go on the REDO list */
         /* (sixteen waves per block and no more than two blocks per CU: every block ends with a few hundred global atomics on
@@ -405,7 +410,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
                no plan, the bucket kernels and k_stats_sorted need nothing of it, and -- when that pass forks the side stream for
                its post-only part anyway -- it runs there, in front of that part, beside them (0.15 ms of a mostly idle chip on
                the bench batch; the fragments it finds go on the EXTRA list, which only the post-only pass reads) */
-            const bool sorted = run_back && stats_takes_sorted(n, a.n_bytes, a.max_read_len, a.n_cu, a.tune, a.defer);
+            const bool sorted = run_back && takes_sorted;
             fpl_stream_t rs = stream;
             if (sorted && a.aux != nullptr && a.extra_scratch != nullptr && !a.tune.redo_inline) {
                 FPL_FORK_MARK(a, stream);
@@ -453,7 +458,7 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         }
     };
     const u32 per_sorted = stats_items_per_slice(n, (u32)(a.n_bytes / n), a.n_cu, a.tune);
-    if (stats_takes_sorted(n, a.n_bytes, a.max_read_len, a.n_cu, a.tune, a.defer)) {
+    if (takes_sorted) {
         const u32 per = per_sorted;
         const u32 max_slices = stats_sorted_max_slices(n, per, a.tune);
         zero_sorted_ws();
