@@ -316,6 +316,8 @@ int fpl_in_flight(const fpl_ctx* ctx);
  * of it was processed or counted; the caller parses the chunk with its own reader (the reference's rules for such text are
  * the sequential reader's: skipped lines, the error texts of :326-341) and submits it through fpl_process_batch_async.
  * FPL_TEXT_TOO_MANY: more than n_bytes / 64 + 16 records (reads shorter than 30 bases on average): same treatment.
+ * A text batch is in the counters (fpl_get_counters, fpl_counters_device_ptr) once fpl_wait_text has returned for it: its per-read
+ * kernels are enqueued when its header is in, which may be as late as that call.  n_bytes < 4 GiB (line positions are 32 bits).
  */
 #define FPL_TEXT_OK 0
 #define FPL_TEXT_IRREGULAR 1
