@@ -893,15 +893,10 @@ static int ensure_text_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, uint64_t n_bytes) {
 }
 
 /* stage 2 of a text batch: the header is in -- enqueue the per-read kernels and the way back of the records and line starts */
-/* block = false (a submission): only when the header is in already -- the caller's copies then go out behind this batch's parse at
-   once, instead of after a round trip to the host between two chunks on the link.  Returns 1 when the batch is still parsing. */
-static int text_continue(fpl_ctx* ctx, fpl_ctx::Slot& sl, bool block) {
+/* (called by fpl_wait_text only: a submission never waits for a parse, so the next chunk's copy goes out behind this one's at
+   once -- no round trip to the host between two chunks on the link -- and a batch that has only been peeked at is in no counter) */
+static int text_continue(fpl_ctx* ctx, fpl_ctx::Slot& sl) {
     if (sl.kind != 1 || sl.stage != 1) return FPL_OK;
-    if (!block) {
-        const hipError_t q = hipEventQuery(sl.ev_parsed);
-        if (q == hipErrorNotReady) return 1;
-        FPL_HIP(q);
-    }
     sl.stage = 2;
     FPL_HIP(hipEventSynchronize(sl.ev_parsed));
     const TextHeader h = *sl.h_hdr;
@@ -929,25 +924,13 @@ static int text_continue(fpl_ctx* ctx, fpl_ctx::Slot& sl, bool block) {
     sl.n_reads = n;
     return FPL_OK;
 }
-static int text_continue_all(fpl_ctx* ctx, bool block) {
-    for (u32 k = ctx->waited; k != ctx->submitted; k++) { /* oldest first: the kernels keep the order of submission */
-        fpl_ctx::Slot& sl = ctx->slot[k % FPL_MAX_IN_FLIGHT];
-        if (sl.rc != FPL_OK) continue;
-        const int r = text_continue(ctx, sl, block);
-        if (r == 1) break; /* still parsing: it, and everything behind it, later */
-        if (r != FPL_OK) sl.rc = r; /* (reported by the wait for that batch) */
-    }
-    return FPL_OK;
-}
-
 int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) {
     if (!ctx || (n_bytes && !text)) return FPL_ERR_ARG;
     if (n_bytes > 0xFFFFFFF0ull) return FPL_ERR_ARG; /* (line positions are 32 bits wide: cut the file in smaller chunks) */
     if (ctx->submitted - ctx->waited >= FPL_MAX_IN_FLIGHT) return FPL_ERR_STATE;
     FPL_HIP(hipSetDevice(ctx->device));
     if (ctx->hcfg.defer) return FPL_ERR_STATE; /* (--break / --mask read their fragment lists batch by batch: the CSR entry points) */
-    int r = text_continue_all(ctx, false);
-    if (r != FPL_OK) return r;
+    int r = FPL_OK;
     fpl_ctx::Slot& sl = ctx->slot[ctx->submitted % FPL_MAX_IN_FLIGHT];
     sl.kind = 1;
     sl.stage = 2;
@@ -996,6 +979,45 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
     return FPL_OK;
 }
 
+static void text_info(const fpl_ctx::Slot& sl, fpl_text_result* out) {
+    const TextHeader& h = *sl.h_hdr;
+    memset(out, 0, sizeof(*out));
+    out->n_lines = h.n_lines;
+    out->bad_record = h.bad_record;
+    out->status = (h.status & 1u) ? FPL_TEXT_IRREGULAR : (h.status & 2u) ? FPL_TEXT_TOO_MANY : FPL_TEXT_OK;
+    if (out->status == FPL_TEXT_OK) {
+        out->n_reads = h.n_records;
+        out->n_bases = h.n_bases;
+        out->max_read_len = h.max_len;
+    }
+}
+
+int fpl_peek_text(fpl_ctx* ctx, fpl_text_result* out) {
+    if (!ctx || !out) return FPL_ERR_ARG;
+    if (ctx->submitted == ctx->waited) return FPL_ERR_STATE;
+    fpl_ctx::Slot& sl = ctx->slot[ctx->waited % FPL_MAX_IN_FLIGHT];
+    if (sl.kind != 1) return FPL_ERR_STATE;
+    memset(out, 0, sizeof(*out));
+    if (sl.rc != FPL_OK) return sl.rc;
+    FPL_HIP(hipSetDevice(ctx->device));
+    if (sl.text_bytes) FPL_HIP(hipEventSynchronize(sl.ev_parsed));
+    text_info(sl, out);
+    return FPL_OK;
+}
+
+int fpl_cancel_text(fpl_ctx* ctx) {
+    if (!ctx) return FPL_ERR_ARG;
+    if (ctx->submitted == ctx->waited) return FPL_ERR_STATE;
+    fpl_ctx::Slot& sl = ctx->slot[ctx->waited % FPL_MAX_IN_FLIGHT];
+    if (sl.kind != 1) return FPL_ERR_STATE;
+    FPL_HIP(hipSetDevice(ctx->device));
+    if (sl.rc == FPL_OK && sl.text_bytes) FPL_HIP(hipEventSynchronize(sl.ev_parsed)); /* (its copy and parse read the caller's text) */
+    sl.stage = 2;
+    sl.n_reads = 0;
+    ctx->waited++;
+    return FPL_OK;
+}
+
 int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts) {
     if (!ctx || !out) return FPL_ERR_ARG;
     if (ctx->submitted == ctx->waited) return FPL_ERR_STATE;
@@ -1006,20 +1028,14 @@ int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** re
     if (line_starts) *line_starts = nullptr;
     FPL_HIP(hipSetDevice(ctx->device));
     if (sl.rc == FPL_OK) {
-        const int r = text_continue(ctx, sl, true);
+        const int r = text_continue(ctx, sl);
         if (r != FPL_OK) sl.rc = r;
     }
     ctx->waited++;
     if (sl.rc != FPL_OK) return sl.rc;
-    const TextHeader& h = *sl.h_hdr;
-    out->n_lines = h.n_lines;
-    out->bad_record = h.bad_record;
-    out->status = (h.status & 1u) ? FPL_TEXT_IRREGULAR : (h.status & 2u) ? FPL_TEXT_TOO_MANY : FPL_TEXT_OK;
+    text_info(sl, out);
     if (out->status != FPL_TEXT_OK || sl.n_reads == 0) return FPL_OK;
     FPL_HIP(hipEventSynchronize(sl.ev_done));
-    out->n_reads = sl.n_reads;
-    out->n_bases = h.n_bases;
-    out->max_read_len = h.max_len;
     if (results) *results = sl.h_results;
     if (line_starts) *line_starts = sl.h_line;
     return FPL_OK;
@@ -1049,10 +1065,8 @@ int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qua
     FPL_HIP(hipSetDevice(ctx->device));
     /* --break / --mask: the fragment lists of the batch in flight live in buffers this batch's kernels reuse */
     if (ctx->hcfg.defer && ctx->submitted != ctx->waited) return FPL_ERR_STATE;
-    {
-        const int rt = text_continue_all(ctx, true); /* (a text batch in flight gets its kernels in front of this batch's) */
-        if (rt != FPL_OK) return rt;
-    }
+    /* (a text batch in flight keeps waiting for ITS wait: the kernels of this batch go first -- the order of the kernels is free,
+       the slots are collected in the order of submission) */
     fpl_ctx::Slot& sl = ctx->slot[ctx->submitted % FPL_MAX_IN_FLIGHT];
     sl.kind = 0;
     sl.n_reads = n_reads;

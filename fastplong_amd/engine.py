@@ -23,7 +23,7 @@ EXPORTS = [
     "fpl_enable_timing", "fpl_get_kernel_times", "fpl_fragment_counts", "fpl_get_fragments",
     "fpl_process_batch_async", "fpl_wait", "fpl_in_flight", "fpl_host_alloc", "fpl_host_free", "fpl_allreduce_counters",
     "fpl_count_end_kmers", "fpl_pick_adapter", "fpl_rccl_library", "fpl_comm_init", "fpl_get_batch_forms", "fpl_assume_inputs_ready",
-    "fpl_process_text_async", "fpl_wait_text",
+    "fpl_process_text_async", "fpl_wait_text", "fpl_peek_text", "fpl_cancel_text",
 ]
 
 
@@ -122,6 +122,10 @@ def load_library(path=None):
                                    C.POINTER(abi.FplAdapterPick)]
     L.fpl_process_text_async.restype = C.c_int
     L.fpl_process_text_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.fpl_peek_text.restype = C.c_int
+    L.fpl_peek_text.argtypes = [C.c_void_p, C.POINTER(abi.FplTextResult)]
+    L.fpl_cancel_text.restype = C.c_int
+    L.fpl_cancel_text.argtypes = [C.c_void_p]
     L.fpl_wait_text.restype = C.c_int
     L.fpl_wait_text.argtypes = [C.c_void_p, C.POINTER(abi.FplTextResult), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     if L.fpl_abi_version() != abi.FPL_ABI_VERSION:
@@ -211,6 +215,15 @@ class Engine:
         self._keep_text = getattr(self, "_keep_text", []) + [text]
         self._keep_text = self._keep_text[-(abi.FPL_MAX_IN_FLIGHT + 1):]
         self._check(self.L.fpl_process_text_async(self.h, text.ctypes.data, len(text)), "fpl_process_text_async")
+
+    def peek_text(self):
+        """fpl_peek_text: the parse's verdict for the oldest text batch (nothing of it is counted yet)"""
+        out = abi.FplTextResult()
+        self._check(self.L.fpl_peek_text(self.h, C.byref(out)), "fpl_peek_text")
+        return {k: getattr(out, k) for k, _ in abi.FplTextResult._fields_}
+
+    def cancel_text(self):
+        self._check(self.L.fpl_cancel_text(self.h), "fpl_cancel_text")
 
     def wait_text(self):
         """fpl_wait_text -> (fpl_text_result as a dict, records [n] as a numpy copy, line starts [n, 4] as a numpy copy)"""

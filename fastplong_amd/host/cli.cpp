@@ -168,6 +168,7 @@ struct Work {
     int rc = 0;
     string err;
     std::atomic<int> holders{0}; /* --split*: the per-worker writer threads that still read this batch (+ the in-order thread) */
+    bool verdict_done = false;   /* --device_parse: this batch's verdict is published (a chunk that came back from the host's reader is submitted a second time) */
 };
 /* The passing reads of a batch as they go to --out (Read::appendToString, src/read.cpp:119-143), NOT copied together: every
  * line is a slice of what the batch already holds -- names and '+' lines in Batch::text, bases and qualities in the
@@ -750,6 +751,37 @@ int main(int argc, char* argv[]) {
     uint64_t nRedo = 0;
     vector<double> tGpu(nGpus, 0), tFormat(nFmt, 0);
     std::atomic<uint64_t> nTextBatches{0}, nTextFallbacks{0}; /* --device_parse: chunks the device parsed / chunks handed back to the host's reader */
+    /* --device_parse: the reference stops READING at a malformed record (FastqReader::read returns NULL, src/fastqreader.cpp:326-341),
+       so nothing behind one may be counted -- but a chunk's verdict comes from its device, and the chunks of several devices are
+       under way side by side.  Every chunk's verdict is published here (fpl_peek_text: the parse only, nothing counted yet), and a
+       chunk's per-read kernels are let go (fpl_wait_text; a CSR batch: its submission) only when every chunk in front of it was
+       good; a chunk behind a malformed record is dropped (fpl_cancel_text).  Waits only ever look at smaller sequence numbers. */
+    struct Verdicts {
+        mutex m;
+        condition_variable cv;
+        vector<uint8_t> v; /* 0 unknown, 1 good, 2 holds a malformed record */
+        uint64_t frontier = 0, bad = ~0ull;
+        string bad_text;
+        void publish(uint64_t j, bool good, const string& text = string()) {
+            {
+                lock_guard<mutex> g(m);
+                if (v.size() <= j) v.resize(j + 1, 0);
+                v[j] = good ? 1 : 2;
+                if (!good && j < bad) {
+                    bad = j;
+                    bad_text = text;
+                }
+                while (frontier < v.size() && v[frontier] == 1) frontier++;
+            }
+            cv.notify_all();
+        }
+        bool wait_before(uint64_t j) { /* true: a chunk in front of j holds a malformed record -- j is not part of the input */
+            unique_lock<mutex> g(m);
+            cv.wait(g, [&] { return frontier >= j || bad < j; });
+            return bad < j;
+        }
+    } verdicts;
+    std::atomic<bool> stopInput{false};
     string inputError; /* a malformed record: reported the way the sequential reader does, the input ends there */
     string ioError;    /* the input could not be read / decompressed to its end: the run fails (src/fastqreader.cpp:92-137) */
 
@@ -779,6 +811,7 @@ int main(int argc, char* argv[]) {
             auto acquire = [&]() {
                 fplh::ChunkedReader::Item it;
                 Work* w = freeq.pop();
+                w->verdict_done = false;
                 it.batch = &w->batch;
                 it.token = w;
                 return it;
@@ -789,6 +822,10 @@ int main(int argc, char* argv[]) {
             uint64_t unmapped = 0;
             while (cr.next(it)) {
                 Work* w = (Work*)it.token;
+                if (stopInput.load()) { /* (--device_parse: a device found a malformed record in an earlier chunk) */
+                    freeq.push(w);
+                    break;
+                }
                 w->seq_no = nBatches++;
                 devq[w->seq_no % nGpus].push(w);
                 if (chunkMem) { /* pages no parser looks at again (unmapping 18 GB at exit costs 0.2 s of process time) */
@@ -819,37 +856,55 @@ int main(int argc, char* argv[]) {
                 inflight.pop_front();
                 const double t0 = now();
                 if (w->rc == FPL_OK && w->batch.text_backed && w->batch.off.empty()) {
-                    /* a chunk the device parsed: its records, and where their lines lie in the text this batch still holds */
+                    /* a chunk the device parses.  First its verdict (the parse alone), published for the other devices' threads;
+                       then, when every chunk in front of it was good, its per-read kernels and what they return */
                     fpl_text_result tr;
-                    const fpl_read_result* rr = nullptr;
-                    const uint32_t* ls = nullptr;
-                    w->rc = fpl_wait_text(dev[d].ctx, &tr, &rr, &ls);
-                    if (w->rc == FPL_OK && tr.status == FPL_TEXT_OK) {
-                        w->res.assign(rr, rr + tr.n_reads);
-                        w->batch.adopt_lines(ls, tr.n_reads);
-                        nTextBatches++;
-                    } else if (w->rc == FPL_OK) {
+                    fplh::Batch& b = w->batch;
+                    bool good = true, have_csr = false;
+                    string bad_text;
+                    w->rc = fpl_peek_text(dev[d].ctx, &tr);
+                    if (w->rc == FPL_OK && tr.status != FPL_TEXT_OK) {
                         /* irregular text (blank lines, a lone \r, no line break at the end, a record the reference would stop at):
-                           nothing of it was counted -- the host's reader takes the chunk, by the reference's rules, and the batch
-                           goes in again through the CSR entry point */
+                           nothing of it was counted -- the host's reader takes the chunk, by the reference's rules */
+                        w->rc = fpl_cancel_text(dev[d].ctx);
                         fplh::FastqReader::ChunkInfo ci;
                         vector<char> window;
-                        fplh::Batch& b = w->batch;
                         const uint64_t len = b.raw_len;
                         const char* base = (const char*)b.raw.data() + b.raw_begin;
                         b.text_backed = false;
                         fplh::FastqReader::parse_chunk(-1, len, 0, len, true, window, b, ci, 1, base);
                         nTextFallbacks++;
-                        if (ci.status == 3) {
-                            /* (the reference stops reading at a malformed record and finishes with what it has; chunks behind this
-                               one may be counted already here, so this mode refuses the input instead) */
-                            w->rc = FPL_ERR_STATE;
-                            w->err = ci.err + "\n--device_parse: the input has a malformed record; run without --device_parse to get the reference's behaviour (it stops reading there)";
-                        } else if (b.n() > 0) { /* in again, as a CSR batch, through the loop below (the slots are a FIFO) */
-                            tGpu[d] += now() - t0;
-                            redo.push_back(w);
-                            return;
+                        have_csr = true;
+                        if (ci.status == 3) { /* the input ends at this record, as with the host's reader; what the chunk holds in front of it counts */
+                            good = false;
+                            bad_text = ci.err;
+                            stopInput = true;
                         }
+                    }
+                    verdicts.publish(w->seq_no, good, bad_text);
+                    const bool drop = verdicts.wait_before(w->seq_no);
+                    if (drop) { /* behind a malformed record: not part of the input */
+                        if (!have_csr && w->rc == FPL_OK) w->rc = fpl_cancel_text(dev[d].ctx);
+                        b.clear();
+                        b.off.push_back(0); /* (an empty batch, as the reader makes them) */
+                        b.name_off.push_back(0);
+                        w->res.clear();
+                    } else if (w->rc == FPL_OK && !have_csr) {
+                        const fpl_read_result* rr = nullptr;
+                        const uint32_t* ls = nullptr;
+                        w->rc = fpl_wait_text(dev[d].ctx, &tr, &rr, &ls);
+                        if (w->rc == FPL_OK && tr.status != FPL_TEXT_OK) w->rc = FPL_ERR_STATE; /* (the verdict was "good") */
+                        if (w->rc == FPL_OK) {
+                            w->res.assign(rr, rr + tr.n_reads);
+                            b.adopt_lines(ls, tr.n_reads);
+                            nTextBatches++;
+                        }
+                    } else if (w->rc == FPL_OK && b.n() > 0) { /* in again, as a CSR batch, through the loop below (the slots are a FIFO) */
+                        w->res.resize(b.n());
+                        w->verdict_done = true;
+                        tGpu[d] += now() - t0;
+                        redo.push_back(w);
+                        return;
                     }
                 } else if (w->rc == FPL_OK) {
                     w->rc = fpl_wait(dev[d].ctx);
@@ -888,6 +943,22 @@ int main(int argc, char* argv[]) {
                 if (got && w) {
                     w->res.resize(w->batch.n());
                     w->err.clear();
+                    if (textMode && !w->batch.text_backed && !w->verdict_done) {
+                        /* a CSR batch in a --device_parse run (a chunk the sequencer parsed itself): its kernels are enqueued by the
+                           submission, so it waits for the verdicts in front of it first -- with nothing of this thread in flight,
+                           whose verdicts nobody else could publish */
+                        while (!inflight.empty()) collect();
+                        w->verdict_done = true;
+                        verdicts.publish(w->seq_no, true);
+                        if (verdicts.wait_before(w->seq_no)) {
+                            w->batch.clear();
+                            w->batch.off.push_back(0);
+                            w->batch.name_off.push_back(0);
+                            w->res.clear();
+                            fmtq.push(w);
+                            continue;
+                        }
+                    }
                     const double t0 = now();
                     if (w->batch.text_backed)
                         w->rc = fpl_process_text_async(dev[d].ctx, w->batch.raw.data() + w->batch.raw_begin, w->batch.raw_len);
@@ -1073,6 +1144,7 @@ int main(int argc, char* argv[]) {
     readerThread.join();
     for (auto& t : devThreads) t.join();
     for (auto& t : fmtStage) t.join();
+    if (inputError.empty() && verdicts.bad != ~0ull) inputError = verdicts.bad_text; /* (--device_parse: the record a device's chunk came back with) */
     if (!inputError.empty()) cerr << inputError; /* (the sequential reader printed it when it met the record) */
     if (!ioError.empty()) error_exit(ioError);
     if (cmd.exist("verbose")) {

@@ -215,6 +215,27 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
     ctx->q.push_back(p);
     return FPL_OK;
 }
+int fpl_peek_text(fpl_ctx* ctx, fpl_text_result* out) {
+    if (!ctx || !out) return FPL_ERR_ARG;
+    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
+    StandInText t; /* (parsed again by the wait: the stand-in keeps no state between the two) */
+    stand_in_parse(ctx->q.front().text, ctx->q.front().text_bytes, false, t);
+    *out = t.info;
+    return FPL_OK;
+}
+int fpl_cancel_text(fpl_ctx* ctx) {
+    if (!ctx) return FPL_ERR_ARG;
+    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
+    ctx->q.pop_front();
+    if (const char* lf = getenv("FPL_STUB_LOG")) {
+        std::lock_guard<std::mutex> g(g_log_m);
+        if (FILE* f = fopen(lf, "a")) {
+            fprintf(f, "%d cancel\n", ctx->device);
+            fclose(f);
+        }
+    }
+    return FPL_OK;
+}
 int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts) {
     if (!ctx || !out || ctx->q.empty() || !ctx->q.front().is_text) return ctx && out ? FPL_ERR_STATE : FPL_ERR_ARG;
     const Pending p = ctx->q.front();

@@ -308,22 +308,39 @@ def test_cli_device_parse_hands_irregular_chunks_to_the_host_reader(tmp_path, st
         assert len(_records((outs["device"][1] / "out.fq").read_bytes())) > 0.5 * len(recs)
 
 
-def test_cli_device_parse_refuses_a_malformed_record(tmp_path, stub_env):
-    """a record the reference stops reading at (qualities and bases of different lengths): with --device_parse the run fails with
-    the reference's message and says why (chunks behind the record may be counted already), without it the host's reader
-    ends the input there as the reference does"""
+@pytest.mark.parametrize("gpus", [1, 3])
+@pytest.mark.parametrize("where", ["first chunk", "middle", "last record"])
+def test_cli_device_parse_stops_at_a_malformed_record_like_the_reference(tmp_path, stub_env, gpus, where):
+    """a record the reference stops reading at (qualities and bases of different lengths, src/fastqreader.cpp:326-341): the
+    input ENDS there -- message on stderr, exit code 0, reports over the reads in front of it.  With --device_parse the chunk's
+    verdict comes from its device while chunks behind it are under way on other devices: every chunk's verdict is published
+    (fpl_peek_text) and a chunk runs only when all chunks in front of it were good, so nothing behind the record is counted --
+    output and JSON are those of the host's reader, on one device and on three"""
     case = "c3_full"
     recs = _records(gz(os.path.join(GOLD, case, "in.fq.gz")))
-    bad = len(recs) // 2
+    bad = {"first chunk": 3, "middle": len(recs) // 2, "last record": len(recs) - 1}[where]
     recs[bad][3] = recs[bad][3][:-2]
-    inp = tmp_path / "in.fq"
-    inp.write_bytes(b"".join(b"\n".join(r) + b"\n" for r in recs))
+    text = b"".join(b"\n".join(r) + b"\n" for r in recs)
     meta = json.load(open(os.path.join(GOLD, case, "case.json")))
-    base = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"),
-            "--reader_threads", "3"] + meta["flags"]
-    e = dict(stub_env, FPL_STUB_DEVICES="1", FPLH_CHUNK_BYTES="30000")
-    p = subprocess.run(base + ["--device_parse"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
-    assert p.returncode != 0 and b"sequence and quality have different length" in p.stderr and b"--device_parse" in p.stderr, p.stderr[-1500:]
-    p = subprocess.run(base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
-    assert p.returncode == 0 and b"sequence and quality have different length" in p.stderr
-    assert len(_records((tmp_path / "out.fq").read_bytes())) > 0
+    outs = {}
+    for mode in ("host", "device"):
+        d = tmp_path / mode
+        d.mkdir()
+        inp = d / "in.fq"
+        inp.write_bytes(text)
+        log = d / "stub.log"
+        cmd = [build.CLI, "-i", str(inp), "-o", str(d / "out.fq"), "--failed_out", str(d / "failed.fq"), "-j", str(d / "out.json"),
+               "-h", str(d / "out.html"), "--gpus", str(gpus), "--reader_threads", "3", "-V"] + meta["flags"] + (["--device_parse"] if mode == "device" else [])
+        e = dict(stub_env, FPL_STUB_DEVICES=str(gpus), FPLH_CHUNK_BYTES="30000", FPL_STUB_LOG=str(log))
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert b"sequence and quality have different length" in p.stderr
+        outs[mode] = (p, d)
+    for f in ("out.fq", "failed.fq"):
+        assert (outs["host"][1] / f).read_bytes() == (outs["device"][1] / f).read_bytes(), f
+    strip = lambda b: [l for l in b.split(b"\n") if not l.startswith(b'\t"command":')]  # noqa: E731
+    assert strip((outs["host"][1] / "out.json").read_bytes()) == strip((outs["device"][1] / "out.json").read_bytes())
+    js = json.loads((outs["device"][1] / "out.json").read_bytes().replace(b"},\n}", b"}\n}"))
+    assert js["summary"]["before_filtering"]["total_reads"] == bad  # the reads in front of the record, no more
+    if where == "first chunk" and gpus == 3:  # chunks behind the record were under way on the other devices: dropped, not run
+        assert b"cancel" in open(outs["device"][1] / "stub.log", "rb").read()

@@ -207,3 +207,34 @@ def test_text_batch_of_bench_size_properties(engine_mod):
     assert info["status"] == abi.FPL_TEXT_OK and info["n_reads"] == 20000 and info["n_bases"] == int(off[-1])
     assert np.array_equal(lines, _line_starts(text))
     assert int(v.pre.reads) == 20000 and int(v.pre.length_sum) == int(off[-1])
+
+
+def test_peek_and_cancel(orc, engine_mod):
+    """fpl_peek_text gives the parse's verdict with nothing counted yet; fpl_cancel_text drops the batch un-run; a batch that is
+    waited for after a peek is complete and exact"""
+    seq, qual, off = synth.ont_like(1500, seed=77, median_len=1200, p_middle=0.05)
+    text, _, _ = hostio.make_fastq(seq, qual, off)
+    cfg = orc.Config(abi.FplOptions.default(**OPTS), synth.START_ADAPTER, synth.END_ADAPTER)
+    C = int(np.diff(off.astype(np.int64)).max())
+    want_res, want_cnt = orc.process_batch(cfg, seq, qual, off, max_cycles=C)
+    eng = engine_mod.Engine(cfg.opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=C)
+    buf = _pinned(eng, text)
+    bad = _pinned(eng, text[:-1])
+    eng.submit_text(buf)
+    eng.submit_text(bad)
+    info = eng.peek_text()
+    assert info["status"] == abi.FPL_TEXT_OK and info["n_reads"] == 1500 and info["n_bases"] == int(off[-1])
+    assert not eng.counters().any() and eng.in_flight() == 2  # peeked at, not run
+    eng.cancel_text()
+    assert eng.in_flight() == 1 and not eng.counters().any()
+    assert eng.peek_text()["status"] == abi.FPL_TEXT_IRREGULAR
+    eng.cancel_text()
+    assert eng.in_flight() == 0
+    eng.submit_text(buf)
+    assert eng.peek_text()["n_reads"] == 1500
+    info, res, lines = eng.wait_text()
+    got_cnt = eng.counters()
+    eng.close()
+    assert info["status"] == abi.FPL_TEXT_OK
+    parity.assert_results_equal(res, want_res, seq, off)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)

@@ -119,6 +119,19 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
     ctx->q.push_back(p);
     return FPL_OK;
 }
+int fpl_peek_text(fpl_ctx* ctx, fpl_text_result* out) { /* (a null device's text is always taken: the verdict costs nothing here) */
+    if (!ctx || !out) return FPL_ERR_ARG;
+    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
+    memset(out, 0, sizeof *out);
+    out->bad_record = ~0ull;
+    return FPL_OK;
+}
+int fpl_cancel_text(fpl_ctx* ctx) {
+    if (!ctx) return FPL_ERR_ARG;
+    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
+    ctx->q.pop_front();
+    return FPL_OK;
+}
 int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts) {
     if (!ctx || !out) return FPL_ERR_ARG;
     if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
