@@ -248,8 +248,9 @@ NULLDEV_DEVICES = 8  # the host_ceiling runs: bin/fastplong_amd --gpus 8 against
 E2E_RUNS = (
     dict(name="to_dev_null_first_pass", target="/dev/null"),
     dict(name="to_dev_null", target="/dev/null"),
-    # the same with the parse on the device: the host's chunk parsers only load the file's bytes (fpl_process_text_async)
-    dict(name="device_parse", target="/dev/null", flags=["--device_parse"]),
+    # the same with the HOST's parsers (AVX2 line scan + copies into page-locked CSR arrays); the default lets the device parse:
+    # the chunk parsers only load the file's bytes (fpl_process_text_async)
+    dict(name="host_parse", target="/dev/null", flags=["--host_parse"]),
     dict(name="to_file", target=None),
     dict(name="to_split_files", target=None, flags=["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)]),
     # batches large enough for the kernel forms the headline times (csrc/pipeline.h: k_trim_ends_batched from 65 536 reads,
@@ -261,16 +262,16 @@ E2E_RUNS = (
     dict(name="gz_in_single_stream", target="/dev/null", input="gz_single", flags=["--gz_stream"]),
     dict(name="gz_out", target="GZ", input="fq_sub"),
     dict(name="null8_to_dev_null", target="/dev/null", null=NULLDEV_DEVICES),
-    dict(name="null8_device_parse", target="/dev/null", null=NULLDEV_DEVICES, flags=["--device_parse"]),
+    dict(name="null8_host_parse", target="/dev/null", null=NULLDEV_DEVICES, flags=["--host_parse"]),
     dict(name="null8_to_dev_null_rt16", target="/dev/null", null=NULLDEV_DEVICES, flags=["--reader_threads", "16"]),
     dict(name="null8_to_split_files", target=None, null=NULLDEV_DEVICES, flags=["--split", str(E2E_SPLIT), "-w", str(E2E_SPLIT)]),
     dict(name="null8_to_file", target=None, null=NULLDEV_DEVICES),
 )
 GZ_READS = 50_000  # reads of the gzip legs (the first reads of the batch)
-E2E_DEFAULT_RUNS = ("to_dev_null_first_pass", "to_dev_null", "device_parse", "to_file", "to_split_files")
+E2E_DEFAULT_RUNS = ("to_dev_null_first_pass", "to_dev_null", "host_parse", "to_file", "to_split_files")
 E2E_FULL_RUNS = E2E_DEFAULT_RUNS + ("gz_in_multi", "gz_in_single", "gz_in_single_stream", "gz_out")
-E2E_LARGE_RUNS = ("to_dev_null", "device_parse", "to_file", "to_split_files", "chunk_512mb", "chunk_1536mb", "null8_to_dev_null",
-                  "null8_device_parse", "null8_to_dev_null_rt16", "null8_to_split_files", "null8_to_file")
+E2E_LARGE_RUNS = ("to_dev_null", "host_parse", "to_file", "to_split_files", "chunk_512mb", "chunk_1536mb", "null8_to_dev_null",
+                  "null8_host_parse", "null8_to_dev_null_rt16", "null8_to_split_files", "null8_to_file")
 
 
 def gzip_single_member(src, dst, level=1):
@@ -601,10 +602,11 @@ def compact_line(out):
         ce["value"] = _r(e.get("value"), 4)
         ce["pipeline_value"] = leg(runs, "to_dev_null", "pipeline_value")
         ce["first_pass"] = leg(runs, "to_dev_null_first_pass")
-        ce["device_parse"] = leg(runs, "device_parse")
-        ce["device_parse_pipeline"] = leg(runs, "device_parse", "pipeline_value")
         ce["cpu_s_per_gbase"] = leg(runs, "to_dev_null", "cpu_seconds_per_gbase")
-        ce["device_parse_cpu_s_per_gbase"] = leg(runs, "device_parse", "cpu_seconds_per_gbase")
+        ce["parse"] = "device"  # (the default: fpl_process_text_async; host_parse*: the same run with --host_parse)
+        ce["host_parse"] = leg(runs, "host_parse")
+        ce["host_parse_pipeline"] = leg(runs, "host_parse", "pipeline_value")
+        ce["host_parse_cpu_s_per_gbase"] = leg(runs, "host_parse", "cpu_seconds_per_gbase")
         ce["to_file"] = leg(runs, "to_file")
         ce["to_split"] = leg(runs, "to_split_files")
         if e.get("pcie_call"):
@@ -620,7 +622,7 @@ def compact_line(out):
             ce["large"] = {"reads": big.get("reads"), "value": leg(br, "to_dev_null"), "pipeline_value": leg(br, "to_dev_null", "pipeline_value"),
                            "to_file": leg(br, "to_file"), "to_split": leg(br, "to_split_files"),
                            "chunk_512mb": leg(br, "chunk_512mb"), "chunk_1536mb": leg(br, "chunk_1536mb"),
-                           "device_parse": leg(br, "device_parse"), "null8_device_parse": leg(br, "null8_device_parse", "pipeline_value"),
+                           "host_parse": leg(br, "host_parse"), "null8_host_parse": leg(br, "null8_host_parse", "pipeline_value"),
                            "null8": leg(br, "null8_to_dev_null", "pipeline_value"), "null8_rt16": leg(br, "null8_to_dev_null_rt16", "pipeline_value"),
                            "null8_to_file": leg(br, "null8_to_file")}
             if "error" in big:

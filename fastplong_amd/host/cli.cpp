@@ -82,7 +82,7 @@ static const Flag FLAGS[] = {
     {"report_title", 'R', true, "fastplong report"}, {"thread", 'w', true, "3"}, {"split", 0, true, "0"},
     {"split_by_lines", 0, true, "0"}, {"split_prefix_digits", 0, true, "4"},
     {"gpus", 0, true, "1"}, {"batch_mbases", 0, true, "256"}, {"batch_reads", 0, true, "0"},
-    {"reader_threads", 0, true, "0"}, {"chunk_mb", 0, true, "32"}, {"gz_stream", 0, false, ""}, {"device_parse", 0, false, ""},
+    {"reader_threads", 0, true, "0"}, {"chunk_mb", 0, true, "32"}, {"gz_stream", 0, false, ""}, {"device_parse", 0, false, ""}, {"host_parse", 0, false, ""},
 };
 
 struct Args {
@@ -632,7 +632,10 @@ int main(int argc, char* argv[]) {
     /* --device_parse: the chunk parsers only LOAD the file's bytes (page-locked), the device finds the records
        (fpl_process_text_async); --break / --mask keep the host's reader (their fragment lists come back batch by batch through
        the CSR entry points), and so do inputs that are not cut into chunks (pipes, a streamed gzip, a small file) */
-    const bool textMode = cmd.exist("device_parse") && chunked && !cmd.exist("break") && !cmd.exist("mask") && chunkBytes < (3ull << 30);
+    /* (the default wherever it applies; --host_parse keeps the host's parsers, --device_parse only says so out loud) */
+    if (cmd.exist("device_parse") && cmd.exist("host_parse")) error_exit("--device_parse and --host_parse exclude each other");
+    const bool textMode = !cmd.exist("host_parse") && !getenv("FPLH_HOST_PARSE") && chunked && !cmd.exist("break") && !cmd.exist("mask") &&
+                          chunkBytes < (3ull << 30);
     if (cmd.exist("device_parse") && !textMode && cmd.exist("verbose"))
         cerr << "input: --device_parse does not apply (it needs an uncompressed file or multi-member gzip cut into chunks, --chunk_mb below 3072, no --break / --mask): the host parses" << endl;
     if (chunked && textMode) /* one block holds a chunk's text and the stretch behind it that the last record may run into */

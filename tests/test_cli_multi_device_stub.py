@@ -67,6 +67,8 @@ def run_cli(tmp_path, case, env, gpus, extra=(), chunk=30000, devices=3):
     log = out / "stub.log"
     cmd = [build.CLI, "-i", str(inp), "-o", str(out / "out.fq"), "--failed_out", str(out / "failed.fq"), "-j", str(out / "out.json"),
            "-h", str(out / "out.html"), "--gpus", str(gpus), "--reader_threads", "3", "-V"] + flags + list(extra)
+    if "--device_parse" not in extra:
+        cmd.append("--host_parse")  # (these tests read the stub's log of CSR submissions: the host's parsers; the device-parse tests below take the default)
     e = dict(env, FPL_STUB_DEVICES=str(devices), FPL_STUB_LOG=str(log), FPLH_CHUNK_BYTES=str(chunk))
     if gpus == 3:
         e["FPLH_PARALLEL_WRITE"] = "1"  # (the positional writer: the same bytes)
@@ -293,7 +295,7 @@ def test_cli_device_parse_hands_irregular_chunks_to_the_host_reader(tmp_path, st
         inp = d / "in.fq"
         inp.write_bytes(text)
         cmd = [build.CLI, "-i", str(inp), "-o", str(d / "out.fq"), "--failed_out", str(d / "failed.fq"), "-j", str(d / "out.json"),
-               "-h", str(d / "out.html"), "--gpus", "2", "--reader_threads", "3", "-V"] + meta["flags"] + (["--device_parse"] if mode == "device" else [])
+               "-h", str(d / "out.html"), "--gpus", "2", "--reader_threads", "3", "-V"] + meta["flags"] + (["--device_parse"] if mode == "device" else ["--host_parse"])
         e = dict(stub_env, FPL_STUB_DEVICES="2", FPLH_CHUNK_BYTES="30000")
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -330,7 +332,7 @@ def test_cli_device_parse_stops_at_a_malformed_record_like_the_reference(tmp_pat
         inp.write_bytes(text)
         log = d / "stub.log"
         cmd = [build.CLI, "-i", str(inp), "-o", str(d / "out.fq"), "--failed_out", str(d / "failed.fq"), "-j", str(d / "out.json"),
-               "-h", str(d / "out.html"), "--gpus", str(gpus), "--reader_threads", "3", "-V"] + meta["flags"] + (["--device_parse"] if mode == "device" else [])
+               "-h", str(d / "out.html"), "--gpus", str(gpus), "--reader_threads", "3", "-V"] + meta["flags"] + (["--device_parse"] if mode == "device" else ["--host_parse"])
         e = dict(stub_env, FPL_STUB_DEVICES=str(gpus), FPLH_CHUNK_BYTES="30000", FPL_STUB_LOG=str(log))
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
         assert p.returncode == 0, p.stderr.decode()[-2000:]

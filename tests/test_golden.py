@@ -105,7 +105,8 @@ def test_cli_reproduces_golden_on_gpu(tmp_path, case, batch_reads):
            "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html")] + flags
     env = dict(os.environ)
     if batch_reads in ("chunks", "device_parse"):
-        cmd += ["--reader_threads", "3", "-V"] + (["--device_parse"] if batch_reads == "device_parse" else [])
+        # (the device parses wherever the input is cut into chunks: the default; --host_parse keeps the host's parsers)
+        cmd += ["--reader_threads", "3", "-V"] + ([] if batch_reads == "device_parse" else ["--host_parse"])
         env["FPLH_CHUNK_BYTES"] = "30000"
     else:
         cmd += ["--batch_reads", batch_reads]
@@ -149,8 +150,8 @@ def test_cli_gather_output_reproduces_golden_on_gpu(tmp_path, case, how):
     flags = [f if f != "ADAPTERS.fa" else os.path.join(GOLD, case, "ADAPTERS.fa") for f in meta["flags"]]
     cmd = [build.CLI, "-i", str(inp), "-j", str(tmp_path / "out.json"), "-h", str(tmp_path / "out.html"), "--reader_threads", "3", "-V"] + flags
     env = dict(os.environ, FPLH_CHUNK_BYTES="30000")
-    if how == "stdout_pipe_device_parse":  # the gather lists point into the chunk's text instead of CSR arrays
-        cmd += ["--device_parse"]
+    if how not in ("stdout_pipe_device_parse", "gz_input"):  # (device parse is the default -- the gather lists then point into the chunk's text; gz_input: the text inflated into memory, loaded chunk by chunk)
+        cmd += ["--host_parse"]
     if how != "file_forced":
         cmd += ["--stdout"]
     else:
