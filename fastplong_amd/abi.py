@@ -5,7 +5,7 @@ Pure declarations: importing this module needs neither a GPU nor the built libra
 import ctypes as C
 
 FPL_ABI_VERSION = 7
-FPL_MAX_IN_FLIGHT = 2
+FPL_MAX_IN_FLIGHT = 3
 FPL_MAX_ADAPTER_LEN = 255
 FPL_END_WINDOW = 200
 FPL_PATTERN_LEN = 16
@@ -29,6 +29,7 @@ FPL_ERR_STATE = -6
 FPL_TEXT_OK = 0
 FPL_TEXT_IRREGULAR = 1
 FPL_TEXT_TOO_MANY = 2
+FPL_TEXT_CANCELLED = 3
 
 
 class FplTextResult(C.Structure):

@@ -91,6 +91,7 @@ struct fpl_ctx {
            (copy + parse + the header's way back) is enqueued at submission, stage 2 (the per-read kernels, the records' and line
            starts' way back) once the header is in -- by the next submission or by the wait, whichever comes first */
         int kind = 0;          /* 0 CSR batch, 1 text batch */
+        bool cancelled = false; /* text: fpl_cancel_text -- never run, reported by its wait */
         int stage = 0;         /* text: 1 parse enqueued, 2 batch enqueued (or nothing to enqueue) */
         uint64_t text_cap = 0; /* bytes d_text holds */
         u32 rec_cap = 0;       /* records d_line / d_len / h_line hold */
@@ -110,6 +111,7 @@ struct fpl_ctx {
     u32 submitted = 0, waited = 0; /* batches handed to / collected from the asynchronous path */
     hipStream_t stream = nullptr;  /* owned: the compute stream of the host-pointer entry points */
     hipStream_t s_h2d = nullptr, s_d2h = nullptr; /* owned: copy streams */
+    hipStream_t s_parse = nullptr; /* owned: the text-parse kernels of a chunk (behind its upload, beside the upload of the next) */
     StatsTune tune; /* FPL_STATS_* tuning hooks, read once in fpl_create */
     /* timing */
     int timing = 0;
@@ -293,6 +295,7 @@ void fpl_destroy(fpl_ctx* ctx) {
     }
     if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
+    if (ctx->s_parse) (void)hipStreamDestroy(ctx->s_parse);
     if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
     if (ctx->s_trim) (void)hipStreamDestroy(ctx->s_trim);
     if (ctx->ev_trim_done) (void)hipEventDestroy(ctx->ev_trim_done);
@@ -828,6 +831,7 @@ static int ensure_host_streams(fpl_ctx* ctx) {
     FPL_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     FPL_HIP(hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
     FPL_HIP(hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+    FPL_HIP(hipStreamCreateWithFlags(&ctx->s_parse, hipStreamNonBlocking));
     return FPL_OK;
 }
 
@@ -934,6 +938,7 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
     fpl_ctx::Slot& sl = ctx->slot[ctx->submitted % FPL_MAX_IN_FLIGHT];
     sl.kind = 1;
     sl.stage = 2;
+    sl.cancelled = false;
     sl.n_reads = 0;
     sl.rc = FPL_OK;
     sl.text_bytes = n_bytes;
@@ -948,8 +953,12 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
         return FPL_OK;
     }
     auto enqueue = [&]() -> int {
-        hipStream_t st = ctx->s_h2d; /* copy and parse on the copy stream: beside the kernels of the batch before */
-        FPL_HIP(hipMemcpyAsync(sl.d_text, text, n_bytes, hipMemcpyHostToDevice, st));
+        /* the upload on the copy stream, the parse on a stream of its own behind it: the NEXT chunk's upload starts the moment this
+           one's is done (with the parse on the copy stream the link sat idle for 140 us between two uploads of 590) */
+        FPL_HIP(hipMemcpyAsync(sl.d_text, text, n_bytes, hipMemcpyHostToDevice, ctx->s_h2d));
+        FPL_HIP(hipEventRecord(sl.ev_h2d, ctx->s_h2d));
+        hipStream_t st = ctx->s_parse;
+        FPL_HIP(hipStreamWaitEvent(st, sl.ev_h2d, 0));
         FPL_HIP(hipMemsetAsync(sl.d_hdr, 0, sizeof(TextHeader), st));
         FPL_HIP(hipMemsetAsync(&sl.d_hdr->bad_record, 0xFF, sizeof(u64), st));
         const u32 nblk = (u32)((n_bytes + TP_BLOCK_BYTES - 1) / TP_BLOCK_BYTES);
@@ -972,6 +981,7 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
     r = enqueue();
     if (r != FPL_OK) {
         if (ctx->s_h2d) (void)hipStreamSynchronize(ctx->s_h2d);
+        if (ctx->s_parse) (void)hipStreamSynchronize(ctx->s_parse);
         return r;
     }
     sl.stage = 1;
@@ -992,29 +1002,46 @@ static void text_info(const fpl_ctx::Slot& sl, fpl_text_result* out) {
     }
 }
 
+/* the oldest text batch in flight that is neither started nor cancelled: what fpl_peek_text / fpl_start_text / fpl_cancel_text act on */
+static fpl_ctx::Slot* text_pending(fpl_ctx* ctx) {
+    for (u32 k = ctx->waited; k != ctx->submitted; k++) {
+        fpl_ctx::Slot& sl = ctx->slot[k % FPL_MAX_IN_FLIGHT];
+        if (sl.kind == 1 && sl.stage == 1 && !sl.cancelled) return &sl;
+    }
+    return nullptr;
+}
+
 int fpl_peek_text(fpl_ctx* ctx, fpl_text_result* out) {
     if (!ctx || !out) return FPL_ERR_ARG;
-    if (ctx->submitted == ctx->waited) return FPL_ERR_STATE;
-    fpl_ctx::Slot& sl = ctx->slot[ctx->waited % FPL_MAX_IN_FLIGHT];
-    if (sl.kind != 1) return FPL_ERR_STATE;
+    fpl_ctx::Slot* sl = text_pending(ctx);
+    if (!sl) return FPL_ERR_STATE;
     memset(out, 0, sizeof(*out));
-    if (sl.rc != FPL_OK) return sl.rc;
+    if (sl->rc != FPL_OK) return sl->rc;
     FPL_HIP(hipSetDevice(ctx->device));
-    if (sl.text_bytes) FPL_HIP(hipEventSynchronize(sl.ev_parsed));
-    text_info(sl, out);
+    FPL_HIP(hipEventSynchronize(sl->ev_parsed));
+    text_info(*sl, out);
     return FPL_OK;
+}
+
+int fpl_start_text(fpl_ctx* ctx) {
+    if (!ctx) return FPL_ERR_ARG;
+    fpl_ctx::Slot* sl = text_pending(ctx);
+    if (!sl) return FPL_ERR_STATE;
+    if (sl->rc != FPL_OK) return sl->rc;
+    FPL_HIP(hipSetDevice(ctx->device));
+    const int r = text_continue(ctx, *sl);
+    if (r != FPL_OK) sl->rc = r;
+    return r;
 }
 
 int fpl_cancel_text(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
-    if (ctx->submitted == ctx->waited) return FPL_ERR_STATE;
-    fpl_ctx::Slot& sl = ctx->slot[ctx->waited % FPL_MAX_IN_FLIGHT];
-    if (sl.kind != 1) return FPL_ERR_STATE;
+    fpl_ctx::Slot* sl = text_pending(ctx);
+    if (!sl) return FPL_ERR_STATE;
     FPL_HIP(hipSetDevice(ctx->device));
-    if (sl.rc == FPL_OK && sl.text_bytes) FPL_HIP(hipEventSynchronize(sl.ev_parsed)); /* (its copy and parse read the caller's text) */
-    sl.stage = 2;
-    sl.n_reads = 0;
-    ctx->waited++;
+    if (sl->rc == FPL_OK) FPL_HIP(hipEventSynchronize(sl->ev_parsed)); /* (its copy and parse read the caller's text) */
+    sl->cancelled = true;
+    sl->n_reads = 0;
     return FPL_OK;
 }
 
@@ -1027,8 +1054,14 @@ int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** re
     if (results) *results = nullptr;
     if (line_starts) *line_starts = nullptr;
     FPL_HIP(hipSetDevice(ctx->device));
+    if (sl.cancelled) {
+        ctx->waited++;
+        out->status = FPL_TEXT_CANCELLED;
+        out->bad_record = ~0ull;
+        return FPL_OK;
+    }
     if (sl.rc == FPL_OK) {
-        const int r = text_continue(ctx, sl);
+        const int r = text_continue(ctx, sl); /* (no-op when fpl_start_text did it) */
         if (r != FPL_OK) sl.rc = r;
     }
     ctx->waited++;

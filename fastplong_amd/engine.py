@@ -23,7 +23,7 @@ EXPORTS = [
     "fpl_enable_timing", "fpl_get_kernel_times", "fpl_fragment_counts", "fpl_get_fragments",
     "fpl_process_batch_async", "fpl_wait", "fpl_in_flight", "fpl_host_alloc", "fpl_host_free", "fpl_allreduce_counters",
     "fpl_count_end_kmers", "fpl_pick_adapter", "fpl_rccl_library", "fpl_comm_init", "fpl_get_batch_forms", "fpl_assume_inputs_ready",
-    "fpl_process_text_async", "fpl_wait_text", "fpl_peek_text", "fpl_cancel_text",
+    "fpl_process_text_async", "fpl_wait_text", "fpl_peek_text", "fpl_start_text", "fpl_cancel_text",
 ]
 
 
@@ -124,6 +124,8 @@ def load_library(path=None):
     L.fpl_process_text_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.fpl_peek_text.restype = C.c_int
     L.fpl_peek_text.argtypes = [C.c_void_p, C.POINTER(abi.FplTextResult)]
+    L.fpl_start_text.restype = C.c_int
+    L.fpl_start_text.argtypes = [C.c_void_p]
     L.fpl_cancel_text.restype = C.c_int
     L.fpl_cancel_text.argtypes = [C.c_void_p]
     L.fpl_wait_text.restype = C.c_int
@@ -221,6 +223,10 @@ class Engine:
         out = abi.FplTextResult()
         self._check(self.L.fpl_peek_text(self.h, C.byref(out)), "fpl_peek_text")
         return {k: getattr(out, k) for k, _ in abi.FplTextResult._fields_}
+
+    def start_text(self):
+        """fpl_start_text: the per-read kernels of the next pending text batch"""
+        self._check(self.L.fpl_start_text(self.h), "fpl_start_text")
 
     def cancel_text(self):
         self._check(self.L.fpl_cancel_text(self.h), "fpl_cancel_text")

@@ -628,7 +628,10 @@ int main(int argc, char* argv[]) {
        one per device being formatted, two waiting for the writer */
     auto gz_name = [](const string& p) { return p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0; };
     const bool gzOut = !splitEnabled && (gz_name(out) || gz_name(failedOut)); /* (then up to four batches are formatted at a time) */
-    const int nWork = (chunked ? readerThreads : 1) + (FPL_MAX_IN_FLIGHT + 1) * nGpus + 2 + (gzOut ? 3 : 0);
+    /* (+ FPLH_EXTRA_WORK, default 6: with exactly as many as the stages can hold, a parser waits for a Work object while the writer
+       or a formatter still holds one, and the device thread finds its queue empty -- the link then idles between two uploads) */
+    const int extraWork = getenv("FPLH_EXTRA_WORK") ? atoi(getenv("FPLH_EXTRA_WORK")) : 6;
+    const int nWork = (chunked ? readerThreads : 1) + (FPL_MAX_IN_FLIGHT + 1) * nGpus + 2 + (gzOut ? 3 : 0) + (chunked ? max(0, extraWork) : 0);
     /* --device_parse: the chunk parsers only LOAD the file's bytes (page-locked), the device finds the records
        (fpl_process_text_async); --break / --mask keep the host's reader (their fragment lists come back batch by batch through
        the CSR entry points), and so do inputs that are not cut into chunks (pipes, a streamed gzip, a small file) */
@@ -753,6 +756,10 @@ int main(int argc, char* argv[]) {
     double tParse = 0, tWrite = 0, tRedo = 0;
     uint64_t nRedo = 0;
     vector<double> tGpu(nGpus, 0), tFormat(nFmt, 0);
+    /* --verbose, per device thread: seconds inside the submissions, seconds with nothing in flight and nothing parsed (starved),
+       how often the queue was empty when there was room for another batch, and how deep the submissions found the pipeline */
+    vector<double> tSubmit(nGpus, 0), tStarved(nGpus, 0);
+    vector<uint64_t> nMiss(nGpus, 0), nSubmit(nGpus, 0), depthSum(nGpus, 0);
     std::atomic<uint64_t> nTextBatches{0}, nTextFallbacks{0}; /* --device_parse: chunks the device parsed / chunks handed back to the host's reader */
     /* --device_parse: the reference stops READING at a malformed record (FastqReader::read returns NULL, src/fastqreader.cpp:326-341),
        so nothing behind one may be counted -- but a chunk's verdict comes from its device, and the chunks of several devices are
@@ -848,137 +855,203 @@ int main(int argc, char* argv[]) {
         }
         for (int d = 0; d < nGpus; d++) devq[d].push(nullptr);
     });
-    /* ---- stage 2, one thread per device: copies and kernels, FPL_MAX_IN_FLIGHT batches deep */
+    /* ---- stage 2, one thread per device: copies and kernels, FPL_MAX_IN_FLIGHT batches deep.
+       A text batch (the device parses) goes through three calls: its submission (upload + parse), its APPROVAL (the parse's
+       verdict, published for the other devices' threads; then fpl_start_text: the per-read kernels) and its wait.  The loop
+       approves batch k + 1 before it waits for batch k, so the device's queue holds the next batch's kernels while this thread
+       sits in the wait, and the thread's own time in the runtime (some thirty calls per batch) overlaps the device's. */
     vector<thread> devThreads;
     for (int d = 0; d < nGpus; d++)
         devThreads.emplace_back([&, d]() {
-            deque<Work*> inflight, redo;
+            enum { TEXT_PENDING, TEXT_STARTED, TEXT_DROPPED, TEXT_HANDED_BACK, CSR };
+            struct Flight {
+                Work* w;
+                int state;
+            };
+            deque<Flight> inflight; /* in the order of submission: the library's slots are a FIFO */
+            deque<Work*> redo;      /* chunks the host's reader took: in again as CSR batches */
             bool open = true;
-            auto collect = [&]() {
-                Work* w = inflight.front();
-                inflight.pop_front();
-                const double t0 = now();
-                if (w->rc == FPL_OK && w->batch.text_backed && w->batch.off.empty()) {
-                    /* a chunk the device parses.  First its verdict (the parse alone), published for the other devices' threads;
-                       then, when every chunk in front of it was good, its per-read kernels and what they return */
-                    fpl_text_result tr;
-                    fplh::Batch& b = w->batch;
-                    bool good = true, have_csr = false;
-                    string bad_text;
-                    w->rc = fpl_peek_text(dev[d].ctx, &tr);
-                    if (w->rc == FPL_OK && tr.status != FPL_TEXT_OK) {
-                        /* irregular text (blank lines, a lone \r, no line break at the end, a record the reference would stop at):
-                           nothing of it was counted -- the host's reader takes the chunk, by the reference's rules */
-                        w->rc = fpl_cancel_text(dev[d].ctx);
-                        fplh::FastqReader::ChunkInfo ci;
-                        vector<char> window;
-                        const uint64_t len = b.raw_len;
-                        const char* base = (const char*)b.raw.data() + b.raw_begin;
-                        b.text_backed = false;
-                        fplh::FastqReader::parse_chunk(-1, len, 0, len, true, window, b, ci, 1, base);
-                        nTextFallbacks++;
-                        have_csr = true;
-                        if (ci.status == 3) { /* the input ends at this record, as with the host's reader; what the chunk holds in front of it counts */
-                            good = false;
-                            bad_text = ci.err;
-                            stopInput = true;
-                        }
+            fpl_ctx* const ctx = dev[d].ctx;
+            auto fail = [&](Work* w, int rc) {
+                w->rc = rc;
+                if (w->err.empty()) w->err = string(fpl_strerror(rc)) + " " + fpl_last_error(ctx);
+            };
+            auto make_empty = [](Work* w) { /* an empty batch, as the reader makes them */
+                w->batch.clear();
+                w->batch.off.push_back(0);
+                w->batch.name_off.push_back(0);
+                w->res.clear();
+            };
+            /* the oldest text batch that is still pending: verdict first, then its kernels -- or not.  false: none is pending */
+            auto approve_next = [&]() -> bool {
+                Flight* f = nullptr;
+                for (auto& x : inflight)
+                    if (x.state == TEXT_PENDING) {
+                        f = &x;
+                        break;
                     }
-                    verdicts.publish(w->seq_no, good, bad_text);
-                    const bool drop = verdicts.wait_before(w->seq_no);
-                    if (drop) { /* behind a malformed record: not part of the input */
-                        if (!have_csr && w->rc == FPL_OK) w->rc = fpl_cancel_text(dev[d].ctx);
-                        b.clear();
-                        b.off.push_back(0); /* (an empty batch, as the reader makes them) */
-                        b.name_off.push_back(0);
-                        w->res.clear();
-                    } else if (w->rc == FPL_OK && !have_csr) {
-                        const fpl_read_result* rr = nullptr;
-                        const uint32_t* ls = nullptr;
-                        w->rc = fpl_wait_text(dev[d].ctx, &tr, &rr, &ls);
-                        if (w->rc == FPL_OK && tr.status != FPL_TEXT_OK) w->rc = FPL_ERR_STATE; /* (the verdict was "good") */
-                        if (w->rc == FPL_OK) {
-                            w->res.assign(rr, rr + tr.n_reads);
-                            b.adopt_lines(ls, tr.n_reads);
-                            nTextBatches++;
-                        }
-                    } else if (w->rc == FPL_OK && b.n() > 0) { /* in again, as a CSR batch, through the loop below (the slots are a FIFO) */
+                if (!f) return false;
+                const double t0 = now();
+                Work* w = f->w;
+                fplh::Batch& b = w->batch;
+                fpl_text_result tr;
+                bool good = true, to_csr = false;
+                string bad_text;
+                int rc = fpl_peek_text(ctx, &tr);
+                if (rc == FPL_OK && tr.status != FPL_TEXT_OK) {
+                    /* irregular text (blank lines, a lone \r, no line break at the end, a record the reference would stop at):
+                       nothing of it was counted -- the host's reader takes the chunk, by the reference's rules */
+                    rc = fpl_cancel_text(ctx);
+                    fplh::FastqReader::ChunkInfo ci;
+                    vector<char> window;
+                    const uint64_t len = b.raw_len;
+                    const char* base = (const char*)b.raw.data() + b.raw_begin;
+                    b.text_backed = false;
+                    fplh::FastqReader::parse_chunk(-1, len, 0, len, true, window, b, ci, 1, base);
+                    nTextFallbacks++;
+                    to_csr = true;
+                    if (ci.status == 3) { /* the input ends at this record, as with the host's reader; what the chunk holds in front of it counts */
+                        good = false;
+                        bad_text = ci.err;
+                        stopInput = true;
+                    }
+                }
+                verdicts.publish(w->seq_no, good, bad_text);
+                const bool drop = verdicts.wait_before(w->seq_no);
+                if (rc != FPL_OK) { /* (the run fails with this batch's error) */
+                    if (!to_csr) (void)fpl_cancel_text(ctx);
+                    fail(w, rc);
+                    f->state = TEXT_DROPPED;
+                } else if (drop) { /* behind a malformed record: not part of the input */
+                    if (!to_csr) rc = fpl_cancel_text(ctx);
+                    make_empty(w);
+                    if (rc != FPL_OK) fail(w, rc);
+                    f->state = TEXT_DROPPED;
+                } else if (to_csr) {
+                    if (b.n() > 0) { /* in again, as a CSR batch; the cancelled slot stays in the FIFO until its turn */
                         w->res.resize(b.n());
                         w->verdict_done = true;
-                        tGpu[d] += now() - t0;
                         redo.push_back(w);
-                        return;
+                        f->w = nullptr;
+                        f->state = TEXT_HANDED_BACK;
+                    } else {
+                        make_empty(w);
+                        f->state = TEXT_DROPPED;
                     }
-                } else if (w->rc == FPL_OK) {
-                    w->rc = fpl_wait(dev[d].ctx);
+                } else {
+                    rc = fpl_start_text(ctx);
+                    if (rc != FPL_OK) fail(w, rc);
+                    f->state = TEXT_STARTED;
                 }
-                if (w->rc == FPL_OK && fragmentMode) { /* any number of output reads per read: fetch the list */
-                    uint32_t nf = 0, nr = 0;
-                    w->rc = fpl_fragment_counts(dev[d].ctx, &nf, &nr);
-                    if (w->rc == FPL_OK) {
-                        w->frags.frags.resize(nf);
-                        w->frags.regs.resize(nr);
-                        w->rc = fpl_get_fragments(dev[d].ctx, w->frags.frags.data(), nf, w->frags.regs.data(), nr);
-                        w->frags.index(w->batch.n());
-                    }
-                }
-                if (w->rc != FPL_OK && w->err.empty()) w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
                 tGpu[d] += now() - t0;
-                fmtq.push(w);
+                return true;
+            };
+            auto finish_oldest = [&]() {
+                if (inflight.front().state == TEXT_PENDING) approve_next(); /* (the oldest pending batch is this one) */
+                const Flight f = inflight.front();
+                inflight.pop_front();
+                Work* w = f.w;
+                const double t0 = now();
+                if (f.state == CSR) {
+                    if (w->rc == FPL_OK) {
+                        const int rc = fpl_wait(ctx);
+                        if (rc != FPL_OK) fail(w, rc);
+                    }
+                    if (w->rc == FPL_OK && fragmentMode) { /* any number of output reads per read: fetch the list */
+                        uint32_t nf = 0, nr = 0;
+                        int rc = fpl_fragment_counts(ctx, &nf, &nr);
+                        if (rc == FPL_OK) {
+                            w->frags.frags.resize(nf);
+                            w->frags.regs.resize(nr);
+                            rc = fpl_get_fragments(ctx, w->frags.frags.data(), nf, w->frags.regs.data(), nr);
+                            w->frags.index(w->batch.n());
+                        }
+                        if (rc != FPL_OK) fail(w, rc);
+                    }
+                } else {
+                    fpl_text_result tr;
+                    const fpl_read_result* rr = nullptr;
+                    const uint32_t* ls = nullptr;
+                    const int rc = fpl_wait_text(ctx, &tr, &rr, &ls);
+                    if (f.state == TEXT_STARTED && w->rc == FPL_OK) {
+                        if (rc != FPL_OK) fail(w, rc);
+                        else if (tr.status != FPL_TEXT_OK) fail(w, FPL_ERR_STATE); /* (the verdict was "good") */
+                        else {
+                            w->res.assign(rr, rr + tr.n_reads);
+                            w->batch.adopt_lines(ls, tr.n_reads);
+                            nTextBatches++;
+                        }
+                    } else if (w && rc != FPL_OK && w->rc == FPL_OK) {
+                        fail(w, rc);
+                    }
+                }
+                tGpu[d] += now() - t0;
+                if (w) fmtq.push(w);
             };
             const size_t depth = fragmentMode ? 1 : FPL_MAX_IN_FLIGHT;
             while (open || !inflight.empty() || !redo.empty()) {
-                Work* w = nullptr;
-                bool got = false;
-                if (!redo.empty() && inflight.size() < depth) {
-                    w = redo.front();
-                    redo.pop_front();
-                    got = true;
-                } else if (open && inflight.size() < depth) {
-                    if (inflight.empty()) {
-                        w = devq[d].pop();
+                bool progressed = false;
+                if (inflight.size() < depth) {
+                    Work* w = nullptr;
+                    bool got = false;
+                    if (!redo.empty()) {
+                        w = redo.front();
+                        redo.pop_front();
                         got = true;
-                    } else {
-                        got = devq[d].try_pop(w); /* nothing parsed yet: collect the oldest batch meanwhile */
+                    } else if (open) {
+                        if (inflight.empty()) {
+                            const double ts = now();
+                            w = devq[d].pop();
+                            tStarved[d] += now() - ts;
+                            got = true;
+                        } else {
+                            got = devq[d].try_pop(w); /* nothing parsed yet: go on with what is in flight meanwhile */
+                            if (!got) nMiss[d]++;
+                        }
                     }
-                }
-                if (got && !w) open = false;
-                if (got && w) {
-                    w->res.resize(w->batch.n());
-                    w->err.clear();
-                    if (textMode && !w->batch.text_backed && !w->verdict_done) {
-                        /* a CSR batch in a --device_parse run (a chunk the sequencer parsed itself): its kernels are enqueued by the
-                           submission, so it waits for the verdicts in front of it first -- with nothing of this thread in flight,
-                           whose verdicts nobody else could publish */
-                        while (!inflight.empty()) collect();
-                        w->verdict_done = true;
-                        verdicts.publish(w->seq_no, true);
-                        if (verdicts.wait_before(w->seq_no)) {
-                            w->batch.clear();
-                            w->batch.off.push_back(0);
-                            w->batch.name_off.push_back(0);
-                            w->res.clear();
+                    if (got && !w) open = false;
+                    if (got && w) {
+                        progressed = true;
+                        w->res.resize(w->batch.n());
+                        w->err.clear();
+                        w->rc = FPL_OK;
+                        if (textMode && !w->batch.text_backed && !w->verdict_done) {
+                            /* a CSR batch in a run whose chunks the device parses (a chunk the sequencer parsed itself): its kernels
+                               are enqueued by the submission, so it waits for the verdicts in front of it first -- with nothing of
+                               this thread in flight, whose verdicts nobody else could publish */
+                            while (!inflight.empty()) finish_oldest();
+                            w->verdict_done = true;
+                            verdicts.publish(w->seq_no, true);
+                            if (verdicts.wait_before(w->seq_no)) {
+                                make_empty(w);
+                                fmtq.push(w);
+                                continue;
+                            }
+                        }
+                        depthSum[d] += inflight.size() + 1;
+                        const double t0 = now();
+                        const bool text = w->batch.text_backed;
+                        if (text)
+                            w->rc = fpl_process_text_async(ctx, w->batch.raw.data() + w->batch.raw_begin, w->batch.raw_len);
+                        else
+                            w->rc = fpl_process_batch_async(ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(), w->batch.n(),
+                                                            w->res.data());
+                        tGpu[d] += now() - t0;
+                        tSubmit[d] += now() - t0;
+                        nSubmit[d]++;
+                        if (w->rc != FPL_OK) { /* nothing was enqueued: hand the error on in order */
+                            fail(w, w->rc);
+                            if (textMode && text) verdicts.publish(w->seq_no, true); /* (nobody may wait for this chunk's verdict for ever) */
+                            while (!inflight.empty()) finish_oldest();
                             fmtq.push(w);
                             continue;
                         }
+                        inflight.push_back(Flight{w, text ? (int)TEXT_PENDING : (int)CSR});
                     }
-                    const double t0 = now();
-                    if (w->batch.text_backed)
-                        w->rc = fpl_process_text_async(dev[d].ctx, w->batch.raw.data() + w->batch.raw_begin, w->batch.raw_len);
-                    else
-                        w->rc = fpl_process_batch_async(dev[d].ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(),
-                                                        w->batch.n(), w->res.data());
-                    tGpu[d] += now() - t0;
-                    if (w->rc != FPL_OK) { /* nothing was enqueued: hand the error on in order */
-                        w->err = string(fpl_strerror(w->rc)) + " " + fpl_last_error(dev[d].ctx);
-                        while (!inflight.empty()) collect();
-                        fmtq.push(w);
-                        continue;
-                    }
-                    inflight.push_back(w);
-                    if (inflight.size() < depth) continue; /* room for another submission before waiting */
                 }
-                if (!inflight.empty()) collect();
+                /* the next pending batch's kernels go out before this thread waits for an older batch */
+                if (approve_next()) progressed = true;
+                if (!inflight.empty() && (inflight.size() >= depth || !progressed)) finish_oldest();
             }
             fmtq.push(nullptr);
         });
@@ -1159,6 +1232,11 @@ int main(int argc, char* argv[]) {
              << ", copies + kernels (waits) " << g << " s, format (" << fmtThreads << " threads) " << f << " s, write " << tWrite
              << " s" << endl;
     }
+    if (cmd.exist("verbose"))
+        for (int d = 0; d < nGpus; d++)
+            cerr << "device thread " << d << ": " << nSubmit[d] << " submissions " << tSubmit[d] << " s (mean depth behind them "
+                 << (nSubmit[d] ? (double)depthSum[d] / (double)nSubmit[d] : 0.0) << "), queue empty with room for a batch " << nMiss[d]
+                 << " times, nothing in flight and nothing parsed " << tStarved[d] << " s" << endl;
     if (cmd.exist("verbose") && textMode)
         cerr << "device parse: " << nTextBatches.load() << " chunks parsed on the device, " << nTextFallbacks.load()
              << " handed back to the host's reader (irregular text)" << endl;

@@ -287,7 +287,7 @@ int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, con
  * fpl_get_fragments() refers to the batch most recently waited for.
  * Errors of the asynchronous part are reported by fpl_wait().
  */
-#define FPL_MAX_IN_FLIGHT 2
+#define FPL_MAX_IN_FLIGHT 3
 int fpl_process_batch_async(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint64_t* off,
                             uint32_t n_reads, fpl_read_result* results);
 int fpl_wait(fpl_ctx* ctx);
@@ -305,13 +305,16 @@ int fpl_in_flight(const fpl_ctx* ctx);
  *   fpl_process_text_async  uploads `text` (page-locked memory recommended) and starts the parse; returns at once.  `text`
  *                           must stay valid until the batch has been waited for.  Shares the FPL_MAX_IN_FLIGHT slots and the
  *                           FIFO order of fpl_process_batch_async.
- *   fpl_peek_text           the parse's verdict for the OLDEST batch in flight (a text batch) as soon as it is in -- the upload and
- *                           the parse kernels, not the per-read kernels: those are enqueued by fpl_wait_text, so a batch that has
- *                           only been peeked at is in no counter yet.  Fills *out like fpl_wait_text (n_reads = the records found).
- *   fpl_cancel_text         drops the oldest batch in flight (a text batch that has not been waited for) without running it.
+ *   fpl_peek_text           the parse's verdict for the NEXT PENDING text batch -- the oldest one in flight that has been neither
+ *                           started nor cancelled -- as soon as it is in: the upload and the parse kernels, not the per-read
+ *                           kernels, so a batch that has only been peeked at is in no counter yet.  Fills *out like fpl_wait_text.
+ *   fpl_start_text          enqueues the per-read kernels of the next pending text batch (waits for its parse, not for them).
+ *                           Optional: fpl_wait_text starts a batch that was not.  A host that starts batch k + 1 before it waits
+ *                           for batch k keeps the device's queue filled while it sits in the wait.
+ *   fpl_cancel_text         the next pending text batch will not run; its fpl_wait_text reports FPL_TEXT_CANCELLED.
  *                           Together: a host with several devices publishes every chunk's verdict and lets a chunk run only when
  *                           all chunks in front of it were good -- the reference stops READING at a malformed record
- *                           (src/fastqreader.cpp:326-341), so nothing behind one may be counted (bin/fastplong_amd --device_parse).
+ *                           (src/fastqreader.cpp:326-341), so nothing behind one may be counted (bin/fastplong_amd does this).
  *   fpl_wait_text           blocks until the OLDEST batch in flight (which must be a text batch) is complete.  *out says what
  *                           the chunk held; results[i] is the record of read i and line_starts[4 i + j] the offset, in
  *                           `text`, of line j of record i (0 name, 1 bases, 2 '+', 3 qualities) -- so the caller formats its
@@ -324,12 +327,13 @@ int fpl_in_flight(const fpl_ctx* ctx);
  * the sequential reader's: skipped lines, the error texts of :326-341) and submits it through fpl_process_batch_async.
  * FPL_TEXT_TOO_MANY: more than n_bytes / 64 + 16 records (reads shorter than 30 bases on average): same treatment.
  * A text batch is in the counters (fpl_get_counters, fpl_counters_device_ptr) once fpl_wait_text has returned for it: its per-read
- * kernels are enqueued by that call (the upload of the next chunk, submitted before it, runs beside them).  n_bytes < 4 GiB (line
+ * kernels are enqueued by fpl_start_text or by that call (the uploads of the next chunks, submitted before, run beside them).  n_bytes < 4 GiB (line
  * positions are 32 bits).
  */
 #define FPL_TEXT_OK 0
 #define FPL_TEXT_IRREGULAR 1
 #define FPL_TEXT_TOO_MANY 2
+#define FPL_TEXT_CANCELLED 3
 typedef struct fpl_text_result {
     uint32_t n_reads;      /* records of the chunk (0 unless status is FPL_TEXT_OK) */
     uint32_t status;       /* FPL_TEXT_* */
@@ -340,6 +344,7 @@ typedef struct fpl_text_result {
 } fpl_text_result;
 int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes);
 int fpl_peek_text(fpl_ctx* ctx, fpl_text_result* out);
+int fpl_start_text(fpl_ctx* ctx);
 int fpl_cancel_text(fpl_ctx* ctx);
 int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts);
 

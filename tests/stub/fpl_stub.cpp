@@ -31,6 +31,7 @@ struct Pending {
     const uint8_t* text = nullptr; /* a text batch (fpl_process_text_async): parsed in fpl_wait_text */
     uint64_t text_bytes = 0;
     bool is_text = false;
+    bool started = false, cancelled = false; /* text: fpl_start_text / fpl_cancel_text */
 };
 struct fpl_ctx {
     int device = 0;
@@ -215,18 +216,32 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
     ctx->q.push_back(p);
     return FPL_OK;
 }
+static Pending* text_pending(fpl_ctx* ctx) { /* the oldest text batch that is neither started nor cancelled */
+    for (auto& p : ctx->q)
+        if (p.is_text && !p.started && !p.cancelled) return &p;
+    return nullptr;
+}
 int fpl_peek_text(fpl_ctx* ctx, fpl_text_result* out) {
     if (!ctx || !out) return FPL_ERR_ARG;
-    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
+    Pending* p = text_pending(ctx);
+    if (!p) return FPL_ERR_STATE;
     StandInText t; /* (parsed again by the wait: the stand-in keeps no state between the two) */
-    stand_in_parse(ctx->q.front().text, ctx->q.front().text_bytes, false, t);
+    stand_in_parse(p->text, p->text_bytes, false, t);
     *out = t.info;
+    return FPL_OK;
+}
+int fpl_start_text(fpl_ctx* ctx) {
+    if (!ctx) return FPL_ERR_ARG;
+    Pending* p = text_pending(ctx);
+    if (!p) return FPL_ERR_STATE;
+    p->started = true; /* (the stand-in computes in the wait) */
     return FPL_OK;
 }
 int fpl_cancel_text(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
-    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
-    ctx->q.pop_front();
+    Pending* p = text_pending(ctx);
+    if (!p) return FPL_ERR_STATE;
+    p->cancelled = true;
     if (const char* lf = getenv("FPL_STUB_LOG")) {
         std::lock_guard<std::mutex> g(g_log_m);
         if (FILE* f = fopen(lf, "a")) {
@@ -240,6 +255,14 @@ int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** re
     if (!ctx || !out || ctx->q.empty() || !ctx->q.front().is_text) return ctx && out ? FPL_ERR_STATE : FPL_ERR_ARG;
     const Pending p = ctx->q.front();
     ctx->q.pop_front();
+    if (results) *results = nullptr;
+    if (line_starts) *line_starts = nullptr;
+    if (p.cancelled) {
+        memset(out, 0, sizeof *out);
+        out->status = FPL_TEXT_CANCELLED;
+        out->bad_record = ~0ull;
+        return FPL_OK;
+    }
     const unsigned k = ctx->text_no++ % (FPL_MAX_IN_FLIGHT + 1);
     StandInText& t = ctx->text_slot[k];
     stand_in_parse(p.text, p.text_bytes, true, t);

@@ -209,8 +209,9 @@ def test_text_batch_of_bench_size_properties(engine_mod):
     assert int(v.pre.reads) == 20000 and int(v.pre.length_sum) == int(off[-1])
 
 
-def test_peek_and_cancel(orc, engine_mod):
-    """fpl_peek_text gives the parse's verdict with nothing counted yet; fpl_cancel_text drops the batch un-run; a batch that is
+def test_peek_start_and_cancel(orc, engine_mod):
+    """fpl_peek_text gives the parse's verdict of the next pending batch with nothing counted yet; fpl_cancel_text keeps it from
+    running (its wait says FPL_TEXT_CANCELLED); fpl_start_text enqueues a batch's kernels ahead of its wait; a batch that is
     waited for after a peek is complete and exact"""
     seq, qual, off = synth.ont_like(1500, seed=77, median_len=1200, p_middle=0.05)
     text, _, _ = hostio.make_fastq(seq, qual, off)
@@ -222,19 +223,22 @@ def test_peek_and_cancel(orc, engine_mod):
     bad = _pinned(eng, text[:-1])
     eng.submit_text(buf)
     eng.submit_text(bad)
-    info = eng.peek_text()
-    assert info["status"] == abi.FPL_TEXT_OK and info["n_reads"] == 1500 and info["n_bases"] == int(off[-1])
-    assert not eng.counters().any() and eng.in_flight() == 2  # peeked at, not run
-    eng.cancel_text()
-    assert eng.in_flight() == 1 and not eng.counters().any()
-    assert eng.peek_text()["status"] == abi.FPL_TEXT_IRREGULAR
-    eng.cancel_text()
-    assert eng.in_flight() == 0
     eng.submit_text(buf)
-    assert eng.peek_text()["n_reads"] == 1500
+    info = eng.peek_text()  # the first
+    assert info["status"] == abi.FPL_TEXT_OK and info["n_reads"] == 1500 and info["n_bases"] == int(off[-1])
+    assert not eng.counters().any() and eng.in_flight() == 3  # peeked at, not run
+    eng.cancel_text()  # the first will not run
+    assert eng.peek_text()["status"] == abi.FPL_TEXT_IRREGULAR  # the second is the next pending one
+    eng.cancel_text()
+    assert eng.peek_text()["n_reads"] == 1500  # the third
+    eng.start_text()  # its kernels, ahead of the waits for the two in front of it
+    for _ in range(2):
+        info, res, lines = eng.wait_text()
+        assert info["status"] == abi.FPL_TEXT_CANCELLED and len(res) == 0
     info, res, lines = eng.wait_text()
     got_cnt = eng.counters()
+    assert eng.in_flight() == 0
     eng.close()
     assert info["status"] == abi.FPL_TEXT_OK
     parity.assert_results_equal(res, want_res, seq, off)
-    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)  # the one batch that ran, once

@@ -29,6 +29,7 @@ struct Pending {
     const uint8_t* text = nullptr;
     uint64_t text_bytes = 0;
     bool is_text = false;
+    bool started = false, cancelled = false;
 };
 struct fpl_ctx {
     int device = 0;
@@ -119,17 +120,30 @@ int fpl_process_text_async(fpl_ctx* ctx, const uint8_t* text, uint64_t n_bytes) 
     ctx->q.push_back(p);
     return FPL_OK;
 }
+static Pending* text_pending(fpl_ctx* ctx) {
+    for (auto& p : ctx->q)
+        if (p.is_text && !p.started && !p.cancelled) return &p;
+    return nullptr;
+}
 int fpl_peek_text(fpl_ctx* ctx, fpl_text_result* out) { /* (a null device's text is always taken: the verdict costs nothing here) */
     if (!ctx || !out) return FPL_ERR_ARG;
-    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
+    if (!text_pending(ctx)) return FPL_ERR_STATE;
     memset(out, 0, sizeof *out);
     out->bad_record = ~0ull;
     return FPL_OK;
 }
+int fpl_start_text(fpl_ctx* ctx) {
+    if (!ctx) return FPL_ERR_ARG;
+    Pending* p = text_pending(ctx);
+    if (!p) return FPL_ERR_STATE;
+    p->started = true;
+    return FPL_OK;
+}
 int fpl_cancel_text(fpl_ctx* ctx) {
     if (!ctx) return FPL_ERR_ARG;
-    if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
-    ctx->q.pop_front();
+    Pending* p = text_pending(ctx);
+    if (!p) return FPL_ERR_STATE;
+    p->cancelled = true;
     return FPL_OK;
 }
 int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts) {
@@ -137,6 +151,14 @@ int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** re
     if (ctx->q.empty() || !ctx->q.front().is_text) return FPL_ERR_STATE;
     const Pending p = ctx->q.front();
     ctx->q.pop_front();
+    if (p.cancelled) {
+        memset(out, 0, sizeof *out);
+        out->status = FPL_TEXT_CANCELLED;
+        out->bad_record = ~0ull;
+        if (results) *results = nullptr;
+        if (line_starts) *line_starts = nullptr;
+        return FPL_OK;
+    }
     const unsigned k = ctx->text_no++ % (FPL_MAX_IN_FLIGHT + 1);
     StandInText& t = ctx->text_slot[k];
     stand_in_parse(p.text, p.text_bytes, false, t);
