@@ -989,9 +989,15 @@ int main(int argc, char* argv[]) {
                 if (w) fmtq.push(w);
             };
             const size_t depth = fragmentMode ? 1 : FPL_MAX_IN_FLIGHT;
+            auto n_pending = [&]() {
+                size_t n = 0;
+                for (auto& x : inflight) n += x.state == TEXT_PENDING;
+                return n;
+            };
             while (open || !inflight.empty() || !redo.empty()) {
-                bool progressed = false;
-                if (inflight.size() < depth) {
+                /* 1. fill the pipeline: every free slot gets a batch if one is parsed (uploads queue up behind one another) */
+                bool starved = false;
+                while (inflight.size() < depth) {
                     Work* w = nullptr;
                     bool got = false;
                     if (!redo.empty()) {
@@ -1010,48 +1016,55 @@ int main(int argc, char* argv[]) {
                         }
                     }
                     if (got && !w) open = false;
-                    if (got && w) {
-                        progressed = true;
-                        w->res.resize(w->batch.n());
-                        w->err.clear();
-                        w->rc = FPL_OK;
-                        if (textMode && !w->batch.text_backed && !w->verdict_done) {
-                            /* a CSR batch in a run whose chunks the device parses (a chunk the sequencer parsed itself): its kernels
-                               are enqueued by the submission, so it waits for the verdicts in front of it first -- with nothing of
-                               this thread in flight, whose verdicts nobody else could publish */
-                            while (!inflight.empty()) finish_oldest();
-                            w->verdict_done = true;
-                            verdicts.publish(w->seq_no, true);
-                            if (verdicts.wait_before(w->seq_no)) {
-                                make_empty(w);
-                                fmtq.push(w);
-                                continue;
-                            }
-                        }
-                        depthSum[d] += inflight.size() + 1;
-                        const double t0 = now();
-                        const bool text = w->batch.text_backed;
-                        if (text)
-                            w->rc = fpl_process_text_async(ctx, w->batch.raw.data() + w->batch.raw_begin, w->batch.raw_len);
-                        else
-                            w->rc = fpl_process_batch_async(ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(), w->batch.n(),
-                                                            w->res.data());
-                        tGpu[d] += now() - t0;
-                        tSubmit[d] += now() - t0;
-                        nSubmit[d]++;
-                        if (w->rc != FPL_OK) { /* nothing was enqueued: hand the error on in order */
-                            fail(w, w->rc);
-                            if (textMode && text) verdicts.publish(w->seq_no, true); /* (nobody may wait for this chunk's verdict for ever) */
-                            while (!inflight.empty()) finish_oldest();
+                    if (!got || !w) {
+                        starved = true;
+                        break;
+                    }
+                    w->res.resize(w->batch.n());
+                    w->err.clear();
+                    w->rc = FPL_OK;
+                    if (textMode && !w->batch.text_backed && !w->verdict_done) {
+                        /* a CSR batch in a run whose chunks the device parses (a chunk the sequencer parsed itself): its kernels
+                           are enqueued by the submission, so it waits for the verdicts in front of it first -- with nothing of
+                           this thread in flight, whose verdicts nobody else could publish */
+                        while (!inflight.empty()) finish_oldest();
+                        w->verdict_done = true;
+                        verdicts.publish(w->seq_no, true);
+                        if (verdicts.wait_before(w->seq_no)) {
+                            make_empty(w);
                             fmtq.push(w);
                             continue;
                         }
-                        inflight.push_back(Flight{w, text ? (int)TEXT_PENDING : (int)CSR});
                     }
+                    depthSum[d] += inflight.size() + 1;
+                    const double t0 = now();
+                    const bool text = w->batch.text_backed;
+                    if (text)
+                        w->rc = fpl_process_text_async(ctx, w->batch.raw.data() + w->batch.raw_begin, w->batch.raw_len);
+                    else
+                        w->rc = fpl_process_batch_async(ctx, w->batch.seq.data(), w->batch.qual.data(), w->batch.off.data(), w->batch.n(),
+                                                        w->res.data());
+                    tGpu[d] += now() - t0;
+                    tSubmit[d] += now() - t0;
+                    nSubmit[d]++;
+                    if (w->rc != FPL_OK) { /* nothing was enqueued: hand the error on in order */
+                        fail(w, w->rc);
+                        if (textMode && text) verdicts.publish(w->seq_no, true); /* (nobody may wait for this chunk's verdict for ever) */
+                        while (!inflight.empty()) finish_oldest();
+                        fmtq.push(w);
+                        continue;
+                    }
+                    inflight.push_back(Flight{w, text ? (int)TEXT_PENDING : (int)CSR});
                 }
-                /* the next pending batch's kernels go out before this thread waits for an older batch */
-                if (approve_next()) progressed = true;
-                if (!inflight.empty() && (inflight.size() >= depth || !progressed)) finish_oldest();
+                if (inflight.empty()) continue;
+                /* 2. the oldest pending batch's verdict and kernels -- while another upload is queued behind it (or nothing more is
+                   to come): the wait inside is for ITS upload, and the link must not run dry meanwhile */
+                /* (all but the newest pending batch: the batch this thread is about to wait for was then started an iteration ago,
+                   and the next one's kernels sit in the device's queue behind its) */
+                while (n_pending() >= 2) approve_next();
+                if (n_pending() == 1 && starved) approve_next();
+                /* 3. the oldest batch's results, when the pipeline is full or has nothing else to do */
+                if (inflight.size() >= depth || starved) finish_oldest();
             }
             fmtq.push(nullptr);
         });

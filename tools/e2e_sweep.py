@@ -21,16 +21,14 @@ print("input %.2f GB, %.2f Gbases" % (os.path.getsize(fq) / 1e9, nb / 1e9), flus
 base = [build.CLI, "-i", fq, "-o", "/dev/null", "-s", synth.START_ADAPTER, "-e", synth.END_ADAPTER, "--cut_front", "--cut_tail",
         "-W", "5", "-x", "-y", "-j", "/dev/shm/e2e.json", "-h", "/dev/shm/e2e.html", "-V"]
 configs = [
-    ("device parse (default) 32MB R=8", [], {}),
-    ("device parse 32MB R=8 again", [], {}),
-    ("host parse 32MB R=8", ["--host_parse"], {}),
+    ("device parse 32MB", [], {}),
     ("device parse 64MB", ["--chunk_mb", "64"], {}),
     ("device parse 128MB", ["--chunk_mb", "128"], {}),
     ("device parse 256MB", ["--chunk_mb", "256"], {}),
-    ("device parse 512MB", ["--chunk_mb", "512"], {}),
-    ("device parse 128MB R=16", ["--chunk_mb", "128", "--reader_threads", "16"], {}),
-    ("host parse 128MB R=16", ["--host_parse", "--chunk_mb", "128", "--reader_threads", "16"], {}),
-    ("device parse 16MB", ["--chunk_mb", "16"], {}),
+    ("host parse 32MB", ["--host_parse"], {}),
+    ("host parse 64MB", ["--host_parse", "--chunk_mb", "64"], {}),
+    ("host parse 128MB", ["--host_parse", "--chunk_mb", "128"], {}),
+    ("device parse 64MB R=12", ["--chunk_mb", "64", "--reader_threads", "12"], {}),
 ]
 for name, extra, env in configs:
     e = dict(os.environ, FPLH_TIMING="1", FPLH_T0=repr(time.time()), **env)
@@ -39,7 +37,7 @@ for name, extra, env in configs:
     dt = time.perf_counter() - t0
     print("%-34s rc=%d process %.2f s -> %.2f Gbases/s" % (name, r.returncode, dt, nb / dt / 1e9))
     for l in r.stderr.splitlines():
-        if any(k in l for k in ("host pipeline", "since launch")) or r.returncode:
+        if any(k in l for k in ("host pipeline", "device thread")) or r.returncode:
             print("     " + l)
     sys.stdout.flush()
 os.remove(fq)

@@ -16,7 +16,7 @@ host.fplh_write_fastq_ex.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_voi
 assert host.fplh_write_fastq_ex(sys.argv[1].encode(), seq.ctypes.data, qual.ctypes.data, off.ctypes.data, len(off) - 1, b"r", 16, 0) == 0
 print("bases", int(off[-1]))
 PY
-run() { echo "== $1"; shift; "$@" $ROOT/bin/fastplong_amd -i $FQ -o /dev/null -j /tmp/n.json -h /tmp/n.html --cut_front --cut_tail -x -y -V 2>&1 | grep -E "host pipeline|device thread" | cut -c1-260; }
+run() { echo "== $1"; shift; "$@" $ROOT/bin/fastplong_amd -i $FQ -o /dev/null -j /tmp/n.json -h /tmp/n.html --cut_front --cut_tail -x -y -V 2>&1 | grep -E "host pipeline|device thread|text submissions" | tail -4 | cut -c1-260; }
 echo "GPU numa node: $(cat /sys/class/drm/card*/device/numa_node 2>/dev/null | tr '\n' ' ')"
 lscpu | grep -E "NUMA node"
 run "unpinned" env
