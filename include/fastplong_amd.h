@@ -279,7 +279,7 @@ int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, con
  * the kernels on the context's compute stream behind them, the D2H of the records on a third
  * stream, and returns; fpl_wait() blocks until the OLDEST batch in flight is complete and its
  * records are in the `results` array given at submission.  Up to FPL_MAX_IN_FLIGHT batches may be
- * in flight per context (the device staging is double-buffered): the copies of batch k+1 overlap
+ * in flight per context (one set of device staging buffers per batch in flight): the copies of batch k+1 overlap
  * the kernels of batch k.  seq / qual / off must stay valid until the batch has been waited for;
  * they should come from fpl_host_alloc() (pinned) -- pageable memory works but the runtime then
  * stages the copy on the calling thread.  With break_enabled / mask_enabled, a submission first
