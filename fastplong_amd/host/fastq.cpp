@@ -1140,13 +1140,15 @@ bool FastqReader::load_chunk_text(int fd, uint64_t file_size, uint64_t a, uint64
             }
         }
         FastqReader m(wp, n, w1 >= file_size);
-        /* parse_chunk's guess: the first header at or behind `pos` that validates, or the first one at or behind `limit`
-           (beyond its chunk nothing is taken anyway).  short_of_window: the search ran into the end of the window although the
-           file goes on -- look again with more of it */
+        /* The first header at or behind `pos` that VALIDATES (its third line starts with '+', its second and fourth are equally
+           long).  parse_chunk's guess stops at the first candidate beyond its chunk, valid or not, because it takes nothing from
+           there anyway and the sequencer puts a wrong announcement right; here the position IS the end of this chunk's text and the
+           start of the next one's, so both are searched to the end -- through a read of any length (the window grows).
+           short_of_window: the search ran into the end of the window although the file goes on */
         bool short_of_window = false;
-        auto guess = [&](size_t pos, size_t limit) -> size_t {
+        auto find_header = [&](size_t pos) -> size_t {
             Line ln;
-            if (wp[pos - 1] != '\n' && wp[pos - 1] != '\r') m.scan_line(pos, ln); /* finish the line we fell into */
+            if (pos > 0 && wp[pos - 1] != '\n' && wp[pos - 1] != '\r') m.scan_line(pos, ln); /* finish the line we fell into */
             for (;;) {
                 const size_t cand = m.next_at_line(pos);
                 if (cand >= n) {
@@ -1157,21 +1159,21 @@ bool FastqReader::load_chunk_text(int fd, uint64_t file_size, uint64_t a, uint64
                 Line l0, l1, l2, l3;
                 const int r0 = m.scan_line(t, l0), r1 = r0 == 1 ? m.scan_line(t, l1) : r0, r2 = r1 == 1 ? m.scan_line(t, l2) : r1,
                           r3 = r2 == 1 ? m.scan_line(t, l3) : r2;
-                if ((r0 == 0 || r1 == 0 || r2 == 0 || r3 == 0) && cand < limit) { /* the window ends inside these four lines */
+                if (r0 == 0 || r1 == 0 || r2 == 0 || r3 == 0) { /* the window ends inside these four lines and the file goes on */
                     short_of_window = true;
                     return n;
                 }
-                const bool good = r3 == 1 && l2.n > 0 && l2.p[0] == '+' && l1.n == l3.n;
-                if (good || cand >= limit) return cand;
+                if (r3 == 1 && l2.n > 0 && l2.p[0] == '+' && l1.n == l3.n) return cand;
                 pos = cand;
                 m.scan_line(pos, ln); /* not a header: move past this line */
             }
         };
         size_t first = (size_t)(a - w0), next = n;
-        if (a > 0) first = guess(first, (size_t)(b - w0));
-        if (!short_of_window && b < file_size) next = guess((size_t)(b - w0), (size_t)(min<uint64_t>(b + chunk_bytes, file_size) - w0));
+        if (a > 0) first = find_header(first);
+        if (!short_of_window && b < file_size) next = first >= (size_t)(b - w0) ? first : find_header((size_t)(b - w0));
         if (short_of_window) continue;
         if (first > next) first = next;
+        if (first >= (size_t)(b - w0) && b < file_size) first = next; /* no record STARTS in this chunk */
         out.raw_begin = first;
         out.raw_len = next - first;
         if (out.raw_len > 0) info.first = w0 + first;

@@ -346,3 +346,47 @@ def test_cli_device_parse_stops_at_a_malformed_record_like_the_reference(tmp_pat
     assert js["summary"]["before_filtering"]["total_reads"] == bad  # the reads in front of the record, no more
     if where == "first chunk" and gpus == 3:  # chunks behind the record were under way on the other devices: dropped, not run
         assert b"cancel" in open(outs["device"][1] / "stub.log", "rb").read()
+
+
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_cli_reads_longer_than_a_chunk(tmp_path, stub_env, mode):
+    long_read_case(tmp_path, dict(stub_env, FPL_STUB_DEVICES="2"), 2, mode)
+
+
+def long_read_case(tmp_path, env, gpus, mode):
+    """reads that run across many 30 kB chunks (200 kb and 95 kb between short ones; quality lines that start with '@' and '+'):
+    chunks in which no record starts hold nothing, the chunk a long read starts in runs on to its end -- with the device parsing
+    (text-backed batches) and with the host's parsers, the output is the oracle's for the records a plain line scan finds"""
+    import numpy as np
+    from fastplong_amd import synth
+    from oracle import oracle
+    from tests import hostio
+
+    rng = np.random.default_rng(11)
+    lens = [400, 200_000, 300, 350, 95_000, 29_990, 30_010, 500, 61_000, 120, 450]
+    reads = []
+    for i, L in enumerate(lens):
+        s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+        q = rng.integers(33 + 10, 33 + 40, L).astype(np.uint8)
+        q[0] = ord("@") if i % 2 else ord("+")
+        reads.append((s, q))
+    seq, qual, off = synth.pack(reads)
+    text, names, strands = hostio.make_fastq(seq, qual, off)
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    cfg = oracle.Config(abi.FplOptions.default(cut_front=1, cut_tail=1), synth.START_ADAPTER, synth.END_ADAPTER)
+    res, _ = oracle.process_batch(cfg, seq, qual, off)
+    want_out, want_failed = hostio.expected_outputs(seq, qual, off, names, strands, res)
+    cmd = [build.CLI, "-i", str(inp), "-o", str(tmp_path / "out.fq"), "--failed_out", str(tmp_path / "failed.fq"), "-j", str(tmp_path / "o.json"),
+           "-h", str(tmp_path / "o.html"), "-s", synth.START_ADAPTER, "-e", synth.END_ADAPTER, "--cut_front", "--cut_tail", "--gpus", str(gpus),
+           "--reader_threads", "3", "-V"] + (["--host_parse"] if mode == "host" else [])
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=dict(env, FPLH_CHUNK_BYTES="30000"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert (tmp_path / "out.fq").read_bytes() == want_out
+    assert (tmp_path / "failed.fq").read_bytes() == want_failed
+    js = json.loads((tmp_path / "o.json").read_bytes().replace(b"},\n}", b"}\n}"))
+    assert js["summary"]["before_filtering"]["total_reads"] == len(lens)
+    assert js["summary"]["before_filtering"]["total_bases"] == sum(lens)
+    if mode == "device":
+        m = re.search(rb"device parse: (\d+) chunks parsed on the device, (\d+) handed back", p.stderr)
+        assert m and int(m.group(2)) == 0 and int(m.group(1)) >= 5, p.stderr[-600:]

@@ -298,3 +298,14 @@ def test_cli_split_rejects_what_the_reference_rejects(tmp_path):
         p = subprocess.run([build.CLI, "-i", inp, "-o", str(tmp_path / "o.fq"), "-j", str(tmp_path / "o.json"), "-h",
                             str(tmp_path / "o.html")] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert p.returncode != 0 and msg in p.stderr.decode(), (extra, p.stderr.decode()[-300:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_cli_reads_longer_than_a_chunk_on_gpu(tmp_path, mode):
+    """tests/test_cli_multi_device_stub.py::long_read_case on the real library: reads of 200 kb / 95 kb / 61 kb across 30 kB chunks,
+    the chunk loader's record boundaries searched through a whole read, chunks that hold nothing"""
+    from tests.test_cli_multi_device_stub import long_read_case
+
+    build.build_all()
+    long_read_case(tmp_path, dict(os.environ), 1, mode)
