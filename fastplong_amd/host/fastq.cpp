@@ -1623,6 +1623,76 @@ void* fplh_batch_read_chunked(const char* path, uint64_t chunk_bytes, int thread
     close(fd);
     return all;
 }
+/* test hook: the whole (regular, uncompressed) file through the chunk LOADER (text-backed batches, ChunkedReader as_text): the file
+   offsets [begin, end) of every chunk's records, in input order, into ranges[2 k], ranges[2 k + 1]; returns the number of chunks
+   that hold records (-1: the file could not be read; more than `cap` chunks: only the first `cap` are stored) */
+int64_t fplh_text_chunk_ranges(const char* path, uint64_t chunk_bytes, int threads, uint64_t* ranges, uint64_t cap) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        return -1;
+    }
+    int64_t n = 0;
+    {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<fplh::Batch*> pool;
+        for (int i = 0; i < threads + 2; i++) pool.push_back(new fplh::Batch());
+        std::vector<fplh::Batch*> owned = pool;
+        auto acquire = [&]() {
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return !pool.empty(); });
+            fplh::ChunkedReader::Item it;
+            it.batch = pool.back();
+            pool.pop_back();
+            return it;
+        };
+        auto release = [&](fplh::ChunkedReader::Item it) {
+            {
+                std::lock_guard<std::mutex> g(mu);
+                pool.push_back(it.batch);
+            }
+            cv.notify_all();
+        };
+        {
+            const char* mem = nullptr;
+            if (getenv("FPLH_CHUNK_MEM") && st.st_size > 0) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) mem = (const char*)m;
+            }
+            fplh::ChunkedReader cr(mem ? -1 : fd, (uint64_t)st.st_size, chunk_bytes, threads, acquire, release, mem, true);
+            fplh::ChunkedReader::Item it;
+            uint64_t at = 0; /* (file offset of a chunk's text: where the one in front of it ended -- checked by the caller) */
+            while (cr.next(it)) {
+                const fplh::Batch& t = *it.batch;
+                /* the loader keeps the window's bytes [w0, w1): raw_begin counts from w0, which the batch does not say; the text
+                   itself does -- compare it with the file at the running offset (the ranges must be contiguous for a regular file) */
+                uint64_t found = ~0ull;
+                if (t.raw_len > 0) {
+                    std::vector<char> buf(t.raw_len);
+                    /* chunks follow one another: try the running offset first, then look ahead (junk lines between records) */
+                    for (uint64_t o = at; o + t.raw_len <= (uint64_t)st.st_size && found == ~0ull; o++) {
+                        if (pread(fd, buf.data(), t.raw_len, (off_t)o) != (ssize_t)t.raw_len) break;
+                        if (memcmp(buf.data(), t.raw.data() + t.raw_begin, t.raw_len) == 0) found = o;
+                        if (o - at > (1u << 16)) break;
+                    }
+                }
+                if ((uint64_t)n < cap) {
+                    ranges[2 * n] = found;
+                    ranges[2 * n + 1] = found == ~0ull ? ~0ull : found + t.raw_len;
+                }
+                if (found != ~0ull) at = found + t.raw_len;
+                n++;
+                release(it);
+            }
+        }
+        for (fplh::Batch* b : owned) delete b;
+    }
+    close(fd);
+    return n;
+}
 /* bench / test helper: a CSR batch as a FASTQ file ("@<prefix><i>" names, "+" strand lines); the text is composed on
    `threads` threads, slice by slice, and written in order.  0 on success. */
 int fplh_write_fastq(const char* path, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n,

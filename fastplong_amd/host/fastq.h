@@ -250,6 +250,8 @@ void* fplh_batch_read(const char* path, uint64_t max_bases, uint32_t max_reads);
 void* fplh_batch_read_all(const char* path, uint64_t max_bases, uint32_t max_reads);
 /* test hook: the whole (regular, uncompressed) file through the chunk-parallel reader, concatenated */
 void* fplh_batch_read_chunked(const char* path, uint64_t chunk_bytes, int threads, uint64_t* chunks_parsed_again);
+/* test hook: the file through the chunk LOADER (text-backed batches): file offsets [begin, end) of every chunk's records */
+int64_t fplh_text_chunk_ranges(const char* path, uint64_t chunk_bytes, int threads, uint64_t* ranges, uint64_t cap);
 int fplh_read_error(const char* path, char* msg, int msg_len);
 int fplh_write_fastq(const char* path, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint32_t n,
                      const char* prefix, int threads);

@@ -388,6 +388,55 @@ def test_chunked_reader_equals_sequential(hostlib, tmp_path, monkeypatch, varian
         assert redo_total < 40  # guesses are right for well-formed input (a cut inside a header line aside)
 
 
+@pytest.mark.parametrize("source", ["file", "memory"])
+@pytest.mark.parametrize("variant", ["clean", "crlf", "at_quals", "long_record", "noeol"])
+def test_chunk_loader_cuts_the_text_at_records(hostlib, tmp_path, monkeypatch, variant, source):
+    """the chunk LOADER of the device-parse path (FastqReader::load_chunk_text + ChunkedReader as_text): every chunk's text starts
+    at the '@' of a record and ends behind the line break of one -- whatever the chunk size, with records longer than a chunk,
+    quality lines that start with '@' / '+', "\r\n" line ends and a missing last line break -- and the chunks follow one another
+    without a gap: concatenated they are the file"""
+    if source == "memory":
+        monkeypatch.setenv("FPLH_CHUNK_MEM", "1")
+    rng = np.random.default_rng(35)
+    reads = []
+    for i in range(300):
+        n = int(rng.integers(1, 700))
+        if variant == "long_record" and i % 50 == 7:
+            n = int(rng.choice([9000, 31000, 2600]))  # records that run across several (tiny) chunks
+        q = rng.integers(33, 75, n).astype(np.uint8)
+        if variant == "at_quals" or rng.random() < 0.3:
+            q[0] = ord("@")
+            if n > 1 and rng.random() < 0.5:
+                q[1] = ord("+")
+        reads.append((synth._ACGT[rng.integers(0, 4, n)].astype(np.uint8), q))
+    seq, qual, off = synth.pack(reads)
+    text, _, _ = hostio.make_fastq(seq, qual, off, crlf=(variant == "crlf"), strand_names=True)
+    if variant == "noeol":
+        text = text[:-1]
+    p = tmp_path / "in.fq"
+    p.write_bytes(text)
+    starts = set()
+    pos = 0
+    for i, line in enumerate(text.split(b"\n")):
+        if i % 4 == 0:
+            starts.add(pos)
+        pos += len(line) + 1
+    hostlib.fplh_text_chunk_ranges.restype = C.c_int64
+    hostlib.fplh_text_chunk_ranges.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_uint64]
+    for chunk, threads in ((997, 3), (4096, 5), (50_000, 2), (10 ** 9, 4)):
+        cap = len(text) // 500 + 64
+        buf = (C.c_uint64 * (2 * cap))()
+        n = hostlib.fplh_text_chunk_ranges(str(p).encode(), chunk, threads, buf, cap)
+        assert 0 < n <= cap, (variant, chunk, n)
+        r = np.frombuffer(buf, np.uint64)[:2 * n].reshape(n, 2).astype(np.int64)
+        assert r[0, 0] == 0 and r[-1, 1] == len(text), (variant, chunk, r[0], r[-1])
+        assert np.array_equal(r[1:, 0], r[:-1, 1])  # no gap, no overlap
+        assert all(int(a) in starts for a in r[:, 0]), (variant, chunk)  # every chunk starts at a record
+        assert (r[:, 1] > r[:, 0]).all()
+        if chunk < 10 ** 6:
+            assert n > 3
+
+
 def test_truncated_gzip_is_an_error(hostlib, tmp_path):
     """a .fq.gz cut short (an incomplete transfer) must not pass for a complete input: the reference aborts with
     "igzip: unexpected eof" (src/fastqreader.cpp:133-137); the reader here ends the input and reports the error"""
