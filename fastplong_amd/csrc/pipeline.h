@@ -59,6 +59,8 @@ struct StatsTune {
     u32 redo_inline = 0;    /* FPL_REDO_INLINE=1: k_redo stays on the main stream (measurement aid) */
     u32 scan_chunk = 0;     /* FPL_SCAN_CHUNK: reads a k_scan wave takes per dequeue, whatever the batch size (the built-in rule gives small
                                batches chunks of one read: no wave then has a NEXT read whose head could ride in a last tile) */
+    u32 trim_ahead_blocks = 0; /* FPL_TRIM_AHEAD_BLOCKS: blocks per CU of k_trim_ends_batched when it runs AHEAD of the main stream (beside the
+                                  batch before): fewer than a CU holds leave the wave slots of the kernel it runs beside alone (0: two) */
     u32 trim_batch_min = 0; /* FPL_TRIM_BATCH_MIN: batches of fewer reads take k_trim_ends<1> (a wave per read) instead of
                                k_trim_ends_batched (64 reads per wave) */
 };
@@ -75,6 +77,7 @@ inline StatsTune stats_tune_from_env() {
     t.min_bucket = get("FPL_STATS_MIN_BUCKET");
     t.sort_min = get("FPL_STATS_SORT_MIN");
     t.trim_batch_min = get("FPL_TRIM_BATCH_MIN");
+    t.trim_ahead_blocks = get("FPL_TRIM_AHEAD_BLOCKS");
     t.scan_chunk = get("FPL_SCAN_CHUNK");
     t.redo_inline = get("FPL_REDO_INLINE");
     t.hi_tile = get("FPL_STATS_HI_TILE");
@@ -317,7 +320,13 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
         if (trim_takes_batched(n, a.trim_mode, a.tune)) {
             /* a wave takes 64 reads per round: enough waves to fill the chip, few enough to keep every wave a few rounds long */
             u32 gblocks = cdiv(cdiv(n, 64u), KWAVES);
-            const u32 gcap = FPL_TRIM_WAVES_PER_SIMD_BATCHED * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
+            u32 gcap = FPL_TRIM_WAVES_PER_SIMD_BATCHED * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
+            /* AHEAD of the main stream the kernel runs beside k_scan of the batch before, whose six blocks per CU leave eight wave
+               slots: two blocks of four waves take exactly those -- with the full grid the two kernels fight for slots and k_scan
+               loses what the trims gain (c3: 11.64 ms per step; two blocks 11.27-11.41, against 11.50-11.60 with the trims held
+               back until the statistics kernel of the batch before is done; profiles/r06_v4/ab_trims_beside_scan.txt) */
+            const u32 ahead_blocks = a.tune.trim_ahead_blocks ? a.tune.trim_ahead_blocks : 2u;
+            if (a.trim_stream && ahead_blocks < FPL_TRIM_WAVES_PER_SIMD_BATCHED) gcap = ahead_blocks * a.n_cu;
             if (gblocks > gcap) gblocks = gcap;
             if (a.trim_mode == 1)
                 FPL_LAUNCH((k_trim_ends_batched<KWAVES>), dim3(gblocks), block, ts, a.seq, a.qual, a.off, n, a.n_bytes, a.cfg,
