@@ -806,6 +806,7 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
         ctx->forms[2] += trim_takes_batched(n_reads, a.trim_mode, a.tune) ? 1 : 0;
         ctx->forms[3] += sorted_form ? 1 : 0;
         if (n_reads > ctx->forms[4]) ctx->forms[4] = n_reads;
+        ctx->forms[5] += ahead ? 1 : 0;
     }
     const bool timing = ctx->timing != 0;
     const int slot = ctx->ev_calls % fpl_ctx::EV_RING;

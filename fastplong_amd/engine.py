@@ -331,10 +331,11 @@ class Engine:
         self._check(self.L.fpl_assume_inputs_ready(self.h, int(bool(yes))), "fpl_assume_inputs_ready")
 
     def batch_forms(self):
-        """-> dict: batches, reads, through k_trim_ends_batched, through k_stats_sorted, largest batch (fpl_get_batch_forms)"""
+        """-> dict: batches, reads, through k_trim_ends_batched, through k_stats_sorted, largest batch, batches whose end trims ran ahead
+        (fpl_get_batch_forms)"""
         out = (C.c_uint64 * 6)()
         self._check(self.L.fpl_get_batch_forms(self.h, out), "fpl_get_batch_forms")
-        return dict(batches=int(out[0]), reads=int(out[1]), trim_batched=int(out[2]), stats_sorted=int(out[3]), largest=int(out[4]))
+        return dict(batches=int(out[0]), reads=int(out[1]), trim_batched=int(out[2]), stats_sorted=int(out[3]), largest=int(out[4]), trims_ahead=int(out[5]))
 
     def kernel_times(self):
         """-> ({kernel name: ms summed over the window}, n_batches)"""

@@ -427,7 +427,8 @@ int fpl_synchronize(fpl_ctx* ctx);
  * never runs the forms a large resident batch is timed on, and this call says so.  The reference has no counterpart (its
  * unit of work is a pack of 16 reads, src/common.h:33).
  *   out[0] batches   out[1] reads   out[2] batches through k_trim_ends_batched   out[3] batches through k_stats_sorted
- *   out[4] reads of the largest batch   out[5] reserved (0)
+ *   out[4] reads of the largest batch   out[5] batches whose end trims started ahead of the main stream (fpl_assume_inputs_ready /
+ *   the asynchronous path's own copy events), beside the scan of the batch before
  */
 /*
  * A promise about fpl_process_batch_device (ABI v6): yes != 0 says that d_seq / d_qual / d_off of every later call are COMPLETE
@@ -435,6 +436,8 @@ int fpl_synchronize(fpl_ctx* ctx);
  * the call's stream.  The library then starts the end trims of a batch beside the kernels of the batch before it (they are
  * bound by memory latency, the scan and the statistics pass by instruction issue).  Without the promise only the library's own
  * asynchronous path (fpl_process_batch_async: it knows when its copies are in) does that.  Results are the same either way.
+ * The promise holds until it is withdrawn (yes == 0): a caller that later hands in inputs which are only ORDERED on the call's
+ * stream -- written by a kernel or a copy still in flight there -- must withdraw it first, or the trims may read them early.
  */
 int fpl_assume_inputs_ready(fpl_ctx* ctx, int yes);
 

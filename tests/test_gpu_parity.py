@@ -826,18 +826,24 @@ def test_full_quality_byte_range_bench_sized_no_hooks_bit_exact(orc, engine_mod,
     assert "no hook set" in what
 
 
-@pytest.mark.parametrize("sorted_stats", [False, True])
-def test_end_trims_ahead_of_the_previous_batch_bit_exact(orc, engine_mod, monkeypatch, sorted_stats):
+@pytest.mark.parametrize("sorted_stats,sizes,gate", [(False, [900, 1500, 700, 2500, 1100], "0"), (True, [900, 1500, 700, 2500, 1100], "0"),
+                                                     (True, [900, 1500, 700, 2500, 1100], "1"), (True, [70000, 90000, 66000, 120000], "0")])
+def test_end_trims_ahead_of_the_previous_batch_bit_exact(orc, engine_mod, monkeypatch, sorted_stats, sizes, gate):
     """fpl_assume_inputs_ready (ABI v6): with resident inputs the end trims of batch k + 1 run on a stream of their own beside the
-    kernels of batch k (two ReadState[] / work-counter sets, batches alternate).  Five different batches back to back, sizes up
-    and down (the workspace grows in between), against the same batches through a context without the promise -- every record,
-    every counter -- and against the oracle for the last one"""
+    kernels of batch k -- beside its k_scan (FPL_TRIM_AHEAD_GATE=0, the default) or behind its statistics pass (=1) -- with two
+    ReadState[] / work-counter sets, batches alternating.  Different batches back to back, sizes up and down (the workspace grows
+    in between), against the same batches through a context without the promise -- every record, every counter -- and against the
+    oracle for the last one; fpl_get_batch_forms says that the trims really ran ahead.  The last case has batches the library
+    sends ahead by its own size rule, large enough for the two kernels to share the chip for a while."""
     import torch
 
     if sorted_stats:
         monkeypatch.setenv("FPL_STATS_SORT_MIN", "1")
+    if max(sizes) < 65536:
+        monkeypatch.setenv("FPL_TRIM_BATCH_MIN", "1")  # (the library only sends the trims of batches of >= 65 536 reads ahead)
+    monkeypatch.setenv("FPL_TRIM_AHEAD_GATE", gate)
     opt = abi.FplOptions.default(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, polyx=1, complexity_filter=1)
-    batches = [synth.ont_like(n, seed=60 + i, median_len=700, p_middle=0.05) for i, n in enumerate([900, 1500, 700, 2500, 1100])]
+    batches = [synth.ont_like(n, seed=60 + i, median_len=700, p_middle=0.05) for i, n in enumerate(sizes)]
     C = max(int(np.diff(o.astype(np.int64)).max()) for _, _, o in batches)
     out = {}
     for promise in (False, True):
@@ -850,6 +856,7 @@ def test_end_trims_ahead_of_the_previous_batch_bit_exact(orc, engine_mod, monkey
         res = [eng.process_device(st, qt, ot, C) for st, qt, ot, _ in dev_batches]  # all five enqueued before anything is waited for
         torch.cuda.synchronize()
         out[promise] = ([eng.results_to_numpy(r, b[3]) for r, b in zip(res, dev_batches)], eng.counters())
+        assert eng.batch_forms()["trims_ahead"] == (len(batches) - 1 if promise else 0)
         eng.close()
     for a, b, (s_, _, o_) in zip(out[False][0], out[True][0], batches):
         parity.assert_results_equal(b, a, s_, o_)
@@ -871,7 +878,7 @@ def test_batch_forms_say_which_kernels_a_batch_took(engine_mod, monkeypatch):
     eng = engine_mod.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=int(np.diff(off.astype(np.int64)).max()))
     eng.process_host(seq, qual, off)
     eng.process_host(seq[:int(off[500])], qual[:int(off[500])], off[:501])
-    assert eng.batch_forms() == dict(batches=2, reads=2500, trim_batched=0, stats_sorted=0, largest=2000)
+    assert eng.batch_forms() == dict(batches=2, reads=2500, trim_batched=0, stats_sorted=0, largest=2000, trims_ahead=0)
     eng.reset_counters()
     assert eng.batch_forms()["batches"] == 0
     # 160 000 short reads: both thresholds crossed
@@ -885,14 +892,14 @@ def test_batch_forms_say_which_kernels_a_batch_took(engine_mod, monkeypatch):
     qt = torch.randint(40, 70, (n * 400,), generator=g, device="cuda", dtype=torch.int64).to(torch.uint8)
     eng.process_device(st, qt, off_t.cuda(), 400)
     torch.cuda.synchronize()
-    assert eng.batch_forms() == dict(batches=1, reads=n, trim_batched=1, stats_sorted=1, largest=n)
+    assert eng.batch_forms() == dict(batches=1, reads=n, trim_batched=1, stats_sorted=1, largest=n, trims_ahead=0)
     eng.close()
     # the test hooks move the thresholds, and the report follows what really ran
     monkeypatch.setenv("FPL_TRIM_BATCH_MIN", "1")
     monkeypatch.setenv("FPL_STATS_SORT_MIN", "1")
     eng = engine_mod.Engine(opt, synth.START_ADAPTER, synth.END_ADAPTER, device=0, max_cycles=int(np.diff(off.astype(np.int64)).max()))
     eng.process_host(seq, qual, off)
-    assert eng.batch_forms() == dict(batches=1, reads=2000, trim_batched=1, stats_sorted=1, largest=2000)
+    assert eng.batch_forms() == dict(batches=1, reads=2000, trim_batched=1, stats_sorted=1, largest=2000, trims_ahead=0)
     eng.close()
 
 
