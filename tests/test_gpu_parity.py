@@ -330,6 +330,46 @@ def test_random_option_sets_bit_exact(orc, engine_mod, seed):
     parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FPL_FUZZ_AHEAD_FROM", "500")),
+                                            int(os.environ.get("FPL_FUZZ_AHEAD_FROM", "500")) + int(os.environ.get("FPL_FUZZ_AHEAD_SEEDS", "12")))))
+def test_random_option_sets_back_to_back_with_trims_ahead(orc, engine_mod, monkeypatch, seed):
+    """the same seeded corners of the option space, three resident batches (case, a second case's reads, the case again) enqueued
+    back to back under fpl_assume_inputs_ready: the end trims of batch k + 1 run beside the kernels of batch k (the lane-per-read
+    trims and the sorted statistics pass, by the size hooks).  Every record of every batch and the accumulated counters against the
+    oracle.  (--break / --mask batches never run ahead: they pass through here as in-line batches.)"""
+    import torch
+
+    for k, v in (("FPL_TRIM_BATCH_MIN", "1"), ("FPL_STATS_SORT_MIN", "1")):
+        if k not in os.environ:
+            monkeypatch.setenv(k, v)
+    okw, start, end, seq, qual, off = random_case(seed)
+    _, _, _, seq2, qual2, off2 = random_case(seed + 7919)
+    batches = [(seq, qual, off), (seq2, qual2, off2), (seq, qual, off)]
+    cfg = orc.Config(abi.FplOptions.default(**okw), start, end)
+    C = max(1, max(int(np.diff(o.astype(np.int64)).max()) for _, _, o in batches))
+    eng = engine_mod.Engine(cfg.opt, start, end, device=0, max_cycles=C)
+    eng.assume_inputs_ready(True)
+    dev = [(torch.from_numpy(s_).cuda(), torch.from_numpy(q_).cuda(), torch.from_numpy(o_.astype(np.int64)).cuda(), len(o_) - 1)
+           for s_, q_, o_ in batches]
+    torch.cuda.synchronize()
+    res = [eng.process_device(st, qt, ot, C) for st, qt, ot, _ in dev]
+    torch.cuda.synchronize()
+    got = [eng.results_to_numpy(r, b[3]) for r, b in zip(res, dev)]
+    got_cnt = eng.counters()
+    deferred = okw["break_enabled"] or okw["mask_enabled"]
+    assert eng.batch_forms()["trims_ahead"] == (0 if deferred else 2)
+    eng.close()
+    want_cnt = np.zeros(abi.counters_len(C, cfg.n_adapters), np.int64)
+    for (s_, q_, o_), g in zip(batches, got):
+        if deferred:
+            want_res, cnt1 = orc.process_batch_ex(cfg, s_, q_, o_, max_cycles=C)[:2]
+            want_cnt += cnt1
+        else:
+            want_res, _ = orc.process_batch(cfg, s_, q_, o_, max_cycles=C, counters=want_cnt)
+        parity.assert_results_equal(g, want_res, s_, o_)
+    parity.assert_counters_equal(got_cnt, want_cnt, C, cfg.n_adapters)
+
+
 def test_very_long_reads_bit_exact(orc, engine_mod):
     """BASELINE configs[3] goes up to 200 kb per read, ultra-long ONT reads beyond a megabase: thousands of cycle
     tiles, long histories in every kernel"""
