@@ -5,12 +5,15 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h> /* types only: the library is loaded with dlopen in fpl_allreduce_counters */
 #include <dlfcn.h>
+#include <sys/mman.h>
 
 #include <new>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -78,6 +81,7 @@ struct fpl_ctx {
     struct Slot {
         uint64_t st_bytes = 0;
         u32 st_reads = 0;
+        u32 h_res_cap = 0; /* records h_results holds (a text slot sizes it by the records its chunk really has) */
         u8* d_seq = nullptr;
         u8* d_qual = nullptr;
         uint64_t* d_off = nullptr;
@@ -667,6 +671,13 @@ static int ensure_break_mask(fpl_ctx* ctx, u32 n_reads, uint64_t n_bytes) {
 
 static int ensure_workspace(fpl_ctx* ctx, u32 n_reads) {
     if (n_reads <= ctx->ws_reads) return FPL_OK;
+    /* 25 % headroom, as the other workspaces: a host that cuts its input by BYTES hands in batches whose read counts wander by a few
+       per cent, and every new record used to cost a device-wide wait, a dozen hipFree and as many hipMalloc -- 3 to 9 ms each, five or
+       six times in the first 60 ms of a run (rocprofv3 timeline of the CLI, tools/cli_timeline.sh) */
+    {
+        const uint64_t want = (uint64_t)n_reads + n_reads / 4 + 1024;
+        n_reads = want > 0xFFFFFFF0ull ? n_reads : (u32)want;
+    }
     FPL_HIP(hipDeviceSynchronize());
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_state2) (void)hipFree(ctx->d_state2);
@@ -712,7 +723,10 @@ int fpl_process_batch_device(fpl_ctx* ctx, const uint8_t* d_seq, const uint8_t* 
     hipStream_t stream = (hipStream_t)stream_v;
     FPL_HIP(hipSetDevice(ctx->device));
     if (max_read_len > ctx->C) {
-        int r = fpl_reserve_cycles(ctx, max_read_len);
+        /* (a quarter more than asked for: the longest read so far is a record that keeps being broken by a little, and every
+           growth waits for the device and moves the counters) */
+        const uint64_t want = (uint64_t)max_read_len + max_read_len / 4;
+        int r = fpl_reserve_cycles(ctx, want > 0x7FFFFFFFull ? max_read_len : (u32)want);
         if (r != FPL_OK) return r;
     }
     /* which statistics pass the batch takes: asked ONCE -- the side stream's slabs, the launch sequence and the form counters all
@@ -837,7 +851,20 @@ static int ensure_host_streams(fpl_ctx* ctx) {
     return FPL_OK;
 }
 
-static int ensure_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, u32 n_reads, uint64_t n_bytes) {
+static int ensure_host_results(fpl_ctx* ctx, fpl_ctx::Slot& sl, u32 n_reads) {
+    if (n_reads <= sl.h_res_cap && sl.h_results) return FPL_OK;
+    if (sl.h_results) (void)hipHostFree(sl.h_results);
+    sl.h_results = nullptr;
+    sl.h_res_cap = 0;
+    const u32 cap = n_reads + n_reads / 4 + 1024;
+    FPL_HIP(hipHostMalloc((void**)&sl.h_results, sizeof(fpl_read_result) * (size_t)cap, hipHostMallocDefault));
+    sl.h_res_cap = cap;
+    return FPL_OK;
+}
+/* host_results: false for a text slot -- its device arrays are sized by the most records its bytes COULD hold (one per 64 bytes),
+   the page-locked host copy of the records by what the chunk turns out to have (text_continue): locking 19 MB of pages per slot
+   for the 1 900 records of a 32 MB chunk of long reads was 3 ms of the link standing still, three times at the start of a run */
+static int ensure_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, u32 n_reads, uint64_t n_bytes, bool host_results = true) {
     if (n_bytes > sl.st_bytes || !sl.d_seq) {
         FPL_HIP(hipDeviceSynchronize());
         if (sl.d_seq) (void)hipFree(sl.d_seq);
@@ -853,24 +880,22 @@ static int ensure_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, u32 n_reads, uint64_t n_
         FPL_HIP(hipDeviceSynchronize());
         if (sl.d_off) (void)hipFree(sl.d_off);
         if (sl.d_results) (void)hipFree(sl.d_results);
-        if (sl.h_results) (void)hipHostFree(sl.h_results);
         sl.d_off = nullptr;
         sl.d_results = nullptr;
-        sl.h_results = nullptr;
         sl.st_reads = 0;
         const u32 cap = n_reads + n_reads / 4 + 16;
         FPL_HIP(hipMalloc((void**)&sl.d_off, sizeof(uint64_t) * ((size_t)cap + 1)));
         FPL_HIP(hipMalloc((void**)&sl.d_results, sizeof(fpl_read_result) * (size_t)cap));
-        FPL_HIP(hipHostMalloc((void**)&sl.h_results, sizeof(fpl_read_result) * (size_t)cap, hipHostMallocDefault));
         sl.st_reads = cap;
     }
+    if (host_results) return ensure_host_results(ctx, sl, n_reads);
     return FPL_OK;
 }
 
 /* ---- FASTQ text in (ABI v7): csrc/text_parse.h ---- */
 static int ensure_text_slot(fpl_ctx* ctx, fpl_ctx::Slot& sl, uint64_t n_bytes) {
     const u32 rec_cap = (u32)(n_bytes / 64 + 16);
-    int r = ensure_slot(ctx, sl, rec_cap, n_bytes / 2 + 64);
+    int r = ensure_slot(ctx, sl, rec_cap, n_bytes / 2 + 64, false);
     if (r != FPL_OK) return r;
     if (!sl.d_hdr) {
         FPL_HIP(hipMalloc((void**)&sl.d_hdr, sizeof(TextHeader)));
@@ -916,6 +941,10 @@ static int text_continue(fpl_ctx* ctx, fpl_ctx::Slot& sl) {
         const u32 cap = n + n / 4 + 16;
         FPL_HIP(hipHostMalloc((void**)&sl.h_line, sizeof(u32) * 4 * (size_t)cap, hipHostMallocDefault));
         sl.h_line_cap = cap;
+    }
+    {
+        const int rh = ensure_host_results(ctx, sl, n);
+        if (rh != FPL_OK) return rh;
     }
     FPL_HIP(hipStreamWaitEvent(ctx->stream, sl.ev_parsed, 0));
     ctx->next_inputs_event = sl.ev_parsed; /* (the end trims may start beside the batch before) */
@@ -1166,13 +1195,70 @@ int fpl_process_batch(fpl_ctx* ctx, const uint8_t* seq, const uint8_t* qual, con
     return fpl_wait(ctx);
 }
 
+/* Large blocks (a host's batch arenas: hundreds of megabytes) are anonymous memory on transparent huge pages, touched once from a few
+   threads and then registered with the runtime: page-locking goes page by page, and hipHostMalloc locks 4 KB pages at 4 GB/s -- 0.18 s
+   for the CLI's 740 MB arena, every run, before the first byte is read; 370 huge pages are touched in 11 ms and registered in 1.5 ms,
+   and the DMA engines read them at the same 56 GB/s (tools/pin_probe.cpp).  Without huge pages (THP off) the same path costs what
+   hipHostMalloc costs.  Small blocks, and any failure on the way, take hipHostMalloc.  FPL_NO_HUGE_PIN: measurement hook. */
+namespace {
+struct HugeBlocks {
+    std::mutex mu;
+    std::map<void*, std::pair<void*, size_t>> m; /* registered address -> (mapping, its length) */
+};
+HugeBlocks* huge_blocks() {
+    static HugeBlocks* h = new HugeBlocks; /* (never destroyed: a buffer may be freed from a static's destructor) */
+    return h;
+}
+constexpr size_t HUGE_PAGE = 2u << 20;
+constexpr size_t HUGE_MIN = 8u << 20;
+}  // namespace
 void* fpl_host_alloc(size_t bytes) {
+    if (bytes >= HUGE_MIN && !getenv("FPL_NO_HUGE_PIN")) {
+        const size_t len = (bytes + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1);
+        void* const m = mmap(nullptr, len + HUGE_PAGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m != MAP_FAILED) {
+            char* const a = (char*)(((size_t)m + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1));
+            (void)madvise(a, len, MADV_HUGEPAGE);
+            /* first touch (the kernel clears a huge page per fault): a few threads side by side, one byte per small page */
+            const int nt = (int)std::min<size_t>(4, len / (64u << 20) + 1);
+            auto touch = [a, len, nt](int t) {
+                const size_t lo = len / HUGE_PAGE * (size_t)t / (size_t)nt * HUGE_PAGE, hi = len / HUGE_PAGE * (size_t)(t + 1) / (size_t)nt * HUGE_PAGE;
+                for (size_t o = lo; o < hi; o += 4096) ((volatile char*)a)[o] = 0;
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; t++) th.emplace_back(touch, t);
+            touch(0);
+            for (auto& x : th) x.join();
+            if (hipHostRegister(a, len, hipHostRegisterPortable) == hipSuccess) {
+                HugeBlocks& h = *huge_blocks();
+                std::lock_guard<std::mutex> g(h.mu);
+                h.m[a] = std::make_pair(m, len + HUGE_PAGE);
+                return a;
+            }
+            (void)hipGetLastError();
+            munmap(m, len + HUGE_PAGE);
+        }
+    }
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
     return p;
 }
 void fpl_host_free(void* p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        HugeBlocks& h = *huge_blocks();
+        std::unique_lock<std::mutex> g(h.mu);
+        auto it = h.m.find(p);
+        if (it != h.m.end()) {
+            const std::pair<void*, size_t> mp = it->second;
+            h.m.erase(it);
+            g.unlock();
+            (void)hipHostUnregister(p);
+            munmap(mp.first, mp.second);
+            return;
+        }
+    }
+    (void)hipHostFree(p);
 }
 
 int fpl_enable_timing(fpl_ctx* ctx, int enable) {

@@ -64,5 +64,23 @@ if h2d:
     print("large uploads: %d, median %.0f us, p90 %.0f us" % (len(d), d[len(d) // 2] / 1e3, d[int(len(d) * 0.9)] / 1e3))
     gaps = sorted(h2d[i + 1][2] - h2d[i][3] for i in range(len(h2d) - 1))
     print("gaps between consecutive large uploads: median %.0f us, p90 %.0f us, sum %.1f ms" % (gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * 0.9)] / 1e3, sum(g for g in gaps if g > 0) / 1e6))
+    # the steady part of the run: from the 20th large upload to the 20th from the end
+    if len(h2d) > 60:
+        # the pipeline's uploads: everything behind the longest pause (adapter detection and the contexts come before it)
+        gl = [h2d[i + 1][2] - h2d[i][3] for i in range(len(h2d) - 1)]
+        st = h2d[gl.index(max(gl)) + 1:]
+        span = st[-1][3] - st[0][2]
+        g2 = [st[i + 1][2] - st[i][3] for i in range(len(st) - 1)]
+        print("steady part: %d uploads in %.1f ms: %.0f us per upload, busy %.0f %%; gaps: <50 us %d, 50-150 %d, 150-400 %d, 400-1000 %d, >1000 %d; sum of gaps %.1f ms" % (
+            len(st), span / 1e6, span / 1e3 / len(st), 100.0 * sum(e[3] - e[2] for e in st) / span,
+            sum(g < 50e3 for g in g2), sum(50e3 <= g < 150e3 for g in g2), sum(150e3 <= g < 400e3 for g in g2), sum(400e3 <= g < 1e6 for g in g2), sum(g >= 1e6 for g in g2), sum(g2) / 1e6))
+        kern = sorted((e[2], e[3]) for e in ev if e[0] == "kernel")
+        big = sorted(range(len(g2)), key=lambda i: -g2[i])[:12]
+        print("the largest gaps (us into the steady part, gap us, kernels busy inside the gap us, what ran last before it ended):")
+        for i in sorted(big):
+            a, b = st[i][3], st[i + 1][2]
+            kb = sum(max(0, min(e, b) - max(s_, a)) for s_, e in kern if e > a and s_ < b)
+            last = [e for e in ev if e[3] <= b and e[3] > a]
+            print("  %9.0f %7.0f %7.0f  %s" % ((a - st[0][2]) / 1e3, (b - a) / 1e3, kb / 1e3, (last[-1][0] + " " + last[-1][1][-30:]) if last else "-"))
 PY
 rm -f $FQ; rm -rf $OUT/tl
