@@ -3,6 +3,8 @@
 #include "report.h"
 #include "report_internal.h"
 
+#include <charconv>
+#include <cmath>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -29,13 +31,13 @@ struct ByLenThenLex {
 };
 
 /* Stats::reportJson, src/stats.cpp:473-548 (curves from Stats::summarize, :204-244) */
-void stats_json(ofstream& ofs, const string& padding, const StatsBlock& s, const StatsSummary& sm, bool is_rna) {
-    ofs << "{" << endl;
-    ofs << padding << "\t" << "\"total_reads\": " << sm.reads << "," << endl;
-    ofs << padding << "\t" << "\"total_bases\": " << sm.bases << "," << endl;
-    ofs << padding << "\t" << "\"q20_bases\": " << sm.q20 << "," << endl;
-    ofs << padding << "\t" << "\"q30_bases\": " << sm.q30 << "," << endl;
-    ofs << padding << "\t" << "\"total_cycles\": " << sm.cycles << "," << endl;
+/* the eleven per-cycle lists of one Stats block as text (five quality curves, six content curves) */
+struct CurveTexts {
+    string t[11];
+};
+CurveTexts curve_texts(const StatsBlock& s, const StatsSummary& sm, bool is_rna) {
+    CurveTexts out;
+    string* const curveText = out.t;
     const int cycles = sm.cycles;
     vector<double> mean(cycles);
     for (int c = 0; c < cycles; c++) mean[c] = (double)s.total_qual(c) / (double)s.total_base(c);
@@ -51,23 +53,47 @@ void stats_json(ofstream& ofs, const string& padding, const StatsBlock& s, const
     string contentNames[6] = {"A", string(1, t_or_u), "C", "G", "N", "GC"};
     /* the eleven per-cycle lists are hundreds of thousands of numbers each for long reads: one thread per list,
        every number still through a default-formatted ostream */
-    string curveText[11];
     {
         vector<thread> th;
         for (int k = 0; k < 11; k++)
             th.emplace_back([&, k]() {
-                ostringstream o;
+                /* (a default-formatted ostream prints a double as printf's %g with six digits, and so does to_chars(general, 6) -- by
+                   its definition, and on 3 000 000 random ratios -- at a third of the time; anything not finite keeps the stream) */
+                string& o = curveText[k];
+                o.reserve((size_t)cycles * 9);
+                char buf[48];
+                auto put = [&](double v) {
+                    if (std::isfinite(v)) {
+                        o.append(buf, (size_t)(std::to_chars(buf, buf + sizeof buf, v, std::chars_format::general, 6).ptr - buf));
+                    } else {
+                        ostringstream t;
+                        t << v;
+                        o += t.str();
+                    }
+                };
                 for (int c = 0; c < cycles; c++) {
-                    if (k < 4) o << qual_curve(qualNames[k][0], c);
-                    else if (k == 4) o << mean[c];
-                    else if (k < 10) o << content_curve(contentNames[k - 5][0], c);
-                    else o << (double)(s.cyc(c, 0, 'G' & 0x07) + s.cyc(c, 0, 'C' & 0x07)) / (double)s.total_base(c);
-                    if (c != cycles - 1) o << ",";
+                    if (k < 4) put(qual_curve(qualNames[k][0], c));
+                    else if (k == 4) put(mean[c]);
+                    else if (k < 10) put(content_curve(contentNames[k - 5][0], c));
+                    else put((double)(s.cyc(c, 0, 'G' & 0x07) + s.cyc(c, 0, 'C' & 0x07)) / (double)s.total_base(c));
+                    if (c != cycles - 1) o += ',';
                 }
-                curveText[k] = o.str();
             });
         for (auto& t : th) t.join();
     }
+    return out;
+}
+void stats_json(ofstream& ofs, const string& padding, const StatsBlock& s, const StatsSummary& sm, bool is_rna, const CurveTexts& curves) {
+    ofs << "{" << endl;
+    ofs << padding << "\t" << "\"total_reads\": " << sm.reads << "," << endl;
+    ofs << padding << "\t" << "\"total_bases\": " << sm.bases << "," << endl;
+    ofs << padding << "\t" << "\"q20_bases\": " << sm.q20 << "," << endl;
+    ofs << padding << "\t" << "\"q30_bases\": " << sm.q30 << "," << endl;
+    ofs << padding << "\t" << "\"total_cycles\": " << sm.cycles << "," << endl;
+    const string* const curveText = curves.t;
+    const char t_or_u = is_rna ? 'U' : 'T';
+    string qualNames[5] = {"A", string(1, t_or_u), "C", "G", "mean"};
+    string contentNames[6] = {"A", string(1, t_or_u), "C", "G", "N", "GC"};
     ofs << padding << "\t" << "\"quality_curves\": {" << endl;
     for (int i = 0; i < 5; i++) {
         ofs << padding << "\t\t" << "\"" << qualNames[i] << "\":[" << curveText[i] << "]";
@@ -161,6 +187,10 @@ bool write_json(const string& path, const ReportInputs& in) {
     const int64_t* post = in.counters + FPL_OFF_POST(C);
     const int64_t* fr = in.counters + FPL_OFF_FR(C);
     StatsSummary a = summarize(pre, C), b = summarize(post, C);
+    /* (the two blocks' per-cycle lists are put together side by side, the second beside the writing of everything in front of it) */
+    CurveTexts curvesPre, curvesPost;
+    thread curvesPostMaker([&]() { curvesPost = curve_texts(StatsBlock{post, C}, b, in.is_rna); });
+    curvesPre = curve_texts(StatsBlock{pre, C}, a, in.is_rna);
     const string start = in.adapters.size() > 0 ? in.adapters[0] : "", end = in.adapters.size() > 1 ? in.adapters[1] : "";
 
     /* JsonReporter::report, src/jsonreporter.cpp:11-94 */
@@ -252,9 +282,10 @@ bool write_json(const string& path, const ReportInputs& in) {
         ofs << endl << padding << "}," << endl;
     }
     ofs << "\t" << "\"read_before_filtering\": ";
-    stats_json(ofs, "\t", StatsBlock{pre, C}, a, in.is_rna);
+    stats_json(ofs, "\t", StatsBlock{pre, C}, a, in.is_rna, curvesPre);
     ofs << "\t" << "\"" << "read_after_filtering" << "\": ";
-    stats_json(ofs, "\t", StatsBlock{post, C}, b, in.is_rna);
+    curvesPostMaker.join();
+    stats_json(ofs, "\t", StatsBlock{post, C}, b, in.is_rna, curvesPost);
     ofs << "\t\"command\": " << "\"" << in.command << "\"" << endl;
     ofs << "}";
     return ofs.good();

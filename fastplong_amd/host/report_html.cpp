@@ -11,6 +11,7 @@
 #include <memory>
 #include <charconv>
 #include <sstream>
+#include <thread>
 #include <type_traits>
 
 #include "fastq.h"
@@ -330,7 +331,16 @@ struct Side {
         o << "<div id='mean_qual_length_density_figure'>\n<div class='figure' id='" << plot
           << "' style='height:400px;'></div>\n</div>\n";
         o << "\n<script type=\"text/javascript\">" << endl;
-        o << "var density={x:[" << joined(x) << "],y:[" << joined(y)
+        string xt, yt; /* (a number per read each: put together side by side) */
+        if (x.size() > 100000) {
+            thread ty([&]() { yt = joined(y); });
+            xt = joined(x);
+            ty.join();
+        } else {
+            xt = joined(x);
+            yt = joined(y);
+        }
+        o << "var density={x:[" << xt << "],y:[" << yt
           << "],name: '% reads',type:'histogram2dcontour',line:{color:'rgba(128,0,128,1.0)', width:1}\n};\n";
         o << "var data = [density];\n";
         o << "var layout={legend: {x: 0, y: 1.0},title:' Density plot of read median quality and read length', "
@@ -506,13 +516,25 @@ bool write_html(const string& path, const ReportInputs& in, const HtmlInputs& h)
     }
     o << "</div>\n</div>\n</div>\n";
 
+    /* the density plots list two numbers per read: the second side's is put together beside everything in front of it */
+    string densityPost;
+    thread densityPostMaker([&]() {
+        ostringstream t;
+        post.density(t);
+        densityPost = t.str();
+    });
     for (const Section& sec : SECTIONS) {
         o << "<div class='section_div'>\n";
         o << "<div class='section_title' onclick=showOrHide('" << sec.id << "')><a name='summary'>" << sec.title << "</a></div>\n";
         o << "<table id='" << sec.id << "' class='section_table'>\n<tr><td>\n";
         (pre.*sec.render)(o);
         o << "</td><td>\n";
-        (post.*sec.render)(o);
+        if (sec.render == &Side::density) {
+            densityPostMaker.join();
+            o << densityPost;
+        } else {
+            (post.*sec.render)(o);
+        }
         o << "</td></tr>\n</table>\n</div>\n";
     }
 
