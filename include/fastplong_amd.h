@@ -348,8 +348,10 @@ int fpl_start_text(fpl_ctx* ctx);
 int fpl_cancel_text(fpl_ctx* ctx);
 int fpl_wait_text(fpl_ctx* ctx, fpl_text_result* out, const fpl_read_result** results, const uint32_t** line_starts);
 
-/* Page-locked host memory for the arrays handed to fpl_process_batch[_async] (hipHostMalloc): the
- * DMA engines read it directly.  NULL when the allocation fails. */
+/* Page-locked host memory for the arrays handed to fpl_process_batch[_async] / fpl_process_text_async: the DMA engines read it
+ * directly.  Blocks of 8 MB and more are anonymous memory on transparent huge pages, touched and registered with the runtime
+ * (hipHostRegister, portable across devices) -- locking 4 KB pages goes at 4 GB/s, 370 huge pages take 13 ms for 740 MB; smaller
+ * blocks, and any failure on that way, come from hipHostMalloc.  NULL when the allocation fails.  Thread-safe. */
 void* fpl_host_alloc(size_t bytes);
 void fpl_host_free(void* p);
 
