@@ -889,7 +889,7 @@ def main(argv=None, rig=None):
                 "reads_per_gpu": n, "bases_per_gpu": n_bases, "max_read_len": max_len,
                 "parallelism": "shard%d (independent read shards, one RCCL all-reduce of the counters)" % world,
                 "pipelining": ("the steps are enqueued back to back on one stream; the end trims of step k + 1 run on a stream of their own beside "
-                               "k_scan of step k, two blocks per CU in the wave slots it leaves (fpl_assume_inputs_ready: the batch is resident), so "
+                               "k_scan of step k, two of their blocks per CU (fpl_assume_inputs_ready: the batch is resident), so "
                                "kernel_ms.k_trim_ends is what is LEFT of them in line and kernel_ms.k_scan is k_scan WITH the trims beside it -- "
                                "roofline.kernel_ms_alone / frac_alone: the same kernel with nothing beside it") if trim_ahead else "none: every kernel of a step in line",
             },
@@ -901,8 +901,8 @@ def main(argv=None, rig=None):
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BASE * n_bases,
                 "kernel_ms": {k: ktimes[k] / max(1, nbatches) for k in ktimes},
                 "kernel_ms_in_line": inline_ms,  # three steps behind the timed region with the trims NOT ahead: k_trim_ends' own duration
-                # the dominant kernel ALONE: the timed region runs it beside the next batch's end trims (two blocks per CU in the wave slots
-                # it leaves), which lengthens it; three in-line steps behind the region time it with nothing beside it
+                # the dominant kernel ALONE: the timed region runs it beside the next batch's end trims (two of their blocks per CU, each in the
+                # place of one of its five), which lengthens it; three in-line steps behind the region time it with nothing beside it
                 "kernel_ms_alone": (inline_ms or {}).get(dom), "frac_alone": (ALGO_BYTES_PER_BASE * n_bases / (inline_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS)
                 if inline_ms and inline_ms.get(dom) else None,
                 "duration_source": ("HIP events of the timed region" if not (inline_ms and dom == "k_trim_ends") else

@@ -67,7 +67,7 @@ struct fpl_ctx {
     hipStream_t s_trim = nullptr;
     hipEvent_t ev_trim_done = nullptr, ev_batch_done[2] = {nullptr, nullptr}, ev_stats_done[2] = {nullptr, nullptr};
     int ahead_gate = 0;             /* FPL_TRIM_AHEAD_GATE: 0 the trims of batch k + 1 start as soon as batch k - 1 is done -- beside k_scan of
-                                       batch k, in the wave slots it leaves (pipeline.h: two blocks per CU) --, 1 when the statistics kernel
+                                       batch k, two of their blocks per CU (pipeline.h) --, 1 when the statistics kernel
                                        of batch k is done (beside its reduce / post-only tail: the default until round 6) */
     uint64_t batch_no = 0;          /* batches enqueued (parity picks the buffers) */
     bool trim_ahead = true;         /* FPL_NO_TRIM_AHEAD=1 (read in fpl_create) turns it off */

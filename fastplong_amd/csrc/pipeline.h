@@ -60,7 +60,7 @@ struct StatsTune {
     u32 scan_chunk = 0;     /* FPL_SCAN_CHUNK: reads a k_scan wave takes per dequeue, whatever the batch size (the built-in rule gives small
                                batches chunks of one read: no wave then has a NEXT read whose head could ride in a last tile) */
     u32 trim_ahead_blocks = 0; /* FPL_TRIM_AHEAD_BLOCKS: blocks per CU of k_trim_ends_batched when it runs AHEAD of the main stream (beside the
-                                  batch before): fewer than a CU holds leave the wave slots of the kernel it runs beside alone (0: two) */
+                                  batch before): fewer than a CU holds leave most of the register file to the kernel it runs beside (0: two) */
     u32 trim_batch_min = 0; /* FPL_TRIM_BATCH_MIN: batches of fewer reads take k_trim_ends<1> (a wave per read) instead of
                                k_trim_ends_batched (64 reads per wave) */
 };
@@ -321,9 +321,10 @@ inline void enqueue_batch(const BatchArgs& a, fpl_stream_t stream, Mark&& mark) 
             /* a wave takes 64 reads per round: enough waves to fill the chip, few enough to keep every wave a few rounds long */
             u32 gblocks = cdiv(cdiv(n, 64u), KWAVES);
             u32 gcap = FPL_TRIM_WAVES_PER_SIMD_BATCHED * a.n_cu; /* blocks of 4 waves a CU holds: waves per SIMD */
-            /* AHEAD of the main stream the kernel runs beside k_scan of the batch before, whose six blocks per CU leave eight wave
-               slots: two blocks of four waves take exactly those -- with the full grid the two kernels fight for slots and k_scan
-               loses what the trims gain (c3: 11.64 ms per step; two blocks 11.27-11.41, against 11.50-11.60 with the trims held
+            /* AHEAD of the main stream the kernel runs beside k_scan of the batch before.  A wave of either holds 96 vector registers:
+               five fill a SIMD, and k_scan's grid is five blocks per CU -- with its full grid the trim kernel takes places k_scan's
+               persistent blocks then lack and k_scan loses what the trims gain; with two blocks per CU three or four k_scan blocks run
+               beside them while they last (c3: 11.64 ms per step; two blocks 11.27-11.41, against 11.50-11.60 with the trims held
                back until the statistics kernel of the batch before is done; profiles/r06_v4/ab_trims_beside_scan.txt) */
             const u32 ahead_blocks = a.tune.trim_ahead_blocks ? a.tune.trim_ahead_blocks : 2u;
             if (a.trim_stream && ahead_blocks < FPL_TRIM_WAVES_PER_SIMD_BATCHED) gcap = ahead_blocks * a.n_cu;

@@ -2,7 +2,7 @@
 Measurement aid: per-kernel times of several builds of libfastplong_amd.so (tools/ab_build.sh) on the SAME resident
 batch, same box, interleaved rounds -- boxes of the pool differ by a few per cent, so kernel variants are only comparable
 side by side."""
-import argparse, os, sys
+import argparse, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (as bench.py: the library's side streams want hardware queues of their own)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -46,13 +46,18 @@ for spec in a.libs:  # lib.so or lib.so@FLAGS (FPL_DEBUG_FLAGS for a build with 
 os.environ.pop("FPL_DEBUG_FLAGS", None)
 ref_cnt = None
 tot = {p: {} for p, _ in engs}
+wall = {}
 for r in range(a.rounds + 1):
     for p, e in engs:
         e.reset_counters()
         e.enable_timing(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         for _ in range(a.steps if r else 2):
             e.process_device(seq_t, qual_t, off_t, max_len, res_t, st)
         torch.cuda.synchronize()
+        if r:
+            wall.setdefault(p, []).append((time.perf_counter() - t0) * 1e3 / a.steps)
         kt, nbat = e.kernel_times()
         e.enable_timing(False)
         if r == 0:  # warm-up round: also check that every build computes the same counters
@@ -68,4 +73,5 @@ print("%d reads, %.2f Gbases, %s; ms per batch (mean of %d rounds x %d steps)" %
 for p, _ in engs:
     m = {k: sum(v) / len(v) for k, v in tot[p].items()}
     s = sum(m.values())
-    print("%-34s total %7.3f  %s  -> %.1f Gbases/s" % (os.path.basename(p), s, "  ".join("%s %.3f" % (k, v) for k, v in m.items()), nb / s / 1e6))
+    w = sum(wall[p]) / len(wall[p])
+    print("%-34s total %7.3f  %s  -> %.1f Gbases/s; wall clock %.3f ms per batch -> %.1f" % (os.path.basename(p), s, "  ".join("%s %.3f" % (k, v) for k, v in m.items()), nb / s / 1e6, w, nb / w / 1e6))
