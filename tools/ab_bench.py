@@ -1,7 +1,9 @@
 """usage: PYTHONPATH=. python tools/ab_bench.py [--reads N] [--workload W] lib1.so lib2.so ...
 Measurement aid: per-kernel times of several builds of libfastplong_amd.so (tools/ab_build.sh) on the SAME resident
 batch, same box, interleaved rounds -- boxes of the pool differ by a few per cent, so kernel variants are only comparable
-side by side."""
+side by side.  With the end trims ahead (--ahead / %AHEAD=1) the POSITION on the command line matters: every context brings two side
+streams, the runtime deals its hardware queues out in turn, and the second context of a process runs ~3 % slower than the first whatever
+its build (base.so twice: 11.6 / 11.9 ms) -- compare builds at the same position of separate runs, or swap them and average."""
 import argparse, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (as bench.py: the library's side streams want hardware queues of their own)
 import torch
